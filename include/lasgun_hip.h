@@ -1,0 +1,149 @@
+/* include/lasgun_hip.h -- C ABI of liblasgun_hip.so, the MI355X-native drop-in for lasgun's
+ * per-pixel ray-trace path.
+ *
+ * Every entry point in the CORE section replaces one item of the reference's public Rust
+ * surface (file:line under nfrasser/lasgun); a Rust shim binds them 1:1.
+ * Plain pointers and sizes only; no C++ exception ever crosses this boundary.  Functions that
+ * can fail return nonzero / NULL and leave a message in lg_last_error() (thread-local).
+ * Panics of the reference (empty aggregate, missing mesh handle, BVH stack overflow) become
+ * such errors.  There is NO CPU fallback: without a usable HIP device every render call fails.
+ *
+ * Film layout (src/film.rs:22-45, src/img.rs:46-67): w*h pixels, row-major, top-left origin,
+ * 4 bytes RGBA per pixel, A = 255.
+ */
+#ifndef LASGUN_HIP_H
+#define LASGUN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lg_scene lg_scene;         /* src/scene.rs:11-40      Scene      */
+typedef struct lg_aggregate lg_aggregate; /* src/scene/node.rs:25-33 Aggregate  */
+typedef struct lg_accel lg_accel;         /* src/lib.rs:42           Accel<'s>  */
+typedef struct lg_film lg_film;           /* src/film.rs:7-20        Film       */
+
+/* src/material/mod.rs:3-10 -- `Material` is a Copy enum; here a tagged POD.
+ * kind 0 Matte   p = kd[3], sigma
+ * kind 1 Plastic p = kd[3], ks[3], roughness
+ * kind 2 Metal   p = eta[3], k[3], u_roughness, v_roughness
+ * kind 3 Glass   p = kr[3], kt[3], eta
+ * kind 4 Mirror  p = kr[3] */
+typedef struct lg_material {
+    int32_t kind;
+    double p[10];
+} lg_material;
+
+/* ------------------------------- CORE: the reference's surface ------------------------------ */
+const char *lg_last_error(void);
+
+lg_material lg_material_default(void);                                                        /* material/mod.rs:15 */
+lg_material lg_material_matte(const double kd[3], double sigma);                              /* material/mod.rs:19 */
+lg_material lg_material_plastic(const double kd[3], const double ks[3], double roughness);    /* material/mod.rs:24 */
+lg_material lg_material_metal(const double eta[3], const double k[3], double u_roughness, double v_roughness); /* :30 */
+lg_material lg_material_glass(const double kr[3], const double kt[3], double eta);            /* material/mod.rs:36 */
+lg_material lg_material_mirror(const double kr[3]);                                           /* material/mod.rs:43 */
+
+lg_scene *lg_scene_new(void);                                                                 /* scene.rs:50 */
+void lg_scene_free(lg_scene *);
+void lg_scene_set_perspective_camera(lg_scene *, double fov);                                 /* scene.rs:69 */
+void lg_scene_set_orthographic_camera(lg_scene *, double scale);                              /* scene.rs:74 */
+/* The Rust setters return `&mut Camera`; the camera lives in the scene, so these take the scene. */
+void lg_camera_look_at(lg_scene *, const double origin[3], const double look[3], const double up[3]); /* camera.rs:85 */
+void lg_camera_set_supersampling(lg_scene *, uint8_t base);                                   /* camera.rs:96 */
+void lg_camera_set_aperture_radius(lg_scene *, double radius);                                /* camera.rs:100 */
+void lg_scene_set_solid_background(lg_scene *, const double color[3]);                        /* scene.rs:79 */
+void lg_scene_set_radial_background(lg_scene *, const double inner[3], const double outer[3], double scale); /* :83 */
+void lg_scene_set_ambient_light(lg_scene *, const double color[3]);                           /* scene.rs:87 */
+void lg_scene_set_mesh_smoothing(lg_scene *, int enabled);                                    /* scene.rs:91 */
+void lg_scene_set_max_recursion_depth(lg_scene *, uint32_t max_depth);                        /* scene.rs:95 */
+void lg_scene_set_threads(lg_scene *, size_t threads);                                        /* scene.rs:99 (ignored by the GPU path) */
+void lg_scene_add_point_light(lg_scene *, const double position[3], const double intensity[3], const double falloff[3]); /* :103 */
+int lg_scene_parse_obj(lg_scene *, const char *text, size_t len, uint32_t *out_ref);          /* scene.rs:120 -> Result */
+int lg_scene_load_obj(lg_scene *, const char *path, uint32_t *out_ref);                       /* scene.rs:127 -> Result */
+lg_aggregate *lg_scene_root(lg_scene *);                   /* `scene.root` (pub field, scene.rs:14): BORROWED */
+void lg_scene_set_root(lg_scene *, lg_aggregate *moved);   /* scene.rs:132: takes ownership */
+
+lg_aggregate *lg_aggregate_new(void);                                                         /* node.rs:36 */
+void lg_aggregate_free(lg_aggregate *);                    /* only for aggregates never moved into a scene/group */
+void lg_aggregate_add_group(lg_aggregate *, lg_aggregate *moved);                             /* node.rs:49 */
+void lg_aggregate_add_sphere(lg_aggregate *, const double center[3], double radius, const lg_material *); /* node.rs:53 */
+void lg_aggregate_add_cube(lg_aggregate *, const double origin[3], double dim, const lg_material *);      /* node.rs:58 */
+void lg_aggregate_add_box(lg_aggregate *, const double minbound[3], const double maxbound[3], const lg_material *); /* :63 */
+void lg_aggregate_add_obj(lg_aggregate *, uint32_t mesh);                                     /* node.rs:70 */
+void lg_aggregate_add_obj_of(lg_aggregate *, uint32_t mesh, const lg_material *);             /* node.rs:75 */
+void lg_aggregate_swap_backface(lg_aggregate *);                                              /* node.rs:80 */
+void lg_aggregate_translate(lg_aggregate *, const double delta[3]);                           /* node.rs:85 */
+void lg_aggregate_scale(lg_aggregate *, double x, double y, double z);                        /* node.rs:91 */
+void lg_aggregate_rotate_x(lg_aggregate *, double theta_deg);                                 /* node.rs:96 */
+void lg_aggregate_rotate_y(lg_aggregate *, double theta_deg);                                 /* node.rs:101 */
+void lg_aggregate_rotate_z(lg_aggregate *, double theta_deg);                                 /* node.rs:106 */
+void lg_aggregate_rotate(lg_aggregate *, double theta_deg, const double axis[3]);             /* node.rs:111 */
+
+lg_film *lg_film_new(uint32_t width, uint32_t height);                     /* film.rs:24 (zero-filled) */
+lg_film *lg_film_wrap(uint32_t width, uint32_t height, uint8_t *rgba);     /* film.rs:36 new_with_output: caller owns rgba */
+uint8_t *lg_film_pixels(lg_film *);
+uint32_t lg_film_width(lg_film *);
+uint32_t lg_film_height(lg_film *);
+void lg_film_free(lg_film *);
+
+/* Accel::from(&scene) (lib.rs:42, bvh.rs:135): builds the nested HLBVH on the host exactly as
+ * the reference does, flattens it and uploads it to HBM.  Borrows `scene` until lg_accel_free. */
+lg_accel *lg_accel_from(const lg_scene *);
+void lg_accel_free(lg_accel *);
+
+int lg_capture(const lg_scene *, lg_film *);                                       /* lib.rs:55 */
+int lg_capture_subset(size_t k, size_t n, const lg_accel *, lg_film *);            /* lib.rs:110 */
+lg_film *lg_render(const lg_scene *, uint32_t width, uint32_t height);             /* lib.rs:46 */
+
+/* ----------------------- EXTRAS: no counterpart in the reference ---------------------------- */
+typedef struct lg_stats { /* deterministic work counters of one render (stats kernel variant) */
+    uint64_t primary_rays, shadow_rays, secondary_rays, nodes_tested, spheres_tested, cuboids_tested, triangles_tested,
+        accel_entries, hits;
+} lg_stats;
+
+int lg_set_device(int device);      /* HIP device used by this process (default 0) */
+int lg_device_count(void);
+
+/* Render image rows [y0, y1) of a width x height film straight into DEVICE memory, no host copy:
+ * dev_rgba[0] is pixel (0, row0) of the image.  `hip_stream` is a hipStream_t (NULL = the
+ * accel's own stream); the call only enqueues.  This is the multi-GPU row-tile entry point. */
+int lg_capture_rows_device(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, uint32_t row0,
+                           void *dev_rgba, void *hip_stream);
+/* capture_subset into a full width*height device film (pixels outside the subset untouched). */
+int lg_capture_subset_device(size_t k, size_t n, const lg_accel *, uint32_t width, uint32_t height, void *dev_rgba,
+                             void *hip_stream);
+int lg_accel_synchronize(const lg_accel *);
+
+/* f64 radiance before quantisation for subset (k, n); rgb = width*height*3 doubles on the HOST,
+ * pixels outside the subset are left untouched. */
+int lg_capture_radiance(size_t k, size_t n, const lg_accel *, uint32_t width, uint32_t height, double *rgb);
+/* Work counters for rendering rows [y0, y1) (runs the counting kernel variant once). */
+int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, lg_stats *out);
+
+/* Kernel timing with HIP events on the launch stream: enable, render, then read. */
+void lg_profile_enable(const lg_accel *, int enabled);
+int lg_profile_read(const lg_accel *, double *total_ms, uint64_t *launches); /* synchronises; resets the tally */
+
+/* Scene-structure introspection (tests) */
+int lg_accel_dump(const lg_accel *, const double **f, size_t *nf, const int64_t **i, size_t *ni);
+int lg_accel_info(const lg_accel *, uint64_t out[8]); /* nodes, primrefs, spheres, cuboids, triangles, accels, max_stack, bytes */
+void lg_aggregate_get_transform(lg_aggregate *, double m[16], double minv[16]);
+/* Host-only HLBVH build + flatten of a scene, no device needed: structure dump + counts
+ * (nodes, primrefs, spheres, cuboids, triangles, accels, max_stack, has_specular). */
+int lg_host_build_dump(const lg_scene *, const double **f, size_t *nf, const int64_t **i, size_t *ni, uint64_t info[8]);
+
+/* Known-answer and arithmetic probes: run the DEVICE intersectors / math on one thread. */
+int lg_kat_intersect(int kind, const double *params, const char *obj_text, size_t obj_len, const double origin[3],
+                     const double d[3], double out[8]);
+int lg_kat_surface_interaction(const double origin[3], const double d[3], double t, const double dpdu[3],
+                               const double dpdv[3], double out_ng[3]);
+int lg_math_eval(int op, size_t n, const double *a, const double *b, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LASGUN_HIP_H */

@@ -1,0 +1,111 @@
+"""lasgun_amd -- MI355X-native drop-in for nfrasser/lasgun's per-pixel ray-trace path.
+
+The package is a thin host-side mirror of the reference's `Scene` / `Aggregate` / `Material` /
+`Film` / `Accel` / `capture` / `capture_subset` / `render` surface (see `_capi.py`) over the C ABI
+of `liblasgun_hip.so` (include/lasgun_hip.h), whose render entry points run hand-written HIP
+kernels for gfx950.  There is no CPU render path: importing this package without the built
+library raises ImportError, and every render call fails without a HIP device.
+"""
+import ctypes as _C
+import os as _os
+
+import numpy as _np
+
+from ._capi import Api, CStats, LasgunError, ObjError  # noqa: F401
+from . import scenes  # noqa: F401
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+LIB_PATH = _os.path.join(_HERE, "liblasgun_hip.so")
+
+if not _os.path.exists(LIB_PATH):
+    raise ImportError(
+        "lasgun_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C lasgun_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+
+_EXTRA = {
+    "set_device": (_C.c_int, [_C.c_int]),
+    "device_count": (_C.c_int, []),
+    "capture_rows_device": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32,
+                                       _C.c_void_p, _C.c_void_p]),
+    "capture_subset_device": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p,
+                                         _C.c_void_p]),
+    "accel_synchronize": (_C.c_int, [_C.c_void_p]),
+    "capture_radiance": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
+    "capture_stats": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.POINTER(CStats)]),
+    "profile_enable": (None, [_C.c_void_p, _C.c_int]),
+    "profile_read": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.c_double), _C.POINTER(_C.c_uint64)]),
+    "accel_info": (_C.c_int, [_C.c_void_p, _C.c_uint64 * 8]),
+    "host_build_dump": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.POINTER(_C.c_double)), _C.POINTER(_C.c_size_t),
+                                   _C.POINTER(_C.POINTER(_C.c_int64)), _C.POINTER(_C.c_size_t), _C.c_uint64 * 8]),
+}
+
+
+class HipApi(Api):
+    """The product's binding: core surface + the GPU-only extras of include/lasgun_hip.h."""
+
+    def set_device(self, device):
+        if self.call("set_device", int(device)):
+            raise LasgunError(self.last_error())
+
+    def device_count(self):
+        return int(self.call("device_count"))
+
+    def capture_rows_device(self, accel, width, height, y0, y1, dev_ptr, row0=None, stream=None):
+        """Enqueue rows [y0, y1) into device memory at `dev_ptr` (pixel (0,row0) first). No host copy."""
+        if self.call("capture_rows_device", accel.h, width, height, y0, y1, y0 if row0 is None else row0,
+                     _C.c_void_p(int(dev_ptr)), _C.c_void_p(int(stream)) if stream else None):
+            raise LasgunError(self.last_error())
+
+    def capture_subset_device(self, k, n, accel, width, height, dev_ptr, stream=None):
+        if self.call("capture_subset_device", k, n, accel.h, width, height, _C.c_void_p(int(dev_ptr)),
+                     _C.c_void_p(int(stream)) if stream else None):
+            raise LasgunError(self.last_error())
+
+    def synchronize(self, accel):
+        if self.call("accel_synchronize", accel.h):
+            raise LasgunError(self.last_error())
+
+    def capture_radiance(self, accel, w, h, k=0, n=1, **_):
+        rgb = _np.full((h, w, 3), _np.nan, dtype=_np.float64)
+        if self.call("capture_radiance", k, n, accel.h, w, h, rgb.ctypes.data):
+            raise LasgunError(self.last_error())
+        return rgb
+
+    def capture_stats(self, accel, w, h, y0=0, y1=None):
+        s = CStats()
+        if self.call("capture_stats", accel.h, w, h, y0, h if y1 is None else y1, _C.byref(s)):
+            raise LasgunError(self.last_error())
+        return s.as_dict()
+
+    def profile_enable(self, accel, enabled=True):
+        self.call("profile_enable", accel.h, 1 if enabled else 0)
+
+    def profile_read(self, accel):
+        ms = _C.c_double(); n = _C.c_uint64()
+        if self.call("profile_read", accel.h, _C.byref(ms), _C.byref(n)):
+            raise LasgunError(self.last_error())
+        return ms.value, int(n.value)
+
+    def host_build_dump(self, scene):
+        """Host-only BVH build + flatten (no GPU needed): (floats, ints, info dict)."""
+        pf = _C.POINTER(_C.c_double)(); nf = _C.c_size_t(); pi = _C.POINTER(_C.c_int64)(); ni = _C.c_size_t()
+        info = (_C.c_uint64 * 8)()
+        if self.call("host_build_dump", scene.h, _C.byref(pf), _C.byref(nf), _C.byref(pi), _C.byref(ni), info):
+            raise LasgunError(self.last_error())
+        f = _np.ctypeslib.as_array(pf, shape=(nf.value,)).copy()
+        i = _np.ctypeslib.as_array(pi, shape=(ni.value,)).copy()
+        keys = ("nodes", "primrefs", "spheres", "cuboids", "triangles", "accels", "max_stack", "has_specular")
+        return f, i, dict(zip(keys, [int(v) for v in info]))
+
+    def accel_info(self, accel):
+        out = (_C.c_uint64 * 8)()
+        self.call("accel_info", accel.h, out)
+        keys = ("nodes", "primrefs", "spheres", "cuboids", "triangles", "accels", "max_stack", "device_bytes")
+        return dict(zip(keys, [int(v) for v in out]))
+
+
+api = HipApi(_C.CDLL(LIB_PATH), "lg_", _EXTRA)
+
+# reference-shaped names at package level: `from lasgun_amd import Scene, Material, capture`
+Scene, Aggregate, Material, Camera, Film, Accel = api.Scene, api.Aggregate, api.Material, api.Camera, api.Film, api.Accel
+capture, capture_subset, render = api.capture, api.capture_subset, api.render

@@ -1,0 +1,561 @@
+// lasgun_amd/csrc/capi.cpp -- the C ABI of include/lasgun_hip.h: host objects, device upload,
+// kernel launches.  No torch types, no C++ exceptions across the boundary, no CPU render path.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lasgun_hip.h"
+#include "host.h"
+
+namespace lg {
+// kernels.hip
+hipError_t launch_trace(const DParams &P, bool stats, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
+hipError_t trace_occupancy(uint32_t stack_depth, int *blocks_per_cu);
+hipError_t trace_set_lds_limit(size_t bytes);
+hipError_t launch_kat(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d, double *out,
+                      hipStream_t stream);
+hipError_t launch_kat_si(V3 o, V3 d, double t, V3 dpdu, V3 dpdv, double *out, hipStream_t stream);
+hipError_t launch_math(int op, size_t n, const double *a, const double *b, double *out, hipStream_t stream);
+} // namespace lg
+
+using namespace lg;
+
+static thread_local std::string tl_error;
+static int g_device = 0;
+
+static int fail(const std::string &msg) {
+    tl_error = msg;
+    return 1;
+}
+#define HIP_TRY(expr)                                                                                                   \
+    do {                                                                                                                \
+        hipError_t _e = (expr);                                                                                         \
+        if (_e != hipSuccess) throw Error(std::string(#expr) + ": " + hipGetErrorString(_e));                           \
+    } while (0)
+
+static void use_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        throw Error("no HIP device available: liblasgun_hip has no CPU fallback (hipGetDeviceCount: " +
+                    std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")");
+    if (g_device >= n) throw Error("device index out of range");
+    HIP_TRY(hipSetDevice(g_device));
+}
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    void upload(const std::vector<T> &v) {
+        release();
+        n = v.size();
+        size_t bytes = (n ? n : 1) * sizeof(T);
+        HIP_TRY(hipMalloc((void **)&p, bytes));
+        if (n) HIP_TRY(hipMemcpy(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        HIP_TRY(hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct lg_scene {
+    Scene s;
+};
+struct lg_aggregate {
+    Aggregate a;
+};
+struct lg_film {
+    uint32_t w = 0, h = 0;
+    std::vector<uint8_t> owned;
+    uint8_t *px = nullptr;
+};
+
+struct lg_accel {
+    const Scene *scene = nullptr;
+    FlatScene flat;
+    DevBuf<DNode> nodes;
+    DevBuf<uint32_t> primref;
+    DevBuf<DSphere> spheres;
+    DevBuf<int32_t> sphere_mat;
+    DevBuf<DCuboid> cuboids;
+    DevBuf<int32_t> cuboid_mat;
+    DevBuf<uint32_t> tri_v, tri_n, tri_t;
+    DevBuf<float> vpos, vnorm, vtex;
+    DevBuf<DAccel> accels;
+    DevBuf<DMaterial> materials;
+    DevBuf<DLight> lights;
+    // launch resources (mutable: a `const lg_accel*` render call still enqueues work)
+    mutable DevBuf<uint32_t> tile_counter;
+    mutable DevBuf<double> frames;
+    mutable DevBuf<DStats> stats;
+    mutable DevBuf<uint8_t> staging;    // device film for host-film captures
+    mutable DevBuf<double> staging_rad;
+    mutable std::mutex mtx;
+    hipStream_t stream = nullptr;
+    uint32_t stack_depth = 1;
+    uint32_t max_blocks = 1;
+    uint64_t device_bytes = 0;
+    mutable bool profiling = false;
+    mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    ~lg_accel() {
+        for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
+    const Scene &s = *a.scene;
+    DParams P{};
+    P.nodes = a.nodes.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
+    P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
+    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.accels = a.accels.p; P.materials = a.materials.p;
+    P.lights = a.lights.p;
+    P.nlights = (uint32_t)a.flat.lights.size();
+    P.recursion = s.recursion;
+    P.default_material = a.flat.default_material;
+    P.stack_depth = a.stack_depth;
+    P.cam_origin = s.camera.origin; P.cam_view = s.camera.view; P.cam_up = s.camera.up; P.cam_aux = s.camera.aux;
+    P.image_plane_height = s.camera.image_plane_height;
+    P.pixel_separation = s.camera.pixel_separation;
+    P.ss_distance = s.camera.ss_distance;
+    P.ss_root = s.camera.ss_root;
+    P.bg_inner = s.bg_inner; P.bg_outer = s.bg_outer; P.bg_scale = s.bg_scale;
+    P.ambient = s.ambient;
+    P.w = w; P.h = h;
+    P.winv = 1. / (double)w; P.hinv = 1. / (double)h; P.aspect = (double)w / (double)h; // film.rs:40-42
+    P.tile_counter = a.tile_counter.p;
+    return P;
+}
+
+// Enqueue one render on `stream`.  Caller holds a.mtx.
+static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t stream) {
+    if (P.ntiles == 0) return;
+    uint32_t blocks = (P.ntiles + 3u) / 4u;
+    if (blocks > a.max_blocks) blocks = a.max_blocks;
+    // Whitted frames: one slot per resident lane and recursion level, only for glass / mirror scenes
+    if (a.flat.has_specular && P.recursion > 0) {
+        unsigned long long threads = (unsigned long long)a.max_blocks * 256ull;
+        size_t need = (size_t)threads * P.recursion * FRAME_DOUBLES;
+        if (a.frames.n < need) {
+            HIP_TRY(hipStreamSynchronize(a.stream));
+            a.frames.alloc(need);
+        }
+        P.frames = a.frames.p;
+        P.frame_threads = threads;
+    }
+    if (stats) {
+        P.stats = a.stats.p;
+        HIP_TRY(hipMemsetAsync(a.stats.p, 0, sizeof(DStats), stream));
+    }
+    HIP_TRY(hipMemsetAsync(a.tile_counter.p, 0, sizeof(uint32_t), stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (a.profiling) {
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, stream));
+    }
+    HIP_TRY(launch_trace(P, stats, blocks, a.stack_depth, stream));
+    if (a.profiling) {
+        HIP_TRY(hipEventRecord(e1, stream));
+        a.events.emplace_back(e0, e1);
+    }
+}
+
+static void set_rect(DParams &P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    P.mode = 0; P.x0 = x0; P.y0 = y0; P.x1 = x1; P.y1 = y1;
+    P.tiles_x = (x1 - x0 + 7u) / 8u;
+    uint32_t tiles_y = (y1 - y0 + 7u) / 8u;
+    P.ntiles = P.tiles_x * tiles_y;
+}
+static void set_subset(DParams &P, size_t k, size_t n, uint32_t w, uint32_t h) {
+    unsigned long long area = (unsigned long long)w * h;
+    P.mode = 1; P.sub_k = k; P.sub_n = n;
+    P.sub_count = k < area ? (area - k + n - 1) / n : 0;
+    P.ntiles = (uint32_t)((P.sub_count + 63ull) / 64ull);
+}
+
+template <class F> static int guarded(F f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(e.what());
+    }
+}
+
+// ============================================================================================
+extern "C" {
+
+const char *lg_last_error(void) { return tl_error.c_str(); }
+
+static lg_material pack(const Material &m) { lg_material r; r.kind = m.kind; std::memcpy(r.p, m.p, sizeof r.p); return r; }
+static Material unpack(const lg_material *m) { Material r; r.kind = m->kind; std::memcpy(r.p, m->p, sizeof r.p); return r; }
+static lg_material mat2(int kind, const double a[3], const double b[3], double s0, double s1) {
+    lg_material m{}; m.kind = kind;
+    for (int i = 0; i < 3; ++i) { m.p[i] = a[i]; if (b) m.p[3 + i] = b[i]; }
+    m.p[6] = s0; m.p[7] = s1;
+    return m;
+}
+lg_material lg_material_default(void) { return pack(material_default()); }
+lg_material lg_material_matte(const double kd[3], double sigma) { return pack(material_matte(kd, sigma)); }
+lg_material lg_material_plastic(const double kd[3], const double ks[3], double roughness) { return mat2(MAT_PLASTIC, kd, ks, roughness, 0.0); }
+lg_material lg_material_metal(const double eta[3], const double k[3], double u, double v) { return mat2(MAT_METAL, eta, k, u, v); }
+lg_material lg_material_glass(const double kr[3], const double kt[3], double eta) { return mat2(MAT_GLASS, kr, kt, eta, 0.0); }
+lg_material lg_material_mirror(const double kr[3]) { return mat2(MAT_MIRROR, kr, nullptr, 0.0, 0.0); }
+
+lg_scene *lg_scene_new(void) { return new lg_scene(); }
+void lg_scene_free(lg_scene *s) { delete s; }
+void lg_scene_set_perspective_camera(lg_scene *s, double fov) { s->s.camera.init(true, fov); }
+void lg_scene_set_orthographic_camera(lg_scene *s, double scale) { s->s.camera.init(false, scale); }
+void lg_camera_look_at(lg_scene *s, const double o[3], const double l[3], const double u[3]) {
+    s->s.camera.look_at(V3{o[0], o[1], o[2]}, V3{l[0], l[1], l[2]}, V3{u[0], u[1], u[2]});
+}
+void lg_camera_set_supersampling(lg_scene *s, uint8_t base) { s->s.camera.set_supersampling(base); }
+void lg_camera_set_aperture_radius(lg_scene *s, double r) { s->s.camera.aperture_radius = r; }
+void lg_scene_set_solid_background(lg_scene *s, const double c[3]) {
+    s->s.bg_inner = V3{c[0], c[1], c[2]}; s->s.bg_outer = s->s.bg_inner; s->s.bg_scale = 1.0; // background.rs:18-20
+}
+void lg_scene_set_radial_background(lg_scene *s, const double i[3], const double o[3], double scale) {
+    s->s.bg_inner = V3{i[0], i[1], i[2]}; s->s.bg_outer = V3{o[0], o[1], o[2]}; s->s.bg_scale = scale;
+}
+void lg_scene_set_ambient_light(lg_scene *s, const double c[3]) { s->s.ambient = V3{c[0], c[1], c[2]}; }
+void lg_scene_set_mesh_smoothing(lg_scene *s, int e) { s->s.smoothing = e != 0; }
+void lg_scene_set_max_recursion_depth(lg_scene *s, uint32_t d) { s->s.recursion = d; }
+void lg_scene_set_threads(lg_scene *s, size_t t) { s->s.threads = t; }
+void lg_scene_add_point_light(lg_scene *s, const double p[3], const double i[3], const double f[3]) {
+    Light l;
+    std::memcpy(l.pos, p, sizeof l.pos); std::memcpy(l.intensity, i, sizeof l.intensity); std::memcpy(l.falloff, f, sizeof l.falloff);
+    s->s.lights.push_back(l);
+}
+int lg_scene_parse_obj(lg_scene *s, const char *text, size_t len, uint32_t *out_ref) { // scene.rs:109-123
+    return guarded([&] {
+        std::unique_ptr<Obj> obj(new Obj());
+        parse_obj_text(text, len, *obj);
+        if (!s->s.smoothing) obj->normal.clear();
+        *out_ref = (uint32_t)s->s.meshes.size();
+        s->s.meshes.push_back(std::move(obj));
+    });
+}
+int lg_scene_load_obj(lg_scene *s, const char *path, uint32_t *out_ref) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(std::string("cannot open ") + path);
+    std::string buf;
+    char tmp[65536];
+    size_t n;
+    while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.append(tmp, n);
+    std::fclose(f);
+    return lg_scene_parse_obj(s, buf.data(), buf.size(), out_ref);
+}
+lg_aggregate *lg_scene_root(lg_scene *s) { return reinterpret_cast<lg_aggregate *>(s->s.root.get()); }
+void lg_scene_set_root(lg_scene *s, lg_aggregate *moved) {
+    s->s.root.reset(new Aggregate(std::move(moved->a)));
+    delete moved;
+}
+
+// lg_aggregate is layout-compatible with its only member, so a borrowed `Aggregate*` (scene
+// root) can be handed out as lg_aggregate*.
+static_assert(sizeof(lg_aggregate) == sizeof(Aggregate), "lg_aggregate must wrap Aggregate exactly");
+lg_aggregate *lg_aggregate_new(void) { return new lg_aggregate(); }
+void lg_aggregate_free(lg_aggregate *a) { delete a; }
+static SceneNode node_of(SceneNode::Kind k) { SceneNode n; n.kind = k; n.mat = material_default(); return n; }
+void lg_aggregate_add_group(lg_aggregate *a, lg_aggregate *moved) {
+    SceneNode n = node_of(SceneNode::GROUP);
+    n.group.reset(new Aggregate(std::move(moved->a)));
+    delete moved;
+    a->a.contents.push_back(std::move(n));
+}
+void lg_aggregate_add_sphere(lg_aggregate *a, const double c[3], double r, const lg_material *m) {
+    SceneNode n = node_of(SceneNode::SPHERE);
+    std::memcpy(n.a, c, sizeof n.a); n.b[0] = r; n.mat = unpack(m); n.has_mat = true;
+    a->a.contents.push_back(std::move(n));
+}
+void lg_aggregate_add_cube(lg_aggregate *a, const double o[3], double dim, const lg_material *m) {
+    SceneNode n = node_of(SceneNode::CUBE);
+    std::memcpy(n.a, o, sizeof n.a); n.b[0] = dim; n.mat = unpack(m); n.has_mat = true;
+    a->a.contents.push_back(std::move(n));
+}
+void lg_aggregate_add_box(lg_aggregate *a, const double mn[3], const double mx[3], const lg_material *m) {
+    SceneNode n = node_of(SceneNode::CUBOID);
+    std::memcpy(n.a, mn, sizeof n.a); std::memcpy(n.b, mx, sizeof n.b); n.mat = unpack(m); n.has_mat = true;
+    a->a.contents.push_back(std::move(n));
+}
+void lg_aggregate_add_obj(lg_aggregate *a, uint32_t mesh) {
+    SceneNode n = node_of(SceneNode::MESH); n.obj = mesh;
+    a->a.contents.push_back(std::move(n));
+}
+void lg_aggregate_add_obj_of(lg_aggregate *a, uint32_t mesh, const lg_material *m) {
+    SceneNode n = node_of(SceneNode::MESH); n.obj = mesh; n.mat = unpack(m); n.has_mat = true;
+    a->a.contents.push_back(std::move(n));
+}
+void lg_aggregate_swap_backface(lg_aggregate *a) { a->a.swap_backface = !a->a.swap_backface; }
+void lg_aggregate_translate(lg_aggregate *a, const double d[3]) { transform_concat_self(a->a.transform, transform_translate(d)); }
+void lg_aggregate_scale(lg_aggregate *a, double x, double y, double z) { transform_concat_self(a->a.transform, transform_scale(x, y, z)); }
+void lg_aggregate_rotate_x(lg_aggregate *a, double t) { transform_concat_self(a->a.transform, transform_rotate_x(t)); }
+void lg_aggregate_rotate_y(lg_aggregate *a, double t) { transform_concat_self(a->a.transform, transform_rotate_y(t)); }
+void lg_aggregate_rotate_z(lg_aggregate *a, double t) { transform_concat_self(a->a.transform, transform_rotate_z(t)); }
+void lg_aggregate_rotate(lg_aggregate *a, double t, const double axis[3]) { transform_concat_self(a->a.transform, transform_rotate(t, axis)); }
+void lg_aggregate_get_transform(lg_aggregate *a, double m[16], double minv[16]) {
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) { m[4 * c + r] = a->a.transform.m.m[c][r]; minv[4 * c + r] = a->a.transform.minv.m[c][r]; }
+}
+
+lg_film *lg_film_new(uint32_t w, uint32_t h) {
+    lg_film *f = new lg_film();
+    f->w = w; f->h = h;
+    f->owned.assign((size_t)w * h * 4, 0);
+    f->px = f->owned.data();
+    return f;
+}
+lg_film *lg_film_wrap(uint32_t w, uint32_t h, uint8_t *rgba) {
+    lg_film *f = new lg_film();
+    f->w = w; f->h = h; f->px = rgba;
+    return f;
+}
+uint8_t *lg_film_pixels(lg_film *f) { return f->px; }
+uint32_t lg_film_width(lg_film *f) { return f->w; }
+uint32_t lg_film_height(lg_film *f) { return f->h; }
+void lg_film_free(lg_film *f) { delete f; }
+
+int lg_set_device(int device) {
+    g_device = device;
+    return guarded([] { use_device(); });
+}
+int lg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+lg_accel *lg_accel_from(const lg_scene *s) {
+    lg_accel *a = nullptr;
+    int rc = guarded([&] {
+        a = new lg_accel();
+        a->scene = &s->s;
+        flatten_scene(s->s, a->flat); // host HLBVH build + flatten (throws on what the reference would panic on)
+        use_device();
+        const FlatScene &f = a->flat;
+        a->nodes.upload(f.nodes); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
+        a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
+        a->tri_t.upload(f.tri_t); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
+        a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
+        a->tile_counter.alloc(1);
+        a->stats.alloc(1);
+        a->device_bytes = f.nodes.size() * sizeof(DNode) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
+                          f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 +
+                          f.accels.size() * sizeof(DAccel) + f.materials.size() * sizeof(DMaterial);
+        HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+        // per-lane LDS stack: worst case of this scene graph, +2 guard entries
+        a->stack_depth = f.max_stack + 2;
+        size_t lds = (size_t)a->stack_depth * 256 * 4;
+        if (lds > 160 * 1024) throw Error("BVH too deep for the LDS traversal stack (" + std::to_string(a->stack_depth) + " entries per lane)");
+        if (lds > 64 * 1024) HIP_TRY(trace_set_lds_limit(lds));
+        int per_cu = 0, cus = 0;
+        HIP_TRY(trace_occupancy(a->stack_depth, &per_cu));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device));
+        if (per_cu < 1) per_cu = 1;
+        a->max_blocks = (uint32_t)(per_cu * cus);
+    });
+    if (rc) { delete a; return nullptr; }
+    return a;
+}
+void lg_accel_free(lg_accel *a) {
+    if (!a) return;
+    if (a->stream) (void)hipStreamSynchronize(a->stream);
+    delete a;
+}
+int lg_accel_synchronize(const lg_accel *a) {
+    return guarded([&] { HIP_TRY(hipStreamSynchronize(a->stream)); });
+}
+
+int lg_capture_rows_device(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t row0, void *dev_rgba, void *hip_stream) {
+    return guarded([&] {
+        if (y1 > h || y0 > y1 || row0 > y0) throw Error("bad row range");
+        std::lock_guard<std::mutex> g(a->mtx);
+        use_device();
+        DParams P = base_params(*a, w, h);
+        set_rect(P, 0, y0, w, y1);
+        P.out_row0 = row0;
+        P.out_rgba = (uint8_t *)dev_rgba;
+        enqueue(*a, P, false, hip_stream ? (hipStream_t)hip_stream : a->stream);
+    });
+}
+int lg_capture_subset_device(size_t k, size_t n, const lg_accel *a, uint32_t w, uint32_t h, void *dev_rgba, void *hip_stream) {
+    return guarded([&] {
+        if (n == 0) throw Error("n must be > 0");
+        std::lock_guard<std::mutex> g(a->mtx);
+        use_device();
+        DParams P = base_params(*a, w, h);
+        if (n == 1 && k == 0) set_rect(P, 0, 0, w, h);
+        else set_subset(P, k, n, w, h);
+        P.out_row0 = 0;
+        P.out_rgba = (uint8_t *)dev_rgba;
+        enqueue(*a, P, false, hip_stream ? (hipStream_t)hip_stream : a->stream);
+    });
+}
+
+int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) { // lib.rs:110-162
+    return guarded([&] {
+        if (n == 0) throw Error("n must be > 0");
+        size_t bytes = (size_t)film->w * film->h * 4;
+        {
+            std::lock_guard<std::mutex> g(a->mtx);
+            use_device();
+            if (a->staging.n < bytes) { HIP_TRY(hipStreamSynchronize(a->stream)); a->staging.alloc(bytes); }
+            // pixels outside the subset must keep their current value (lib.rs:152)
+            if (!(n == 1 && k == 0)) HIP_TRY(hipMemcpyAsync(a->staging.p, film->px, bytes, hipMemcpyHostToDevice, a->stream));
+        }
+        if (lg_capture_subset_device(k, n, a, film->w, film->h, a->staging.p, nullptr)) throw Error(tl_error);
+        std::lock_guard<std::mutex> g(a->mtx);
+        HIP_TRY(hipMemcpyAsync(film->px, a->staging.p, bytes, hipMemcpyDeviceToHost, a->stream));
+        HIP_TRY(hipStreamSynchronize(a->stream));
+    });
+}
+int lg_capture(const lg_scene *s, lg_film *film) { // lib.rs:55-104: the BVH is (re)built inside every capture
+    lg_accel *a = lg_accel_from(s);
+    if (!a) return 1;
+    int rc = lg_capture_subset(0, 1, a, film);
+    lg_accel_free(a);
+    return rc;
+}
+lg_film *lg_render(const lg_scene *s, uint32_t w, uint32_t h) { // lib.rs:46-50
+    lg_film *f = lg_film_new(w, h);
+    if (lg_capture(s, f)) { lg_film_free(f); return nullptr; }
+    return f;
+}
+
+int lg_capture_radiance(size_t k, size_t n, const lg_accel *a, uint32_t w, uint32_t h, double *rgb) {
+    return guarded([&] {
+        if (n == 0) throw Error("n must be > 0");
+        std::lock_guard<std::mutex> g(a->mtx);
+        use_device();
+        size_t count = (size_t)w * h * 3;
+        if (a->staging_rad.n < count) { HIP_TRY(hipStreamSynchronize(a->stream)); a->staging_rad.alloc(count); }
+        HIP_TRY(hipMemcpyAsync(a->staging_rad.p, rgb, count * 8, hipMemcpyHostToDevice, a->stream));
+        DParams P = base_params(*a, w, h);
+        if (n == 1 && k == 0) set_rect(P, 0, 0, w, h);
+        else set_subset(P, k, n, w, h);
+        P.out_row0 = 0;
+        P.out_radiance = a->staging_rad.p;
+        enqueue(*a, P, false, a->stream);
+        HIP_TRY(hipMemcpyAsync(rgb, a->staging_rad.p, count * 8, hipMemcpyDeviceToHost, a->stream));
+        HIP_TRY(hipStreamSynchronize(a->stream));
+    });
+}
+int lg_capture_stats(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, lg_stats *out) {
+    return guarded([&] {
+        if (y1 > h || y0 > y1) throw Error("bad row range");
+        std::lock_guard<std::mutex> g(a->mtx);
+        use_device();
+        DParams P = base_params(*a, w, h);
+        set_rect(P, 0, y0, w, y1);
+        P.out_row0 = y0;
+        enqueue(*a, P, true, a->stream);
+        DStats s;
+        HIP_TRY(hipMemcpyAsync(&s, a->stats.p, sizeof s, hipMemcpyDeviceToHost, a->stream));
+        HIP_TRY(hipStreamSynchronize(a->stream));
+        *out = lg_stats{s.primary_rays, s.shadow_rays, s.secondary_rays, s.nodes_tested, s.spheres_tested, s.cuboids_tested,
+                        s.triangles_tested, s.accel_entries, s.hits};
+    });
+}
+
+void lg_profile_enable(const lg_accel *a, int enabled) {
+    std::lock_guard<std::mutex> g(a->mtx);
+    a->profiling = enabled != 0;
+}
+int lg_profile_read(const lg_accel *a, double *total_ms, uint64_t *launches) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> g(a->mtx);
+        double total = 0.0;
+        for (auto &e : a->events) {
+            HIP_TRY(hipEventSynchronize(e.second));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+            total += ms;
+            (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+        }
+        *total_ms = total;
+        *launches = a->events.size();
+        a->events.clear();
+    });
+}
+
+int lg_accel_dump(const lg_accel *a, const double **f, size_t *nf, const int64_t **i, size_t *ni) {
+    *f = a->flat.dump_f.data(); *nf = a->flat.dump_f.size();
+    *i = a->flat.dump_i.data(); *ni = a->flat.dump_i.size();
+    return 0;
+}
+// Host-only: run the HLBVH build + flattening of `scene` WITHOUT touching a device and hand back
+// the structure dump (same format as lg_accel_dump).  Lets CPU-only tests check the host builder.
+int lg_host_build_dump(const lg_scene *s, const double **f, size_t *nf, const int64_t **i, size_t *ni, uint64_t info[8]) {
+    static thread_local FlatScene flat;
+    return guarded([&] {
+        flatten_scene(s->s, flat);
+        *f = flat.dump_f.data(); *nf = flat.dump_f.size();
+        *i = flat.dump_i.data(); *ni = flat.dump_i.size();
+        info[0] = flat.nodes.size(); info[1] = flat.primref.size(); info[2] = flat.spheres.size(); info[3] = flat.cuboids.size();
+        info[4] = flat.tri_v.size() / 3; info[5] = flat.accels.size(); info[6] = flat.max_stack; info[7] = flat.has_specular ? 1 : 0;
+    });
+}
+int lg_accel_info(const lg_accel *a, uint64_t out[8]) {
+    const FlatScene &f = a->flat;
+    out[0] = f.nodes.size(); out[1] = f.primref.size(); out[2] = f.spheres.size(); out[3] = f.cuboids.size();
+    out[4] = f.tri_v.size() / 3; out[5] = f.accels.size(); out[6] = f.max_stack; out[7] = a->device_bytes;
+    return 0;
+}
+
+int lg_kat_intersect(int kind, const double *params, const char *obj_text, size_t obj_len, const double o[3], const double d[3], double out[8]) {
+    return guarded([&] {
+        use_device();
+        DevBuf<double> dparams, dout;
+        DevBuf<float> dpos;
+        DevBuf<uint32_t> dtri;
+        std::vector<double> pv(params, params + 8);
+        dparams.upload(pv);
+        dout.alloc(8);
+        uint32_t ntri = 0;
+        if (kind == 2) {
+            Obj obj;
+            parse_obj_text(obj_text, obj_len, obj);
+            std::vector<uint32_t> tv;
+            for (auto &t : obj.tri) tv.push_back(t.v);
+            ntri = (uint32_t)(tv.size() / 3);
+            dpos.upload(obj.position);
+            dtri.upload(tv);
+        } else if (kind != 0 && kind != 1) throw Error("bad kind");
+        HIP_TRY(launch_kat(kind, dparams.p, dpos.p, dtri.p, ntri, V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]}, dout.p, nullptr));
+        HIP_TRY(hipMemcpy(out, dout.p, 8 * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+int lg_kat_surface_interaction(const double o[3], const double d[3], double t, const double dpdu[3], const double dpdv[3], double out_ng[3]) {
+    return guarded([&] {
+        use_device();
+        DevBuf<double> dout;
+        dout.alloc(3);
+        HIP_TRY(launch_kat_si(V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]}, t, V3{dpdu[0], dpdu[1], dpdu[2]}, V3{dpdv[0], dpdv[1], dpdv[2]}, dout.p, nullptr));
+        HIP_TRY(hipMemcpy(out_ng, dout.p, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+int lg_math_eval(int op, size_t n, const double *a, const double *b, double *out) {
+    return guarded([&] {
+        use_device();
+        if (op < 0 || op > 8) throw Error("bad op");
+        DevBuf<double> da, db, dout;
+        std::vector<double> va(a, a + n), vb(b, b + n);
+        da.upload(va); db.upload(vb); dout.alloc(n);
+        HIP_TRY(launch_math(op, n, da.p, db.p, dout.p, nullptr));
+        HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+} // extern "C"

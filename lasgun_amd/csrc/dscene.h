@@ -1,0 +1,124 @@
+// lasgun_amd/csrc/dscene.h -- the flattened scene as the HIP kernels see it in HBM.
+//
+// The reference walks a tree of boxed `dyn Primitive`s (one BVHAccel per Aggregate and per
+// mesh, /root/reference/src/accelerators/bvh.rs:45-70,150-162).  The device gets flat tables:
+//
+//   DNode[]     64-byte AoS records {bmin[3], bmax[3], link, meta}: a lane fetches one whole
+//               node with four 16-byte loads that fall in ONE cache line.  Lanes of a wave walk
+//               different nodes, so a per-field SoA split would cost seven lines per visit
+//               instead of one; coalescing across lanes happens whenever neighbouring pixels
+//               visit the same node (same address -> one request).
+//   primref[]   per accel, in the reference's `order[]` sequence: kind<<30 | index.
+//   DSphere[] / DCuboid[] 32/48-byte records; triangles as u32 index triples into f32 vertex
+//               tables (f32 is what obj::ObjData holds; widened on every access exactly like
+//               `.into()`, src/shape/triangle.rs:40-43).
+//   DAccel[]    one per BVHAccel instance: 3x4 m / minv, parent link, root->self chain,
+//               default material, swap_backface.  Mesh instances share nodes and primrefs.
+#pragma once
+#include "vecmath.h"
+
+namespace lg {
+
+enum PrimKind : uint32_t { PK_SPHERE = 0, PK_CUBOID = 1, PK_TRIANGLE = 2, PK_ACCEL = 3 };
+constexpr uint32_t PRIM_INDEX_MASK = 0x3FFFFFFFu;
+constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
+constexpr int MAX_CHAIN = 8;      // scene-graph nesting levels (root = 1)
+constexpr uint32_t NODE_LEAF = 0x80000000u;
+
+struct alignas(64) DNode {
+    double bmin[3];
+    double bmax[3];
+    uint32_t link; // leaf: offset of its first primref (relative to the accel's prim_base); interior: second child (relative to node_base)
+    uint32_t meta; // leaf: NODE_LEAF | nprims (u16, bvh.rs:440) ; interior: split axis
+    uint32_t pad[2];
+};
+static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
+
+struct alignas(32) DSphere {
+    double cx, cy, cz, r;
+};
+struct alignas(16) DCuboid {
+    double mn[3], mx[3];
+};
+struct DMaterial { // == lg_material of include/lasgun_hip.h
+    int32_t kind;
+    int32_t pad;
+    double p[10];
+};
+enum MatKind : int32_t { MAT_MATTE = 0, MAT_PLASTIC = 1, MAT_METAL = 2, MAT_GLASS = 3, MAT_MIRROR = 4 };
+
+struct DLight {
+    double pos[3], intensity[3], falloff[3];
+};
+
+enum AccelFlags : uint32_t { AF_SWAP_BACKFACE = 1, AF_MESH = 2, AF_HAS_N = 4, AF_HAS_UV = 8 };
+
+struct alignas(16) DAccel {
+    Affine m;    // 96 B
+    Affine minv; // 96 B
+    uint32_t node_base;
+    uint32_t prim_base;
+    int32_t parent;   // -1 for the root
+    int32_t material; // default material id (bvh.rs:63), -1 = None
+    uint32_t flags;
+    uint32_t nchain;  // number of accels on the path root..self
+    uint32_t chain[MAX_CHAIN];
+    uint32_t pad[2];
+};
+
+struct DStats { // per-launch counters (stats kernel variant only)
+    unsigned long long primary_rays, shadow_rays, secondary_rays, nodes_tested, spheres_tested, cuboids_tested,
+        triangles_tested, accel_entries, hits;
+};
+
+// Per-frame record of the explicit Whitted recursion stack (integrate.rs:69-79), in doubles.
+constexpr int FRAME_DOUBLES = 18;
+
+struct DParams {
+    // ---- scene tables
+    const DNode *nodes;
+    const uint32_t *primref;
+    const DSphere *spheres;
+    const int32_t *sphere_mat;
+    const DCuboid *cuboids;
+    const int32_t *cuboid_mat;
+    const uint32_t *tri_v; // 3 per triangle, global vertex ids
+    const uint32_t *tri_n; // 3 per triangle, global normal ids (valid when the mesh has normals)
+    const uint32_t *tri_t; // 3 per triangle, global uv ids (valid when the mesh has uvs)
+    const float *vpos;
+    const float *vnorm;
+    const float *vtex;
+    const DAccel *accels;
+    const DMaterial *materials;
+    const DLight *lights;
+    uint32_t nlights;
+    uint32_t recursion;
+    int32_t default_material; // id of Material::default()
+    uint32_t stack_depth;     // per-lane LDS stack entries
+    // ---- camera (camera.rs:6-37), background, ambient
+    V3 cam_origin, cam_view, cam_up, cam_aux;
+    double image_plane_height, pixel_separation, ss_distance;
+    uint32_t ss_root;
+    uint32_t pad0;
+    V3 bg_inner, bg_outer;
+    double bg_scale;
+    V3 ambient;
+    // ---- film (film.rs:36-45)
+    uint32_t w, h;
+    double winv, hinv, aspect;
+    // ---- work: either a rectangle of 8x8 tiles or a strided pixel subset (lib.rs:152)
+    uint32_t mode; // 0 = rectangle [x0,x1) x [y0,y1); 1 = subset {k + i*n}
+    uint32_t x0, y0, x1, y1;
+    uint32_t tiles_x;
+    unsigned long long sub_k, sub_n, sub_count;
+    uint32_t ntiles;
+    uint32_t out_row0; // row of the image stored at out_rgba[0] (0 for a full film, y0 for a row tile)
+    uint8_t *out_rgba;
+    double *out_radiance; // optional f64 RGB, same addressing as out_rgba (3 doubles per pixel)
+    uint32_t *tile_counter;
+    double *frames;        // [recursion][FRAME_DOUBLES][nthreads]
+    unsigned long long frame_threads;
+    DStats *stats;
+};
+
+} // namespace lg

@@ -1,0 +1,700 @@
+// lasgun_amd/csrc/host.cpp -- scene description, OBJ reader, HLBVH builder, flattening.
+// See host.h for the reference files each part mirrors.  Compiled with -ffp-contract=off.
+#include "host.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+
+namespace lg {
+
+// ------------------------------------------------------------------------------------------
+// Materials (material/mod.rs:15-46, matte.rs:14-16)
+// ------------------------------------------------------------------------------------------
+Material material_matte(const double kd[3], double sigma) {
+    Material m{};
+    m.kind = MAT_MATTE;
+    m.p[0] = kd[0]; m.p[1] = kd[1]; m.p[2] = kd[2];
+    m.p[3] = fmin(fmax(sigma, 0.0), 90.0);
+    return m;
+}
+Material material_default() {
+    const double kd[3] = {0.5, 0.5, 0.5};
+    return material_matte(kd, 0.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Transform (space/transform.rs:49-197) on top of cgmath's column-combination products
+// ------------------------------------------------------------------------------------------
+static Mat4 mat_identity() {
+    Mat4 r{};
+    for (int i = 0; i < 4; ++i) r.m[i][i] = 1.0;
+    return r;
+}
+// lhs * rhs: result column j = ((a*r[j][0] + b*r[j][1]) + c*r[j][2]) + d*r[j][3], a..d = lhs columns
+static Mat4 mat_mul(const Mat4 &l, const Mat4 &r) {
+    Mat4 o;
+    for (int j = 0; j < 4; ++j)
+        for (int row = 0; row < 4; ++row)
+            o.m[j][row] = ((l.m[0][row] * r.m[j][0] + l.m[1][row] * r.m[j][1]) + l.m[2][row] * r.m[j][2]) + l.m[3][row] * r.m[j][3];
+    return o;
+}
+static Mat4 mat_transpose(const Mat4 &a) {
+    Mat4 o;
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) o.m[c][r] = a.m[r][c];
+    return o;
+}
+Transform transform_identity() { return Transform{mat_identity(), mat_identity()}; }
+void transform_concat_self(Transform &self, const Transform &other) { // transform.rs:191-197
+    Mat4 m = mat_mul(other.m, self.m);
+    Mat4 minv = mat_mul(self.minv, other.minv);
+    self.m = m;
+    self.minv = minv;
+}
+Transform transform_translate(const double d[3]) { // transform.rs:94-99
+    Transform t = transform_identity();
+    for (int i = 0; i < 3; ++i) { t.m.m[3][i] = d[i]; t.minv.m[3][i] = -d[i]; }
+    return t;
+}
+Transform transform_scale(double x, double y, double z) { // transform.rs:101-108
+    Transform t = transform_identity();
+    t.m.m[0][0] = x; t.m.m[1][1] = y; t.m.m[2][2] = z;
+    t.minv.m[0][0] = 1.0 / x; t.minv.m[1][1] = 1.0 / y; t.minv.m[2][2] = 1.0 / z;
+    return t;
+}
+static inline double to_rad(double deg) { return deg * (PI / 180.0); } // cgmath Rad::from(Deg)
+static Transform from_rotation(const Mat4 &m) { return Transform{m, mat_transpose(m)}; } // transform.rs:125-147
+Transform transform_rotate_x(double deg) {
+    double th = to_rad(deg), s = std::sin(th), c = std::cos(th);
+    Mat4 m = mat_identity();
+    m.m[1][1] = c; m.m[1][2] = s; m.m[2][1] = -s; m.m[2][2] = c;
+    return from_rotation(m);
+}
+Transform transform_rotate_y(double deg) {
+    double th = to_rad(deg), s = std::sin(th), c = std::cos(th);
+    Mat4 m = mat_identity();
+    m.m[0][0] = c; m.m[0][2] = -s; m.m[2][0] = s; m.m[2][2] = c;
+    return from_rotation(m);
+}
+Transform transform_rotate_z(double deg) {
+    double th = to_rad(deg), s = std::sin(th), c = std::cos(th);
+    Mat4 m = mat_identity();
+    m.m[0][0] = c; m.m[0][1] = s; m.m[1][0] = -s; m.m[1][1] = c;
+    return from_rotation(m);
+}
+Transform transform_rotate(double deg, const double ax[3]) { // cgmath Matrix4::from_axis_angle
+    double th = to_rad(deg), s = std::sin(th), c = std::cos(th), k = 1.0 - c;
+    double x = ax[0], y = ax[1], z = ax[2];
+    Mat4 m = mat_identity();
+    m.m[0][0] = k * x * x + c;     m.m[0][1] = k * x * y + s * z; m.m[0][2] = k * x * z - s * y;
+    m.m[1][0] = k * x * y - s * z; m.m[1][1] = k * y * y + c;     m.m[1][2] = k * y * z + s * x;
+    m.m[2][0] = k * x * z + s * y; m.m[2][1] = k * y * z - s * x; m.m[2][2] = k * z * z + c;
+    return from_rotation(m);
+}
+
+// ------------------------------------------------------------------------------------------
+// Camera (camera.rs:61-102,155-194)
+// ------------------------------------------------------------------------------------------
+static double plane_height(bool persp, double param, double focal) {
+    if (persp) return focal * std::tan(param * PI / 360.) * 2.;
+    return param;
+}
+void Camera::init(bool persp, double p) {
+    *this = Camera();
+    perspective = persp;
+    param = p;
+    image_plane_height = plane_height(persp, p, 1.);
+    pixel_separation = persp ? 0. : 1.;
+}
+void Camera::look_at(V3 o, V3 look, V3 upv) {
+    V3 v = look - o;
+    V3 a = cross(v, upv);
+    origin = o;
+    up = normalize(cross(a, v));
+    aux = normalize(a);
+    view = v;
+    image_plane_height = plane_height(perspective, param, magnitude(v));
+}
+void Camera::set_supersampling(uint8_t base) {
+    ss_root = (uint32_t)base + 1u;
+    ss_distance = 1. / (double)ss_root;
+}
+
+// ------------------------------------------------------------------------------------------
+// OBJ text (third-party `obj ^0.10` behaviour restated; triangle.rs:373-395)
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Cursor {
+    const char *p, *end;
+    bool eof() const { return p >= end; }
+};
+// next whitespace-separated word on the current line; false at end of line
+bool next_word(Cursor &c, const char *&ws, const char *&we) {
+    while (c.p < c.end && *c.p != '\n' && (*c.p == ' ' || *c.p == '\t' || *c.p == '\r' || *c.p == '\v' || *c.p == '\f')) ++c.p;
+    if (c.p >= c.end || *c.p == '\n') return false;
+    ws = c.p;
+    while (c.p < c.end && *c.p != '\n' && !(*c.p == ' ' || *c.p == '\t' || *c.p == '\r' || *c.p == '\v' || *c.p == '\f')) ++c.p;
+    we = c.p;
+    return true;
+}
+void skip_line(Cursor &c) {
+    while (c.p < c.end && *c.p != '\n') ++c.p;
+    if (c.p < c.end) ++c.p;
+}
+float word_f32(const char *ws, const char *we, int line) {
+    std::string w(ws, we);
+    char *ep = nullptr;
+    float v = std::strtof(w.c_str(), &ep); // correctly rounded, like Rust's str::parse::<f32>
+    if (w.empty() || *ep != 0) throw Error("obj: bad number '" + w + "' on line " + std::to_string(line));
+    return v;
+}
+long resolve_index(const char *s, const char *e, long count, int line) {
+    std::string w(s, e);
+    char *ep = nullptr;
+    long v = std::strtol(w.c_str(), &ep, 10);
+    if (w.empty() || *ep != 0) throw Error("obj: bad index '" + w + "' on line " + std::to_string(line));
+    v = v < 0 ? count + v : v - 1;
+    if (v < 0 || v >= count) throw Error("obj: index out of range on line " + std::to_string(line));
+    return v;
+}
+} // namespace
+
+void parse_obj_text(const char *text, size_t len, Obj &out) {
+    Cursor c{text, text + len};
+    int line = 0;
+    while (!c.eof()) {
+        ++line;
+        const char *ws, *we;
+        if (!next_word(c, ws, we)) { skip_line(c); continue; }
+        std::string cmd(ws, we);
+        if (cmd == "v" || cmd == "vn" || cmd == "vt") {
+            int need = cmd == "vt" ? 2 : 3;
+            float f[3] = {0, 0, 0};
+            for (int i = 0; i < need; ++i) {
+                if (!next_word(c, ws, we)) throw Error("obj: too few components on line " + std::to_string(line));
+                f[i] = word_f32(ws, we, line);
+            }
+            std::vector<float> &dst = cmd == "v" ? out.position : (cmd == "vn" ? out.normal : out.texture);
+            for (int i = 0; i < need; ++i) dst.push_back(f[i]);
+        } else if (cmd == "f") {
+            // Only the first three index tuples of a polygon are ever read (triangle.rs:41,47,53).
+            for (int k = 0; k < 3; ++k) {
+                if (!next_word(c, ws, we)) throw Error("obj: face with fewer than 3 vertices on line " + std::to_string(line));
+                const char *s1 = ws;
+                while (s1 < we && *s1 != '/') ++s1;
+                Obj::Tuple tp{0, -1, -1};
+                tp.v = (uint32_t)resolve_index(ws, s1, (long)out.position.size() / 3, line);
+                if (s1 < we) {
+                    const char *s2 = s1 + 1;
+                    while (s2 < we && *s2 != '/') ++s2;
+                    if (s2 > s1 + 1) tp.t = (int32_t)resolve_index(s1 + 1, s2, (long)out.texture.size() / 2, line);
+                    if (s2 < we && we > s2 + 1) tp.n = (int32_t)resolve_index(s2 + 1, we, (long)out.normal.size() / 3, line);
+                }
+                out.tri.push_back(tp);
+            }
+        } else if (cmd == "o" || cmd == "g" || cmd == "s" || cmd == "mtllib" || cmd == "usemtl" || cmd[0] == '#') {
+            // grouping never changes the order of `f` lines, which is TriangleIterator's order (triangle.rs:315-371)
+        } else {
+            throw Error("obj: unexpected command '" + cmd + "' on line " + std::to_string(line));
+        }
+        skip_line(c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Bounds (space/bounds.rs) and their transform (space/transform.rs:219-240)
+// ------------------------------------------------------------------------------------------
+namespace {
+Bounds b_new(V3 p0, V3 p1) {
+    return Bounds{V3{bmin(p0.x, p1.x), bmin(p0.y, p1.y), bmin(p0.z, p1.z)}, V3{bmax(p0.x, p1.x), bmax(p0.y, p1.y), bmax(p0.z, p1.z)}};
+}
+Bounds b_none() { return Bounds{V3{F64_MAX, F64_MAX, F64_MAX}, V3{-F64_MAX, -F64_MAX, -F64_MAX}}; }
+Bounds b_union(const Bounds &a, const Bounds &b) {
+    return Bounds{V3{bmin(a.min.x, b.min.x), bmin(a.min.y, b.min.y), bmin(a.min.z, b.min.z)},
+                  V3{bmax(a.max.x, b.max.x), bmax(a.max.y, b.max.y), bmax(a.max.z, b.max.z)}};
+}
+Bounds b_add_point(const Bounds &a, V3 p) {
+    return Bounds{V3{bmin(a.min.x, p.x), bmin(a.min.y, p.y), bmin(a.min.z, p.z)}, V3{bmax(a.max.x, p.x), bmax(a.max.y, p.y), bmax(a.max.z, p.z)}};
+}
+double b_area(const Bounds &b) { // bounds.rs:110-114
+    V3 d = b.max - b.min;
+    double half = d.x * d.y + d.x * d.z + d.y * d.z;
+    return half + half;
+}
+int b_max_extent(const Bounds &b) { // bounds.rs:125-130: `d.z > d.z` is never true, so never 0 (kept)
+    V3 d = b.max - b.min;
+    if (d.x > d.y && d.z > d.z) return 0;
+    if (d.y > d.z) return 1;
+    return 2;
+}
+V3 b_offset(const Bounds &b, V3 p) { // bounds.rs:133-139
+    V3 o = p - b.min;
+    if (b.max.x > b.min.x) o.x /= b.max.x - b.min.x;
+    if (b.max.y > b.min.y) o.y /= b.max.y - b.min.y;
+    if (b.max.z > b.min.z) o.z /= b.max.z - b.min.z;
+    return o;
+}
+Bounds b_transform(const Mat4 &m, const Bounds &b) {
+    V3 lo{0, 0, 0}, hi{0, 0, 0};
+    double *plo = &lo.x, *phi = &hi.x;
+    for (int row = 0; row < 3; ++row) {
+        double xa = m.m[0][row] * b.min.x, xb = m.m[0][row] * b.max.x;
+        double ya = m.m[1][row] * b.min.y, yb = m.m[1][row] * b.max.y;
+        double za = m.m[2][row] * b.min.z, zb = m.m[2][row] * b.max.z;
+        plo[row] = ((bmin(xa, xb) + bmin(ya, yb)) + bmin(za, zb)) + m.m[3][row];
+        phi[row] = ((bmax(xa, xb) + bmax(ya, yb)) + bmax(za, zb)) + m.m[3][row];
+    }
+    return b_new(lo, hi);
+}
+
+// ------------------------------------------------------------------------------------------
+// HLBVH build (bvh.rs:164-453,575-635), index-based
+// ------------------------------------------------------------------------------------------
+struct LinNode {
+    Bounds b;
+    bool leaf;
+    uint32_t a, c; // leaf: (prim offset, nprims as u16) ; interior: (axis, second child)
+};
+struct BuiltBVH {
+    std::vector<LinNode> nodes;
+    std::vector<uint32_t> order;
+};
+
+uint32_t spread3(uint32_t x) { // bvh.rs:590-598
+    if (x == 1024u) x = 1023u;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+uint32_t morton_zyz(V3 v) { // bvh.rs:575-579: z, y, z -- x never contributes (kept)
+    return (spread3(as_u32(v.z)) << 2) | (spread3(as_u32(v.y)) << 1) | spread3(as_u32(v.z));
+}
+
+class Builder {
+  public:
+    Builder(const std::vector<Bounds> &prim_bounds, size_t max_prims) : pb_(prim_bounds) {
+        leaf_limit_ = (uint32_t)(uint8_t)(max_prims < 255 ? max_prims : 255); // bvh.rs:187
+    }
+    BuiltBVH run() {
+        size_t n = pb_.size();
+        if (n == 0) throw Error("empty aggregate: the reference recurses without bound in build_upper_sah (bvh.rs:355-424)");
+        out_.order.assign(n, 0xFFFFFFFFu);
+        centroid_.resize(n);
+        Bounds all = b_none();
+        for (size_t i = 0; i < n; ++i) {
+            centroid_[i] = 0.5 * pb_[i].min + 0.5 * pb_[i].max; // bvh.rs:530
+            all = b_union(all, pb_[i]);
+        }
+        // Morton codes + stable LSD radix sort, 5 passes of 6 bits (bvh.rs:217-229,600-635)
+        std::vector<std::pair<uint32_t, uint32_t>> cur(n), tmp(n); // (code, prim)
+        for (size_t i = 0; i < n; ++i) cur[i] = {morton_zyz(b_offset(all, centroid_[i]) * 1024.0), (uint32_t)i};
+        for (int pass = 0; pass < 5; ++pass) {
+            int shift = 6 * pass;
+            size_t hist[64] = {0};
+            for (auto &e : cur) hist[(e.first >> shift) & 63]++;
+            size_t pos[64];
+            size_t acc = 0;
+            for (int b = 0; b < 64; ++b) { pos[b] = acc; acc += hist[b]; }
+            for (auto &e : cur) tmp[pos[(e.first >> shift) & 63]++] = e;
+            cur.swap(tmp);
+        }
+        code_.resize(n); prim_.resize(n);
+        for (size_t i = 0; i < n; ++i) { code_[i] = cur[i].first; prim_[i] = cur[i].second; }
+        // treelets: runs of equal top-12 bits (bvh.rs:240-265)
+        std::vector<int32_t> roots;
+        size_t start = 0;
+        for (size_t end = 1; end <= n; ++end) {
+            if (end == n || ((code_[start] & 0x3FFC0000u) != (code_[end] & 0x3FFC0000u))) {
+                roots.push_back(emit(start, end - start, 17));
+                start = end;
+            }
+        }
+        int32_t root = upper(roots.data(), roots.size(), 0);
+        out_.nodes.resize(pool_.size() - dead_);
+        uint32_t off = 0;
+        emit_linear(root, off);
+        out_.nodes.resize(off);
+        return std::move(out_);
+    }
+
+  private:
+    struct BNode {
+        Bounds b;
+        int32_t c0, c1; // c0 < 0: leaf
+        uint32_t first, count;
+        int axis;
+    };
+    int32_t leaf(uint32_t first, uint32_t count, const Bounds &b) {
+        pool_.push_back(BNode{b, -1, -1, first, count, 0});
+        return (int32_t)pool_.size() - 1;
+    }
+    int32_t interior(int axis, int32_t c0, int32_t c1) {
+        pool_.push_back(BNode{b_union(pool_[c0].b, pool_[c1].b), c0, c1, 0, 0, axis});
+        return (int32_t)pool_.size() - 1;
+    }
+    // bvh.rs:278-347 over the sorted slice [s, s+n)
+    int32_t emit(size_t s, size_t n, int bit) {
+        for (;;) {
+            if (bit == -1 || n < (size_t)leaf_limit_) {
+                uint32_t first = next_order_;
+                Bounds b = b_none();
+                for (size_t i = 0; i < n; ++i) {
+                    out_.order[first + i] = prim_[s + i];
+                    b = b_union(b, pb_[prim_[s + i]]);
+                }
+                next_order_ += (uint32_t)n;
+                return leaf(first, (uint32_t)n, b);
+            }
+            uint32_t mask = 1u << bit;
+            if ((code_[s] & mask) == (code_[s + n - 1] & mask)) { --bit; continue; }
+            size_t lo = 0, hi = n - 1;
+            while (lo + 1 != hi) {
+                size_t mid = (lo + hi) / 2;
+                if ((code_[s + lo] & mask) == (code_[s + mid] & mask)) lo = mid; else hi = mid;
+            }
+            int32_t c0 = emit(s, hi, bit - 1);
+            int32_t c1 = emit(s + hi, n - hi, bit - 1);
+            return interior(bit % 3, c0, c1);
+        }
+    }
+    size_t bucket_of(int32_t node, int dim, const Bounds &cb) const { // bvh.rs:383-387,415-419
+        const Bounds &b = pool_[node].b;
+        double centroid = (comp(b.min, dim) + comp(b.max, dim)) * 0.5;
+        double f = (centroid - comp(cb.min, dim)) / (comp(cb.max, dim) - comp(cb.min, dim));
+        size_t k = (size_t)as_u32(12.0 * f);
+        return k == 12 ? 11 : k;
+    }
+    // bvh.rs:350-427
+    int32_t upper(int32_t *roots, size_t n, int depth) {
+        if (n == 1) return roots[0];
+        if (n == 0 || depth > 4096)
+            throw Error("degenerate upper-SAH split: the reference recurses without bound here (bvh.rs:414-424)");
+        Bounds all = b_none(), cb = b_none();
+        for (size_t i = 0; i < n; ++i) {
+            const Bounds &b = pool_[roots[i]].b;
+            all = b_union(all, b);
+            cb = b_add_point(cb, 0.5 * (b.min + b.max));
+        }
+        int dim = b_max_extent(cb);
+        size_t count[12] = {0};
+        Bounds bb[12];
+        for (auto &x : bb) x = b_none();
+        for (size_t i = 0; i < n; ++i) {
+            size_t k = bucket_of(roots[i], dim, cb);
+            if (k > 11) throw Error("SAH bucket index out of range (the reference would panic)");
+            count[k]++;
+            bb[k] = b_union(bb[k], pool_[roots[i]].b);
+        }
+        double cost[12];
+        for (int i = 0; i < 12; ++i) {
+            Bounds b0 = b_none(), b1 = b_none();
+            size_t n0 = 0, n1 = 0;
+            for (int j = 0; j <= i; ++j) { b0 = b_union(b0, bb[j]); n0 += count[j]; }
+            for (int j = i + 1; j < 12; ++j) { b1 = b_union(b1, bb[j]); n1 += count[j]; }
+            cost[i] = 0.125 + ((double)n0 * b_area(b0) + (double)n1 * b_area(b1)) / b_area(all);
+        }
+        size_t split = 0;
+        for (size_t i = 0; i < 12; ++i)
+            if (cost[i] < cost[split]) split = i;
+        // `partition ^0.1`: in-place two-pointer swap partition (third-party; parity unpinned)
+        size_t mid;
+        {
+            size_t l = 0, r = n - 1;
+            for (;;) {
+                while (l < n && bucket_of(roots[l], dim, cb) <= split) ++l;
+                while (r > 0 && !(bucket_of(roots[r], dim, cb) <= split)) --r;
+                if (l >= r) { mid = l; break; }
+                std::swap(roots[l], roots[r]);
+            }
+        }
+        int32_t lo = upper(roots, mid, depth + 1);
+        int32_t hi = upper(roots + mid, n - mid, depth + 1);
+        return interior(dim, lo, hi);
+    }
+    uint32_t emit_linear(int32_t node, uint32_t &off) { // bvh.rs:430-453
+        uint32_t my = off++;
+        const BNode &bn = pool_[node];
+        out_.nodes[my].b = bn.b;
+        if (bn.c0 < 0) {
+            out_.nodes[my].leaf = true;
+            out_.nodes[my].a = bn.first;
+            out_.nodes[my].c = (uint32_t)(uint16_t)bn.count; // `nprims as u16` (bvh.rs:440)
+        } else {
+            emit_linear(bn.c0, off);
+            uint32_t second = emit_linear(bn.c1, off);
+            out_.nodes[my].leaf = false;
+            out_.nodes[my].a = (uint32_t)(uint8_t)bn.axis;
+            out_.nodes[my].c = second;
+        }
+        return my;
+    }
+
+    const std::vector<Bounds> &pb_;
+    std::vector<V3> centroid_;
+    std::vector<uint32_t> code_, prim_;
+    std::vector<BNode> pool_;
+    size_t dead_ = 0;
+    uint32_t leaf_limit_ = 0;
+    uint32_t next_order_ = 0;
+    BuiltBVH out_;
+};
+
+// ------------------------------------------------------------------------------------------
+// Flattening
+// ------------------------------------------------------------------------------------------
+struct MeshTables { // per scene mesh, shared by all its instances
+    bool built = false;
+    uint32_t node_base = 0, prim_base = 0, nnodes = 0, norder = 0;
+    uint32_t max_stack = 0;
+    Bounds root_bounds{};
+    uint32_t tri_base = 0;
+    bool has_n = false, has_uv = false;
+    BuiltBVH bvh; // kept for the structure dump
+};
+
+struct Flattener {
+    const Scene &scene;
+    FlatScene &out;
+    std::vector<MeshTables> meshes;
+
+    int32_t add_material(const Material &m) {
+        DMaterial d{};
+        d.kind = m.kind;
+        std::memcpy(d.p, m.p, sizeof d.p);
+        out.materials.push_back(d);
+        if (m.kind == MAT_GLASS || m.kind == MAT_MIRROR) out.has_specular = true;
+        return (int32_t)out.materials.size() - 1;
+    }
+
+    static Affine to_affine(const Mat4 &m) {
+        Affine a;
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 3; ++r) a.c[c][r] = m.m[c][r];
+        // bottom row must be (0,0,0,1) for the 3x4 shortcut to be exact
+        if (m.m[0][3] != 0.0 || m.m[1][3] != 0.0 || m.m[2][3] != 0.0 || m.m[3][3] != 1.0)
+            throw Error("non-affine transform");
+        return a;
+    }
+
+    // worst-case traversal stack use of one BVH; child_extra(prim ref) = extra entries when a leaf holds a child accel
+    template <class F> static uint32_t stack_need(const std::vector<LinNode> &nodes, const std::vector<uint32_t> &refs_in_order, F child_extra) {
+        uint32_t worst = 0;
+        struct It { uint32_t node, depth; };
+        std::vector<It> st{{0, 0}};
+        while (!st.empty()) {
+            It it = st.back(); st.pop_back();
+            const LinNode &n = nodes[it.node];
+            if (n.leaf) {
+                uint32_t extra = 0;
+                for (uint32_t i = 0; i < n.c; ++i) extra = std::max(extra, child_extra(refs_in_order[n.a + i]));
+                worst = std::max(worst, it.depth + extra);
+            } else {
+                st.push_back({it.node + 1, it.depth + 1});
+                st.push_back({n.c, it.depth + 1});
+            }
+        }
+        return worst;
+    }
+
+    void append_nodes(const BuiltBVH &bvh, uint32_t &node_base) {
+        node_base = (uint32_t)out.nodes.size();
+        for (const LinNode &n : bvh.nodes) {
+            DNode d{};
+            d.bmin[0] = n.b.min.x; d.bmin[1] = n.b.min.y; d.bmin[2] = n.b.min.z;
+            d.bmax[0] = n.b.max.x; d.bmax[1] = n.b.max.y; d.bmax[2] = n.b.max.z;
+            if (n.leaf) { d.link = n.a; d.meta = NODE_LEAF | (n.c & 0xFFFFu); }
+            else { d.link = n.c; d.meta = n.a & 3u; }
+            out.nodes.push_back(d);
+        }
+    }
+
+    void dump(const BuiltBVH &bvh, bool has_mat, bool swap, const Transform &t) {
+        auto &f = out.dump_f; auto &i = out.dump_i;
+        i.push_back((int64_t)bvh.nodes.size()); i.push_back((int64_t)bvh.order.size());
+        i.push_back(has_mat ? 1 : 0); i.push_back(swap ? 1 : 0);
+        for (const LinNode &n : bvh.nodes) {
+            f.push_back(n.b.min.x); f.push_back(n.b.min.y); f.push_back(n.b.min.z);
+            f.push_back(n.b.max.x); f.push_back(n.b.max.y); f.push_back(n.b.max.z);
+            i.push_back(n.leaf ? 1 : 0); i.push_back(n.a); i.push_back(n.c);
+        }
+        for (uint32_t o : bvh.order) i.push_back((int64_t)o);
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) f.push_back(t.m.m[c][r]);
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) f.push_back(t.minv.m[c][r]);
+    }
+
+    MeshTables &mesh_tables(uint32_t id) { // BVHAccel::from_mesh (bvh.rs:141-148), built once per mesh
+        if (id >= scene.meshes.size()) throw Error("mesh handle out of range (the reference panics, bvh.rs:142)");
+        MeshTables &mt = meshes[id];
+        if (mt.built) return mt;
+        const Obj &obj = *scene.meshes[id];
+        size_t nf = obj.tri.size() / 3;
+        mt.has_n = !obj.normal.empty();
+        mt.has_uv = !obj.texture.empty();
+        uint32_t vbase = (uint32_t)(out.vpos.size() / 3), nbase = (uint32_t)(out.vnorm.size() / 3), tbase = (uint32_t)(out.vtex.size() / 2);
+        out.vpos.insert(out.vpos.end(), obj.position.begin(), obj.position.end());
+        out.vnorm.insert(out.vnorm.end(), obj.normal.begin(), obj.normal.end());
+        out.vtex.insert(out.vtex.end(), obj.texture.begin(), obj.texture.end());
+        mt.tri_base = (uint32_t)(out.tri_v.size() / 3);
+        std::vector<Bounds> pb(nf);
+        for (size_t f = 0; f < nf; ++f) {
+            V3 p[3];
+            for (int k = 0; k < 3; ++k) {
+                const Obj::Tuple &tp = obj.tri[3 * f + k];
+                if (mt.has_n && tp.n < 0) throw Error("mesh has normals but a face lacks a vn index (the reference panics, triangle.rs:60)");
+                if (mt.has_uv && tp.t < 0) throw Error("mesh has vt but a face lacks a vt index (the reference panics, triangle.rs:96)");
+                const float *v = &obj.position[3 * (size_t)tp.v];
+                p[k] = V3{(double)v[0], (double)v[1], (double)v[2]};
+                out.tri_v.push_back(vbase + tp.v);
+                out.tri_n.push_back(mt.has_n ? nbase + (uint32_t)tp.n : 0u);
+                out.tri_t.push_back(mt.has_uv ? tbase + (uint32_t)tp.t : 0u);
+            }
+            pb[f] = b_add_point(b_new(p[0], p[1]), p[2]); // triangle.rs:157-159
+        }
+        mt.bvh = Builder(pb, nf).run();
+        append_nodes(mt.bvh, mt.node_base);
+        mt.prim_base = (uint32_t)out.primref.size();
+        for (uint32_t o : mt.bvh.order) out.primref.push_back((PK_TRIANGLE << 30) | (mt.tri_base + o));
+        mt.nnodes = (uint32_t)mt.bvh.nodes.size();
+        mt.norder = (uint32_t)mt.bvh.order.size();
+        mt.root_bounds = mt.bvh.nodes[0].b;
+        std::vector<uint32_t> refs(mt.bvh.order.size(), 0);
+        mt.max_stack = stack_need(mt.bvh.nodes, refs, [](uint32_t) { return 0u; });
+        mt.built = true;
+        return mt;
+    }
+
+    void set_chain(DAccel &a, int32_t parent, uint32_t self) {
+        a.parent = parent;
+        if (parent < 0) { a.nchain = 1; a.chain[0] = self; return; }
+        const DAccel &p = out.accels[parent];
+        if (p.nchain >= (uint32_t)MAX_CHAIN) throw Error("scene graph nested deeper than " + std::to_string(MAX_CHAIN) + " levels");
+        a.nchain = p.nchain + 1;
+        for (uint32_t i = 0; i < p.nchain; ++i) a.chain[i] = p.chain[i];
+        a.chain[p.nchain] = self;
+    }
+
+    // returns accel id; sets bound = BVHAccel::bound() (bvh.rs:457-459) and need = stack entries
+    uint32_t mesh_instance(uint32_t mesh, bool has_mat, const Material &mat, int32_t parent, Bounds &bound, uint32_t &need) {
+        uint32_t id = (uint32_t)out.accels.size();
+        out.accels.emplace_back();
+        MeshTables &mt = mesh_tables(mesh);
+        Transform idt = transform_identity();
+        DAccel a{};
+        a.m = to_affine(idt.m); a.minv = to_affine(idt.minv);
+        a.node_base = mt.node_base; a.prim_base = mt.prim_base;
+        a.material = has_mat ? add_material(mat) : -1;
+        a.flags = AF_MESH | (mt.has_n ? AF_HAS_N : 0u) | (mt.has_uv ? AF_HAS_UV : 0u);
+        set_chain(a, parent, id);
+        out.accels[id] = a;
+        dump(mt.bvh, has_mat, false, idt);
+        bound = b_transform(idt.m, mt.root_bounds);
+        need = mt.max_stack;
+        return id;
+    }
+
+    uint32_t aggregate(const Aggregate &agg, int32_t parent, Bounds &bound, uint32_t &need) { // bvh.rs:150-162
+        uint32_t id = (uint32_t)out.accels.size();
+        out.accels.emplace_back();
+        {
+            DAccel a{};
+            a.m = to_affine(agg.transform.m); a.minv = to_affine(agg.transform.minv);
+            a.material = -1;
+            a.flags = agg.swap_backface ? AF_SWAP_BACKFACE : 0u;
+            set_chain(a, parent, id);
+            out.accels[id] = a;
+        }
+        size_t n = agg.contents.size();
+        if (n == 0) throw Error("empty aggregate: the reference recurses without bound in build_upper_sah (bvh.rs:355-424)");
+        // The dump is pre-order (accel, then its child accels): reserve this accel's slot now.
+        size_t dump_f_at = out.dump_f.size(), dump_i_at = out.dump_i.size();
+        std::vector<double> child_f; std::vector<int64_t> child_i;
+        std::swap(child_f, out.dump_f); std::swap(child_i, out.dump_i); // children dump into fresh vectors
+        std::vector<Bounds> pb(n);
+        std::vector<uint32_t> ref(n), extra(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            const SceneNode &nd = agg.contents[i];
+            switch (nd.kind) {
+            case SceneNode::SPHERE: { // sphere.rs:19-25,73-77
+                V3 c{nd.a[0], nd.a[1], nd.a[2]};
+                double r = nd.b[0];
+                out.spheres.push_back(DSphere{c.x, c.y, c.z, r});
+                out.sphere_mat.push_back(add_material(nd.mat));
+                pb[i] = b_new(c - V3{r, r, r}, c + V3{r, r, r});
+                ref[i] = (PK_SPHERE << 30) | (uint32_t)(out.spheres.size() - 1);
+                break;
+            }
+            case SceneNode::CUBE:   // cuboid.rs:24-30
+            case SceneNode::CUBOID: { // cuboid.rs:18-22
+                V3 p0{nd.a[0], nd.a[1], nd.a[2]};
+                V3 p1 = nd.kind == SceneNode::CUBE ? p0 + V3{nd.b[0], nd.b[0], nd.b[0]} : V3{nd.b[0], nd.b[1], nd.b[2]};
+                Bounds b = b_new(p0, p1);
+                DCuboid dc{{b.min.x, b.min.y, b.min.z}, {b.max.x, b.max.y, b.max.z}};
+                out.cuboids.push_back(dc);
+                out.cuboid_mat.push_back(add_material(nd.mat));
+                pb[i] = b;
+                ref[i] = (PK_CUBOID << 30) | (uint32_t)(out.cuboids.size() - 1);
+                break;
+            }
+            case SceneNode::MESH: {
+                uint32_t cn = 0;
+                uint32_t cid = mesh_instance(nd.obj, nd.has_mat, nd.mat, (int32_t)id, pb[i], cn);
+                ref[i] = (PK_ACCEL << 30) | cid;
+                extra[i] = 3 + cn;
+                break;
+            }
+            case SceneNode::GROUP: {
+                uint32_t cn = 0;
+                uint32_t cid = aggregate(*nd.group, (int32_t)id, pb[i], cn);
+                ref[i] = (PK_ACCEL << 30) | cid;
+                extra[i] = 3 + cn;
+                break;
+            }
+            }
+        }
+        BuiltBVH bvh = Builder(pb, n).run();
+        uint32_t node_base;
+        append_nodes(bvh, node_base);
+        uint32_t prim_base = (uint32_t)out.primref.size();
+        std::vector<uint32_t> extra_in_order(bvh.order.size());
+        for (size_t i = 0; i < bvh.order.size(); ++i) {
+            out.primref.push_back(ref[bvh.order[i]]);
+            extra_in_order[i] = extra[bvh.order[i]];
+        }
+        out.accels[id].node_base = node_base;
+        out.accels[id].prim_base = prim_base;
+        need = stack_need(bvh.nodes, extra_in_order, [](uint32_t e) { return e; });
+        bound = b_transform(agg.transform.m, bvh.nodes[0].b);
+        // stitch the dump: [prefix][this accel][children]
+        std::swap(child_f, out.dump_f); std::swap(child_i, out.dump_i); // out.* = prefix again, child_* = children
+        (void)dump_f_at; (void)dump_i_at;
+        dump(bvh, false, agg.swap_backface, agg.transform);
+        out.dump_f.insert(out.dump_f.end(), child_f.begin(), child_f.end());
+        out.dump_i.insert(out.dump_i.end(), child_i.begin(), child_i.end());
+        return id;
+    }
+};
+} // namespace
+
+void flatten_scene(const Scene &scene, FlatScene &out) {
+    out = FlatScene();
+    Flattener fl{scene, out, {}};
+    fl.meshes.resize(scene.meshes.size());
+    out.default_material = fl.add_material(material_default());
+    Bounds b;
+    uint32_t need = 0;
+    fl.aggregate(*scene.root, -1, b, need);
+    out.max_stack = need;
+    for (const Light &l : scene.lights) {
+        DLight d;
+        std::memcpy(d.pos, l.pos, sizeof d.pos);
+        std::memcpy(d.intensity, l.intensity, sizeof d.intensity);
+        std::memcpy(d.falloff, l.falloff, sizeof d.falloff);
+        out.lights.push_back(d);
+    }
+}
+
+} // namespace lg

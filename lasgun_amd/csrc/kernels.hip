@@ -1,0 +1,902 @@
+// lasgun_amd/csrc/kernels.hip -- CDNA4 (gfx950) kernels of the per-pixel ray-trace path.
+//
+// One lane = one pixel (an 8x8 pixel tile per 64-wide wavefront, fetched from a global tile
+// counter so the persistent grid drains evenly).  Per lane: camera ray -> nested-BVH traversal
+// with a short per-lane stack in LDS -> hit resolution -> Whitted shading with one any-hit
+// shadow traversal per point light -> optional specular recursion through an explicit frame
+// stack -> RGBA8.  All arithmetic is f64 in the reference's order of operations (vecmath.h);
+// compile with -ffp-contract=off.  No MFMA: this is branchy traversal, not a contraction.
+//
+// What is restated from where (file:line under /root/reference):
+//   pixel loop / quantisation   src/lib.rs:110-162, src/img.rs:56-67
+//   camera rays                 src/camera.rs:113-146
+//   traversal                   src/accelerators/bvh.rs:461-522, src/shape/cuboid.rs:104-121
+//   sphere / box / triangle     src/shape/sphere.rs:30-123, cuboid.rs:55-102, triangle.rs:161-307
+//   hit records, transforms     src/interaction/surface.rs:57-183, src/space/transform.rs:243-264
+//   materials / BxDFs           src/material/*.rs, src/core/bxdf/*.rs, src/interaction/bsdf.rs:73-145
+//   integrator, lights, bg      src/integrate/integrate.rs:16-132, src/light/point.rs:42-54,
+//                               src/material/background.rs:25-34
+//
+// Legal restructurings (each leaves every produced f64 bit-identical):
+//   * traversal only tracks (t, primitive, accel) of the best hit; dpdu/dpdv/normals of the
+//     WINNING primitive are computed once afterwards (the reference overwrites them on every
+//     closer hit, so only the last accepted ones survive: sphere.rs:120, bvh.rs:510);
+//   * shadow rays stop at the first accepted hit with t < 1 (point.rs:49 only tests isect.t < 1.0
+//     and t only ever decreases);
+//   * a lane's visit order is exactly the reference's (near child first by dir_is_neg[axis],
+//     leaf primitives in order[]), which is what breaks ties between equal t.
+#include <hip/hip_runtime.h>
+
+#include "dscene.h"
+#include "trig.h"
+
+namespace lg {
+
+// ------------------------------------------------------------------------------------------
+// primitives
+// ------------------------------------------------------------------------------------------
+// Bounds::intersects (cuboid.rs:104-121): slab test, fmin/fmax absorb the NaN of 0*inf.
+__device__ __forceinline__ bool slab_intersects(const double bmin[3], const double bmax[3], const Ray &r) {
+    double t1 = (bmin[0] - r.o.x) * r.dinv.x, t2 = (bmax[0] - r.o.x) * r.dinv.x;
+    double tnear = fmax_(-INFINITY, fmin_(t1, t2));
+    double tfar = fmin_(INFINITY, fmax_(t1, t2));
+    t1 = (bmin[1] - r.o.y) * r.dinv.y; t2 = (bmax[1] - r.o.y) * r.dinv.y;
+    tnear = fmax_(tnear, fmin_(t1, t2));
+    tfar = fmin_(tfar, fmax_(t1, t2));
+    t1 = (bmin[2] - r.o.z) * r.dinv.z; t2 = (bmax[2] - r.o.z) * r.dinv.z;
+    tnear = fmax_(tnear, fmin_(t1, t2));
+    tfar = fmin_(tfar, fmax_(t1, t2));
+    return tnear <= tfar && tfar > 0.0;
+}
+
+__device__ __forceinline__ V3 cube_diff(int axis, int which) { // CUBE_DIFFERENTIALS cuboid.rs:126-130
+    // axis 0: (y, z)   axis 1: (z, x)   axis 2: (x, y)
+    int a = which == 0 ? (axis + 1) % 3 : (axis + 2) % 3;
+    return V3{a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0};
+}
+
+// Bounds::intersect (cuboid.rs:55-102).  Returns false on a miss; on a hit t is the cuboid's t
+// (NOT yet compared with the current best).  With FULL also the differentials of the hit face.
+template <bool FULL>
+__device__ __forceinline__ bool cuboid_hit(const double mn[3], const double mx[3], const Ray &r, double &t, V3 &d0, V3 &d1) {
+    double tnear = -INFINITY, tfar = INFINITY;
+    // codes: axis*2 + flipped  (flipped: the pair is (dp.1, dp.0))
+    int near_code = 0, far_code = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double o = comp(r.o, i), di = comp(r.dinv, i);
+        double t1 = (mn[i] - o) * di;
+        double t2 = (mx[i] - o) * di;
+        double tmin, tmax;
+        bool lt = t1 < t2;
+        if (lt) { tmin = t1; tmax = t2; } else { tmin = t2; tmax = t1; }
+        if (FULL) {
+            // (dp0, dp1) = lt ? (dp.1, dp.0) : (dp.0, dp.1); near = (dp0, dp1); far = (dp1, dp0)
+            if (tmin > tnear) near_code = i * 2 + (lt ? 1 : 0);
+            if (tmax < tfar) far_code = i * 2 + (lt ? 0 : 1);
+        }
+        tnear = fmax_(tnear, tmin);
+        tfar = fmin_(tfar, tmax);
+    }
+    if (tnear > tfar || tfar <= 0.0) return false;
+    int code;
+    if (tnear <= 0.0) { t = tfar; code = far_code; } else { t = tnear; code = near_code; }
+    if (FULL) {
+        int axis = code >> 1, flipped = code & 1;
+        d0 = cube_diff(axis, flipped ? 1 : 0);
+        d1 = cube_diff(axis, flipped ? 0 : 1);
+    }
+    return true;
+}
+
+struct TriHit {
+    double t, b0, b1, b2;
+};
+// Triangle::intersect up to the `t >= isect.t` test (triangle.rs:161-251).
+__device__ __forceinline__ bool triangle_t(V3 p0, V3 p1, V3 p2, const Ray &ray, TriHit &h) {
+    V3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
+    int kz = max_dimension(vabs(ray.d));
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    V3 d{comp(ray.d, kx), comp(ray.d, ky), comp(ray.d, kz)};
+    p0t = V3{comp(p0t, kx), comp(p0t, ky), comp(p0t, kz)};
+    p1t = V3{comp(p1t, kx), comp(p1t, ky), comp(p1t, kz)};
+    p2t = V3{comp(p2t, kx), comp(p2t, ky), comp(p2t, kz)};
+    double sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.0 / d.z;
+    p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
+    p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
+    p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+    double e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    double e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    double e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if ((e0 < 0.0 || e1 < 0.0 || e2 < 0.0) && (e0 > 0.0 || e1 > 0.0 || e2 > 0.0)) return false;
+    double det = e0 + e1 + e2;
+    if (det == 0.0) return false;
+    p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+    double tscaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if ((det < 0.0 && tscaled >= 0.0) || (det > 0.0 && tscaled <= 0.0)) return false;
+    double invdet = 1.0 / det;
+    h.b0 = e0 * invdet; h.b1 = e1 * invdet; h.b2 = e2 * invdet;
+    h.t = tscaled * invdet;
+    return true;
+}
+
+__device__ __forceinline__ V3 load_f3(const float *base, uint32_t idx) {
+    const float *p = base + 3ull * idx;
+    return V3{(double)p[0], (double)p[1], (double)p[2]};
+}
+
+// ------------------------------------------------------------------------------------------
+// hit record (surface.rs:33-119)
+// ------------------------------------------------------------------------------------------
+struct Isect {
+    double t;
+    V3 gu, gv; // geometry dpdu / dpdv
+    V3 su, sv; // surface dpdu / dpdv
+    V3 n;
+    bool has_n;
+};
+__device__ __forceinline__ void isect_set(Isect &i, double t, V3 dpdu, V3 dpdv) { // RayIntersection::new
+    i.t = t; i.gu = dpdu; i.gv = dpdv; i.su = dpdu; i.sv = dpdv; i.has_n = false; i.n = vzero();
+}
+
+// Sphere::intersect (sphere.rs:79-123), for an accepted t
+__device__ __forceinline__ void sphere_full(const DSphere &s, const Ray &ray, double t, bool inside, Isect &is) {
+    V3 cen{s.cx, s.cy, s.cz};
+    V3 p = ray.o + ray.d * t - cen;
+    if (p.x == 0.0 && p.y == 0.0) p.x = 1e-5 * s.r;
+    double phi = p_atan2(p.y, p.x);
+    if (phi < 0.0) phi += 2.0 * PI;
+    double theta = p_acos(fmin_(fmax_(p.z / s.r, -1.0), 1.0));
+    V3 dpdu{-2.0 * PI * p.y, 2.0 * PI * p.x, 0.0};
+    V3 dpdv = PI * V3{p.z * p_cos(phi), p.z * p_sin(phi), -s.r * p_sin(theta)};
+    if (inside) isect_set(is, t, dpdu, dpdv);
+    else isect_set(is, t, dpdv, dpdu);
+}
+
+// Triangle::intersect from the partial derivatives on (triangle.rs:257-304)
+__device__ __forceinline__ void triangle_full(const DParams &P, uint32_t tri, uint32_t aflags, const Ray &ray, Isect &is) {
+    const uint32_t *vi = P.tri_v + 3ull * tri;
+    V3 p0 = load_f3(P.vpos, vi[0]), p1 = load_f3(P.vpos, vi[1]), p2 = load_f3(P.vpos, vi[2]);
+    TriHit h;
+    triangle_t(p0, p1, p2, ray, h);
+    double uv[3][2];
+    if (aflags & AF_HAS_UV) {
+        const uint32_t *ti = P.tri_t + 3ull * tri;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { uv[k][0] = (double)P.vtex[2ull * ti[k]]; uv[k][1] = (double)P.vtex[2ull * ti[k] + 1]; }
+    } else {
+        uv[0][0] = 0.0; uv[0][1] = 0.0; uv[1][0] = 1.0; uv[1][1] = 0.0; uv[2][0] = 1.0; uv[2][1] = 1.0;
+    }
+    double duv02x = uv[0][0] - uv[2][0], duv02y = uv[0][1] - uv[2][1];
+    double duv12x = uv[1][0] - uv[2][0], duv12y = uv[1][1] - uv[2][1];
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    double determinant = (duv02x * duv12y) - (duv02y * duv12x);
+    V3 dpdu, dpdv;
+    if (determinant == 0.0) {
+        coordinate_system(cross(p2 - p1, p1 - p0), dpdu, dpdv);
+    } else {
+        double inv = 1.0 / determinant;
+        dpdu = (duv12y * dp02 - duv02y * dp12) * inv;
+        dpdv = (-duv12x * dp02 - duv02x * dp12) * inv;
+    }
+    isect_set(is, h.t, dpdu, dpdv);
+    if (aflags & AF_HAS_N) {
+        const uint32_t *ni = P.tri_n + 3ull * tri;
+        V3 n0 = load_f3(P.vnorm, ni[0]), n1 = load_f3(P.vnorm, ni[1]), n2 = load_f3(P.vnorm, ni[2]);
+        V3 ns = h.b0 * n0 + h.b1 * n1 + h.b2 * n2;
+        V3 ss = is.gu;
+        V3 ts = cross(ns, ss);
+        if (magnitude2(ts) > 0.0) ss = cross(ts, ns);
+        else coordinate_system(ns, ss, ts);
+        is.has_n = true; is.n = ns;
+        is.su = ss; is.sv = ts;
+    } else {
+        is.has_n = true;
+        is.n = face_forward(cross(dp02, dp12), -ray.d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// traversal
+// ------------------------------------------------------------------------------------------
+struct Counters {
+    uint32_t primary, shadow, secondary, nodes, spheres, cuboids, triangles, entries, hits;
+};
+
+__device__ __forceinline__ Affine load_affine(const Affine *p) { return *p; }
+
+// ray in the local space of `accel`: apply minv of every accel on the chain root..accel, in
+// order, exactly as the nested BVHAccel::intersect calls do (bvh.rs:462).
+__device__ __forceinline__ Ray local_ray(const DParams &P, const Ray &wray, uint32_t accel) {
+    const DAccel *a = P.accels + accel;
+    uint32_t n = a->nchain;
+    Ray r = wray;
+    for (uint32_t i = 0; i < n; ++i) r = ray_to_local(P.accels[a->chain[i]].minv, r);
+    return r;
+}
+
+struct Best {
+    double t;
+    uint32_t ref;   // primref of the closest accepted primitive, NO_HIT if none
+    uint32_t accel; // accel instance it was hit in
+};
+
+// BVHAccel::intersect over the whole nested scene graph (bvh.rs:461-522), one lane = one ray.
+// `stack` is this lane's LDS stack: entry i lives at stack[i * stride].
+template <bool STATS>
+__device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool anyhit, uint32_t *stack, uint32_t stride,
+                                         Best &best, Counters &cnt) {
+    best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
+    uint32_t accel = 0;
+    const DAccel *A = P.accels;
+    Ray ray = ray_to_local(A->minv, wray);
+    if (STATS) cnt.entries++;
+    uint32_t node_base = A->node_base, prim_base = A->prim_base;
+    uint32_t cur = 0;      // node index relative to node_base
+    uint32_t sp = 0, base = 0;
+    uint32_t li = 0, le = 0; // leaf cursor (absolute primref indices)
+    bool in_leaf = false;
+    for (;;) {
+        if (!in_leaf) {
+            const DNode *nd = P.nodes + (node_base + cur);
+            // one 64-byte record: four 16-byte loads from a single line
+            double bmin[3] = {nd->bmin[0], nd->bmin[1], nd->bmin[2]};
+            double bmax[3] = {nd->bmax[0], nd->bmax[1], nd->bmax[2]};
+            uint32_t link = nd->link, meta = nd->meta;
+            if (STATS) cnt.nodes++;
+            bool hitbox = slab_intersects(bmin, bmax, ray);
+            if (hitbox && !(meta & NODE_LEAF)) {
+                // near child first (bvh.rs:493-504)
+                uint32_t axis = meta & 3u;
+                bool neg = (axis == 0 ? ray.dinv.x : (axis == 1 ? ray.dinv.y : ray.dinv.z)) < 0.0;
+                uint32_t far_node = neg ? cur + 1 : link;
+                cur = neg ? link : cur + 1;
+                stack[sp * stride] = far_node;
+                ++sp;
+                continue;
+            }
+            if (hitbox) {
+                li = prim_base + link;
+                le = li + (meta & 0xFFFFu);
+                in_leaf = true;
+            } else {
+                li = le = 0;
+                in_leaf = true; // empty leaf -> falls through to the pop below
+            }
+        }
+        // ---- leaf: primitives in order[] sequence (bvh.rs:481-488)
+        bool entered = false;
+        while (li < le) {
+            uint32_t ref = P.primref[li++];
+            uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
+            if (kind == PK_SPHERE) {
+                if (STATS) cnt.spheres++;
+                DSphere s = P.spheres[idx];
+                bool inside;
+                double t = sphere_t(ray, V3{s.cx, s.cy, s.cz}, s.r, inside);
+                if (t < 0.0) continue;
+                if (t >= best.t) continue;
+                best.t = t; best.ref = ref; best.accel = accel;
+            } else if (kind == PK_TRIANGLE) {
+                if (STATS) cnt.triangles++;
+                const uint32_t *vi = P.tri_v + 3ull * idx;
+                V3 p0 = load_f3(P.vpos, vi[0]), p1 = load_f3(P.vpos, vi[1]), p2 = load_f3(P.vpos, vi[2]);
+                TriHit h;
+                if (!triangle_t(p0, p1, p2, ray, h)) continue;
+                if (h.t >= best.t) continue;
+                best.t = h.t; best.ref = ref; best.accel = accel;
+            } else if (kind == PK_CUBOID) {
+                if (STATS) cnt.cuboids++;
+                DCuboid c = P.cuboids[idx];
+                double t; V3 d0, d1;
+                if (!cuboid_hit<false>(c.mn, c.mx, ray, t, d0, d1)) continue;
+                if (t >= best.t) continue;
+                best.t = t; best.ref = ref; best.accel = accel;
+            } else {
+                // nested BVHAccel (Group / Mesh): save this level, re-express the ray (bvh.rs:462)
+                stack[sp * stride] = li; stack[(sp + 1) * stride] = le; stack[(sp + 2) * stride] = base;
+                sp += 3; base = sp;
+                accel = idx;
+                const DAccel *C = P.accels + idx;
+                ray = ray_to_local(C->minv, ray);
+                if (STATS) cnt.entries++;
+                node_base = C->node_base; prim_base = C->prim_base;
+                cur = 0; in_leaf = false; entered = true;
+                break;
+            }
+            if (anyhit && best.t < 1.0) return; // occluded: point.rs:49 only asks isect.t < 1.0
+        }
+        if (entered) continue;
+        // ---- pop
+        while (sp == base) { // this accel is exhausted
+            if (accel == 0) return;
+            base = stack[(sp - 1) * stride]; le = stack[(sp - 2) * stride]; li = stack[(sp - 3) * stride];
+            sp -= 3;
+            accel = (uint32_t)P.accels[accel].parent;
+            ray = local_ray(P, wray, accel);
+            const DAccel *Q = P.accels + accel;
+            node_base = Q->node_base; prim_base = Q->prim_base;
+            if (li < le) break; // resume the parent's leaf
+        }
+        if (sp == base && li >= le && accel == 0) return; // (unreachable; kept as a guard)
+        if (li < le) { in_leaf = true; continue; }
+        --sp;
+        cur = stack[sp * stride];
+        in_leaf = false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// hit resolution: the winning primitive's RayIntersection carried back to world space
+// (primitive intersect, then bvh.rs:509-519 / transform.rs:243-264 for every accel on the way up)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t resolve_hit(const DParams &P, const Ray &wray, const Best &best, Isect &is) {
+    Ray lr = local_ray(P, wray, best.accel);
+    uint32_t kind = best.ref >> 30, idx = best.ref & PRIM_INDEX_MASK;
+    int32_t prim_mat = -1;
+    if (kind == PK_SPHERE) {
+        DSphere s = P.spheres[idx];
+        bool inside;
+        double t = sphere_t(lr, V3{s.cx, s.cy, s.cz}, s.r, inside);
+        sphere_full(s, lr, t, inside, is);
+        prim_mat = P.sphere_mat[idx];
+    } else if (kind == PK_CUBOID) {
+        DCuboid c = P.cuboids[idx];
+        double t; V3 d0, d1;
+        cuboid_hit<true>(c.mn, c.mx, lr, t, d0, d1);
+        isect_set(is, t, d0, d1);
+        is.has_n = true;
+        is.n = face_forward(cross(d0, d1), -lr.d);
+        prim_mat = P.cuboid_mat[idx];
+    } else {
+        triangle_full(P, idx, P.accels[best.accel].flags, lr, is);
+    }
+    int32_t isect_mat = P.default_material; // RayIntersection::new -> Material::default()
+    int32_t a = (int32_t)best.accel;
+    while (a >= 0) {
+        const DAccel *A = P.accels + a;
+        // transform_ray_intersection (transform.rs:243-264)
+        V3 gu = xf_vector(A->m, is.gu), gv = xf_vector(A->m, is.gv);
+        if (vne(is.gu, is.su) || vne(is.gv, is.sv)) {
+            is.su = xf_vector(A->m, is.su); is.sv = xf_vector(A->m, is.sv);
+        } else {
+            is.su = gu; is.sv = gv;
+        }
+        is.gu = gu; is.gv = gv;
+        if (is.has_n) is.n = xf_normal(A->minv, is.n);
+        if (A->material >= 0) isect_mat = A->material; // bvh.rs:513-515
+        if (A->flags & AF_SWAP_BACKFACE) {             // surface.rs:88-99
+            V3 tmp = is.gu; is.gu = is.gv; is.gv = tmp;
+            tmp = is.su; is.su = is.sv; is.sv = tmp;
+            if (is.has_n) is.n = -is.n;
+        }
+        a = A->parent;
+    }
+    return prim_mat >= 0 ? prim_mat : isect_mat; // integrate.rs:30
+}
+
+// ------------------------------------------------------------------------------------------
+// BxDFs (core/bxdf/*.rs) in shading space
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double cos2_theta(V3 w) { return w.z * w.z; }
+__device__ __forceinline__ double abs_cos_theta(V3 w) { return fabs(w.z); }
+__device__ __forceinline__ double sin2_theta(V3 w) { return fmax_(1.0 - cos2_theta(w), 0.0); }
+__device__ __forceinline__ double sin_theta(V3 w) { return sqrt(sin2_theta(w)); }
+__device__ __forceinline__ double tan_theta(V3 w) { return sin_theta(w) / w.z; }
+__device__ __forceinline__ double tan2_theta(V3 w) { return sin2_theta(w) / cos2_theta(w); }
+__device__ __forceinline__ double cos_phi(V3 w) { double s = sin_theta(w); return s == 0.0 ? 1.0 : fmin_(fmax_(w.x / s, -1.0), 1.0); }
+__device__ __forceinline__ double sin_phi(V3 w) { double s = sin_theta(w); return s == 0.0 ? 0.0 : fmin_(fmax_(w.y / s, -1.0), 1.0); }
+
+__device__ __forceinline__ double fr_dielectric(double cos_i, double eta_i, double eta_t) { // fresnel.rs:37-64
+    cos_i = fmin_(fmax_(cos_i, -1.0), 1.0);
+    bool entering = cos_i > 0.0;
+    if (!entering) { double tmp = eta_i; eta_i = eta_t; eta_t = tmp; cos_i = fabs(cos_i); }
+    double sin_i = sqrt(fmax_(1.0 - cos_i * cos_i, 0.0));
+    double sin_t = eta_i / eta_t * sin_i;
+    if (sin_t >= 1.0) return 1.0;
+    double cos_t = sqrt(fmax_(1.0 - sin_t * sin_t, 0.0));
+    double r_parl = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+    double r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+    return (r_parl * r_parl + r_perp * r_perp) * 0.5;
+}
+__device__ __forceinline__ V3 fr_conductor(double cos_i, V3 eta_i, V3 eta_t, V3 k) { // fresnel.rs:69-91
+    cos_i = fmin_(fmax_(cos_i, -1.0), 1.0);
+    V3 eta = div_ew(eta_t, eta_i);
+    V3 etak = div_ew(k, eta_i);
+    double c2 = cos_i * cos_i;
+    double s2 = 1.0 - c2;
+    V3 eta2 = mul_ew(eta, eta), etak2 = mul_ew(etak, etak);
+    V3 t0 = eta2 - etak2 - splat(s2);
+    V3 a2plusb2 = vsqrt(mul_ew(t0, t0) + 4.0 * mul_ew(eta2, etak2));
+    V3 t1 = a2plusb2 + splat(c2);
+    V3 a = vsqrt(0.5 * (a2plusb2 + t0));
+    V3 t2 = 2.0 * cos_i * a;
+    V3 rs = div_ew(t1 - t2, t1 + t2);
+    V3 t3 = c2 * a2plusb2 + splat(s2 * s2);
+    V3 t4 = t2 * s2;
+    V3 rp = div_ew(mul_ew(rs, t3 - t4), t3 + t4);
+    return 0.5 * (rp + rs);
+}
+__device__ __forceinline__ double tr_d(double ax, double ay, V3 wh) { // microfacet.rs:31-40
+    double tan2 = tan2_theta(wh);
+    if (isinf(tan2)) return 0.0;
+    double cos4 = cos2_theta(wh) * cos2_theta(wh);
+    double cp = cos_phi(wh), sp = sin_phi(wh);
+    double e = ((cp * cp) / (ax * ax) + (sp * sp) / (ay * ay)) * tan2;
+    return 1.0 / (PI * ax * ay * cos4 * (1.0 + e) * (1.0 + e));
+}
+__device__ __forceinline__ double tr_lambda(double ax, double ay, V3 w) { // microfacet.rs:55-66
+    double abs_tan = fabs(tan_theta(w));
+    if (isinf(abs_tan)) return 0.0;
+    double cp = cos_phi(w), sp = sin_phi(w);
+    double alpha = sqrt((cp * cp) * ax * ax + (sp * sp) * ay * ay);
+    double a2t2 = (alpha * abs_tan) * (alpha * abs_tan);
+    return (sqrt(1.0 + a2t2) - 1.0) / 2.0;
+}
+// microfacet::Reflection::f (microfacet.rs:101-115); conductor selects Substance::Conductor(1, eta, k)
+__device__ __forceinline__ V3 microfacet_f(V3 r, bool conductor, double d_eta_i, double d_eta_t, V3 c_eta, V3 c_k, double ax, double ay, V3 wo, V3 wi) {
+    double cos_o = abs_cos_theta(wo), cos_i = abs_cos_theta(wi);
+    V3 wh = wi + wo;
+    if (cos_i == 0.0 || cos_o == 0.0) return vzero();
+    if (wh.x == 0.0 && wh.y == 0.0 && wh.z == 0.0) return vzero();
+    wh = normalize(wh);
+    double ci = dot(wi, wh);
+    V3 spectrum = conductor ? fr_conductor(ci, splat(1.0), c_eta, c_k) : splat(fr_dielectric(ci, d_eta_i, d_eta_t));
+    double g = 1.0 / (1.0 + tr_lambda(ax, ay, wo) + tr_lambda(ax, ay, wi));
+    return mul_ew(r * tr_d(ax, ay, wh) * g, spectrum) / (4.0 * cos_i * cos_o);
+}
+__device__ __forceinline__ V3 oren_nayar_f(V3 r, double sigma_deg, V3 wo, V3 wi) { // diffuse.rs:29-56
+    double s = sigma_deg * (PI / 180.0), s2 = s * s;
+    double A = 1.0 - (s2 / 2.0 * (s2 + 0.33));
+    double B = 0.45 * s2 / (s2 + 0.09);
+    double sin_i = sin_theta(wi), sin_o = sin_theta(wo);
+    double max_cos = 0.0;
+    if (sin_i > 1e-4 && sin_o > 1e-4) {
+        double sp_i = sin_phi(wi), cp_i = cos_phi(wi), sp_o = sin_phi(wo), cp_o = cos_phi(wo);
+        double d_cos = cp_i * cp_o + sp_i * sp_o;
+        max_cos = fmax_(d_cos, 0.0);
+    }
+    double sin_alpha, tan_beta;
+    if (abs_cos_theta(wi) > abs_cos_theta(wo)) { sin_alpha = sin_o; tan_beta = sin_i / abs_cos_theta(wi); }
+    else { sin_alpha = sin_i; tan_beta = sin_o / abs_cos_theta(wo); }
+    return r * FRAC_1_PI * (A + B * max_cos * sin_alpha * tan_beta);
+}
+
+// Shading frame of one hit: what Material::scattering + BSDF::new keep (bsdf.rs:29-46)
+struct Shade {
+    V3 p;      // interaction.p + interaction.p_err (integrate.rs:40)
+    V3 pm;     // interaction.p - interaction.p_err (integrate.rs:127)
+    V3 wo, ng, ns, ss, ts;
+    int32_t mat;
+};
+
+// BSDF::f (bsdf.rs:73-92) with the BxDF list of Material::scattering (material/*.rs) inlined
+__device__ __forceinline__ V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo, V3 wi) {
+    bool reflect = dot(wi, sh.ng) * dot(wo, sh.ng) > 0.0;
+    V3 wo_l{dot(wo, sh.ss), dot(wo, sh.ts), dot(wo, sh.ns)};
+    V3 wi_l{dot(wi, sh.ss), dot(wi, sh.ts), dot(wi, sh.ns)};
+    if (wo_l.z == 0.0) return vzero();
+    V3 f = vzero();
+    switch (m.kind) {
+    case MAT_MATTE: { // matte.rs:18-26 -- REFLECTION | DIFFUSE
+        if (reflect) {
+            V3 kd{m.p[0], m.p[1], m.p[2]};
+            f = f + (m.p[3] == 0.0 ? kd * FRAC_1_PI : oren_nayar_f(kd, m.p[3], wo_l, wi_l));
+        }
+        break;
+    }
+    case MAT_PLASTIC: { // plastic.rs:20-37 -- Lambertian then microfacet reflection, both REFLECTION
+        if (reflect) {
+            V3 kd{m.p[0], m.p[1], m.p[2]}, ks{m.p[3], m.p[4], m.p[5]};
+            if (vne(kd, vzero())) f = f + kd * FRAC_1_PI;
+            if (vne(ks, vzero())) f = f + microfacet_f(ks, false, 1.0, 1.5, vzero(), vzero(), m.p[6], m.p[6], wo_l, wi_l);
+        }
+        break;
+    }
+    case MAT_METAL: { // metal.rs:17-26
+        if (reflect) {
+            V3 eta{m.p[0], m.p[1], m.p[2]}, k{m.p[3], m.p[4], m.p[5]};
+            f = f + microfacet_f(splat(1.0), true, 0.0, 0.0, eta, k, m.p[6], m.p[7], wo_l, wi_l);
+        }
+        break;
+    }
+    case MAT_GLASS: { // glass.rs:33-56: specular BxDFs evaluate to zero (bxdf/mod.rs:172)
+        V3 kr{m.p[0], m.p[1], m.p[2]}, kt{m.p[3], m.p[4], m.p[5]};
+        if (reflect && vne(kr, vzero())) f = f + vzero();
+        if (!reflect && vne(kt, vzero())) f = f + vzero();
+        break;
+    }
+    default: // MAT_MIRROR, mirror.rs:15-17
+        if (reflect) f = f + vzero();
+        break;
+    }
+    return f;
+}
+
+struct Sample { // bxdf::LightSample
+    V3 spectrum, wi;
+    double pdf;
+};
+__device__ __forceinline__ V3 to_world(const Shade &sh, V3 v) { // bsdf.rs:165-171
+    return V3{sh.ss.x * v.x + sh.ts.x * v.y + sh.ns.x * v.z, sh.ss.y * v.x + sh.ts.y * v.y + sh.ns.y * v.z,
+              sh.ss.z * v.x + sh.ts.z * v.y + sh.ns.z * v.z};
+}
+__device__ __forceinline__ V3 clamp01(V3 v) {
+    return V3{fmin_(fmax_(v.x, 0.0), 1.0), fmin_(fmax_(v.y, 0.0), 1.0), fmin_(fmax_(v.z, 0.0), 1.0)};
+}
+// BSDF::sample_f(wo, (0.5, 0.5), REFLECTION | SPECULAR) (bsdf.rs:94-145, specular.rs:17-24):
+// only Mirror and Glass(kr != 0) own a matching component; exactly one, so comp = 0 and pdf / 1.
+__device__ __forceinline__ bool sample_specular_reflection(const DMaterial &m, const Shade &sh, Sample &s) {
+    bool glass = m.kind == MAT_GLASS;
+    if (!(m.kind == MAT_MIRROR || glass)) return false;
+    V3 r{m.p[0], m.p[1], m.p[2]};
+    if (glass && !vne(r, vzero())) return false; // component not present
+    V3 wo_l{dot(sh.wo, sh.ss), dot(sh.wo, sh.ts), dot(sh.wo, sh.ns)};
+    if (wo_l.z == 0.0) return false; // LightSample::zero(): pdf 0 -> caller returns zero
+    V3 wi_l{-wo_l.x, -wo_l.y, wo_l.z};
+    V3 fr = glass ? splat(fr_dielectric(wi_l.z, 1.0, m.p[6])) : splat(1.0);
+    V3 spectrum = mul_ew(fr, r) / abs_cos_theta(wi_l);
+    s.wi = to_world(sh, wi_l);
+    s.spectrum = clamp01(spectrum);
+    s.pdf = 1.0 / 1.0;
+    return true;
+}
+// BSDF::sample_f(wo, (0.5, 0.5), TRANSMISSION | SPECULAR) (specular.rs:43-63, bxdf/mod.rs:276-288)
+__device__ __forceinline__ bool sample_specular_transmission(const DMaterial &m, const Shade &sh, Sample &s) {
+    if (m.kind != MAT_GLASS) return false;
+    V3 kt{m.p[3], m.p[4], m.p[5]};
+    if (!vne(kt, vzero())) return false;
+    double eta_a = 1.0, eta_b = m.p[6];
+    V3 wo_l{dot(sh.wo, sh.ss), dot(sh.wo, sh.ts), dot(sh.wo, sh.ns)};
+    if (wo_l.z == 0.0) return false;
+    bool entering = wo_l.z > 0.0;
+    double eta_i = entering ? eta_a : eta_b, eta_t = entering ? eta_b : eta_a;
+    double eta = eta_i / eta_t;
+    // refract(wo, n = (0,0,1), eta)
+    V3 n{0.0, 0.0, 1.0};
+    double cos_i = dot(n, wo_l);
+    double sin2_i = fmax_(1.0 - cos_i * cos_i, 0.0);
+    double sin2_t = eta * eta * sin2_i;
+    if (sin2_t >= 1.0) return false; // total internal reflection: LightSample::zero()
+    double cos_t = sqrt(1.0 - sin2_t);
+    V3 wi_l = eta * -1.0 * wo_l + (eta * cos_i - cos_t) * n;
+    V3 spectrum = mul_ew(kt, splat(1.0) - splat(fr_dielectric(wi_l.z, eta_a, eta_b))) / abs_cos_theta(wi_l);
+    s.wi = to_world(sh, wi_l);
+    s.spectrum = clamp01(spectrum);
+    s.pdf = 1.0 / 1.0;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// the render kernel
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t to_byte(double c) { // img.rs:65-67
+    return (uint32_t)as_u8(round(fmin_(fmax_(c, 0.0), 1.0) * 255.0));
+}
+__device__ __forceinline__ V3 background(const DParams &P, V3 d) { // background.rs:25-34; powf(2.) == x*x
+    double a = fabs(dot(V3{0.0, 0.0, 1.0}, d));
+    double t = fmin_(sqrt(1.0 - a * a) / P.bg_scale, 1.0);
+    return V3{lerp(t, P.bg_inner.x, P.bg_outer.x), lerp(t, P.bg_inner.y, P.bg_outer.y), lerp(t, P.bg_inner.z, P.bg_outer.z)};
+}
+
+// frame fields
+enum { FR_ACC = 0, FR_SPEC_R = 3, FR_STATE = 6, FR_TO = 7, FR_TD = 10, FR_SPEC_T = 13, FR_A = 16, FR_PDF = 17 };
+__device__ __forceinline__ double &frame_at(const DParams &P, uint32_t depth, int field, unsigned long long gtid) {
+    return P.frames[((unsigned long long)depth * FRAME_DOUBLES + field) * P.frame_threads + gtid];
+}
+__device__ __forceinline__ void frame_put3(const DParams &P, uint32_t depth, int field, unsigned long long g, V3 v) {
+    frame_at(P, depth, field, g) = v.x; frame_at(P, depth, field + 1, g) = v.y; frame_at(P, depth, field + 2, g) = v.z;
+}
+__device__ __forceinline__ V3 frame_get3(const DParams &P, uint32_t depth, int field, unsigned long long g) {
+    return V3{frame_at(P, depth, field, g), frame_at(P, depth, field + 1, g), frame_at(P, depth, field + 2, g)};
+}
+
+extern __shared__ uint32_t lds_stack[];
+
+template <bool STATS>
+__global__ void __launch_bounds__(256) trace_kernel(const DParams P) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + tid;
+    uint32_t *stack = lds_stack + tid; // entry i at stack[i * blockDim.x]: bank = tid % 32 for every i
+    const uint32_t stride = blockDim.x;
+    Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (;;) {
+        // ---- fetch the next 64-pixel tile for this wavefront
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+        if (tile >= P.ntiles) break; // every wave reaches this exit
+
+        uint32_t x, y;
+        bool active;
+        if (P.mode == 0) {
+            uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+            x = P.x0 + tx * 8u + (lane & 7u);
+            y = P.y0 + ty * 8u + (lane >> 3);
+            active = x < P.x1 && y < P.y1;
+        } else {
+            unsigned long long i = (unsigned long long)tile * 64ull + lane;
+            active = i < P.sub_count;
+            unsigned long long off = P.sub_k + i * P.sub_n;
+            x = (uint32_t)(off % P.w);
+            y = (uint32_t)(off / P.w);
+        }
+        if (!active) continue; // lanes past the edge idle for this tile
+
+        // ---- Camera::sample (camera.rs:113-146)
+        double img_plane_height = P.image_plane_height;
+        double img_plane_width = img_plane_height * P.aspect;
+        double pixel_size = img_plane_height * P.hinv;
+        double sample_separation = P.ss_distance * pixel_size;
+        double sox = ((double)x * P.winv - 0.5) * img_plane_width;
+        double soy = (0.5 - (double)(y + 1u) * P.hinv) * img_plane_height;
+        V3 cam_o = P.cam_origin + ((soy * P.pixel_separation) * P.cam_up) + ((sox * P.pixel_separation) * P.cam_aux);
+        V3 cam_d = P.cam_view + (soy * P.cam_up) + (sox * P.cam_aux);
+        V3 updiff = P.cam_up * sample_separation;
+        V3 auxdiff = P.cam_aux * sample_separation;
+        V3 halfdiff = updiff * 0.5 + auxdiff * 0.5;
+        const uint32_t dim = P.ss_root;
+        const uint32_t nsamples = dim * dim;
+        const double weight = 1. / (double)nsamples;
+
+        V3 color = vzero(); // integrate.rs:17
+        for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
+            uint32_t si = sidx / dim, sj = sidx % dim;
+            V3 dd = cam_d + ((double)sj * updiff) + ((double)si * auxdiff) + halfdiff;
+            Ray ray = ray_new(cam_o, dd);
+            if (STATS) cnt.primary++;
+
+            // ---- li() with an explicit frame stack (integrate.rs:23-80)
+            uint32_t depth = 0;
+            V3 value = vzero();
+            for (;;) { // one iteration = one li() invocation at `depth` along `ray`
+                Best best;
+                traverse<STATS>(P, ray, false, stack, stride, best, cnt);
+                bool have_value = false;
+                if (best.ref == NO_HIT) {
+                    value = background(P, normalize(ray.d)); // integrate.rs:26-28
+                    have_value = true;
+                } else {
+                    if (STATS) cnt.hits++;
+                    Isect is;
+                    Shade sh;
+                    sh.mat = resolve_hit(P, ray, best, is);
+                    const DMaterial m = P.materials[sh.mat];
+                    // SurfaceInteraction::from (surface.rs:158-183)
+                    sh.wo = -normalize(ray.d);
+                    sh.ng = face_forward(normalize(cross(is.gu, is.gv)), sh.wo);
+                    sh.ns = is.has_n ? normalize(is.n) : normalize(cross(is.su, is.sv));
+                    const double err = 2.220446049250313e-16 * 65536.0;
+                    V3 p = ray.o + ray.d * is.t;
+                    V3 p_err = sh.ng * err;
+                    sh.p = p + p_err;
+                    sh.pm = p - p_err;
+                    sh.ss = normalize(is.su);   // si.surface.dpdu (bsdf.rs:34)
+                    sh.ts = cross(sh.ns, sh.ss); // bsdf.rs:35
+                    V3 n = sh.ns;
+
+                    // direct lighting (integrate.rs:47-66, point.rs:42-54)
+                    V3 output = vzero();
+                    for (uint32_t l = 0; l < P.nlights; ++l) {
+                        const DLight L = P.lights[l];
+                        V3 lpos{L.pos[0], L.pos[1], L.pos[2]};
+                        V3 wi = lpos - sh.p;
+                        Ray sray = ray_new(sh.p, wi);
+                        if (STATS) cnt.shadow++;
+                        Best sb;
+                        traverse<STATS>(P, sray, true, stack, stride, sb, cnt);
+                        if (sb.t < 1.0) continue;
+                        double d = magnitude(wi);
+                        double f_att = L.falloff[0] + L.falloff[1] * d + L.falloff[2] * d * d;
+                        if (f_att == 0.0) continue;
+                        wi = normalize(wi);
+                        double wi_dot_n = dot(wi, n);
+                        V3 f = bsdf_f(m, sh, sh.wo, wi);
+                        V3 li_col{L.intensity[0], L.intensity[1], L.intensity[2]};
+                        output = output + (mul_ew(PI * li_col, f) * wi_dot_n / f_att);
+                    }
+                    output = output + mul_ew(P.ambient, bsdf_f(m, sh, sh.wo, n)); // integrate.rs:67
+
+                    // specular children (integrate.rs:69-77,82-132)
+                    bool has_r = false, has_t = false;
+                    Sample sr, st;
+                    if (depth < P.recursion && (m.kind == MAT_GLASS || m.kind == MAT_MIRROR)) {
+                        if (sample_specular_transmission(m, sh, st))
+                            has_t = !(st.pdf <= 0.0 || veq(st.spectrum, vzero()) || fabs(dot(st.wi, sh.ns)) == 0.0);
+                        if (sample_specular_reflection(m, sh, sr))
+                            has_r = !(sr.pdf <= 0.0 || veq(sr.spectrum, vzero()) || dot(sr.wi, sh.ns) <= 0.0);
+                    }
+                    if (!has_r && !has_t) {
+                        value = output + vzero() + vzero(); // integrate.rs:79
+                        have_value = true;
+                    } else {
+                        // push a frame; the reflected child is evaluated first because the sum is
+                        // (output + reflected) + refracted
+                        if (has_t) {
+                            frame_put3(P, depth, FR_TO, gtid, sh.pm);
+                            frame_put3(P, depth, FR_TD, gtid, st.wi);
+                            frame_put3(P, depth, FR_SPEC_T, gtid, st.spectrum);
+                            frame_at(P, depth, FR_A, gtid) = fabs(dot(st.wi, sh.ns));
+                            frame_at(P, depth, FR_PDF, gtid) = st.pdf;
+                        }
+                        if (has_r) {
+                            frame_put3(P, depth, FR_ACC, gtid, output);
+                            frame_put3(P, depth, FR_SPEC_R, gtid, sr.spectrum);
+                            frame_at(P, depth, FR_STATE, gtid) = has_t ? 1.0 : 2.0;
+                            V3 wr = -1.0 * sh.wo + 2.0 * dot(sh.wo, sh.ns) * sh.ns; // bxdf::util::reflect (integrate.rs:100)
+                            ray = ray_new(sh.p, wr);
+                        } else {
+                            frame_put3(P, depth, FR_ACC, gtid, output + vzero());
+                            frame_at(P, depth, FR_STATE, gtid) = 3.0;
+                            ray = ray_new(sh.pm, st.wi);
+                        }
+                        if (STATS) cnt.secondary++;
+                        depth += 1;
+                    }
+                }
+                // ---- return `value` up the frame stack
+                bool finished = false;
+                while (have_value) {
+                    if (depth == 0) { finished = true; break; }
+                    uint32_t fd = depth - 1;
+                    double state = frame_at(P, fd, FR_STATE, gtid);
+                    if (state == 3.0) {
+                        V3 acc = frame_get3(P, fd, FR_ACC, gtid);
+                        V3 spec = frame_get3(P, fd, FR_SPEC_T, gtid);
+                        double a = frame_at(P, fd, FR_A, gtid), pdf = frame_at(P, fd, FR_PDF, gtid);
+                        V3 refracted = mul_ew(spec, value) * a / pdf; // integrate.rs:129
+                        value = acc + refracted;
+                        depth = fd;
+                    } else {
+                        V3 acc = frame_get3(P, fd, FR_ACC, gtid);
+                        V3 spec = frame_get3(P, fd, FR_SPEC_R, gtid);
+                        V3 reflected = mul_ew(spec, value); // integrate.rs:103
+                        acc = acc + reflected;
+                        if (state == 1.0) {
+                            frame_put3(P, fd, FR_ACC, gtid, acc);
+                            frame_at(P, fd, FR_STATE, gtid) = 3.0;
+                            ray = ray_new(frame_get3(P, fd, FR_TO, gtid), frame_get3(P, fd, FR_TD, gtid));
+                            if (STATS) cnt.secondary++;
+                            have_value = false; // trace the transmitted child at depth fd + 1
+                        } else {
+                            value = acc + vzero();
+                            depth = fd;
+                        }
+                    }
+                }
+                if (finished) break;
+            }
+            color = color + value;
+        }
+        color = color * weight; // integrate.rs:19
+
+        // ---- Img::set (img.rs:46-67)
+        unsigned long long pix = (unsigned long long)(y - P.out_row0) * P.w + x;
+        if (P.out_rgba) {
+            uint32_t rgba = to_byte(color.x) | (to_byte(color.y) << 8) | (to_byte(color.z) << 16) | (255u << 24);
+            reinterpret_cast<uint32_t *>(P.out_rgba)[pix] = rgba;
+        }
+        if (P.out_radiance) {
+            P.out_radiance[3 * pix] = color.x; P.out_radiance[3 * pix + 1] = color.y; P.out_radiance[3 * pix + 2] = color.z;
+        }
+    }
+
+    if (STATS) {
+        atomicAdd(&P.stats->primary_rays, (unsigned long long)cnt.primary);
+        atomicAdd(&P.stats->shadow_rays, (unsigned long long)cnt.shadow);
+        atomicAdd(&P.stats->secondary_rays, (unsigned long long)cnt.secondary);
+        atomicAdd(&P.stats->nodes_tested, (unsigned long long)cnt.nodes);
+        atomicAdd(&P.stats->spheres_tested, (unsigned long long)cnt.spheres);
+        atomicAdd(&P.stats->cuboids_tested, (unsigned long long)cnt.cuboids);
+        atomicAdd(&P.stats->triangles_tested, (unsigned long long)cnt.triangles);
+        atomicAdd(&P.stats->accel_entries, (unsigned long long)cnt.entries);
+        atomicAdd(&P.stats->hits, (unsigned long long)cnt.hits);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// known-answer / arithmetic probe kernels (one thread; test hooks of the C ABI)
+// ------------------------------------------------------------------------------------------
+// kind 0 sphere (cx,cy,cz,r), 1 cuboid (min,max), 2 every triangle of a mesh in order.
+// out = { hit, t, ng.xyz, ns.xyz } -- what the reference's inline tests assert on.
+__global__ void kat_kernel(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d,
+                           double *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ray ray = ray_new(o, d);
+    Isect is;
+    isect_set(is, INFINITY, vzero(), vzero());
+    bool hit = false;
+    if (kind == 0) {
+        DSphere s{params[0], params[1], params[2], params[3]};
+        bool inside;
+        double t = sphere_t(ray, V3{s.cx, s.cy, s.cz}, s.r, inside);
+        if (!(t < 0.0) && !(t >= is.t)) { sphere_full(s, ray, t, inside, is); hit = true; }
+    } else if (kind == 1) {
+        double mn[3] = {params[0], params[1], params[2]}, mx[3] = {params[3], params[4], params[5]};
+        double t; V3 d0, d1;
+        if (cuboid_hit<true>(mn, mx, ray, t, d0, d1) && !(t >= is.t)) {
+            isect_set(is, t, d0, d1);
+            is.has_n = true; is.n = face_forward(cross(d0, d1), -ray.d);
+            hit = true;
+        }
+    } else {
+        DParams P{};
+        P.vpos = vpos; P.tri_v = tri_v;
+        for (uint32_t f = 0; f < ntri; ++f) {
+            const uint32_t *vi = tri_v + 3ull * f;
+            TriHit h;
+            if (!triangle_t(load_f3(vpos, vi[0]), load_f3(vpos, vi[1]), load_f3(vpos, vi[2]), ray, h)) continue;
+            if (h.t >= is.t) continue;
+            triangle_full(P, f, 0u, ray, is);
+            hit = true;
+        }
+    }
+    V3 ng = normalize(cross(is.gu, is.gv));
+    V3 ns = is.has_n ? normalize(is.n) : normalize(cross(is.su, is.sv));
+    out[0] = hit ? 1.0 : 0.0; out[1] = is.t;
+    out[2] = ng.x; out[3] = ng.y; out[4] = ng.z; out[5] = ns.x; out[6] = ns.y; out[7] = ns.z;
+}
+// surface.rs:194-200
+__global__ void kat_si_kernel(V3 o, V3 d, double t, V3 dpdu, V3 dpdv, double *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    V3 wo = -normalize(d);
+    V3 ng = face_forward(normalize(cross(dpdu, dpdv)), wo);
+    (void)o; (void)t;
+    out[0] = ng.x; out[1] = ng.y; out[2] = ng.z;
+}
+__global__ void math_kernel(int op, size_t n, const double *a, const double *b, double *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    switch (op) {
+    case 0: r = sqrt(a[i]); break;
+    case 1: r = a[i] / b[i]; break;
+    case 2: r = p_sin(a[i]); break;
+    case 3: r = p_cos(a[i]); break;
+    case 4: r = p_atan2(a[i], b[i]); break;
+    case 5: r = p_acos(a[i]); break;
+    case 6: r = fmin_(a[i], b[i]); break;
+    case 7: r = fmax_(a[i], b[i]); break;
+    case 8: r = (double)to_byte(a[i]); break;
+    default: r = 0.0; break;
+    }
+    out[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-callable launchers (used by capi.cpp)
+// ------------------------------------------------------------------------------------------
+hipError_t launch_trace(const DParams &P, bool stats, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
+    size_t lds = (size_t)stack_depth * 256u * sizeof(uint32_t);
+    if (stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(256), lds, stream, P);
+    else hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(256), lds, stream, P);
+    return hipGetLastError();
+}
+hipError_t trace_occupancy(uint32_t stack_depth, int *blocks_per_cu) {
+    size_t lds = (size_t)stack_depth * 256u * sizeof(uint32_t);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false>, 256, lds);
+}
+hipError_t trace_set_lds_limit(size_t bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+hipError_t launch_kat(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d, double *out,
+                      hipStream_t stream) {
+    hipLaunchKernelGGL(kat_kernel, dim3(1), dim3(64), 0, stream, kind, params, vpos, tri_v, ntri, o, d, out);
+    return hipGetLastError();
+}
+hipError_t launch_kat_si(V3 o, V3 d, double t, V3 dpdu, V3 dpdv, double *out, hipStream_t stream) {
+    hipLaunchKernelGGL(kat_si_kernel, dim3(1), dim3(64), 0, stream, o, d, t, dpdu, dpdv, out);
+    return hipGetLastError();
+}
+hipError_t launch_math(int op, size_t n, const double *a, const double *b, double *out, hipStream_t stream) {
+    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(math_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, op, n, a, b, out);
+    return hipGetLastError();
+}
+
+} // namespace lg

@@ -1,0 +1,237 @@
+"""Synthetic scenes of BASELINE.json's configs, built through the reference-shaped API.
+
+Every builder takes an `api` (a bound `lasgun_amd._capi.Api`) and issues exactly the calls a
+user of the reference would make (`Scene::new`, `set_perspective_camera`, `Aggregate::add_sphere`
+...), so the same function drives the product and -- in tests only -- the CPU oracle.
+Templates: /root/reference/README.md:57-94, src/examples/simple.rs:7-41,
+src/examples/cornell.rs:7-69.  The reference's .obj meshes are Git-LFS stubs, so the plane is
+the 4-vertex/2-face OBJ of src/shape/triangle.rs:412-421 and bigger meshes are generated here.
+"""
+import math
+
+# OBJ text of the reference's own inline plane fixture (src/shape/triangle.rs:412-421)
+PLANE_OBJ = """o plane
+v -1 0 -1
+v 1 0 -1
+v 1 0 1
+v -1 0 1
+
+f 1 2 3
+f 1 3 4
+"""
+
+MASK64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    """Deterministic PRNG for scene generation (never used at render time)."""
+
+    def __init__(self, seed):
+        self.s = seed & MASK64
+
+    def next_u64(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        return z ^ (z >> 31)
+
+    def next_f64(self):
+        return (self.next_u64() >> 11) * (1.0 / 9007199254740992.0)
+
+    def uniform(self, lo, hi):
+        return lo + (hi - lo) * self.next_f64()
+
+
+def readme_scene(api):
+    """Config 1a: README.md:57-94 -- one sphere, one point light."""
+    scene = api.Scene.new()
+    camera = scene.set_perspective_camera(45.0)
+    camera.look_at([0, 0, 0], [0, 0, 1], [0, 1, 0])
+    scene.add_point_light([100, 200, 400], [0.8, 0.8, 0.8], [1, 0, 0])
+    mat = api.Material.plastic([0.7, 1.0, 0.7], [0.5, 0.7, 0.5], 0.25)
+    node = api.Aggregate.new()
+    node.add_sphere([0, 0, 100], 50, mat)
+    scene.set_root(node)
+    return scene
+
+
+def simple_scene(api, supersampling=2, reflect=False):
+    """Config 1b: src/examples/simple.rs:7-41 (simplereflect.rs when reflect=True) minus the LFS mesh."""
+    scene = api.Scene.new()
+    scene.set_ambient_light([0.2, 0.2, 0.2])
+    if reflect:
+        scene.set_radial_background([0.93, 0.87, 0.36], [0.94, 0.6, 0.1], 0.5)
+        scene.set_max_recursion_depth(4)
+    else:
+        scene.set_radial_background([0.26, 0.78, 0.67], [0.1, 0.09, 0.33], 0.5)
+    camera = scene.set_perspective_camera(45.0)
+    camera.look_at([25.0, 0.0, 800.0], [25.0, 0.0, 0.0], [0.0, 1.0, 0.0])
+    camera.set_supersampling(supersampling)
+    M = api.Material
+    if reflect:
+        mat0 = M.glass([0.7, 1.0, 0.7], [0.5, 0.7, 0.5], 1.333)
+        mat1 = M.mirror([0.5, 0.5, 0.5])
+        mat2 = M.glass([1.0, 0.6, 0.1], [0.7, 0.7, 1.0], 1.75)
+        mat3 = M.glass([0.7, 0.6, 1.0], [0.5, 0.4, 0.8], 1.5)
+    else:
+        mat0 = M.plastic([0.7, 1.0, 0.7], [0.5, 0.7, 0.5], 0.25)
+        mat1 = M.plastic([0.5, 0.5, 0.5], [0.5, 0.7, 0.5], 0.25)
+        mat2 = M.plastic([1.0, 0.6, 0.1], [0.5, 0.7, 0.5], 0.25)
+        mat3 = M.plastic([0.7, 0.6, 1.0], [0.5, 0.4, 0.8], 0.25)
+    scene.add_point_light([-100.0, 150.0, 400.0], [0.9, 0.9, 0.9], [1.0, 0.0, 0.0])
+    scene.add_point_light([400.0, 100.0, 150.0], [0.7, 0.0, 0.7], [1.0, 0.0, 0.0])
+    root = scene.root
+    root.add_sphere([0.0, 0.0, -400.0], 100.0, mat0)
+    root.add_sphere([200.0, 50.0, -100.0], 150.0, mat0)
+    root.add_sphere([0.0, -1200.0, -500.0], 1000.0, mat1)
+    root.add_sphere([-100.0, 25.0, -300.0], 50.0, mat2)
+    root.add_sphere([0.0, 100.0, -250.0], 25.0, mat0)
+    root.add_cube([-200.0, -125.0, 0.0], 100.0, mat3)
+    return scene
+
+
+def _cornell_shell(api, scene, supersampling):
+    """Camera, light and the five plane walls of src/examples/cornell.rs:7-62."""
+    scene.set_ambient_light([0.2, 0.2, 0.2])
+    camera = scene.set_perspective_camera(60.0)
+    camera.look_at([0.0, 0.0, 5.0], [0.0, 0.0, 0.0], [0.0, 1.0, 0.0])
+    camera.set_supersampling(supersampling)
+    M = api.Material
+    white = M.plastic([0.9, 0.9, 0.9], [0.5, 0.7, 0.5], 0.25)
+    r = M.plastic([1.0, 0.0, 0.0], [0.5, 0.7, 0.5], 0.25)
+    g = M.plastic([0.0, 1.0, 0.0], [0.5, 0.7, 0.5], 0.25)
+    plane = scene.parse_obj(PLANE_OBJ)
+    scene.add_point_light([0.0, 1.75, 0.0], [0.9, 0.9, 0.9], [1.0, 0.0, 0.0])
+    A = api.Aggregate
+
+    floor = A.new(); floor.scale(2.0, 1.0, 2.0); floor.translate([0.0, -2.0, 0.0]); floor.add_obj_of(plane, white)
+    scene.root.add_group(floor)
+    ceiling = A.new(); ceiling.scale(2.0, 1.0, 2.0); ceiling.translate([0.0, 2.0, 0.0]); ceiling.add_obj_of(plane, white)
+    scene.root.add_group(ceiling)
+    left = A.new(); left.scale(2.0, 1.0, 2.0); left.rotate_z(90.0); left.translate([-2.0, 0.0, 0.0]); left.add_obj_of(plane, r)
+    scene.root.add_group(left)
+    right = A.new(); right.scale(2.0, 1.0, 2.0); right.rotate_z(90.0); right.translate([2.0, 0.0, 0.0]); right.add_obj_of(plane, g)
+    scene.root.add_group(right)
+    back = A.new(); back.scale(2.0, 1.0, 2.0); back.rotate_x(90.0); back.translate([0.0, 0.0, -2.0]); back.add_obj_of(plane, white)
+    scene.root.add_group(back)
+    return white
+
+
+def cornell_scene(api, variant="plastic", supersampling=0):
+    """Config 2: cornell.rs with 1 spp.  variant "plastic" (2P, the primary+shadow metric scene) or
+    "glass" (2G, the reference's own materials: recursion 3)."""
+    scene = api.Scene.new()
+    white = _cornell_shell(api, scene, supersampling)
+    if variant == "glass":
+        mat = api.Material.glass([1.0, 0.7, 1.0], [0.7, 1.0, 0.7], 1.25)
+    elif variant == "plastic":
+        mat = white
+    else:
+        raise ValueError(variant)
+    scene.root.add_sphere([1.0, -1.25, 0.0], 1.0, mat)
+    scene.root.add_cube([-1.999, -1.999, 0.0], 1.0, mat)
+    return scene
+
+
+PALETTE = [
+    [0.9, 0.9, 0.9], [1.0, 0.2, 0.2], [0.2, 1.0, 0.2], [0.2, 0.3, 1.0],
+    [1.0, 0.8, 0.1], [0.8, 0.2, 0.9], [0.1, 0.8, 0.8], [0.95, 0.5, 0.1],
+]
+
+
+def spheres_scene(api, nspheres=1024, seed=0x1A560001, supersampling=0):
+    """Config 3 (headline): Cornell shell + `nspheres` random plastic spheres, direct children of root.
+    Draw order per sphere: cx, cy, cz, r, material index (SplitMix64, doubles = (x>>11)*2^-53)."""
+    scene = api.Scene.new()
+    _cornell_shell(api, scene, supersampling)
+    mats = [api.Material.plastic(kd, [0.5, 0.7, 0.5], 0.25) for kd in PALETTE]
+    rng = SplitMix64(seed)
+    root = scene.root
+    for _ in range(nspheres):
+        cx = rng.uniform(-1.8, 1.8)
+        cy = rng.uniform(-1.8, 1.8)
+        cz = rng.uniform(-1.8, 1.8)
+        r = rng.uniform(0.02, 0.06)
+        mi = min(int(rng.next_f64() * len(mats)), len(mats) - 1)
+        root.add_sphere([cx, cy, cz], r, mats[mi])
+    return scene
+
+
+def torus_obj(nu=224, nv=224, R=0.9, r=0.35, normals=True):
+    """OBJ text of a torus: nu*nv quads -> 2*nu*nv triangles (224x224 -> 100,352).
+    Coordinates are printed with %.6f and parsed back as f32 by the OBJ reader."""
+    lines = ["o torus"]
+    for i in range(nu):
+        u = 2.0 * math.pi * i / nu
+        cu, su = math.cos(u), math.sin(u)
+        for j in range(nv):
+            v = 2.0 * math.pi * j / nv
+            cv, sv = math.cos(v), math.sin(v)
+            x = (R + r * cv) * cu
+            y = r * sv
+            z = (R + r * cv) * su
+            lines.append("v %.6f %.6f %.6f" % (x, y, z))
+    if normals:
+        for i in range(nu):
+            u = 2.0 * math.pi * i / nu
+            cu, su = math.cos(u), math.sin(u)
+            for j in range(nv):
+                v = 2.0 * math.pi * j / nv
+                cv, sv = math.cos(v), math.sin(v)
+                lines.append("vn %.6f %.6f %.6f" % (cv * cu, sv, cv * su))
+    def vid(i, j):
+        return (i % nu) * nv + (j % nv) + 1
+    for i in range(nu):
+        for j in range(nv):
+            a, b, c, d = vid(i, j), vid(i + 1, j), vid(i + 1, j + 1), vid(i, j + 1)
+            if normals:
+                lines.append("f %d//%d %d//%d %d//%d" % (a, a, d, d, c, c))
+                lines.append("f %d//%d %d//%d %d//%d" % (a, a, c, c, b, b))
+            else:
+                lines.append("f %d %d %d" % (a, d, c))
+                lines.append("f %d %d %d" % (a, c, b))
+    return "\n".join(lines) + "\n"
+
+
+def mesh_scene(api, nu=224, nv=224, material="glass", smoothing=True, supersampling=0):
+    """Config 4: Cornell shell + a generated torus mesh in a transformed group + a mirror sphere."""
+    scene = api.Scene.new()
+    scene.set_mesh_smoothing(smoothing)
+    _cornell_shell(api, scene, supersampling)
+    M = api.Material
+    if material == "glass":
+        mat = M.glass([1.0, 0.7, 1.0], [0.7, 1.0, 0.7], 1.25)
+    elif material == "metal":
+        mat = M.metal([0.2, 0.9, 1.1], [3.9, 2.4, 2.2], 0.1, 0.1)
+    elif material == "plastic":
+        mat = M.plastic([0.2, 0.3, 1.0], [0.5, 0.7, 0.5], 0.25)
+    elif material == "default":
+        mat = None
+    else:
+        raise ValueError(material)
+    mesh = scene.parse_obj(torus_obj(nu, nv, normals=True))
+    grp = api.Aggregate.new()
+    grp.scale(1.2, 1.2, 1.2)
+    grp.rotate_x(35.0)
+    grp.rotate_y(30.0)
+    if mat is None:
+        grp.add_obj(mesh)
+    else:
+        grp.add_obj_of(mesh, mat)
+    scene.root.add_group(grp)
+    scene.root.add_sphere([1.1, -1.4, 0.6], 0.6, M.mirror([0.5, 0.5, 0.5]))
+    return scene
+
+
+def mixed_scene(api, nspheres=1024, nu=224, nv=224, supersampling=0):
+    """Config 5: config 3's spheres + config 4's mesh (plastic) in the shell."""
+    scene = spheres_scene(api, nspheres=nspheres, supersampling=supersampling)
+    mesh = scene.parse_obj(torus_obj(nu, nv, normals=True))
+    grp = api.Aggregate.new()
+    grp.scale(1.2, 1.2, 1.2)
+    grp.rotate_x(35.0)
+    grp.rotate_y(30.0)
+    grp.add_obj_of(mesh, api.Material.plastic([0.2, 0.3, 1.0], [0.5, 0.7, 0.5], 0.25))
+    scene.root.add_group(grp)
+    return scene

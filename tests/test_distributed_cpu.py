@@ -1,0 +1,59 @@
+"""The N>1 path on CPU: world_size-2 gloo, row tiles rendered by the oracle (stand-in for the
+GPU renderer), one gather, image identical to a single full render."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lasgun_amd.distributed import gather_tiles, max_tile_rows, row_tile
+
+W, H = 40, 37  # odd height: tiles of 19 and 18 rows
+
+
+def test_row_tiles_cover_exactly():
+    for world in (1, 2, 3, 4, 8):
+        for h in (1, 7, 8, 37, 4096):
+            rows = [row_tile(r, world, h) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == h
+            for a, b in zip(rows, rows[1:]):
+                assert a[1] == b[0]
+            assert max(y1 - y0 for y0, y1 in rows) == max_tile_rows(world, h)
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_lib import oracle
+    from lasgun_amd import scenes as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        o = oracle()
+        acc = o.Accel(S.cornell_scene(o, "plastic"))
+        # render this rank's rows through capture_subset semantics: full oracle film, keep the tile
+        film = o.Film(W, H)
+        o.capture_subset(0, 1, acc, film)
+        y0, y1 = row_tile(rank, world, H)
+        tile = torch.from_numpy(film.pixels()[y0:y1].copy())
+        full = gather_tiles(tile, W, H, rank, world)
+        if rank == 0:
+            np.save(out_path, full.numpy())
+        else:
+            assert full is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    out = str(tmp_path / "full.npy")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    from oracle_lib import oracle
+    from lasgun_amd import scenes as S
+    o = oracle()
+    want = o.render(S.cornell_scene(o, "plastic"), (W, H)).pixels()
+    assert np.array_equal(np.load(out), want)
