@@ -15,7 +15,7 @@ from ._capi import Api, CStats, LasgunError, ObjError  # noqa: F401
 from . import scenes  # noqa: F401
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
-LIB_PATH = _os.path.join(_HERE, "liblasgun_hip.so")
+LIB_PATH = _os.environ.get("LASGUN_HIP_LIB") or _os.path.join(_HERE, "liblasgun_hip.so")  # env override: A/B builds
 
 if not _os.path.exists(LIB_PATH):
     raise ImportError(

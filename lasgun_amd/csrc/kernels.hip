@@ -30,6 +30,14 @@
 #include "dscene.h"
 #include "trig.h"
 
+#ifndef LG_TRAVERSE_INLINE
+#define LG_TRAVERSE_INLINE __forceinline__
+#endif
+#define LG_BLOCK 256 // threads per workgroup; also the per-entry stride (in dwords) of the LDS stacks
+#ifndef LG_WAVES_PER_SIMD
+#define LG_WAVES_PER_SIMD 4 // register budget: 512 / 4 = 128 VGPRs per lane
+#endif
+
 namespace lg {
 
 // ------------------------------------------------------------------------------------------
@@ -224,106 +232,133 @@ struct Best {
 
 // BVHAccel::intersect over the whole nested scene graph (bvh.rs:461-522), one lane = one ray.
 // `stack` is this lane's LDS stack: entry i lives at stack[i * stride].
+//
+// Control flow is "while-while": all lanes of the wavefront first descend interior nodes until
+// each has reached a leaf (or finished), then all process their leaf primitives together, so
+// the two instruction streams are not interleaved lane by lane.  A lane's own visit sequence
+// (near child first by dir_is_neg[axis], leaf primitives in order[], nested accels entered in
+// place) is exactly the reference's, which is what decides ties between equal t.
+struct Trav {
+    Ray ray;             // ray in the current accel's local space
+    uint32_t accel;      // current accel instance
+    uint32_t node_base, prim_base;
+    uint32_t cur;        // node index relative to node_base
+    uint32_t sp, base;   // stack pointer / first entry of the current accel level
+    uint32_t li, le;     // leaf cursor (absolute primref indices)
+    bool in_leaf, done, level_done;
+};
+
+// leave the current node / leaf: next pending node of this accel level, or flag the level as exhausted
+__device__ __forceinline__ void trav_pop(Trav &T, uint32_t *stack, uint32_t stride) {
+    T.in_leaf = false;
+    if (T.sp != T.base) {
+        --T.sp;
+        T.cur = stack[T.sp * stride];
+    } else {
+        T.level_done = true;
+    }
+}
+
 template <bool STATS>
-__device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool anyhit, uint32_t *stack, uint32_t stride,
+__device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, bool anyhit, uint32_t *stack, uint32_t stride,
                                          Best &best, Counters &cnt) {
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
-    uint32_t accel = 0;
-    const DAccel *A = P.accels;
-    Ray ray = ray_to_local(A->minv, wray);
+    Trav T;
+    {
+        const DAccel *A = P.accels;
+        T.ray = ray_to_local(A->minv, wray);
+        T.accel = 0; T.node_base = A->node_base; T.prim_base = A->prim_base;
+        T.cur = 0; T.sp = 0; T.base = 0; T.li = 0; T.le = 0; T.in_leaf = false; T.done = false; T.level_done = false;
+    }
     if (STATS) cnt.entries++;
-    uint32_t node_base = A->node_base, prim_base = A->prim_base;
-    uint32_t cur = 0;      // node index relative to node_base
-    uint32_t sp = 0, base = 0;
-    uint32_t li = 0, le = 0; // leaf cursor (absolute primref indices)
-    bool in_leaf = false;
-    for (;;) {
-        if (!in_leaf) {
-            const DNode *nd = P.nodes + (node_base + cur);
-            // one 64-byte record: four 16-byte loads from a single line
+    while (!T.done) {
+        // ---- phase A: interior nodes
+        while (!T.in_leaf && !T.level_done) {
+            const DNode *nd = P.nodes + (T.node_base + T.cur);
+            // one 64-byte record = four 16-byte loads from a single line, all issued before the
+            // slab test; link/meta are decoded branch-free so the compiler cannot sink their load
+            // behind the hit test (that would put a second memory latency on the critical path)
             double bmin[3] = {nd->bmin[0], nd->bmin[1], nd->bmin[2]};
             double bmax[3] = {nd->bmax[0], nd->bmax[1], nd->bmax[2]};
             uint32_t link = nd->link, meta = nd->meta;
             if (STATS) cnt.nodes++;
-            bool hitbox = slab_intersects(bmin, bmax, ray);
-            if (hitbox && !(meta & NODE_LEAF)) {
-                // near child first (bvh.rs:493-504)
-                uint32_t axis = meta & 3u;
-                bool neg = (axis == 0 ? ray.dinv.x : (axis == 1 ? ray.dinv.y : ray.dinv.z)) < 0.0;
-                uint32_t far_node = neg ? cur + 1 : link;
-                cur = neg ? link : cur + 1;
-                stack[sp * stride] = far_node;
-                ++sp;
-                continue;
-            }
-            if (hitbox) {
-                li = prim_base + link;
-                le = li + (meta & 0xFFFFu);
-                in_leaf = true;
+            bool hit = slab_intersects(bmin, bmax, T.ray);
+            bool leaf = (meta & NODE_LEAF) != 0u;
+            uint32_t axis = meta & 3u;
+            uint32_t count = meta & 0xFFFFu;
+            bool neg = (axis == 0 ? T.ray.dinv.x : (axis == 1 ? T.ray.dinv.y : T.ray.dinv.z)) < 0.0; // bvh.rs:463,496
+            uint32_t near_node = neg ? link : T.cur + 1;
+            uint32_t far_node = neg ? T.cur + 1 : link;
+            bool descend = hit && !leaf;
+            bool open_leaf = hit && leaf && count != 0u;
+            if (descend) { // near child first, far child on the stack (bvh.rs:493-504)
+                stack[T.sp * stride] = far_node;
+                ++T.sp;
+                T.cur = near_node;
+            } else if (open_leaf) {
+                T.li = T.prim_base + link;
+                T.le = T.li + count;
+                T.in_leaf = true;
             } else {
-                li = le = 0;
-                in_leaf = true; // empty leaf -> falls through to the pop below
+                trav_pop(T, stack, stride);
             }
         }
-        // ---- leaf: primitives in order[] sequence (bvh.rs:481-488)
-        bool entered = false;
-        while (li < le) {
-            uint32_t ref = P.primref[li++];
+        // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
+        while (T.in_leaf) {
+            uint32_t ref = P.primref[T.li++];
             uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
+            bool accepted = false;
+            double t = 0.0;
             if (kind == PK_SPHERE) {
                 if (STATS) cnt.spheres++;
                 DSphere s = P.spheres[idx];
                 bool inside;
-                double t = sphere_t(ray, V3{s.cx, s.cy, s.cz}, s.r, inside);
-                if (t < 0.0) continue;
-                if (t >= best.t) continue;
-                best.t = t; best.ref = ref; best.accel = accel;
+                t = sphere_t(T.ray, V3{s.cx, s.cy, s.cz}, s.r, inside);
+                accepted = !(t < 0.0) && !(t >= best.t);
             } else if (kind == PK_TRIANGLE) {
                 if (STATS) cnt.triangles++;
                 const uint32_t *vi = P.tri_v + 3ull * idx;
                 V3 p0 = load_f3(P.vpos, vi[0]), p1 = load_f3(P.vpos, vi[1]), p2 = load_f3(P.vpos, vi[2]);
                 TriHit h;
-                if (!triangle_t(p0, p1, p2, ray, h)) continue;
-                if (h.t >= best.t) continue;
-                best.t = h.t; best.ref = ref; best.accel = accel;
+                if (triangle_t(p0, p1, p2, T.ray, h)) { t = h.t; accepted = !(t >= best.t); }
             } else if (kind == PK_CUBOID) {
                 if (STATS) cnt.cuboids++;
                 DCuboid c = P.cuboids[idx];
-                double t; V3 d0, d1;
-                if (!cuboid_hit<false>(c.mn, c.mx, ray, t, d0, d1)) continue;
-                if (t >= best.t) continue;
-                best.t = t; best.ref = ref; best.accel = accel;
+                V3 d0, d1;
+                if (cuboid_hit<false>(c.mn, c.mx, T.ray, t, d0, d1)) accepted = !(t >= best.t);
             } else {
                 // nested BVHAccel (Group / Mesh): save this level, re-express the ray (bvh.rs:462)
-                stack[sp * stride] = li; stack[(sp + 1) * stride] = le; stack[(sp + 2) * stride] = base;
-                sp += 3; base = sp;
-                accel = idx;
+                stack[T.sp * stride] = T.li; stack[(T.sp + 1) * stride] = T.le; stack[(T.sp + 2) * stride] = T.base;
+                T.sp += 3; T.base = T.sp;
+                T.accel = idx;
                 const DAccel *C = P.accels + idx;
-                ray = ray_to_local(C->minv, ray);
+                T.ray = ray_to_local(C->minv, T.ray);
                 if (STATS) cnt.entries++;
-                node_base = C->node_base; prim_base = C->prim_base;
-                cur = 0; in_leaf = false; entered = true;
+                T.node_base = C->node_base; T.prim_base = C->prim_base;
+                T.cur = 0; T.in_leaf = false;
                 break;
             }
-            if (anyhit && best.t < 1.0) return; // occluded: point.rs:49 only asks isect.t < 1.0
+            if (accepted) {
+                best.t = t; best.ref = ref; best.accel = T.accel;
+                if (anyhit && t < 1.0) { T.done = true; T.in_leaf = false; break; } // occluded: point.rs:49 only asks isect.t < 1.0
+            }
+            if (T.li >= T.le) trav_pop(T, stack, stride);
         }
-        if (entered) continue;
-        // ---- pop
-        while (sp == base) { // this accel is exhausted
-            if (accel == 0) return;
-            base = stack[(sp - 1) * stride]; le = stack[(sp - 2) * stride]; li = stack[(sp - 3) * stride];
-            sp -= 3;
-            accel = (uint32_t)P.accels[accel].parent;
-            ray = local_ray(P, wray, accel);
-            const DAccel *Q = P.accels + accel;
-            node_base = Q->node_base; prim_base = Q->prim_base;
-            if (li < le) break; // resume the parent's leaf
+        // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
+        if (T.level_done) {
+            T.level_done = false;
+            if (T.accel == 0) { T.done = true; }
+            else {
+                T.base = stack[(T.sp - 1) * stride]; T.le = stack[(T.sp - 2) * stride]; T.li = stack[(T.sp - 3) * stride];
+                T.sp -= 3;
+                T.accel = (uint32_t)P.accels[T.accel].parent;
+                T.ray = local_ray(P, wray, T.accel);
+                const DAccel *Q = P.accels + T.accel;
+                T.node_base = Q->node_base; T.prim_base = Q->prim_base;
+                if (T.li < T.le) T.in_leaf = true;
+                else trav_pop(T, stack, stride);
+            }
         }
-        if (sp == base && li >= le && accel == 0) return; // (unreachable; kept as a guard)
-        if (li < le) { in_leaf = true; continue; }
-        --sp;
-        cur = stack[sp * stride];
-        in_leaf = false;
     }
 }
 
@@ -594,13 +629,31 @@ __device__ __forceinline__ V3 frame_get3(const DParams &P, uint32_t depth, int f
 
 extern __shared__ uint32_t lds_stack[];
 
+// Shading frame of a hit from the ray that found it (resolve_hit + SurfaceInteraction::from,
+// surface.rs:158-183).  Pure function of (ray, best): recomputed after each shadow traversal
+// instead of being kept in registers across it, which is what lets 4-5 waves share a SIMD.
+__device__ __forceinline__ void shade_frame(const DParams &P, const Ray &ray, const Best &best, Shade &sh) {
+    Isect is;
+    sh.mat = resolve_hit(P, ray, best, is);
+    sh.wo = -normalize(ray.d);
+    sh.ng = face_forward(normalize(cross(is.gu, is.gv)), sh.wo);
+    sh.ns = is.has_n ? normalize(is.n) : normalize(cross(is.su, is.sv));
+    const double err = 2.220446049250313e-16 * 65536.0; // N::epsilon() * 2^16
+    V3 p = ray.o + ray.d * is.t;
+    V3 p_err = sh.ng * err;
+    sh.p = p + p_err;
+    sh.pm = p - p_err;
+    sh.ss = normalize(is.su);    // si.surface.dpdu (bsdf.rs:34)
+    sh.ts = cross(sh.ns, sh.ss); // bsdf.rs:35
+}
+
 template <bool STATS>
-__global__ void __launch_bounds__(256) trace_kernel(const DParams P) {
+__global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(const DParams P) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + tid;
-    uint32_t *stack = lds_stack + tid; // entry i at stack[i * blockDim.x]: bank = tid % 32 for every i
-    const uint32_t stride = blockDim.x;
+    uint32_t *stack = lds_stack + tid; // entry i at stack[i * LG_BLOCK]: bank = tid % 32 for every i
+    constexpr uint32_t stride = LG_BLOCK;
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (;;) {
@@ -633,73 +686,93 @@ __global__ void __launch_bounds__(256) trace_kernel(const DParams P) {
         double sample_separation = P.ss_distance * pixel_size;
         double sox = ((double)x * P.winv - 0.5) * img_plane_width;
         double soy = (0.5 - (double)(y + 1u) * P.hinv) * img_plane_height;
-        V3 cam_o = P.cam_origin + ((soy * P.pixel_separation) * P.cam_up) + ((sox * P.pixel_separation) * P.cam_aux);
-        V3 cam_d = P.cam_view + (soy * P.cam_up) + (sox * P.cam_aux);
-        V3 updiff = P.cam_up * sample_separation;
-        V3 auxdiff = P.cam_aux * sample_separation;
-        V3 halfdiff = updiff * 0.5 + auxdiff * 0.5;
         const uint32_t dim = P.ss_root;
         const uint32_t nsamples = dim * dim;
         const double weight = 1. / (double)nsamples;
 
         V3 color = vzero(); // integrate.rs:17
         for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
-            uint32_t si = sidx / dim, sj = sidx % dim;
-            V3 dd = cam_d + ((double)sj * updiff) + ((double)si * auxdiff) + halfdiff;
-            Ray ray = ray_new(cam_o, dd);
+            Ray pray; // the ray of the li() invocation being evaluated
+            {
+                V3 cam_o = P.cam_origin + ((soy * P.pixel_separation) * P.cam_up) + ((sox * P.pixel_separation) * P.cam_aux);
+                V3 cam_d = P.cam_view + (soy * P.cam_up) + (sox * P.cam_aux);
+                V3 updiff = P.cam_up * sample_separation;
+                V3 auxdiff = P.cam_aux * sample_separation;
+                V3 halfdiff = updiff * 0.5 + auxdiff * 0.5;
+                uint32_t si = sidx / dim, sj = sidx % dim;
+                V3 dd = cam_d + ((double)sj * updiff) + ((double)si * auxdiff) + halfdiff;
+                pray = ray_new(cam_o, dd);
+            }
             if (STATS) cnt.primary++;
 
-            // ---- li() with an explicit frame stack (integrate.rs:23-80)
-            uint32_t depth = 0;
+            // ---- li() (integrate.rs:23-80) as a state machine with ONE traversal call site:
+            // job 0 = closest hit along `pray`; job 1 = any-hit shadow ray for light `light`.
+            uint32_t depth = 0, light = 0;
+            bool shadow_job = false;
+            Best pbest;              // closest hit of pray
+            V3 hit_p = vzero();      // interaction.p + p_err: origin of the shadow rays
+            V3 output = vzero();     // running sum over lights (integrate.rs:47-66)
             V3 value = vzero();
-            for (;;) { // one iteration = one li() invocation at `depth` along `ray`
-                Best best;
-                traverse<STATS>(P, ray, false, stack, stride, best, cnt);
-                bool have_value = false;
-                if (best.ref == NO_HIT) {
-                    value = background(P, normalize(ray.d)); // integrate.rs:26-28
-                    have_value = true;
+            Ray tray = pray;         // the ray handed to the traversal
+            for (;;) {
+                Best b;
+                traverse<STATS>(P, tray, shadow_job, stack, stride, b, cnt);
+                bool have_value = false, need_shade = false, visible = false;
+#if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 1 /* timing only: primary traversal, nothing else */
+                value = V3{b.t, (double)b.ref, (double)b.accel}; have_value = true; (void)need_shade; (void)visible;
+                if (false)
+#endif
+                if (!shadow_job) {
+                    if (b.ref == NO_HIT) {
+                        value = background(P, normalize(pray.d)); // integrate.rs:26-28
+                        have_value = true;
+                    } else {
+                        if (STATS) cnt.hits++;
+                        pbest = b;
+                        output = vzero();
+                        need_shade = true;
+                    }
                 } else {
-                    if (STATS) cnt.hits++;
-                    Isect is;
-                    Shade sh;
-                    sh.mat = resolve_hit(P, ray, best, is);
-                    const DMaterial m = P.materials[sh.mat];
-                    // SurfaceInteraction::from (surface.rs:158-183)
-                    sh.wo = -normalize(ray.d);
-                    sh.ng = face_forward(normalize(cross(is.gu, is.gv)), sh.wo);
-                    sh.ns = is.has_n ? normalize(is.n) : normalize(cross(is.su, is.sv));
-                    const double err = 2.220446049250313e-16 * 65536.0;
-                    V3 p = ray.o + ray.d * is.t;
-                    V3 p_err = sh.ng * err;
-                    sh.p = p + p_err;
-                    sh.pm = p - p_err;
-                    sh.ss = normalize(is.su);   // si.surface.dpdu (bsdf.rs:34)
-                    sh.ts = cross(sh.ns, sh.ss); // bsdf.rs:35
-                    V3 n = sh.ns;
-
-                    // direct lighting (integrate.rs:47-66, point.rs:42-54)
-                    V3 output = vzero();
-                    for (uint32_t l = 0; l < P.nlights; ++l) {
-                        const DLight L = P.lights[l];
-                        V3 lpos{L.pos[0], L.pos[1], L.pos[2]};
-                        V3 wi = lpos - sh.p;
-                        Ray sray = ray_new(sh.p, wi);
+                    visible = !(b.t < 1.0); // point.rs:49
+                    need_shade = visible || (light + 1 == P.nlights);
+                    if (!need_shade) {
+                        ++light;
+                        const DLight L = P.lights[light];
+                        tray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p);
                         if (STATS) cnt.shadow++;
-                        Best sb;
-                        traverse<STATS>(P, sray, true, stack, stride, sb, cnt);
-                        if (sb.t < 1.0) continue;
+                        continue;
+                    }
+                }
+                if (need_shade) {
+                    Shade sh;
+                    shade_frame(P, pray, pbest, sh);
+                    const DMaterial m = P.materials[sh.mat];
+                    V3 n = sh.ns;
+                    if (shadow_job && visible) { // integrate.rs:53-65
+                        const DLight L = P.lights[light];
+                        V3 wi = V3{L.pos[0], L.pos[1], L.pos[2]} - sh.p;
                         double d = magnitude(wi);
                         double f_att = L.falloff[0] + L.falloff[1] * d + L.falloff[2] * d * d;
-                        if (f_att == 0.0) continue;
-                        wi = normalize(wi);
-                        double wi_dot_n = dot(wi, n);
-                        V3 f = bsdf_f(m, sh, sh.wo, wi);
-                        V3 li_col{L.intensity[0], L.intensity[1], L.intensity[2]};
-                        output = output + (mul_ew(PI * li_col, f) * wi_dot_n / f_att);
+                        if (f_att != 0.0) {
+                            wi = normalize(wi);
+                            double wi_dot_n = dot(wi, n);
+                            V3 f = bsdf_f(m, sh, sh.wo, wi);
+                            V3 li_col{L.intensity[0], L.intensity[1], L.intensity[2]};
+                            output = output + (mul_ew(PI * li_col, f) * wi_dot_n / f_att);
+                        }
                     }
+                    uint32_t next_light = shadow_job ? light + 1 : 0;
+                    if (next_light < P.nlights) {
+                        light = next_light;
+                        shadow_job = true;
+                        hit_p = sh.p;
+                        const DLight L = P.lights[light];
+                        tray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
+                        if (STATS) cnt.shadow++;
+                        continue;
+                    }
+                    // ---- all lights done
                     output = output + mul_ew(P.ambient, bsdf_f(m, sh, sh.wo, n)); // integrate.rs:67
-
                     // specular children (integrate.rs:69-77,82-132)
                     bool has_r = false, has_t = false;
                     Sample sr, st;
@@ -727,14 +800,16 @@ __global__ void __launch_bounds__(256) trace_kernel(const DParams P) {
                             frame_put3(P, depth, FR_SPEC_R, gtid, sr.spectrum);
                             frame_at(P, depth, FR_STATE, gtid) = has_t ? 1.0 : 2.0;
                             V3 wr = -1.0 * sh.wo + 2.0 * dot(sh.wo, sh.ns) * sh.ns; // bxdf::util::reflect (integrate.rs:100)
-                            ray = ray_new(sh.p, wr);
+                            pray = ray_new(sh.p, wr);
                         } else {
                             frame_put3(P, depth, FR_ACC, gtid, output + vzero());
                             frame_at(P, depth, FR_STATE, gtid) = 3.0;
-                            ray = ray_new(sh.pm, st.wi);
+                            pray = ray_new(sh.pm, st.wi);
                         }
                         if (STATS) cnt.secondary++;
                         depth += 1;
+                        shadow_job = false;
+                        tray = pray;
                     }
                 }
                 // ---- return `value` up the frame stack
@@ -758,8 +833,10 @@ __global__ void __launch_bounds__(256) trace_kernel(const DParams P) {
                         if (state == 1.0) {
                             frame_put3(P, fd, FR_ACC, gtid, acc);
                             frame_at(P, fd, FR_STATE, gtid) = 3.0;
-                            ray = ray_new(frame_get3(P, fd, FR_TO, gtid), frame_get3(P, fd, FR_TD, gtid));
+                            pray = ray_new(frame_get3(P, fd, FR_TO, gtid), frame_get3(P, fd, FR_TD, gtid));
                             if (STATS) cnt.secondary++;
+                            shadow_job = false;
+                            tray = pray;
                             have_value = false; // trace the transmitted child at depth fd + 1
                         } else {
                             value = acc + vzero();
