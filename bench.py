@@ -140,6 +140,14 @@ def main():
     kernel_ms_avg = float(tmax[1])  # slowest rank's average launch: the one that bounds the frame
     rays = total["primary_rays"] + total["shadow_rays"] + total["secondary_rays"]
 
+    # PCIe-inclusive figure (never `value`): lg_capture into a HOST film = host BVH build + upload + render + 64 MiB D2H
+    e2e_ms = None
+    if rank == 0 and world == 1:
+        film = G.Film(w, h)
+        t0 = time.perf_counter()
+        G.capture(scene, film)
+        e2e_ms = (time.perf_counter() - t0) * 1e3
+
     if rank == 0:
         value = rays * args.steps / elapsed / 1e6
         # roofline of the dominant (only) kernel: this rank's launch
@@ -153,7 +161,8 @@ def main():
             "config": {"workload": "configs[2]: %dx%d, Cornell shell + 1024 random plastic spheres (SplitMix64 0x1A560001), 1 spp, 1 point light" % (w, h),
                        "rays_per_frame": rays, "primary": total["primary_rays"], "shadow": total["shadow_rays"],
                        "secondary": total["secondary_rays"], "parallelism": "row-tiles x%d + 1 RCCL gather" % world,
-                       "accel_build_s": accel_build_s},
+                       "accel_build_s": accel_build_s, "host_film_capture_ms": e2e_ms,
+                       "work_per_frame": {k: total[k] for k in ("nodes_tested", "spheres_tested", "cuboids_tested", "triangles_tested", "accel_entries", "hits")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "trace_kernel<false>", "kernel_ms_avg": kernel_ms / max(launches, 1),
                          "algorithmic_bytes_per_launch": my_bytes,

@@ -212,6 +212,19 @@ def test_row_tiles_on_device_assemble_to_the_full_film():
     assert np.array_equal(full.cpu().numpy(), film.pixels())
 
 
+def test_cpp_host_example_matches_oracle(tmp_path):
+    """examples/cornell.cpp (src/examples/cornell.rs through include/lasgun.hpp) == oracle, byte for byte."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    out = str(tmp_path / "cornell.rgba")
+    subprocess.check_call([os.path.join(root, "examples", "cornell"), out, "96"])
+    got = np.fromfile(out, dtype=np.uint8).reshape(96, 96, 4)
+    o = oracle()
+    want = o.render(S.cornell_scene(o, "glass", supersampling=2), (96, 96)).pixels()
+    assert np.array_equal(got, want)
+
+
 def test_errors_instead_of_panics():
     with pytest.raises(la.LasgunError):
         G.Accel(G.Scene.new())  # empty root aggregate

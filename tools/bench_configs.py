@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Time every BASELINE.json config on one GPU (device-resident film) and print one JSON line each.
+Not the driver's bench (that is bench.py, config 3); this fills BASELINE.md's results table."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import lasgun_amd as la  # noqa: E402
+
+G = la.api
+S = la.scenes
+CONFIGS = [
+    ("1a readme 512^2", lambda: S.readme_scene(G), 512),
+    ("1b simple ss2 512^2 (9 spp)", lambda: S.simple_scene(G, 2), 512),
+    ("2P cornell plastic 512^2", lambda: S.cornell_scene(G, "plastic"), 512),
+    ("2G cornell glass 512^2", lambda: S.cornell_scene(G, "glass"), 512),
+    ("3 spheres1024 4096^2", lambda: S.spheres_scene(G), 4096),
+    ("4 mesh100k glass+mirror 4096^2", lambda: S.mesh_scene(G, 224, 224, "glass"), 4096),
+    ("4m mesh100k metal 4096^2", lambda: S.mesh_scene(G, 224, 224, "metal"), 4096),
+    ("5 mixed 8192^2", lambda: S.mixed_scene(G), 8192),
+]
+
+
+def main():
+    only = sys.argv[1:]
+    G.set_device(0)
+    for name, build, size in CONFIGS:
+        if only and not any(o in name for o in only):
+            continue
+        scene = build()
+        t0 = time.perf_counter()
+        acc = G.Accel(scene)
+        build_s = time.perf_counter() - t0
+        film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        st = G.capture_stats(acc, size, size)
+        rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
+        print(json.dumps({"config": name, "ms": round(ms, 3), "Mrays_s": round(rays / ms / 1e3, 1), "rays": rays,
+                          "accel_build_s": round(build_s, 3), "info": G.accel_info(acc), "stats": st}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
