@@ -92,12 +92,14 @@ struct lg_accel {
     DevBuf<int32_t> cuboid_mat;
     DevBuf<uint32_t> tri_v, tri_n, tri_t;
     DevBuf<float> vpos, vnorm, vtex;
+    DevBuf<DLeafRec> leaf_soup;
     DevBuf<DAccel> accels;
     DevBuf<DMaterial> materials;
     DevBuf<DLight> lights;
     // launch resources (mutable: a `const lg_accel*` render call still enqueues work)
     mutable DevBuf<uint32_t> tile_counter;
     mutable DevBuf<double> frames;
+    mutable DevBuf<double> stash;
     mutable DevBuf<DStats> stats;
     mutable DevBuf<uint8_t> staging;    // device film for host-film captures
     mutable DevBuf<double> staging_rad;
@@ -120,7 +122,7 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     DParams P{};
     P.nodes = a.nodes.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
     P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
-    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.accels = a.accels.p; P.materials = a.materials.p;
+    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.accels = a.accels.p; P.materials = a.materials.p;
     P.lights = a.lights.p;
     P.nlights = (uint32_t)a.flat.lights.size();
     P.recursion = s.recursion;
@@ -153,6 +155,16 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
             a.frames.alloc(need);
         }
         P.frames = a.frames.p;
+        P.frame_threads = threads;
+    }
+    if (P.nlights > 0) { // shading frame parked across the shadow traversals
+        unsigned long long threads = (unsigned long long)a.max_blocks * 256ull;
+        size_t need = (size_t)threads * STASH_DOUBLES;
+        if (a.stash.n < need) {
+            HIP_TRY(hipStreamSynchronize(a.stream));
+            a.stash.alloc(need);
+        }
+        P.stash = a.stash.p;
         P.frame_threads = threads;
     }
     if (stats) {
@@ -347,12 +359,12 @@ lg_accel *lg_accel_from(const lg_scene *s) {
         const FlatScene &f = a->flat;
         a->nodes.upload(f.nodes); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
-        a->tri_t.upload(f.tri_t); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
+        a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
         a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
         a->tile_counter.alloc(1);
         a->stats.alloc(1);
         a->device_bytes = f.nodes.size() * sizeof(DNode) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
-                          f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 +
+                          f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 + f.leaf_soup.size() * sizeof(DLeafRec) +
                           f.accels.size() * sizeof(DAccel) + f.materials.size() * sizeof(DMaterial);
         HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
         // per-lane LDS stack: worst case of this scene graph, +2 guard entries

@@ -12,6 +12,12 @@
 //   DSphere[] / DCuboid[] 32/48-byte records; triangles as u32 index triples into f32 vertex
 //               tables (f32 is what obj::ObjData holds; widened on every access exactly like
 //               `.into()`, src/shape/triangle.rs:40-43).
+//   leaf_soup[] the geometry of every primitive again, one 48-byte record per primref slot in
+//               LEAF ORDER (triangle: 9 x f32 positions; sphere: c, r as 4 x f64; cuboid: min, max
+//               as 6 x f64).  The traversal streams a leaf with three aligned 16-byte loads per
+//               slot, issued together with the primref load and one slot ahead, instead of the
+//               primref -> index -> vertex dependent-load chain (the reference builds leaves of
+//               up to 254 triangles, bvh.rs:187,289).
 //   DAccel[]    one per BVHAccel instance: 3x4 m / minv, parent link, root->self chain,
 //               default material, swap_backface.  Mesh instances share nodes and primrefs.
 #pragma once
@@ -39,6 +45,9 @@ struct alignas(32) DSphere {
 };
 struct alignas(16) DCuboid {
     double mn[3], mx[3];
+};
+struct alignas(16) DLeafRec { // 48-byte leaf-ordered geometry record (see header comment)
+    uint32_t w[12];
 };
 struct DMaterial { // == lg_material of include/lasgun_hip.h
     int32_t kind;
@@ -73,6 +82,7 @@ struct DStats { // per-launch counters (stats kernel variant only)
 
 // Per-frame record of the explicit Whitted recursion stack (integrate.rs:69-79), in doubles.
 constexpr int FRAME_DOUBLES = 18;
+constexpr int STASH_DOUBLES = 13; // p(3) ng(3) ns(3) ss(3) material id
 
 struct DParams {
     // ---- scene tables
@@ -88,6 +98,7 @@ struct DParams {
     const float *vpos;
     const float *vnorm;
     const float *vtex;
+    const DLeafRec *leaf_soup; // slot j <-> primref[j]
     const DAccel *accels;
     const DMaterial *materials;
     const DLight *lights;
@@ -118,6 +129,7 @@ struct DParams {
     uint32_t *tile_counter;
     double *frames;        // [recursion][FRAME_DOUBLES][nthreads]
     unsigned long long frame_threads;
+    double *stash;         // [STASH_DOUBLES][nthreads]: shading frame parked across the shadow traversals
     DStats *stats;
 };
 

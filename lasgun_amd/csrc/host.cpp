@@ -557,7 +557,15 @@ struct Flattener {
         mt.bvh = Builder(pb, nf).run();
         append_nodes(mt.bvh, mt.node_base);
         mt.prim_base = (uint32_t)out.primref.size();
-        for (uint32_t o : mt.bvh.order) out.primref.push_back((PK_TRIANGLE << 30) | (mt.tri_base + o));
+        out.leaf_soup.resize(mt.prim_base, DLeafRec{}); // keep slot j of the soup aligned with primref[j]
+        for (uint32_t o : mt.bvh.order) {
+            out.primref.push_back((PK_TRIANGLE << 30) | (mt.tri_base + o));
+            // leaf-ordered copy of the three positions (f32, exactly the table entries), padded to 48 B
+            DLeafRec rec{};
+            for (int k = 0; k < 3; ++k)
+                std::memcpy(&rec.w[3 * k], &obj.position[3 * (size_t)obj.tri[3 * (size_t)o + k].v], 12);
+            out.leaf_soup.push_back(rec);
+        }
         mt.nnodes = (uint32_t)mt.bvh.nodes.size();
         mt.norder = (uint32_t)mt.bvh.order.size();
         mt.root_bounds = mt.bvh.nodes[0].b;
@@ -615,6 +623,7 @@ struct Flattener {
         std::swap(child_f, out.dump_f); std::swap(child_i, out.dump_i); // children dump into fresh vectors
         std::vector<Bounds> pb(n);
         std::vector<uint32_t> ref(n), extra(n, 0);
+        std::vector<DLeafRec> rec(n, DLeafRec{});
         for (size_t i = 0; i < n; ++i) {
             const SceneNode &nd = agg.contents[i];
             switch (nd.kind) {
@@ -625,6 +634,7 @@ struct Flattener {
                 out.sphere_mat.push_back(add_material(nd.mat));
                 pb[i] = b_new(c - V3{r, r, r}, c + V3{r, r, r});
                 ref[i] = (PK_SPHERE << 30) | (uint32_t)(out.spheres.size() - 1);
+                std::memcpy(rec[i].w, &out.spheres.back(), sizeof(DSphere));
                 break;
             }
             case SceneNode::CUBE:   // cuboid.rs:24-30
@@ -637,6 +647,7 @@ struct Flattener {
                 out.cuboid_mat.push_back(add_material(nd.mat));
                 pb[i] = b;
                 ref[i] = (PK_CUBOID << 30) | (uint32_t)(out.cuboids.size() - 1);
+                std::memcpy(rec[i].w, &dc, sizeof(DCuboid));
                 break;
             }
             case SceneNode::MESH: {
@@ -660,8 +671,10 @@ struct Flattener {
         append_nodes(bvh, node_base);
         uint32_t prim_base = (uint32_t)out.primref.size();
         std::vector<uint32_t> extra_in_order(bvh.order.size());
+        out.leaf_soup.resize(prim_base, DLeafRec{});
         for (size_t i = 0; i < bvh.order.size(); ++i) {
             out.primref.push_back(ref[bvh.order[i]]);
+            out.leaf_soup.push_back(rec[bvh.order[i]]);
             extra_in_order[i] = extra[bvh.order[i]];
         }
         out.accels[id].node_base = node_base;
@@ -688,6 +701,7 @@ void flatten_scene(const Scene &scene, FlatScene &out) {
     uint32_t need = 0;
     fl.aggregate(*scene.root, -1, b, need);
     out.max_stack = need;
+    out.leaf_soup.resize(out.primref.size(), DLeafRec{});
     for (const Light &l : scene.lights) {
         DLight d;
         std::memcpy(d.pos, l.pos, sizeof d.pos);

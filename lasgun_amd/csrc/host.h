@@ -114,6 +114,7 @@ struct FlatScene {
     std::vector<int32_t> cuboid_mat;
     std::vector<uint32_t> tri_v, tri_n, tri_t;
     std::vector<float> vpos, vnorm, vtex;
+    std::vector<DLeafRec> leaf_soup; // one per primref slot
     std::vector<DAccel> accels;
     std::vector<DMaterial> materials;
     std::vector<DLight> lights;

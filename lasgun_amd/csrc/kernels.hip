@@ -129,6 +129,49 @@ __device__ __forceinline__ bool triangle_t(V3 p0, V3 p1, V3 p2, const Ray &ray, 
     return true;
 }
 
+// The ray-only part of Triangle::intersect (triangle.rs:186-201): permutation and shear
+// constants.  They depend on the ray alone, so they are computed once per mesh-accel entry
+// instead of once per triangle; the values are the same f64s the reference recomputes.
+struct TriSetup {
+    int kz;
+    double sx, sy, sz;
+};
+__device__ __forceinline__ TriSetup tri_setup(const Ray &ray) {
+    TriSetup s;
+    s.kz = max_dimension(vabs(ray.d));
+    int kx = s.kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    double dx = comp(ray.d, kx), dy = comp(ray.d, ky), dz = comp(ray.d, s.kz);
+    s.sx = -dx / dz; s.sy = -dy / dz; s.sz = 1.0 / dz;
+    return s;
+}
+template <int KZ> __device__ __forceinline__ V3 permute_kz(V3 v) { // (kx, ky, kz) = (KZ+1, KZ+2, KZ) mod 3
+    if (KZ == 0) return V3{v.y, v.z, v.x};
+    if (KZ == 1) return V3{v.z, v.x, v.y};
+    return v;
+}
+// triangle_t with the setup hoisted and the permutation resolved at compile time
+template <int KZ>
+__device__ __forceinline__ bool triangle_t_pre(V3 p0, V3 p1, V3 p2, V3 o, double sx, double sy, double sz, TriHit &h) {
+    V3 p0t = permute_kz<KZ>(p0 - o), p1t = permute_kz<KZ>(p1 - o), p2t = permute_kz<KZ>(p2 - o);
+    p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
+    p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
+    p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+    double e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    double e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    double e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if ((e0 < 0.0 || e1 < 0.0 || e2 < 0.0) && (e0 > 0.0 || e1 > 0.0 || e2 > 0.0)) return false;
+    double det = e0 + e1 + e2;
+    if (det == 0.0) return false;
+    p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+    double tscaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if ((det < 0.0 && tscaled >= 0.0) || (det > 0.0 && tscaled <= 0.0)) return false;
+    double invdet = 1.0 / det;
+    h.b0 = e0 * invdet; h.b1 = e1 * invdet; h.b2 = e2 * invdet;
+    h.t = tscaled * invdet;
+    return true;
+}
+
 __device__ __forceinline__ V3 load_f3(const float *base, uint32_t idx) {
     const float *p = base + 3ull * idx;
     return V3{(double)p[0], (double)p[1], (double)p[2]};
@@ -246,8 +289,54 @@ struct Trav {
     uint32_t sp, base;   // stack pointer / first entry of the current accel level
     uint32_t li, le;     // leaf cursor (absolute primref indices)
     bool in_leaf, done, level_done;
+    uint32_t negmask;    // bit a set <=> dinv[a] < 0 (dir_is_neg, bvh.rs:463)
+    bool mesh;           // current accel is a triangle mesh (every leaf slot is a triangle)
+    TriSetup tri;        // valid while `mesh`
 };
+__device__ __forceinline__ void trav_set_level(const DParams &P, Trav &T, uint32_t accel, const Ray &local) {
+    const DAccel *A = P.accels + accel;
+    T.accel = accel;
+    T.ray = local;
+    T.node_base = A->node_base; T.prim_base = A->prim_base;
+    T.negmask = (local.dinv.x < 0.0 ? 1u : 0u) | (local.dinv.y < 0.0 ? 2u : 0u) | (local.dinv.z < 0.0 ? 4u : 0u);
+    T.mesh = (A->flags & AF_MESH) != 0u;
+    if (T.mesh) T.tri = tri_setup(local);
+}
 
+// leaf-ordered 48-byte geometry records: three 16-byte loads per slot
+struct LeafRec {
+    uint4 a, b, c;
+};
+__device__ __forceinline__ LeafRec load_rec(const DParams &P, uint32_t slot) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(P.leaf_soup + slot);
+    return LeafRec{q[0], q[1], q[2]};
+}
+__device__ __forceinline__ double rec_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+__device__ __forceinline__ double rec_f32(uint32_t w) { return (double)__uint_as_float(w); } // f32 -> f64 `.into()`
+
+// One fat mesh leaf [li, le): the reference's leaf loop (bvh.rs:483-488) specialised for
+// triangles, streaming the leaf-ordered records one slot ahead of the test.
+template <int KZ, bool STATS>
+__device__ __forceinline__ void mesh_leaf(const DParams &P, Trav &T, bool anyhit, Best &best, Counters &cnt) {
+    const V3 o = T.ray.o;
+    const double sx = T.tri.sx, sy = T.tri.sy, sz = T.tri.sz;
+    uint32_t li = T.li;
+    const uint32_t le = T.le, last = le - 1u;
+    LeafRec cur = load_rec(P, li);
+    for (; li < le; ++li) {
+        LeafRec r = cur;
+        cur = load_rec(P, li < last ? li + 1u : last); // prefetch the next slot (clamped: always a valid slot)
+        V3 p0{rec_f32(r.a.x), rec_f32(r.a.y), rec_f32(r.a.z)}, p1{rec_f32(r.a.w), rec_f32(r.b.x), rec_f32(r.b.y)},
+            p2{rec_f32(r.b.z), rec_f32(r.b.w), rec_f32(r.c.x)};
+        if (STATS) cnt.triangles++;
+        TriHit h;
+        if (!triangle_t_pre<KZ>(p0, p1, p2, o, sx, sy, sz, h)) continue;
+        if (h.t >= best.t) continue;
+        best.t = h.t; best.ref = P.primref[li]; best.accel = T.accel;
+        if (anyhit && h.t < 1.0) { T.done = true; break; } // point.rs:49
+    }
+    T.li = le;
+}
 // leave the current node / leaf: next pending node of this accel level, or flag the level as exhausted
 __device__ __forceinline__ void trav_pop(Trav &T, uint32_t *stack, uint32_t stride) {
     T.in_leaf = false;
@@ -264,12 +353,8 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
                                          Best &best, Counters &cnt) {
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
     Trav T;
-    {
-        const DAccel *A = P.accels;
-        T.ray = ray_to_local(A->minv, wray);
-        T.accel = 0; T.node_base = A->node_base; T.prim_base = A->prim_base;
-        T.cur = 0; T.sp = 0; T.base = 0; T.li = 0; T.le = 0; T.in_leaf = false; T.done = false; T.level_done = false;
-    }
+    trav_set_level(P, T, 0u, ray_to_local(P.accels->minv, wray));
+    T.cur = 0; T.sp = 0; T.base = 0; T.li = 0; T.le = 0; T.in_leaf = false; T.done = false; T.level_done = false;
     if (STATS) cnt.entries++;
     while (!T.done) {
         // ---- phase A: interior nodes
@@ -284,9 +369,8 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
             if (STATS) cnt.nodes++;
             bool hit = slab_intersects(bmin, bmax, T.ray);
             bool leaf = (meta & NODE_LEAF) != 0u;
-            uint32_t axis = meta & 3u;
             uint32_t count = meta & 0xFFFFu;
-            bool neg = (axis == 0 ? T.ray.dinv.x : (axis == 1 ? T.ray.dinv.y : T.ray.dinv.z)) < 0.0; // bvh.rs:463,496
+            bool neg = ((T.negmask >> (meta & 3u)) & 1u) != 0u; // dir_is_neg[axis] (bvh.rs:463,496)
             uint32_t near_node = neg ? link : T.cur + 1;
             uint32_t far_node = neg ? T.cur + 1 : link;
             bool descend = hit && !leaf;
@@ -304,45 +388,59 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
             }
         }
         // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
-        while (T.in_leaf) {
-            uint32_t ref = P.primref[T.li++];
-            uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
-            bool accepted = false;
-            double t = 0.0;
-            if (kind == PK_SPHERE) {
-                if (STATS) cnt.spheres++;
-                DSphere s = P.spheres[idx];
-                bool inside;
-                t = sphere_t(T.ray, V3{s.cx, s.cy, s.cz}, s.r, inside);
-                accepted = !(t < 0.0) && !(t >= best.t);
-            } else if (kind == PK_TRIANGLE) {
-                if (STATS) cnt.triangles++;
-                const uint32_t *vi = P.tri_v + 3ull * idx;
-                V3 p0 = load_f3(P.vpos, vi[0]), p1 = load_f3(P.vpos, vi[1]), p2 = load_f3(P.vpos, vi[2]);
-                TriHit h;
-                if (triangle_t(p0, p1, p2, T.ray, h)) { t = h.t; accepted = !(t >= best.t); }
-            } else if (kind == PK_CUBOID) {
-                if (STATS) cnt.cuboids++;
-                DCuboid c = P.cuboids[idx];
-                V3 d0, d1;
-                if (cuboid_hit<false>(c.mn, c.mx, T.ray, t, d0, d1)) accepted = !(t >= best.t);
-            } else {
-                // nested BVHAccel (Group / Mesh): save this level, re-express the ray (bvh.rs:462)
-                stack[T.sp * stride] = T.li; stack[(T.sp + 1) * stride] = T.le; stack[(T.sp + 2) * stride] = T.base;
-                T.sp += 3; T.base = T.sp;
-                T.accel = idx;
-                const DAccel *C = P.accels + idx;
-                T.ray = ray_to_local(C->minv, T.ray);
-                if (STATS) cnt.entries++;
-                T.node_base = C->node_base; T.prim_base = C->prim_base;
-                T.cur = 0; T.in_leaf = false;
-                break;
+        if (T.in_leaf && T.mesh) {
+            if (T.tri.kz == 0) mesh_leaf<0, STATS>(P, T, anyhit, best, cnt);
+            else if (T.tri.kz == 1) mesh_leaf<1, STATS>(P, T, anyhit, best, cnt);
+            else mesh_leaf<2, STATS>(P, T, anyhit, best, cnt);
+            if (!T.done) trav_pop(T, stack, stride);
+            else T.in_leaf = false;
+        }
+        if (T.in_leaf) {
+            uint32_t nref = P.primref[T.li];
+            LeafRec nrec = load_rec(P, T.li);
+            while (T.in_leaf) {
+                const uint32_t ref = nref;
+                const LeafRec r = nrec;
+                ++T.li;
+                {   // prefetch the next slot (clamped to this leaf: always valid)
+                    uint32_t nx = T.li < T.le ? T.li : T.le - 1u;
+                    nref = P.primref[nx];
+                    nrec = load_rec(P, nx);
+                }
+                uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
+                bool accepted = false;
+                double t = 0.0;
+                if (kind == PK_SPHERE) {
+                    if (STATS) cnt.spheres++;
+                    bool inside;
+                    t = sphere_t(T.ray, V3{rec_f64(r.a.x, r.a.y), rec_f64(r.a.z, r.a.w), rec_f64(r.b.x, r.b.y)}, rec_f64(r.b.z, r.b.w), inside);
+                    accepted = !(t < 0.0) && !(t >= best.t);
+                } else if (kind == PK_CUBOID) {
+                    if (STATS) cnt.cuboids++;
+                    double mn[3] = {rec_f64(r.a.x, r.a.y), rec_f64(r.a.z, r.a.w), rec_f64(r.b.x, r.b.y)};
+                    double mx[3] = {rec_f64(r.b.z, r.b.w), rec_f64(r.c.x, r.c.y), rec_f64(r.c.z, r.c.w)};
+                    V3 d0, d1;
+                    if (cuboid_hit<false>(mn, mx, T.ray, t, d0, d1)) accepted = !(t >= best.t);
+                } else if (kind == PK_ACCEL) {
+                    // nested BVHAccel (Group / Mesh): save this level, re-express the ray (bvh.rs:462)
+                    stack[T.sp * stride] = T.li; stack[(T.sp + 1) * stride] = T.le; stack[(T.sp + 2) * stride] = T.base;
+                    T.sp += 3; T.base = T.sp;
+                    trav_set_level(P, T, idx, ray_to_local(P.accels[idx].minv, T.ray));
+                    if (STATS) cnt.entries++;
+                    T.cur = 0; T.in_leaf = false;
+                    break;
+                } else { // a triangle outside a mesh accel cannot be built by the scene API; kept for completeness
+                    if (STATS) cnt.triangles++;
+                    const uint32_t *vi = P.tri_v + 3ull * idx;
+                    TriHit h;
+                    if (triangle_t(load_f3(P.vpos, vi[0]), load_f3(P.vpos, vi[1]), load_f3(P.vpos, vi[2]), T.ray, h)) { t = h.t; accepted = !(t >= best.t); }
+                }
+                if (accepted) {
+                    best.t = t; best.ref = ref; best.accel = T.accel;
+                    if (anyhit && t < 1.0) { T.done = true; T.in_leaf = false; break; } // occluded: point.rs:49 only asks isect.t < 1.0
+                }
+                if (T.li >= T.le) trav_pop(T, stack, stride);
             }
-            if (accepted) {
-                best.t = t; best.ref = ref; best.accel = T.accel;
-                if (anyhit && t < 1.0) { T.done = true; T.in_leaf = false; break; } // occluded: point.rs:49 only asks isect.t < 1.0
-            }
-            if (T.li >= T.le) trav_pop(T, stack, stride);
         }
         // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
         if (T.level_done) {
@@ -351,10 +449,8 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
             else {
                 T.base = stack[(T.sp - 1) * stride]; T.le = stack[(T.sp - 2) * stride]; T.li = stack[(T.sp - 3) * stride];
                 T.sp -= 3;
-                T.accel = (uint32_t)P.accels[T.accel].parent;
-                T.ray = local_ray(P, wray, T.accel);
-                const DAccel *Q = P.accels + T.accel;
-                T.node_base = Q->node_base; T.prim_base = Q->prim_base;
+                uint32_t parent = (uint32_t)P.accels[T.accel].parent;
+                trav_set_level(P, T, parent, local_ray(P, wray, parent));
                 if (T.li < T.le) T.in_leaf = true;
                 else trav_pop(T, stack, stride);
             }
@@ -500,6 +596,7 @@ __device__ __forceinline__ V3 oren_nayar_f(V3 r, double sigma_deg, V3 wo, V3 wi)
 
 // Shading frame of one hit: what Material::scattering + BSDF::new keep (bsdf.rs:29-46)
 struct Shade {
+    V3 praw;   // interaction.p = ray.origin + ray.d * t (surface.rs:169)
     V3 p;      // interaction.p + interaction.p_err (integrate.rs:40)
     V3 pm;     // interaction.p - interaction.p_err (integrate.rs:127)
     V3 wo, ng, ns, ss, ts;
@@ -508,11 +605,17 @@ struct Shade {
 
 // BSDF::f (bsdf.rs:73-92) with the BxDF list of Material::scattering (material/*.rs) inlined
 __device__ __forceinline__ V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo, V3 wi) {
+#if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 3 /* timing only: constant BSDF */
+    return V3{m.p[0], m.p[1], m.p[2]} * dot(wo, wi) * dot(sh.ns, sh.ss);
+#endif
     bool reflect = dot(wi, sh.ng) * dot(wo, sh.ng) > 0.0;
     V3 wo_l{dot(wo, sh.ss), dot(wo, sh.ts), dot(wo, sh.ns)};
     V3 wi_l{dot(wi, sh.ss), dot(wi, sh.ts), dot(wi, sh.ns)};
     if (wo_l.z == 0.0) return vzero();
     V3 f = vzero();
+#ifdef LG_MATMASK
+    if (!((LG_MATMASK >> m.kind) & 1)) return f;
+#endif
     switch (m.kind) {
     case MAT_MATTE: { // matte.rs:18-26 -- REFLECTION | DIFFUSE
         if (reflect) {
@@ -529,6 +632,7 @@ __device__ __forceinline__ V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo,
         }
         break;
     }
+#if !defined(LG_MATMASK) || (LG_MATMASK & 4)
     case MAT_METAL: { // metal.rs:17-26
         if (reflect) {
             V3 eta{m.p[0], m.p[1], m.p[2]}, k{m.p[3], m.p[4], m.p[5]};
@@ -536,6 +640,7 @@ __device__ __forceinline__ V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo,
         }
         break;
     }
+#endif
     case MAT_GLASS: { // glass.rs:33-56: specular BxDFs evaluate to zero (bxdf/mod.rs:172)
         V3 kr{m.p[0], m.p[1], m.p[2]}, kt{m.p[3], m.p[4], m.p[5]};
         if (reflect && vne(kr, vzero())) f = f + vzero();
@@ -641,10 +746,41 @@ __device__ __forceinline__ void shade_frame(const DParams &P, const Ray &ray, co
     const double err = 2.220446049250313e-16 * 65536.0; // N::epsilon() * 2^16
     V3 p = ray.o + ray.d * is.t;
     V3 p_err = sh.ng * err;
+    sh.praw = p;
     sh.p = p + p_err;
     sh.pm = p - p_err;
     sh.ss = normalize(is.su);    // si.surface.dpdu (bsdf.rs:34)
     sh.ts = cross(sh.ns, sh.ss); // bsdf.rs:35
+}
+
+// Park / restore the shading frame in HBM across the shadow traversals ([field][lane]: coalesced).
+// What is stored are the very f64s shade_frame produced; wo, ts, p +- p_err are re-derived by
+// the same expressions, so the restored frame is bit-identical to a recomputed one.
+__device__ __forceinline__ void stash_put(const DParams &P, unsigned long long g, const Shade &sh) {
+    const unsigned long long n = P.frame_threads;
+    V3 p = sh.praw;
+    double *s = P.stash + g;
+    s[0 * n] = p.x; s[1 * n] = p.y; s[2 * n] = p.z;
+    s[3 * n] = sh.ng.x; s[4 * n] = sh.ng.y; s[5 * n] = sh.ng.z;
+    s[6 * n] = sh.ns.x; s[7 * n] = sh.ns.y; s[8 * n] = sh.ns.z;
+    s[9 * n] = sh.ss.x; s[10 * n] = sh.ss.y; s[11 * n] = sh.ss.z;
+    s[12 * n] = (double)sh.mat;
+}
+__device__ __forceinline__ void stash_get(const DParams &P, unsigned long long g, Shade &sh, const Ray &ray) {
+    const unsigned long long n = P.frame_threads;
+    const double *s = P.stash + g;
+    V3 p{s[0 * n], s[1 * n], s[2 * n]};
+    sh.ng = V3{s[3 * n], s[4 * n], s[5 * n]};
+    sh.ns = V3{s[6 * n], s[7 * n], s[8 * n]};
+    sh.ss = V3{s[9 * n], s[10 * n], s[11 * n]};
+    sh.mat = (int32_t)s[12 * n];
+    sh.wo = -normalize(ray.d);
+    const double err = 2.220446049250313e-16 * 65536.0;
+    V3 p_err = sh.ng * err;
+    sh.praw = p;
+    sh.p = p + p_err;
+    sh.pm = p - p_err;
+    sh.ts = cross(sh.ns, sh.ss);
 }
 
 template <bool STATS>
@@ -710,12 +846,14 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
             uint32_t depth = 0, light = 0;
             bool shadow_job = false;
             Best pbest;              // closest hit of pray
-            V3 hit_p = vzero();      // interaction.p + p_err: origin of the shadow rays
             V3 output = vzero();     // running sum over lights (integrate.rs:47-66)
             V3 value = vzero();
             Ray tray = pray;         // the ray handed to the traversal
             for (;;) {
                 Best b;
+#if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 2 /* timing only: shadow rays are not traced */
+                if (shadow_job) { b.t = INFINITY; b.ref = NO_HIT; b.accel = 0; } else
+#endif
                 traverse<STATS>(P, tray, shadow_job, stack, stride, b, cnt);
                 bool have_value = false, need_shade = false, visible = false;
 #if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 1 /* timing only: primary traversal, nothing else */
@@ -738,6 +876,7 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
                     if (!need_shade) {
                         ++light;
                         const DLight L = P.lights[light];
+                        V3 hit_p = tray.o; // interaction.p + p_err: every shadow ray of this hit starts there
                         tray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p);
                         if (STATS) cnt.shadow++;
                         continue;
@@ -745,7 +884,12 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
                 }
                 if (need_shade) {
                     Shade sh;
-                    shade_frame(P, pray, pbest, sh);
+                    if (!shadow_job) {
+                        shade_frame(P, pray, pbest, sh);
+                        if (P.nlights > 0) stash_put(P, gtid, sh);
+                    } else {
+                        stash_get(P, gtid, sh, pray);
+                    }
                     const DMaterial m = P.materials[sh.mat];
                     V3 n = sh.ns;
                     if (shadow_job && visible) { // integrate.rs:53-65
@@ -765,9 +909,8 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
                     if (next_light < P.nlights) {
                         light = next_light;
                         shadow_job = true;
-                        hit_p = sh.p;
                         const DLight L = P.lights[light];
-                        tray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
+                        tray = ray_new(sh.p, V3{L.pos[0], L.pos[1], L.pos[2]} - sh.p); // point.rs:43-44
                         if (STATS) cnt.shadow++;
                         continue;
                     }
@@ -776,7 +919,11 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
                     // specular children (integrate.rs:69-77,82-132)
                     bool has_r = false, has_t = false;
                     Sample sr, st;
+#if defined(LG_MATMASK) && !(LG_MATMASK & 24)
+                    if (false) {
+#else
                     if (depth < P.recursion && (m.kind == MAT_GLASS || m.kind == MAT_MIRROR)) {
+#endif
                         if (sample_specular_transmission(m, sh, st))
                             has_t = !(st.pdf <= 0.0 || veq(st.spectrum, vzero()) || fabs(dot(st.wi, sh.ns)) == 0.0);
                         if (sample_specular_reflection(m, sh, sr))
