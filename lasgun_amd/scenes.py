@@ -235,3 +235,89 @@ def mixed_scene(api, nspheres=1024, nu=224, nv=224, supersampling=0):
     grp.add_obj_of(mesh, api.Material.plastic([0.2, 0.3, 1.0], [0.5, 0.7, 0.5], 0.25))
     scene.root.add_group(grp)
     return scene
+
+
+def quad_obj_with_uv():
+    """A unit quad given as ONE 4-vertex polygon (only its first three vertices are used,
+    src/shape/triangle.rs:41-53) plus two triangles, with vt and vn on every vertex."""
+    return """o quad
+v -1 -1 0
+v 1 -1 0
+v 1 1 0
+v -1 1 0
+v 0 2 0.5
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vt 0.5 0.25
+vn 0 0 1
+vn 0.2 0 1
+vn 0 0.2 1
+g first
+f 1/1/1 2/2/2 3/3/3 4/4/1
+g second
+f 1/1/1 3/3/3 4/4/2
+f -2/4/1 -3/3/2 -1/5/3
+"""
+
+
+def kitchen_sink_scene(api, camera="perspective", recursion=2, supersampling=1):
+    """Every feature of the path in one scene: orthographic / perspective camera, radial background,
+    three lights (one with distance falloff, one with f_att == 0), all five materials incl.
+    Oren-Nayar and metal, cube + box, nested groups three levels deep with rotate(axis),
+    swap_backface, the same mesh instanced three times (with / without material, with vt + vn),
+    a flat-shaded mesh, supersampling."""
+    scene = api.Scene.new()
+    scene.set_ambient_light([0.15, 0.12, 0.1])
+    scene.set_radial_background([0.2, 0.3, 0.6], [0.9, 0.8, 0.7], 0.7)
+    scene.set_max_recursion_depth(recursion)
+    if camera == "orthographic":
+        cam = scene.set_orthographic_camera(7.0)
+    else:
+        cam = scene.set_perspective_camera(50.0)
+    cam.look_at([0.5, 1.0, 9.0], [0.0, 0.0, 0.0], [0.1, 1.0, 0.0])
+    cam.set_supersampling(supersampling)
+    cam.set_aperture_radius(0.1)  # accepted and unused, as in the reference (camera.rs:142)
+    M = api.Material
+    matte = M.matte([0.8, 0.7, 0.6], 0.0)
+    oren = M.matte([0.3, 0.8, 0.4], 35.0)
+    plastic = M.plastic([0.2, 0.3, 1.0], [0.5, 0.7, 0.5], 0.25)
+    shiny = M.plastic([0.0, 0.0, 0.0], [0.9, 0.9, 0.9], 0.05)  # kd == 0: microfacet only
+    metal = M.metal([0.2, 0.9, 1.1], [3.9, 2.4, 2.2], 0.15, 0.3)
+    glass = M.glass([1.0, 0.8, 1.0], [0.8, 1.0, 0.8], 1.4)
+    mirror = M.mirror([0.7, 0.7, 0.7])
+    scene.add_point_light([3.0, 5.0, 6.0], [0.9, 0.85, 0.8], [1.0, 0.0, 0.0])
+    scene.add_point_light([-4.0, 2.0, 3.0], [0.5, 0.6, 0.9], [0.2, 0.05, 0.01])
+    scene.add_point_light([0.0, 8.0, 0.0], [1.0, 1.0, 1.0], [0.0, 0.0, 0.0])  # f_att == 0: contributes nothing
+    quad = scene.parse_obj(quad_obj_with_uv())
+    torus = scene.parse_obj(torus_obj(20, 12, normals=True))
+    scene.set_mesh_smoothing(False)
+    flat_torus = scene.parse_obj(torus_obj(10, 8, normals=True))  # normals dropped (scene.rs:111)
+    scene.set_mesh_smoothing(True)
+    root = scene.root
+    root.rotate_y(8.0)
+    root.add_sphere([0.0, -101.5, 0.0], 100.0, matte)           # ground
+    root.add_sphere([-2.2, -0.5, 0.5], 1.0, glass)
+    root.add_sphere([2.4, -0.7, 1.0], 0.8, mirror)
+    root.add_sphere([0.2, -1.0, 2.6], 0.5, oren)
+    root.add_cube([-0.6, -1.5, -0.6], 1.2, metal)
+    root.add_box([1.0, -1.5, -2.5], [3.0, 0.5, -1.5], shiny)
+    A = api.Aggregate
+    g1 = A.new(); g1.translate([-3.0, 1.0, -2.0]).rotate(25.0, [0.0, 0.6, 0.8]).scale(1.2, 0.8, 1.0)
+    g1.add_obj_of(torus, plastic)
+    g2 = A.new(); g2.rotate_x(-60.0).translate([0.0, 1.6, 0.0])
+    g2.add_obj(quad)                      # no material: Material::default()
+    g3 = A.new(); g3.scale(0.5, 0.5, 0.5).rotate_z(45.0).translate([0.0, 0.0, 1.5])
+    g3.add_obj_of(quad, oren)
+    g3.add_sphere([0.0, 0.0, 1.0], 0.6, plastic)
+    g3.swap_backface()
+    g2.add_group(g3)
+    g1.add_group(g2)
+    root.add_group(g1)
+    g4 = A.new(); g4.translate([2.5, 1.4, 0.0]).rotate_y(30.0)
+    g4.add_obj_of(flat_torus, metal)
+    g4.add_obj_of(torus, glass)           # same mesh, second instance
+    g4.swap_backface(); g4.swap_backface()  # toggles twice: off
+    root.add_group(g4)
+    return scene

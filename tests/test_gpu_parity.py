@@ -127,6 +127,13 @@ MID = {
     "mesh_glass_128": (lambda api: S.mesh_scene(api, 64, 64, "glass"), 128, 128),
     "mesh_plastic_flat_128": (lambda api: S.mesh_scene(api, 48, 48, "plastic", smoothing=False), 128, 96),
     "mixed_128": (lambda api: S.mixed_scene(api, 256, 48, 48), 128, 128),
+    "kitchen_sink_persp": (lambda api: S.kitchen_sink_scene(api, "perspective"), 192, 160),
+    "kitchen_sink_ortho": (lambda api: S.kitchen_sink_scene(api, "orthographic", recursion=4, supersampling=0), 160, 120),
+    "kitchen_sink_rec0": (lambda api: S.kitchen_sink_scene(api, "perspective", recursion=0, supersampling=2), 96, 72),
+    # ragged / tiny films: tiles cut by the right and bottom edges, and a single pixel
+    "ragged_67x13": (lambda api: S.cornell_scene(api, "glass"), 67, 13),
+    "ragged_5x131": (lambda api: S.spheres_scene(api, 64, seed=11), 5, 131),
+    "one_pixel": (lambda api: S.simple_scene(api, 1), 1, 1),
 }
 
 
