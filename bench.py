@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (tiles staged through host memory)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,25 +91,57 @@ def main():
 
     import lasgun_amd as la
     G = la.api
-    torch.cuda.set_device(local_rank)
-    G.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev)
+    G.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    from lasgun_amd.distributed import gather_tiles, row_tile
+        if args.backend == "nccl":  # RCCL over xGMI
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lasgun_amd.distributed import InterleavedGather, gather_tiles, interleave_ok, row_tile
 
     w = h = args.size
     scene = la.scenes.spheres_scene(G)  # replicated on every GPU
     t0 = time.perf_counter()
     acc = G.Accel(scene)  # host HLBVH build + flatten + upload (outside the timed region, reported below)
     accel_build_s = time.perf_counter() - t0
-    y0, y1 = row_tile(rank, world, h)
-    tile = torch.zeros((y1 - y0, w, 4), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    BLOCK_ROWS = 64
+    balanced = world > 1 and interleave_ok(world, h, BLOCK_ROWS)
+    y0, y1 = row_tile(rank, world, h)
+    if balanced:
+        # rank r renders the 64-row blocks {r, r+N, r+2N, ...} (even load) into a compact tile; the
+        # gather of frame k overlaps the render of frame k+1 (two tile buffers)
+        ig = InterleavedGather(w, h, rank, world, BLOCK_ROWS, "cuda" if args.backend == "nccl" else "cpu")
+        cuda_tile = torch.zeros((h // world, w, 4), dtype=torch.uint8, device="cuda")
 
-    def step():
-        G.capture_rows_device(acc, w, h, y0, y1, tile.data_ptr(), stream=stream)
-        return gather_tiles(tile, w, h, rank, world)
+        def step():
+            t = ig.tile()
+            if t.is_cuda:
+                G.capture_interleaved_device(acc, w, h, BLOCK_ROWS, world, rank, t.data_ptr(), stream=stream)
+            else:  # gloo rehearsal: stage through host memory
+                G.capture_interleaved_device(acc, w, h, BLOCK_ROWS, world, rank, cuda_tile.data_ptr(), stream=stream)
+                t.copy_(cuda_tile)
+            ig.submit()
+
+        def finish():
+            return ig.finish()
+    else:
+        tile = torch.zeros((y1 - y0, w, 4), dtype=torch.uint8, device="cuda")
+        last = [None]
+
+        def step():
+            G.capture_rows_device(acc, w, h, y0, y1, tile.data_ptr(), stream=stream)
+            if args.backend == "gloo" and world > 1:
+                last[0] = gather_tiles(tile.cpu(), w, h, rank, world)
+            else:
+                last[0] = gather_tiles(tile, w, h, rank, world)
+
+        def finish():
+            return last[0]
 
     def fence():
         torch.cuda.synchronize()
@@ -117,21 +151,31 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    finish()
     fence()
     G.profile_enable(acc, True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        full = step()
+        step()
+    full = finish()  # waits for the last gather (inside the timed region)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = G.profile_read(acc)
     G.profile_enable(acc, False)
 
     # deterministic work counters of this rank's tile (untimed, counting kernel variant)
-    st = G.capture_stats(acc, w, h, y0, y1)
+    if balanced:  # counters of the rows this rank owns: sum over its 64-row blocks
+        st = None
+        for g in range(h // (BLOCK_ROWS * world)):
+            yb = (g * world + rank) * BLOCK_ROWS
+            part = G.capture_stats(acc, w, h, yb, yb + BLOCK_ROWS)
+            st = part if st is None else {k: st[k] + part[k] for k in st}
+    else:
+        st = G.capture_stats(acc, w, h, y0, y1)
     keys = sorted(st)
-    vec = torch.tensor([st[k] for k in keys] + [0], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64, device="cuda")
+    rdev = "cuda" if args.backend == "nccl" else "cpu"
+    vec = torch.tensor([st[k] for k in keys] + [0], dtype=torch.float64, device=rdev)
+    tmax = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -148,6 +192,13 @@ def main():
         G.capture(scene, film)
         e2e_ms = (time.perf_counter() - t0) * 1e3
 
+    if rank == 0 and world > 1 and os.environ.get("LASGUN_BENCH_VERIFY"):
+        ref = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        G.capture_rows_device(acc, w, h, 0, h, ref.data_ptr(), row0=0, stream=stream)
+        torch.cuda.synchronize()
+        assert torch.equal(full.to("cuda"), ref), "gathered film differs from the single-GPU film"
+        print("verify: gathered %d-rank film == single-GPU film" % world, file=sys.stderr)
+
     if rank == 0:
         value = rays * args.steps / elapsed / 1e6
         # roofline of the dominant (only) kernel: this rank's launch
@@ -160,7 +211,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[2]: %dx%d, Cornell shell + 1024 random plastic spheres (SplitMix64 0x1A560001), 1 spp, 1 point light" % (w, h),
                        "rays_per_frame": rays, "primary": total["primary_rays"], "shadow": total["shadow_rays"],
-                       "secondary": total["secondary_rays"], "parallelism": "row-tiles x%d + 1 RCCL gather" % world,
+                       "secondary": total["secondary_rays"], "parallelism": ("64-row blocks interleaved over %d ranks + 1 RCCL gather per frame (overlapped with the next frame)" % world) if balanced else ("row-tiles x%d + 1 gather" % world),
                        "accel_build_s": accel_build_s, "host_film_capture_ms": e2e_ms,
                        "work_per_frame": {k: total[k] for k in ("nodes_tested", "spheres_tested", "cuboids_tested", "triangles_tested", "accel_entries", "hits")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -109,14 +109,21 @@ int lg_set_device(int device);      /* HIP device used by this process (default 
 int lg_device_count(void);
 
 /* Render image rows [y0, y1) of a width x height film straight into DEVICE memory, no host copy:
- * dev_rgba[0] is pixel (0, row0) of the image.  `hip_stream` is a hipStream_t (NULL = the
- * accel's own stream); the call only enqueues.  This is the multi-GPU row-tile entry point. */
+ * dev_rgba[0] is pixel (0, row0) of the image.  `hip_stream` is the hipStream_t to enqueue on,
+ * used as given (NULL = HIP's default stream, as everywhere in HIP; lg_accel_stream() = the
+ * accel's own non-blocking stream); the call only enqueues.  One stream at a time per accel.  This is the multi-GPU row-tile entry point. */
 int lg_capture_rows_device(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, uint32_t row0,
                            void *dev_rgba, void *hip_stream);
+/* Balanced multi-GPU sharding: render the rows y with (y / block_rows) % n == r into a COMPACT
+ * device tile of height/n rows (tile row vy <-> image row ((vy/block_rows)*n + r)*block_rows +
+ * vy%block_rows).  height must be a multiple of block_rows*n. */
+int lg_capture_interleaved_device(const lg_accel *, uint32_t width, uint32_t height, uint32_t block_rows, uint32_t n,
+                                  uint32_t r, void *dev_rgba, void *hip_stream);
 /* capture_subset into a full width*height device film (pixels outside the subset untouched). */
 int lg_capture_subset_device(size_t k, size_t n, const lg_accel *, uint32_t width, uint32_t height, void *dev_rgba,
                              void *hip_stream);
-int lg_accel_synchronize(const lg_accel *);
+void *lg_accel_stream(const lg_accel *);      /* the accel's own hipStream_t */
+int lg_accel_synchronize(const lg_accel *);    /* hipStreamSynchronize(lg_accel_stream()) */
 
 /* f64 radiance before quantisation for subset (k, n); rgb = width*height*3 doubles on the HOST,
  * pixels outside the subset are left untouched. */

@@ -29,6 +29,9 @@ _EXTRA = {
                                        _C.c_void_p, _C.c_void_p]),
     "capture_subset_device": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p,
                                          _C.c_void_p]),
+    "capture_interleaved_device": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32,
+                                              _C.c_void_p, _C.c_void_p]),
+    "accel_stream": (_C.c_void_p, [_C.c_void_p]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
     "capture_radiance": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
     "capture_stats": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.POINTER(CStats)]),
@@ -43,6 +46,13 @@ _EXTRA = {
 class HipApi(Api):
     """The product's binding: core surface + the GPU-only extras of include/lasgun_hip.h."""
 
+    def _stream(self, accel, stream):
+        """hipStream_t to enqueue on: an explicit handle (0 = HIP's default stream, e.g. torch's
+        `current_stream().cuda_stream`) or, when None, the accel's own stream."""
+        if stream is None:
+            return _C.c_void_p(self.call("accel_stream", accel.h))
+        return _C.c_void_p(int(stream))
+
     def set_device(self, device):
         if self.call("set_device", int(device)):
             raise LasgunError(self.last_error())
@@ -53,12 +63,18 @@ class HipApi(Api):
     def capture_rows_device(self, accel, width, height, y0, y1, dev_ptr, row0=None, stream=None):
         """Enqueue rows [y0, y1) into device memory at `dev_ptr` (pixel (0,row0) first). No host copy."""
         if self.call("capture_rows_device", accel.h, width, height, y0, y1, y0 if row0 is None else row0,
-                     _C.c_void_p(int(dev_ptr)), _C.c_void_p(int(stream)) if stream else None):
+                     _C.c_void_p(int(dev_ptr)), self._stream(accel, stream)):
+            raise LasgunError(self.last_error())
+
+    def capture_interleaved_device(self, accel, width, height, block_rows, n, r, dev_ptr, stream=None):
+        """Enqueue the rows {y : (y // block_rows) % n == r} into a compact (height/n)-row device tile."""
+        if self.call("capture_interleaved_device", accel.h, width, height, block_rows, n, r, _C.c_void_p(int(dev_ptr)),
+                     self._stream(accel, stream)):
             raise LasgunError(self.last_error())
 
     def capture_subset_device(self, k, n, accel, width, height, dev_ptr, stream=None):
         if self.call("capture_subset_device", k, n, accel.h, width, height, _C.c_void_p(int(dev_ptr)),
-                     _C.c_void_p(int(stream)) if stream else None):
+                     self._stream(accel, stream)):
             raise LasgunError(self.last_error())
 
     def synchronize(self, accel):

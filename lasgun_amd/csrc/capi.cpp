@@ -151,7 +151,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         unsigned long long threads = (unsigned long long)a.max_blocks * 256ull;
         size_t need = (size_t)threads * P.recursion * FRAME_DOUBLES;
         if (a.frames.n < need) {
-            HIP_TRY(hipStreamSynchronize(a.stream));
+            HIP_TRY(hipDeviceSynchronize()); // (re)allocation: nothing may still use the old buffer
             a.frames.alloc(need);
         }
         P.frames = a.frames.p;
@@ -161,7 +161,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         unsigned long long threads = (unsigned long long)a.max_blocks * 256ull;
         size_t need = (size_t)threads * STASH_DOUBLES;
         if (a.stash.n < need) {
-            HIP_TRY(hipStreamSynchronize(a.stream));
+            HIP_TRY(hipDeviceSynchronize()); // (re)allocation: nothing may still use the old buffer
             a.stash.alloc(need);
         }
         P.stash = a.stash.p;
@@ -189,6 +189,7 @@ static void set_rect(DParams &P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t
     P.tiles_x = (x1 - x0 + 7u) / 8u;
     uint32_t tiles_y = (y1 - y0 + 7u) / 8u;
     P.ntiles = P.tiles_x * tiles_y;
+    P.ilv_n = 1; P.ilv_r = 0; P.ilv_b = 1;
 }
 static void set_subset(DParams &P, size_t k, size_t n, uint32_t w, uint32_t h) {
     unsigned long long area = (unsigned long long)w * h;
@@ -386,6 +387,7 @@ void lg_accel_free(lg_accel *a) {
     if (a->stream) (void)hipStreamSynchronize(a->stream);
     delete a;
 }
+void *lg_accel_stream(const lg_accel *a) { return (void *)a->stream; }
 int lg_accel_synchronize(const lg_accel *a) {
     return guarded([&] { HIP_TRY(hipStreamSynchronize(a->stream)); });
 }
@@ -399,7 +401,20 @@ int lg_capture_rows_device(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y
         set_rect(P, 0, y0, w, y1);
         P.out_row0 = row0;
         P.out_rgba = (uint8_t *)dev_rgba;
-        enqueue(*a, P, false, hip_stream ? (hipStream_t)hip_stream : a->stream);
+        enqueue(*a, P, false, (hipStream_t)hip_stream);
+    });
+}
+int lg_capture_interleaved_device(const lg_accel *a, uint32_t w, uint32_t h, uint32_t block_rows, uint32_t n, uint32_t r, void *dev_rgba, void *hip_stream) {
+    return guarded([&] {
+        if (n == 0 || r >= n || block_rows == 0 || h % (block_rows * n) != 0) throw Error("height must be a multiple of block_rows * n");
+        std::lock_guard<std::mutex> g(a->mtx);
+        use_device();
+        DParams P = base_params(*a, w, h);
+        set_rect(P, 0, 0, w, h / n); // virtual rows of the compact tile
+        P.ilv_n = n; P.ilv_r = r; P.ilv_b = block_rows;
+        P.out_row0 = 0;
+        P.out_rgba = (uint8_t *)dev_rgba;
+        enqueue(*a, P, false, (hipStream_t)hip_stream);
     });
 }
 int lg_capture_subset_device(size_t k, size_t n, const lg_accel *a, uint32_t w, uint32_t h, void *dev_rgba, void *hip_stream) {
@@ -412,7 +427,7 @@ int lg_capture_subset_device(size_t k, size_t n, const lg_accel *a, uint32_t w, 
         else set_subset(P, k, n, w, h);
         P.out_row0 = 0;
         P.out_rgba = (uint8_t *)dev_rgba;
-        enqueue(*a, P, false, hip_stream ? (hipStream_t)hip_stream : a->stream);
+        enqueue(*a, P, false, (hipStream_t)hip_stream);
     });
 }
 
@@ -427,7 +442,7 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) { //
             // pixels outside the subset must keep their current value (lib.rs:152)
             if (!(n == 1 && k == 0)) HIP_TRY(hipMemcpyAsync(a->staging.p, film->px, bytes, hipMemcpyHostToDevice, a->stream));
         }
-        if (lg_capture_subset_device(k, n, a, film->w, film->h, a->staging.p, nullptr)) throw Error(tl_error);
+        if (lg_capture_subset_device(k, n, a, film->w, film->h, a->staging.p, (void *)a->stream)) throw Error(tl_error);
         std::lock_guard<std::mutex> g(a->mtx);
         HIP_TRY(hipMemcpyAsync(film->px, a->staging.p, bytes, hipMemcpyDeviceToHost, a->stream));
         HIP_TRY(hipStreamSynchronize(a->stream));

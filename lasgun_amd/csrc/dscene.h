@@ -121,6 +121,9 @@ struct DParams {
     uint32_t mode; // 0 = rectangle [x0,x1) x [y0,y1); 1 = subset {k + i*n}
     uint32_t x0, y0, x1, y1;
     uint32_t tiles_x;
+    // row-block interleave for multi-GPU balance (mode 0): with ilv_n > 1 the rows [y0, y1) are
+    // VIRTUAL rows of a compact tile; image row = ((vy / ilv_b) * ilv_n + ilv_r) * ilv_b + vy % ilv_b
+    uint32_t ilv_n, ilv_r, ilv_b;
     unsigned long long sub_k, sub_n, sub_count;
     uint32_t ntiles;
     uint32_t out_row0; // row of the image stored at out_rgba[0] (0 for a full film, y0 for a row tile)

@@ -799,19 +799,21 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
         tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
         if (tile >= P.ntiles) break; // every wave reaches this exit
 
-        uint32_t x, y;
+        uint32_t x, y, vy; // vy = row of the output buffer's addressing (== y unless rows are interleaved)
         bool active;
         if (P.mode == 0) {
             uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
             x = P.x0 + tx * 8u + (lane & 7u);
-            y = P.y0 + ty * 8u + (lane >> 3);
-            active = x < P.x1 && y < P.y1;
+            vy = P.y0 + ty * 8u + (lane >> 3);
+            active = x < P.x1 && vy < P.y1;
+            y = P.ilv_n > 1u ? ((vy / P.ilv_b) * P.ilv_n + P.ilv_r) * P.ilv_b + vy % P.ilv_b : vy;
         } else {
             unsigned long long i = (unsigned long long)tile * 64ull + lane;
             active = i < P.sub_count;
             unsigned long long off = P.sub_k + i * P.sub_n;
             x = (uint32_t)(off % P.w);
             y = (uint32_t)(off / P.w);
+            vy = y;
         }
         if (!active) continue; // lanes past the edge idle for this tile
 
@@ -998,7 +1000,7 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
         color = color * weight; // integrate.rs:19
 
         // ---- Img::set (img.rs:46-67)
-        unsigned long long pix = (unsigned long long)(y - P.out_row0) * P.w + x;
+        unsigned long long pix = (unsigned long long)(vy - P.out_row0) * P.w + x;
         if (P.out_rgba) {
             uint32_t rgba = to_byte(color.x) | (to_byte(color.y) << 8) | (to_byte(color.z) << 16) | (255u << 24);
             reinterpret_cast<uint32_t *>(P.out_rgba)[pix] = rgba;

@@ -52,3 +52,68 @@ def gather_tiles(tile, width, height, rank, world, group=None):
         a, b = row_tile(r, world, height)
         out[a:b] = recv[r][: b - a]
     return out
+
+
+# ---- balanced variant: interleaved row blocks -------------------------------------------------
+def interleave_ok(world, height, block_rows):
+    return world > 0 and block_rows > 0 and height % (block_rows * world) == 0
+
+
+def interleaved_rows(rank, world, height, block_rows):
+    """Image rows owned by `rank`, in the order they are stored in its compact tile."""
+    assert interleave_ok(world, height, block_rows)
+    rows = []
+    for g in range(height // (block_rows * world)):
+        y = (g * world + rank) * block_rows
+        rows.extend(range(y, y + block_rows))
+    return rows
+
+
+class InterleavedGather:
+    """One RCCL gather per frame of compact interleaved tiles, double-buffered so that the gather of
+    frame k overlaps the render of frame k+1 (separate streams; `tile()` hands out the buffer to
+    render into after making the current stream wait for the gather that last read it)."""
+
+    def __init__(self, width, height, rank, world, block_rows, device, group=None):
+        assert interleave_ok(world, height, block_rows)
+        self.w, self.h, self.rank, self.world, self.b, self.group = width, height, rank, world, block_rows, group
+        self.rows = height // world
+        self.tiles = [torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.pending = [None, None]
+        self.k = 0
+        self.recv = None
+        self.out = None
+        if rank == 0:
+            self.recv = torch.empty((world, self.rows, width, 4), dtype=torch.uint8, device=device)
+            self.out = torch.empty((height, width, 4), dtype=torch.uint8, device=device)
+
+    def tile(self):
+        i = self.k % 2
+        if self.pending[i] is not None:
+            self.pending[i].wait()  # stream-level wait: the buffer is free again
+            self.pending[i] = None
+        return self.tiles[i]
+
+    def submit(self):
+        """Start the gather of the tile handed out by the last tile() call."""
+        i = self.k % 2
+        self.k += 1
+        if self.world == 1:
+            return
+        glist = [self.recv[r] for r in range(self.world)] if self.rank == 0 else None
+        self.pending[i] = dist.gather(self.tiles[i], gather_list=glist, dst=0, group=self.group, async_op=True)
+
+    def finish(self):
+        """Wait for outstanding gathers; on rank 0 return the assembled (height, width, 4) film."""
+        for i in range(2):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
+        if self.rank != 0:
+            return None
+        if self.world == 1:
+            return self.tiles[(self.k - 1) % 2]
+        g = self.h // (self.b * self.world)
+        self.out.view(g, self.world, self.b, self.w, 4).copy_(
+            self.recv.view(self.world, g, self.b, self.w, 4).permute(1, 0, 2, 3, 4))
+        return self.out

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from lasgun_amd.distributed import gather_tiles, max_tile_rows, row_tile
+from lasgun_amd.distributed import InterleavedGather, gather_tiles, interleaved_rows, max_tile_rows, row_tile
 
 W, H = 40, 37  # odd height: tiles of 19 and 18 rows
 
@@ -56,4 +56,50 @@ def test_two_rank_gloo_gather(tmp_path):
     from lasgun_amd import scenes as S
     o = oracle()
     want = o.render(S.cornell_scene(o, "plastic"), (W, H)).pixels()
+    assert np.array_equal(np.load(out), want)
+
+
+def test_interleaved_rows_partition():
+    for world in (1, 2, 4, 8):
+        h, b = 64 * world, 8
+        seen = sorted(y for r in range(world) for y in interleaved_rows(r, world, h, b))
+        assert seen == list(range(h))
+        assert all(len(interleaved_rows(r, world, h, b)) == h // world for r in range(world))
+
+
+def _ilv_worker(rank, world, port, out_path):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_lib import oracle
+    from lasgun_amd import scenes as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        o = oracle()
+        w, h, b = 24, 32, 4
+        acc = o.Accel(S.cornell_scene(o, "glass"))
+        film = o.Film(w, h)
+        o.capture_subset(0, 1, acc, film)
+        mine = torch.from_numpy(film.pixels()[interleaved_rows(rank, world, h, b)].copy())
+        ig = InterleavedGather(w, h, rank, world, b, "cpu")
+        for frame in range(3):  # three frames through the two-buffer pipeline
+            t = ig.tile()
+            t.copy_(mine if frame == 2 else torch.zeros_like(mine))
+            ig.submit()
+        full = ig.finish()
+        if rank == 0:
+            np.save(out_path, full.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_interleaved_gather_pipeline(tmp_path):
+    out = str(tmp_path / "ilv.npy")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_ilv_worker, args=(2, port, out), nprocs=2, join=True)
+    from oracle_lib import oracle
+    from lasgun_amd import scenes as S
+    o = oracle()
+    want = o.render(S.cornell_scene(o, "glass"), (24, 32)).pixels()
     assert np.array_equal(np.load(out), want)

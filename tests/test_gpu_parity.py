@@ -232,6 +232,23 @@ def test_cpp_host_example_matches_oracle(tmp_path):
     assert np.array_equal(got, want)
 
 
+def test_interleaved_blocks_on_device_match_the_full_film():
+    import torch
+    from lasgun_amd.distributed import interleaved_rows
+    w, h, b, n = 120, 96, 8, 3
+    acc = G.Accel(S.cornell_scene(G, "glass"))
+    full = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    G.capture_rows_device(acc, w, h, 0, h, full.data_ptr(), row0=0)
+    G.synchronize(acc)
+    for r in range(n):
+        t = torch.zeros((h // n, w, 4), dtype=torch.uint8, device="cuda")
+        G.capture_interleaved_device(acc, w, h, b, n, r, t.data_ptr())
+        G.synchronize(acc)
+        assert torch.equal(t, full[interleaved_rows(r, n, h, b)])
+    with pytest.raises(la.LasgunError):
+        G.capture_interleaved_device(acc, w, h, 7, n, 0, full.data_ptr())
+
+
 def test_errors_instead_of_panics():
     with pytest.raises(la.LasgunError):
         G.Accel(G.Scene.new())  # empty root aggregate
