@@ -85,6 +85,7 @@ struct lg_accel {
     const Scene *scene = nullptr;
     FlatScene flat;
     DevBuf<DNode> nodes;
+    DevBuf<DNode2> nodes2;
     DevBuf<uint32_t> primref;
     DevBuf<DSphere> spheres;
     DevBuf<int32_t> sphere_mat;
@@ -120,7 +121,7 @@ struct lg_accel {
 static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     const Scene &s = *a.scene;
     DParams P{};
-    P.nodes = a.nodes.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
+    P.nodes = a.nodes.p; P.nodes2 = a.nodes2.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
     P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
     P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.accels = a.accels.p; P.materials = a.materials.p;
     P.lights = a.lights.p;
@@ -358,13 +359,13 @@ lg_accel *lg_accel_from(const lg_scene *s) {
         flatten_scene(s->s, a->flat); // host HLBVH build + flatten (throws on what the reference would panic on)
         use_device();
         const FlatScene &f = a->flat;
-        a->nodes.upload(f.nodes); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
+        a->nodes.upload(f.nodes); a->nodes2.upload(f.nodes2); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
         a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
         a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
         a->tile_counter.alloc(1);
         a->stats.alloc(1);
-        a->device_bytes = f.nodes.size() * sizeof(DNode) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
+        a->device_bytes = f.nodes.size() * (sizeof(DNode) + sizeof(DNode2)) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
                           f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 + f.leaf_soup.size() * sizeof(DLeafRec) +
                           f.accels.size() * sizeof(DAccel) + f.materials.size() * sizeof(DMaterial);
         HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));

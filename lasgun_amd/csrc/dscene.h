@@ -40,6 +40,22 @@ struct alignas(64) DNode {
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
+// Child-pair record of an INTERIOR node (same index as its DNode): the bounds of BOTH children,
+// so one 128-byte fetch feeds two slab tests and the two tests overlap in the pipeline.  The
+// reference tests a child's box when it visits that child (bvh.rs:472-473); testing it one step
+// earlier, at the parent, is the same pure function of (box, ray) -- nodes are never culled by
+// t -- so every box is still tested exactly once and leaves are still processed near-child-first.
+struct alignas(128) DNode2 {
+    double b0min[3], b0max[3]; // first child  (node + 1)
+    double b1min[3], b1max[3]; // second child (node.link)
+    uint32_t link0, meta0;     // copies of the children's DNode.link / DNode.meta
+    uint32_t link1, meta1;
+    uint32_t axis;             // this node's split axis (dir_is_neg[axis] picks the near child)
+    uint32_t second;           // index of the second child (relative to node_base)
+    uint32_t pad[2];
+};
+static_assert(sizeof(DNode2) == 128, "DNode2 must be 128 bytes");
+
 struct alignas(32) DSphere {
     double cx, cy, cz, r;
 };
@@ -87,6 +103,7 @@ constexpr int STASH_DOUBLES = 13; // p(3) ng(3) ns(3) ss(3) material id
 struct DParams {
     // ---- scene tables
     const DNode *nodes;
+    const DNode2 *nodes2; // valid at interior-node indices
     const uint32_t *primref;
     const DSphere *spheres;
     const int32_t *sphere_mat;

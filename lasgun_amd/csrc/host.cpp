@@ -510,6 +510,18 @@ struct Flattener {
             else { d.link = n.c; d.meta = n.a & 3u; }
             out.nodes.push_back(d);
         }
+        // child-pair records for the interior nodes
+        out.nodes2.resize(out.nodes.size(), DNode2{});
+        for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+            const LinNode &n = bvh.nodes[i];
+            if (n.leaf) continue;
+            const DNode &c0 = out.nodes[node_base + i + 1], &c1 = out.nodes[node_base + n.c];
+            DNode2 &p = out.nodes2[node_base + i];
+            std::memcpy(p.b0min, c0.bmin, 24); std::memcpy(p.b0max, c0.bmax, 24);
+            std::memcpy(p.b1min, c1.bmin, 24); std::memcpy(p.b1max, c1.bmax, 24);
+            p.link0 = c0.link; p.meta0 = c0.meta; p.link1 = c1.link; p.meta1 = c1.meta;
+            p.axis = n.a & 3u; p.second = n.c;
+        }
     }
 
     void dump(const BuiltBVH &bvh, bool has_mat, bool swap, const Transform &t) {

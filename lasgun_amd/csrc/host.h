@@ -107,6 +107,7 @@ struct Scene {
 // ---- flattened scene (host copies of the device tables) ----------------------------------
 struct FlatScene {
     std::vector<DNode> nodes;
+    std::vector<DNode2> nodes2;
     std::vector<uint32_t> primref;
     std::vector<DSphere> spheres;
     std::vector<int32_t> sphere_mat;

@@ -200,7 +200,9 @@ __device__ __forceinline__ void sphere_full(const DSphere &s, const Ray &ray, do
     if (phi < 0.0) phi += 2.0 * PI;
     double theta = p_acos(fmin_(fmax_(p.z / s.r, -1.0), 1.0));
     V3 dpdu{-2.0 * PI * p.y, 2.0 * PI * p.x, 0.0};
-    V3 dpdv = PI * V3{p.z * p_cos(phi), p.z * p_sin(phi), -s.r * p_sin(theta)};
+    double sin_phi, cos_phi;
+    p_sincos(phi, sin_phi, cos_phi);
+    V3 dpdv = PI * V3{p.z * cos_phi, p.z * sin_phi, -s.r * p_sin(theta)};
     if (inside) isect_set(is, t, dpdu, dpdv);
     else isect_set(is, t, dpdv, dpdu);
 }
@@ -289,6 +291,7 @@ struct Trav {
     uint32_t sp, base;   // stack pointer / first entry of the current accel level
     uint32_t li, le;     // leaf cursor (absolute primref indices)
     bool in_leaf, done, level_done;
+    double dd;           // dot(ray.d, ray.d): the `a` of every sphere test at this level (sphere.rs:50)
     uint32_t negmask;    // bit a set <=> dinv[a] < 0 (dir_is_neg, bvh.rs:463)
     bool mesh;           // current accel is a triangle mesh (every leaf slot is a triangle)
     TriSetup tri;        // valid while `mesh`
@@ -301,6 +304,7 @@ __device__ __forceinline__ void trav_set_level(const DParams &P, Trav &T, uint32
     T.negmask = (local.dinv.x < 0.0 ? 1u : 0u) | (local.dinv.y < 0.0 ? 2u : 0u) | (local.dinv.z < 0.0 ? 4u : 0u);
     T.mesh = (A->flags & AF_MESH) != 0u;
     if (T.mesh) T.tri = tri_setup(local);
+    else T.dd = dot(local.d, local.d);
 }
 
 // leaf-ordered 48-byte geometry records: three 16-byte loads per slot
@@ -337,15 +341,42 @@ __device__ __forceinline__ void mesh_leaf(const DParams &P, Trav &T, bool anyhit
     }
     T.li = le;
 }
-// leave the current node / leaf: next pending node of this accel level, or flag the level as exhausted
-__device__ __forceinline__ void trav_pop(Trav &T, uint32_t *stack, uint32_t stride) {
+// Stack entries: child node index (relative to node_base), bit 31 set when that child is a leaf.
+constexpr uint32_t STACK_LEAF = 0x80000000u;
+
+__device__ __forceinline__ void trav_open_leaf(Trav &T, uint32_t link, uint32_t meta) {
+    T.li = T.prim_base + link;
+    T.le = T.li + (meta & 0xFFFFu);
+    T.in_leaf = true;
+}
+// leave the current node / leaf: next pending (already box-tested) child of this accel level,
+// or flag the level as exhausted
+__device__ __forceinline__ void trav_pop(const DParams &P, Trav &T, uint32_t *stack, uint32_t stride) {
     T.in_leaf = false;
     if (T.sp != T.base) {
         --T.sp;
-        T.cur = stack[T.sp * stride];
+        uint32_t e = stack[T.sp * stride];
+        if (e & STACK_LEAF) {
+            const DNode *nd = P.nodes + (T.node_base + (e & ~STACK_LEAF));
+            trav_open_leaf(T, nd->link, nd->meta);
+        } else {
+            T.cur = e;
+        }
     } else {
         T.level_done = true;
     }
+}
+// entering an accel: test the root node's own box once (bvh.rs:472-473 for node 0)
+template <bool STATS>
+__device__ __forceinline__ void trav_enter_root(const DParams &P, Trav &T, Counters &cnt) {
+    const DNode *nd = P.nodes + T.node_base;
+    double bmin[3] = {nd->bmin[0], nd->bmin[1], nd->bmin[2]};
+    double bmax[3] = {nd->bmax[0], nd->bmax[1], nd->bmax[2]};
+    uint32_t link = nd->link, meta = nd->meta;
+    if (STATS) cnt.nodes++;
+    T.cur = 0; T.in_leaf = false;
+    if (!slab_intersects(bmin, bmax, T.ray)) { T.level_done = true; return; }
+    if (meta & NODE_LEAF) trav_open_leaf(T, link, meta);
 }
 
 template <bool STATS>
@@ -354,48 +385,47 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
     Trav T;
     trav_set_level(P, T, 0u, ray_to_local(P.accels->minv, wray));
-    T.cur = 0; T.sp = 0; T.base = 0; T.li = 0; T.le = 0; T.in_leaf = false; T.done = false; T.level_done = false;
+    T.sp = 0; T.base = 0; T.li = 0; T.le = 0; T.done = false; T.level_done = false;
     if (STATS) cnt.entries++;
+    trav_enter_root<STATS>(P, T, cnt);
     while (!T.done) {
-        // ---- phase A: interior nodes
+        // ---- phase A: interior nodes.  T.cur is an interior node whose own box is known to be hit;
+        // one 128-byte child-pair record feeds the slab tests of BOTH children.
         while (!T.in_leaf && !T.level_done) {
-            const DNode *nd = P.nodes + (T.node_base + T.cur);
-            // one 64-byte record = four 16-byte loads from a single line, all issued before the
-            // slab test; link/meta are decoded branch-free so the compiler cannot sink their load
-            // behind the hit test (that would put a second memory latency on the critical path)
-            double bmin[3] = {nd->bmin[0], nd->bmin[1], nd->bmin[2]};
-            double bmax[3] = {nd->bmax[0], nd->bmax[1], nd->bmax[2]};
-            uint32_t link = nd->link, meta = nd->meta;
-            if (STATS) cnt.nodes++;
-            bool hit = slab_intersects(bmin, bmax, T.ray);
-            bool leaf = (meta & NODE_LEAF) != 0u;
-            uint32_t count = meta & 0xFFFFu;
-            bool neg = ((T.negmask >> (meta & 3u)) & 1u) != 0u; // dir_is_neg[axis] (bvh.rs:463,496)
-            uint32_t near_node = neg ? link : T.cur + 1;
-            uint32_t far_node = neg ? T.cur + 1 : link;
-            bool descend = hit && !leaf;
-            bool open_leaf = hit && leaf && count != 0u;
-            if (descend) { // near child first, far child on the stack (bvh.rs:493-504)
-                stack[T.sp * stride] = far_node;
+            const DNode2 *nd = P.nodes2 + (T.node_base + T.cur);
+            double b0min[3] = {nd->b0min[0], nd->b0min[1], nd->b0min[2]}, b0max[3] = {nd->b0max[0], nd->b0max[1], nd->b0max[2]};
+            double b1min[3] = {nd->b1min[0], nd->b1min[1], nd->b1min[2]}, b1max[3] = {nd->b1max[0], nd->b1max[1], nd->b1max[2]};
+            uint32_t link0 = nd->link0, meta0 = nd->meta0, link1 = nd->link1, meta1 = nd->meta1;
+            uint32_t axis = nd->axis, second = nd->second;
+            if (STATS) cnt.nodes += 2;
+            bool hit0 = slab_intersects(b0min, b0max, T.ray);
+            bool hit1 = slab_intersects(b1min, b1max, T.ray);
+            bool neg = ((T.negmask >> axis) & 1u) != 0u; // dir_is_neg[axis]: second child is the near one (bvh.rs:496-499)
+            // near / far child in the reference's visiting order
+            bool near_hit = neg ? hit1 : hit0, far_hit = neg ? hit0 : hit1;
+            uint32_t near_idx = neg ? second : T.cur + 1, far_idx = neg ? T.cur + 1 : second;
+            uint32_t near_link = neg ? link1 : link0, near_meta = neg ? meta1 : meta0;
+            uint32_t far_meta = neg ? meta0 : meta1;
+            if (far_hit) { // visited after the whole near subtree (bvh.rs:497,500)
+                stack[T.sp * stride] = far_idx | ((far_meta & NODE_LEAF) ? STACK_LEAF : 0u);
                 ++T.sp;
-                T.cur = near_node;
-            } else if (open_leaf) {
-                T.li = T.prim_base + link;
-                T.le = T.li + count;
-                T.in_leaf = true;
+            }
+            if (near_hit) {
+                if (near_meta & NODE_LEAF) trav_open_leaf(T, near_link, near_meta);
+                else T.cur = near_idx;
             } else {
-                trav_pop(T, stack, stride);
+                trav_pop(P, T, stack, stride);
             }
         }
+        if (T.in_leaf && T.li >= T.le) { trav_pop(P, T, stack, stride); continue; } // empty leaf (nprims as u16 == 0)
         // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
         if (T.in_leaf && T.mesh) {
             if (T.tri.kz == 0) mesh_leaf<0, STATS>(P, T, anyhit, best, cnt);
             else if (T.tri.kz == 1) mesh_leaf<1, STATS>(P, T, anyhit, best, cnt);
             else mesh_leaf<2, STATS>(P, T, anyhit, best, cnt);
-            if (!T.done) trav_pop(T, stack, stride);
+            if (!T.done) trav_pop(P, T, stack, stride); // may open the next (already box-tested) leaf
             else T.in_leaf = false;
-        }
-        if (T.in_leaf) {
+        } else if (T.in_leaf) {
             uint32_t nref = P.primref[T.li];
             LeafRec nrec = load_rec(P, T.li);
             while (T.in_leaf) {
@@ -413,7 +443,7 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
                 if (kind == PK_SPHERE) {
                     if (STATS) cnt.spheres++;
                     bool inside;
-                    t = sphere_t(T.ray, V3{rec_f64(r.a.x, r.a.y), rec_f64(r.a.z, r.a.w), rec_f64(r.b.x, r.b.y)}, rec_f64(r.b.z, r.b.w), inside);
+                    t = sphere_t_a(T.ray, T.dd, V3{rec_f64(r.a.x, r.a.y), rec_f64(r.a.z, r.a.w), rec_f64(r.b.x, r.b.y)}, rec_f64(r.b.z, r.b.w), inside);
                     accepted = !(t < 0.0) && !(t >= best.t);
                 } else if (kind == PK_CUBOID) {
                     if (STATS) cnt.cuboids++;
@@ -427,7 +457,7 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
                     T.sp += 3; T.base = T.sp;
                     trav_set_level(P, T, idx, ray_to_local(P.accels[idx].minv, T.ray));
                     if (STATS) cnt.entries++;
-                    T.cur = 0; T.in_leaf = false;
+                    trav_enter_root<STATS>(P, T, cnt);
                     break;
                 } else { // a triangle outside a mesh accel cannot be built by the scene API; kept for completeness
                     if (STATS) cnt.triangles++;
@@ -439,7 +469,7 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
                     best.t = t; best.ref = ref; best.accel = T.accel;
                     if (anyhit && t < 1.0) { T.done = true; T.in_leaf = false; break; } // occluded: point.rs:49 only asks isect.t < 1.0
                 }
-                if (T.li >= T.le) trav_pop(T, stack, stride);
+                if (T.li >= T.le) { trav_pop(P, T, stack, stride); break; } // a popped leaf restarts phase B (fresh prefetch)
             }
         }
         // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
@@ -452,7 +482,7 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
                 uint32_t parent = (uint32_t)P.accels[T.accel].parent;
                 trav_set_level(P, T, parent, local_ray(P, wray, parent));
                 if (T.li < T.le) T.in_leaf = true;
-                else trav_pop(T, stack, stride);
+                else trav_pop(P, T, stack, stride);
             }
         }
     }

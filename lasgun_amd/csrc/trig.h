@@ -59,6 +59,16 @@ LG_HD double p_cos(double x) {
     double v = (q & 1) ? s : c;
     return ((q + 1) & 2) ? -v : v;
 }
+// p_sin(x) and p_cos(x) from ONE argument reduction (bit-identical to the two separate calls)
+LG_HD void p_sincos(double x, double &sn, double &cs) {
+    if (!(x == x) || x - x != 0.0 || !(fabs(x) < 1647099.0)) { sn = x - x; cs = x - x; return; }
+    int q;
+    double r = trig_reduce(x, q);
+    double s = ksin(r), c = kcos(r);
+    double vs = (q & 1) ? c : s, vc = (q & 1) ? s : c;
+    sn = (q & 2) ? -vs : vs;
+    cs = ((q + 1) & 2) ? -vc : vc;
+}
 LG_HD double atan01(double t) { // t in [0, 1]
     if (t > LGT_TAN_PIO8) {
         double u = (t - 1.0) / (t + 1.0);

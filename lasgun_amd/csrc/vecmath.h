@@ -121,10 +121,11 @@ LG_HD Ray ray_to_local(const Affine &minv, const Ray &r) { // transform.rs:279-2
 
 // ---- src/core/math.rs ---------------------------------------------------------------------
 // quad_roots + Sphere::intersect_t (sphere.rs:30-69) collapsed: returns t (or -inf) and `inside`.
-LG_HD double sphere_t(const Ray &ray, V3 cen, double rad, bool &inside) {
+// `a` = dot(d, d) depends on the ray alone; callers that test many spheres against one ray pass it
+// in (same f64 value as recomputing it).
+LG_HD double sphere_t_a(const Ray &ray, double a, V3 cen, double rad, bool &inside) {
     V3 d = ray.d;
     V3 l = ray.o - cen;
-    double a = dot(d, d);
     double b = 2.0 * dot(d, l);
     double c = dot(l, l) - rad * rad;
     inside = false;
@@ -142,5 +143,6 @@ LG_HD double sphere_t(const Ray &ray, V3 cen, double rad, bool &inside) {
     if (t0 < 0.0) { inside = true; return t1; }
     return t0;
 }
+LG_HD double sphere_t(const Ray &ray, V3 cen, double rad, bool &inside) { return sphere_t_a(ray, dot(ray.d, ray.d), cen, rad, inside); }
 
 } // namespace lg
