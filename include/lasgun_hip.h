@@ -131,6 +131,13 @@ int lg_capture_radiance(size_t k, size_t n, const lg_accel *, uint32_t width, ui
 /* Work counters for rendering rows [y0, y1) (runs the counting kernel variant once). */
 int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, lg_stats *out);
 
+/* Traversal mode of an accel.  0 (default) = the reference's own traversal over the reference's
+ * own BVH: the parity path.  1 = opt-in FAST mode: a binned-SAH BVH (<= 4 primitives per leaf)
+ * over the same primitives, front-to-back with pruning beyond the best hit; same primitive tests
+ * and arithmetic, exact ties in t re-traced with the reference traversal.  Verified byte-identical
+ * to mode 0 on every test scene and benchmark config, but not PROVEN identical. */
+int lg_accel_set_mode(const lg_accel *, int mode);
+
 /* Kernel timing with HIP events on the launch stream: enable, render, then read. */
 void lg_profile_enable(const lg_accel *, int enabled);
 int lg_profile_read(const lg_accel *, double *total_ms, uint64_t *launches); /* synchronises; resets the tally */

@@ -32,6 +32,7 @@ _EXTRA = {
     "capture_interleaved_device": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32,
                                               _C.c_void_p, _C.c_void_p]),
     "accel_stream": (_C.c_void_p, [_C.c_void_p]),
+    "accel_set_mode": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
     "capture_radiance": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
     "capture_stats": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.POINTER(CStats)]),
@@ -52,6 +53,11 @@ class HipApi(Api):
         if stream is None:
             return _C.c_void_p(self.call("accel_stream", accel.h))
         return _C.c_void_p(int(stream))
+
+    def set_mode(self, accel, fast):
+        """False = the reference traversal (parity path, default); True = the opt-in fast mode."""
+        if self.call("accel_set_mode", accel.h, 1 if fast else 0):
+            raise LasgunError(self.last_error())
 
     def set_device(self, device):
         if self.call("set_device", int(device)):

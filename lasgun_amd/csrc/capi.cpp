@@ -13,8 +13,8 @@
 
 namespace lg {
 // kernels.hip
-hipError_t launch_trace(const DParams &P, bool stats, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
-hipError_t trace_occupancy(uint32_t stack_depth, int *blocks_per_cu);
+hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
+hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
 hipError_t trace_set_lds_limit(size_t bytes);
 hipError_t launch_kat(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d, double *out,
                       hipStream_t stream);
@@ -106,10 +106,13 @@ struct lg_accel {
     mutable DevBuf<double> staging_rad;
     mutable std::mutex mtx;
     hipStream_t stream = nullptr;
-    uint32_t stack_depth = 1;
+    uint32_t stack_depth = 1;      // reference traversal
+    uint32_t stack_depth_fast = 1; // fast traversal (two words per pending child)
     uint32_t max_blocks = 1;
+    uint32_t max_blocks_fast = 1;
     uint64_t device_bytes = 0;
     mutable bool profiling = false;
+    mutable bool fast = false; // opt-in fast traversal mode (lg_accel_set_mode)
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     ~lg_accel() {
         for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -145,11 +148,13 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
 // Enqueue one render on `stream`.  Caller holds a.mtx.
 static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t stream) {
     if (P.ntiles == 0) return;
+    uint32_t cap = a.fast ? a.max_blocks_fast : a.max_blocks;
     uint32_t blocks = (P.ntiles + 3u) / 4u;
-    if (blocks > a.max_blocks) blocks = a.max_blocks;
+    if (blocks > cap) blocks = cap;
+    uint32_t maxb = a.max_blocks > a.max_blocks_fast ? a.max_blocks : a.max_blocks_fast;
     // Whitted frames: one slot per resident lane and recursion level, only for glass / mirror scenes
     if (a.flat.has_specular && P.recursion > 0) {
-        unsigned long long threads = (unsigned long long)a.max_blocks * 256ull;
+        unsigned long long threads = (unsigned long long)maxb * 256ull;
         size_t need = (size_t)threads * P.recursion * FRAME_DOUBLES;
         if (a.frames.n < need) {
             HIP_TRY(hipDeviceSynchronize()); // (re)allocation: nothing may still use the old buffer
@@ -159,7 +164,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         P.frame_threads = threads;
     }
     if (P.nlights > 0) { // shading frame parked across the shadow traversals
-        unsigned long long threads = (unsigned long long)a.max_blocks * 256ull;
+        unsigned long long threads = (unsigned long long)maxb * 256ull;
         size_t need = (size_t)threads * STASH_DOUBLES;
         if (a.stash.n < need) {
             HIP_TRY(hipDeviceSynchronize()); // (re)allocation: nothing may still use the old buffer
@@ -178,7 +183,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    HIP_TRY(launch_trace(P, stats, blocks, a.stack_depth, stream));
+    HIP_TRY(launch_trace(P, stats, a.fast, blocks, a.fast ? a.stack_depth_fast : a.stack_depth, stream));
     if (a.profiling) {
         HIP_TRY(hipEventRecord(e1, stream));
         a.events.emplace_back(e0, e1);
@@ -371,14 +376,21 @@ lg_accel *lg_accel_from(const lg_scene *s) {
         HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
         // per-lane LDS stack: worst case of this scene graph, +2 guard entries
         a->stack_depth = f.max_stack + 2;
-        size_t lds = (size_t)a->stack_depth * 256 * 4;
-        if (lds > 160 * 1024) throw Error("BVH too deep for the LDS traversal stack (" + std::to_string(a->stack_depth) + " entries per lane)");
+        // the fast kernel falls back to the reference traversal on exact ties, so its stack must hold either
+        a->stack_depth_fast = (f.max_stack > f.max_stack_fast ? f.max_stack : f.max_stack_fast) + 2;
+        size_t lds = (size_t)a->stack_depth_fast * 256 * 4;
+        if (lds > 160 * 1024) throw Error("BVH too deep for the LDS traversal stack (" + std::to_string(a->stack_depth_fast) + " entries per lane)");
         if (lds > 64 * 1024) HIP_TRY(trace_set_lds_limit(lds));
         int per_cu = 0, cus = 0;
-        HIP_TRY(trace_occupancy(a->stack_depth, &per_cu));
+        HIP_TRY(trace_occupancy(a->stack_depth, false, &per_cu));
+        int per_cu_fast = 0;
+        HIP_TRY(trace_occupancy(a->stack_depth_fast, true, &per_cu_fast));
+        if (per_cu_fast < 1) per_cu_fast = 1;
+        a->max_blocks_fast = (uint32_t)per_cu_fast;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device));
         if (per_cu < 1) per_cu = 1;
         a->max_blocks = (uint32_t)(per_cu * cus);
+        a->max_blocks_fast *= (uint32_t)cus;
     });
     if (rc) { delete a; return nullptr; }
     return a;
@@ -497,6 +509,12 @@ int lg_capture_stats(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uin
     });
 }
 
+int lg_accel_set_mode(const lg_accel *a, int mode) {
+    if (mode != 0 && mode != 1) return fail("mode must be 0 (reference traversal) or 1 (fast)");
+    std::lock_guard<std::mutex> g(a->mtx);
+    a->fast = mode == 1;
+    return 0;
+}
 void lg_profile_enable(const lg_accel *a, int enabled) {
     std::lock_guard<std::mutex> g(a->mtx);
     a->profiling = enabled != 0;
@@ -538,7 +556,7 @@ int lg_host_build_dump(const lg_scene *s, const double **f, size_t *nf, const in
 int lg_accel_info(const lg_accel *a, uint64_t out[8]) {
     const FlatScene &f = a->flat;
     out[0] = f.nodes.size(); out[1] = f.primref.size(); out[2] = f.spheres.size(); out[3] = f.cuboids.size();
-    out[4] = f.tri_v.size() / 3; out[5] = f.accels.size(); out[6] = f.max_stack; out[7] = a->device_bytes;
+    out[4] = f.tri_v.size() / 3; out[5] = f.accels.size(); out[6] = a->fast ? a->stack_depth_fast : a->stack_depth; out[7] = a->device_bytes;
     return 0;
 }
 

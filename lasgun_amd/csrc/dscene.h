@@ -88,7 +88,8 @@ struct alignas(16) DAccel {
     uint32_t flags;
     uint32_t nchain;  // number of accels on the path root..self
     uint32_t chain[MAX_CHAIN];
-    uint32_t pad[2];
+    uint32_t fnode_base; // the optional fast tree (binned SAH, <= 4 primitives per leaf) over the SAME primitives
+    uint32_t fprim_base;
 };
 
 struct DStats { // per-launch counters (stats kernel variant only)

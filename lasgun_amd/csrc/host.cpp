@@ -444,12 +444,105 @@ class Builder {
 };
 
 // ------------------------------------------------------------------------------------------
+// Fast tree (NOT in the reference): binned-SAH BVH with <= 4 primitives per leaf over the same
+// primitive boxes, emitted in the same pre-order format as the reference tree so the device
+// tables and node records are shared.  Used only by the opt-in fast traversal mode.
+// ------------------------------------------------------------------------------------------
+class FastBuilder {
+  public:
+    explicit FastBuilder(const std::vector<Bounds> &pb) : pb_(pb) {}
+    BuiltBVH run() {
+        size_t n = pb_.size();
+        idx_.resize(n);
+        for (size_t i = 0; i < n; ++i) idx_[i] = (uint32_t)i;
+        cen_.resize(n);
+        for (size_t i = 0; i < n; ++i) cen_[i] = 0.5 * (pb_[i].min + pb_[i].max);
+        out_.order.reserve(n);
+        build(0, n);
+        return std::move(out_);
+    }
+
+  private:
+    static constexpr size_t LEAF_MAX = 4;
+    uint32_t build(size_t s, size_t e) {
+        uint32_t my = (uint32_t)out_.nodes.size();
+        out_.nodes.push_back(LinNode{b_none(), true, 0, 0});
+        Bounds b = b_none(), cb = b_none();
+        for (size_t i = s; i < e; ++i) { b = b_union(b, pb_[idx_[i]]); cb = b_add_point(cb, cen_[idx_[i]]); }
+        size_t n = e - s;
+        if (n <= LEAF_MAX) {
+            out_.nodes[my] = LinNode{b, true, (uint32_t)out_.order.size(), (uint32_t)n};
+            for (size_t i = s; i < e; ++i) out_.order.push_back(idx_[i]);
+            return my;
+        }
+        // peel off primitives that are as large as the node itself (walls, nested groups): left in
+        // place they would inflate every box of the subtree they end up in
+        {
+            double na = b_area(b);
+            auto big = [&](uint32_t p) { return b_area(pb_[p]) >= 0.35 * na; };
+            size_t nbig = 0;
+            for (size_t i = s; i < e; ++i) nbig += big(idx_[i]) ? 1 : 0;
+            if (nbig > 0 && nbig < n && na > 0.0 && std::isfinite(na)) {
+                auto it = std::stable_partition(idx_.begin() + s, idx_.begin() + e, big);
+                size_t m = (size_t)(it - idx_.begin());
+                build(s, m);
+                uint32_t second = build(m, e);
+                out_.nodes[my] = LinNode{b, false, 0u, second};
+                return my;
+            }
+        }
+        V3 ext = cb.max - cb.min;
+        int axis = ext.x >= ext.y ? (ext.x >= ext.z ? 0 : 2) : (ext.y >= ext.z ? 1 : 2);
+        double lo = comp(cb.min, axis), width = comp(ext, axis);
+        size_t mid = s + n / 2;
+        bool split_found = false;
+        if (width > 0.0 && std::isfinite(width)) {
+            const int NB = 16;
+            size_t cnt[NB] = {0};
+            Bounds bb[NB];
+            for (auto &x : bb) x = b_none();
+            auto bin_of = [&](uint32_t p) {
+                int k = (int)((comp(cen_[p], axis) - lo) / width * NB);
+                return k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+            };
+            for (size_t i = s; i < e; ++i) { int k = bin_of(idx_[i]); cnt[k]++; bb[k] = b_union(bb[k], pb_[idx_[i]]); }
+            double best = INFINITY;
+            int best_k = -1;
+            for (int k = 0; k < NB - 1; ++k) {
+                Bounds l = b_none(), r = b_none();
+                size_t nl = 0, nr = 0;
+                for (int j = 0; j <= k; ++j) { l = b_union(l, bb[j]); nl += cnt[j]; }
+                for (int j = k + 1; j < NB; ++j) { r = b_union(r, bb[j]); nr += cnt[j]; }
+                if (nl == 0 || nr == 0) continue;
+                double c = (double)nl * b_area(l) + (double)nr * b_area(r);
+                if (c < best) { best = c; best_k = k; }
+            }
+            if (best_k >= 0) {
+                auto it = std::stable_partition(idx_.begin() + s, idx_.begin() + e, [&](uint32_t p) { return bin_of(p) <= best_k; });
+                mid = (size_t)(it - idx_.begin());
+                split_found = mid > s && mid < e;
+            }
+        }
+        if (!split_found) mid = s + n / 2; // coincident centroids: split the list in half
+        build(s, mid);
+        uint32_t second = build(mid, e);
+        out_.nodes[my] = LinNode{b, false, (uint32_t)axis, second};
+        return my;
+    }
+    const std::vector<Bounds> &pb_;
+    std::vector<uint32_t> idx_;
+    std::vector<V3> cen_;
+    BuiltBVH out_;
+};
+
+// ------------------------------------------------------------------------------------------
 // Flattening
 // ------------------------------------------------------------------------------------------
 struct MeshTables { // per scene mesh, shared by all its instances
     bool built = false;
     uint32_t node_base = 0, prim_base = 0, nnodes = 0, norder = 0;
     uint32_t max_stack = 0;
+    uint32_t fnode_base = 0, fprim_base = 0, fmax_stack = 0;
     Bounds root_bounds{};
     uint32_t tri_base = 0;
     bool has_n = false, has_uv = false;
@@ -583,6 +676,20 @@ struct Flattener {
         mt.root_bounds = mt.bvh.nodes[0].b;
         std::vector<uint32_t> refs(mt.bvh.order.size(), 0);
         mt.max_stack = stack_need(mt.bvh.nodes, refs, [](uint32_t) { return 0u; });
+        {   // fast tree over the same triangles
+            BuiltBVH fb = FastBuilder(pb).run();
+            append_nodes(fb, mt.fnode_base);
+            mt.fprim_base = (uint32_t)out.primref.size();
+            out.leaf_soup.resize(mt.fprim_base, DLeafRec{});
+            for (uint32_t o : fb.order) {
+                out.primref.push_back((PK_TRIANGLE << 30) | (mt.tri_base + o));
+                DLeafRec rec{};
+                for (int k = 0; k < 3; ++k)
+                    std::memcpy(&rec.w[3 * k], &obj.position[3 * (size_t)obj.tri[3 * (size_t)o + k].v], 12);
+                out.leaf_soup.push_back(rec);
+            }
+            mt.fmax_stack = 2 * stack_need(fb.nodes, refs, [](uint32_t) { return 0u; });
+        }
         mt.built = true;
         return mt;
     }
@@ -598,7 +705,7 @@ struct Flattener {
     }
 
     // returns accel id; sets bound = BVHAccel::bound() (bvh.rs:457-459) and need = stack entries
-    uint32_t mesh_instance(uint32_t mesh, bool has_mat, const Material &mat, int32_t parent, Bounds &bound, uint32_t &need) {
+    uint32_t mesh_instance(uint32_t mesh, bool has_mat, const Material &mat, int32_t parent, Bounds &bound, uint32_t &need, uint32_t &fneed) {
         uint32_t id = (uint32_t)out.accels.size();
         out.accels.emplace_back();
         MeshTables &mt = mesh_tables(mesh);
@@ -606,6 +713,7 @@ struct Flattener {
         DAccel a{};
         a.m = to_affine(idt.m); a.minv = to_affine(idt.minv);
         a.node_base = mt.node_base; a.prim_base = mt.prim_base;
+        a.fnode_base = mt.fnode_base; a.fprim_base = mt.fprim_base;
         a.material = has_mat ? add_material(mat) : -1;
         a.flags = AF_MESH | (mt.has_n ? AF_HAS_N : 0u) | (mt.has_uv ? AF_HAS_UV : 0u);
         set_chain(a, parent, id);
@@ -613,10 +721,11 @@ struct Flattener {
         dump(mt.bvh, has_mat, false, idt);
         bound = b_transform(idt.m, mt.root_bounds);
         need = mt.max_stack;
+        fneed = mt.fmax_stack;
         return id;
     }
 
-    uint32_t aggregate(const Aggregate &agg, int32_t parent, Bounds &bound, uint32_t &need) { // bvh.rs:150-162
+    uint32_t aggregate(const Aggregate &agg, int32_t parent, Bounds &bound, uint32_t &need, uint32_t &fneed) { // bvh.rs:150-162
         uint32_t id = (uint32_t)out.accels.size();
         out.accels.emplace_back();
         {
@@ -634,7 +743,7 @@ struct Flattener {
         std::vector<double> child_f; std::vector<int64_t> child_i;
         std::swap(child_f, out.dump_f); std::swap(child_i, out.dump_i); // children dump into fresh vectors
         std::vector<Bounds> pb(n);
-        std::vector<uint32_t> ref(n), extra(n, 0);
+        std::vector<uint32_t> ref(n), extra(n, 0), fextra(n, 0);
         std::vector<DLeafRec> rec(n, DLeafRec{});
         for (size_t i = 0; i < n; ++i) {
             const SceneNode &nd = agg.contents[i];
@@ -663,17 +772,19 @@ struct Flattener {
                 break;
             }
             case SceneNode::MESH: {
-                uint32_t cn = 0;
-                uint32_t cid = mesh_instance(nd.obj, nd.has_mat, nd.mat, (int32_t)id, pb[i], cn);
+                uint32_t cn = 0, fcn = 0;
+                uint32_t cid = mesh_instance(nd.obj, nd.has_mat, nd.mat, (int32_t)id, pb[i], cn, fcn);
                 ref[i] = (PK_ACCEL << 30) | cid;
                 extra[i] = 3 + cn;
+                fextra[i] = 3 + fcn;
                 break;
             }
             case SceneNode::GROUP: {
-                uint32_t cn = 0;
-                uint32_t cid = aggregate(*nd.group, (int32_t)id, pb[i], cn);
+                uint32_t cn = 0, fcn = 0;
+                uint32_t cid = aggregate(*nd.group, (int32_t)id, pb[i], cn, fcn);
                 ref[i] = (PK_ACCEL << 30) | cid;
                 extra[i] = 3 + cn;
+                fextra[i] = 3 + fcn;
                 break;
             }
             }
@@ -693,6 +804,25 @@ struct Flattener {
         out.accels[id].prim_base = prim_base;
         need = stack_need(bvh.nodes, extra_in_order, [](uint32_t e) { return e; });
         bound = b_transform(agg.transform.m, bvh.nodes[0].b);
+        {   // fast tree over the same primitives (child accels included as primitives)
+            BuiltBVH fb = FastBuilder(pb).run();
+            uint32_t fnode_base;
+            append_nodes(fb, fnode_base);
+            uint32_t fprim_base = (uint32_t)out.primref.size();
+            out.leaf_soup.resize(fprim_base, DLeafRec{});
+            std::vector<uint32_t> fextra_in_order(fb.order.size());
+            for (size_t i = 0; i < fb.order.size(); ++i) {
+                out.primref.push_back(ref[fb.order[i]]);
+                out.leaf_soup.push_back(rec[fb.order[i]]);
+                fextra_in_order[i] = fextra[fb.order[i]];
+            }
+            out.accels[id].fnode_base = fnode_base;
+            out.accels[id].fprim_base = fprim_base;
+            // two words per pending child in the fast traversal; nested entries cost what they cost below
+            std::vector<uint32_t> half(fextra_in_order.size());
+            for (size_t i = 0; i < half.size(); ++i) half[i] = (fextra_in_order[i] + 1) / 2;
+            fneed = 2 * stack_need(fb.nodes, half, [](uint32_t e) { return e; });
+        }
         // stitch the dump: [prefix][this accel][children]
         std::swap(child_f, out.dump_f); std::swap(child_i, out.dump_i); // out.* = prefix again, child_* = children
         (void)dump_f_at; (void)dump_i_at;
@@ -710,9 +840,10 @@ void flatten_scene(const Scene &scene, FlatScene &out) {
     fl.meshes.resize(scene.meshes.size());
     out.default_material = fl.add_material(material_default());
     Bounds b;
-    uint32_t need = 0;
-    fl.aggregate(*scene.root, -1, b, need);
+    uint32_t need = 0, fneed = 0;
+    fl.aggregate(*scene.root, -1, b, need, fneed);
     out.max_stack = need;
+    out.max_stack_fast = fneed;
     out.leaf_soup.resize(out.primref.size(), DLeafRec{});
     for (const Light &l : scene.lights) {
         DLight d;

@@ -121,6 +121,7 @@ struct FlatScene {
     std::vector<DLight> lights;
     int32_t default_material = 0;
     uint32_t max_stack = 0;      // worst-case per-lane traversal stack entries
+    uint32_t max_stack_fast = 0; // same for the fast tree (two words per pending child)
     bool has_specular = false;   // any glass / mirror material present
     // structure dump in the same format as the oracle's orc_accel_dump (build-parity tests)
     std::vector<double> dump_f;

@@ -30,6 +30,15 @@
 #include "dscene.h"
 #include "trig.h"
 
+#ifndef LG_TRI_PER_LEAF
+#define LG_TRI_PER_LEAF 1 // reference traversal: shear setup per fat leaf, not held in registers across the traversal (measured faster)
+#endif
+#ifndef LG_SHADE_INLINE
+#define LG_SHADE_INLINE __forceinline__
+#endif
+#ifndef LG_BSDF_INLINE
+#define LG_BSDF_INLINE __forceinline__
+#endif
 #ifndef LG_TRAVERSE_INLINE
 #define LG_TRAVERSE_INLINE __forceinline__
 #endif
@@ -54,6 +63,21 @@ __device__ __forceinline__ bool slab_intersects(const double bmin[3], const doub
     t1 = (bmin[2] - r.o.z) * r.dinv.z; t2 = (bmax[2] - r.o.z) * r.dinv.z;
     tnear = fmax_(tnear, fmin_(t1, t2));
     tfar = fmin_(tfar, fmax_(t1, t2));
+    return tnear <= tfar && tfar > 0.0;
+}
+
+// the same test, also handing back its tnear (used by the fast mode's front-to-back pruning)
+__device__ __forceinline__ bool slab_intersects_t(const double bmin[3], const double bmax[3], const Ray &r, double &tnear_out) {
+    double t1 = (bmin[0] - r.o.x) * r.dinv.x, t2 = (bmax[0] - r.o.x) * r.dinv.x;
+    double tnear = fmax_(-INFINITY, fmin_(t1, t2));
+    double tfar = fmin_(INFINITY, fmax_(t1, t2));
+    t1 = (bmin[1] - r.o.y) * r.dinv.y; t2 = (bmax[1] - r.o.y) * r.dinv.y;
+    tnear = fmax_(tnear, fmin_(t1, t2));
+    tfar = fmin_(tfar, fmax_(t1, t2));
+    t1 = (bmin[2] - r.o.z) * r.dinv.z; t2 = (bmax[2] - r.o.z) * r.dinv.z;
+    tnear = fmax_(tnear, fmin_(t1, t2));
+    tfar = fmin_(tfar, fmax_(t1, t2));
+    tnear_out = tnear;
     return tnear <= tfar && tfar > 0.0;
 }
 
@@ -291,20 +315,21 @@ struct Trav {
     uint32_t sp, base;   // stack pointer / first entry of the current accel level
     uint32_t li, le;     // leaf cursor (absolute primref indices)
     bool in_leaf, done, level_done;
-    double dd;           // dot(ray.d, ray.d): the `a` of every sphere test at this level (sphere.rs:50)
+    bool tie;            // fast mode: two primitives produced exactly the same t
     uint32_t negmask;    // bit a set <=> dinv[a] < 0 (dir_is_neg, bvh.rs:463)
     bool mesh;           // current accel is a triangle mesh (every leaf slot is a triangle)
     TriSetup tri;        // valid while `mesh`
 };
+template <bool FAST>
 __device__ __forceinline__ void trav_set_level(const DParams &P, Trav &T, uint32_t accel, const Ray &local) {
     const DAccel *A = P.accels + accel;
     T.accel = accel;
     T.ray = local;
-    T.node_base = A->node_base; T.prim_base = A->prim_base;
+    T.node_base = FAST ? A->fnode_base : A->node_base;
+    T.prim_base = FAST ? A->fprim_base : A->prim_base;
     T.negmask = (local.dinv.x < 0.0 ? 1u : 0u) | (local.dinv.y < 0.0 ? 2u : 0u) | (local.dinv.z < 0.0 ? 4u : 0u);
     T.mesh = (A->flags & AF_MESH) != 0u;
-    if (T.mesh) T.tri = tri_setup(local);
-    else T.dd = dot(local.d, local.d);
+    if (T.mesh && (FAST || !LG_TRI_PER_LEAF)) T.tri = tri_setup(local);
 }
 
 // leaf-ordered 48-byte geometry records: three 16-byte loads per slot
@@ -320,7 +345,7 @@ __device__ __forceinline__ double rec_f32(uint32_t w) { return (double)__uint_as
 
 // One fat mesh leaf [li, le): the reference's leaf loop (bvh.rs:483-488) specialised for
 // triangles, streaming the leaf-ordered records one slot ahead of the test.
-template <int KZ, bool STATS>
+template <int KZ, bool STATS, bool FAST>
 __device__ __forceinline__ void mesh_leaf(const DParams &P, Trav &T, bool anyhit, Best &best, Counters &cnt) {
     const V3 o = T.ray.o;
     const double sx = T.tri.sx, sy = T.tri.sy, sz = T.tri.sz;
@@ -335,6 +360,7 @@ __device__ __forceinline__ void mesh_leaf(const DParams &P, Trav &T, bool anyhit
         if (STATS) cnt.triangles++;
         TriHit h;
         if (!triangle_t_pre<KZ>(p0, p1, p2, o, sx, sy, sz, h)) continue;
+        if (FAST && h.t == best.t && best.ref != NO_HIT) T.tie = true; // equal t: the reference's visit order decides
         if (h.t >= best.t) continue;
         best.t = h.t; best.ref = P.primref[li]; best.accel = T.accel;
         if (anyhit && h.t < 1.0) { T.done = true; break; } // point.rs:49
@@ -367,8 +393,9 @@ __device__ __forceinline__ void trav_pop(const DParams &P, Trav &T, uint32_t *st
     }
 }
 // entering an accel: test the root node's own box once (bvh.rs:472-473 for node 0)
-template <bool STATS>
+template <bool STATS, bool PAIR>
 __device__ __forceinline__ void trav_enter_root(const DParams &P, Trav &T, Counters &cnt) {
+    if (!PAIR) { T.cur = 0; T.in_leaf = false; return; } // one-node-per-step form: node 0 is tested when visited
     const DNode *nd = P.nodes + T.node_base;
     double bmin[3] = {nd->bmin[0], nd->bmin[1], nd->bmin[2]};
     double bmax[3] = {nd->bmax[0], nd->bmax[1], nd->bmax[2]};
@@ -379,18 +406,57 @@ __device__ __forceinline__ void trav_enter_root(const DParams &P, Trav &T, Count
     if (meta & NODE_LEAF) trav_open_leaf(T, link, meta);
 }
 
-template <bool STATS>
+// ---- fast mode (opt-in; NOT the reference's traversal) ----------------------------------------
+// Same nested accels, same primitive tests, same arithmetic, but over the binned-SAH tree with
+// <= 4 primitives per leaf, visiting the child with the smaller slab tnear first and skipping
+// children whose tnear lies beyond the current best hit (closest) or beyond the light (any-hit).
+// Pending children carry their tnear (as a float rounded down) so they can be skipped at pop time.
+// The candidate set differs from the reference's only by primitives that cannot win unless a
+// computed t is off by more than the margin below; exact ties in t (where the reference's visit
+// order decides) are detected and those rays are re-traced with the reference traversal.
+__device__ __forceinline__ double prune_limit(double tbest, bool anyhit) {
+    double lim = anyhit ? 1.0 : tbest;
+    return lim + 1e-5 * (fabs(lim) + 1.0); // +inf stays +inf
+}
+__device__ __forceinline__ uint32_t f32_bits_down(double t) { // a float <= t
+    float f = (float)t;
+    if ((double)f > t) f = __uint_as_float(__float_as_uint(f) + (f > 0.f ? -1 : 1)); // one ulp towards -inf
+    if (f == 0.f && t < 0.0) f = -1e-30f;
+    return __float_as_uint(f);
+}
+__device__ __forceinline__ void trav_pop_fast(const DParams &P, Trav &T, uint32_t *stack, uint32_t stride, double limit) {
+    T.in_leaf = false;
+    for (;;) {
+        if (T.sp == T.base) { T.level_done = true; return; }
+        T.sp -= 2;
+        uint32_t e = stack[T.sp * stride];
+        float tn = __uint_as_float(stack[(T.sp + 1) * stride]);
+        if ((double)tn > limit) continue; // beyond the best hit found meanwhile
+        if (e & STACK_LEAF) {
+            const DNode *nd = P.nodes + (T.node_base + (e & ~STACK_LEAF));
+            trav_open_leaf(T, nd->link, nd->meta);
+        } else {
+            T.cur = e;
+        }
+        return;
+    }
+}
+
+template <bool STATS, bool FAST>
 __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, bool anyhit, uint32_t *stack, uint32_t stride,
-                                         Best &best, Counters &cnt) {
+                                         Best &best, Counters &cnt, bool &tie) {
+#define LG_POP() do { if (FAST) trav_pop_fast(P, T, stack, stride, prune_limit(best.t, anyhit)); else trav_pop(P, T, stack, stride); } while (0)
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
     Trav T;
-    trav_set_level(P, T, 0u, ray_to_local(P.accels->minv, wray));
-    T.sp = 0; T.base = 0; T.li = 0; T.le = 0; T.done = false; T.level_done = false;
+    trav_set_level<FAST>(P, T, 0u, ray_to_local(P.accels->minv, wray));
+    T.sp = 0; T.base = 0; T.li = 0; T.le = 0; T.done = false; T.level_done = false; T.tie = false;
     if (STATS) cnt.entries++;
-    trav_enter_root<STATS>(P, T, cnt);
+    trav_enter_root<STATS, FAST>(P, T, cnt);
     while (!T.done) {
-        // ---- phase A: interior nodes.  T.cur is an interior node whose own box is known to be hit;
-        // one 128-byte child-pair record feeds the slab tests of BOTH children.
+        // ---- phase A: interior nodes
+        if (FAST) {
+        // T.cur is an interior node whose own box is known to be hit; one 128-byte child-pair
+        // record feeds the slab tests of BOTH children.
         while (!T.in_leaf && !T.level_done) {
             const DNode2 *nd = P.nodes2 + (T.node_base + T.cur);
             double b0min[3] = {nd->b0min[0], nd->b0min[1], nd->b0min[2]}, b0max[3] = {nd->b0max[0], nd->b0max[1], nd->b0max[2]};
@@ -398,66 +464,96 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
             uint32_t link0 = nd->link0, meta0 = nd->meta0, link1 = nd->link1, meta1 = nd->meta1;
             uint32_t axis = nd->axis, second = nd->second;
             if (STATS) cnt.nodes += 2;
-            bool hit0 = slab_intersects(b0min, b0max, T.ray);
-            bool hit1 = slab_intersects(b1min, b1max, T.ray);
-            bool neg = ((T.negmask >> axis) & 1u) != 0u; // dir_is_neg[axis]: second child is the near one (bvh.rs:496-499)
-            // near / far child in the reference's visiting order
-            bool near_hit = neg ? hit1 : hit0, far_hit = neg ? hit0 : hit1;
-            uint32_t near_idx = neg ? second : T.cur + 1, far_idx = neg ? T.cur + 1 : second;
-            uint32_t near_link = neg ? link1 : link0, near_meta = neg ? meta1 : meta0;
-            uint32_t far_meta = neg ? meta0 : meta1;
-            if (far_hit) { // visited after the whole near subtree (bvh.rs:497,500)
-                stack[T.sp * stride] = far_idx | ((far_meta & NODE_LEAF) ? STACK_LEAF : 0u);
-                ++T.sp;
+            if (FAST) {
+                double tn0, tn1;
+                bool hit0 = slab_intersects_t(b0min, b0max, T.ray, tn0);
+                bool hit1 = slab_intersects_t(b1min, b1max, T.ray, tn1);
+                double limit = prune_limit(best.t, anyhit);
+                hit0 = hit0 && !(tn0 > limit);
+                hit1 = hit1 && !(tn1 > limit);
+                bool swap = hit1 && (!hit0 || tn1 < tn0); // nearer child first
+                bool near_hit = swap ? hit1 : hit0, far_hit = swap ? hit0 : hit1;
+                uint32_t near_idx = swap ? second : T.cur + 1, far_idx = swap ? T.cur + 1 : second;
+                uint32_t near_link = swap ? link1 : link0, near_meta = swap ? meta1 : meta0;
+                uint32_t far_meta = swap ? meta0 : meta1;
+                double far_tn = swap ? tn0 : tn1;
+                (void)axis;
+                if (near_hit && far_hit) {
+                    stack[T.sp * stride] = far_idx | ((far_meta & NODE_LEAF) ? STACK_LEAF : 0u);
+                    stack[(T.sp + 1) * stride] = f32_bits_down(far_tn);
+                    T.sp += 2;
+                }
+                if (near_hit) {
+                    if (near_meta & NODE_LEAF) trav_open_leaf(T, near_link, near_meta);
+                    else T.cur = near_idx;
+                } else {
+                    LG_POP();
+                }
             }
-            if (near_hit) {
-                if (near_meta & NODE_LEAF) trav_open_leaf(T, near_link, near_meta);
-                else T.cur = near_idx;
+        }
+        } else {
+        // reference traversal, one node per step (bvh.rs:471-505)
+        while (!T.in_leaf && !T.level_done) {
+            const DNode *nd = P.nodes + (T.node_base + T.cur);
+            // one 64-byte record = four 16-byte loads from a single line, all issued before the
+            // slab test; link/meta are decoded branch-free so the compiler cannot sink their load
+            // behind the hit test (that would put a second memory latency on the critical path)
+            double bmin[3] = {nd->bmin[0], nd->bmin[1], nd->bmin[2]};
+            double bmax[3] = {nd->bmax[0], nd->bmax[1], nd->bmax[2]};
+            uint32_t link = nd->link, meta = nd->meta;
+            if (STATS) cnt.nodes++;
+            bool hit = slab_intersects(bmin, bmax, T.ray);
+            bool leaf = (meta & NODE_LEAF) != 0u;
+            uint32_t count = meta & 0xFFFFu;
+            bool neg = ((T.negmask >> (meta & 3u)) & 1u) != 0u; // dir_is_neg[axis] (bvh.rs:463,496)
+            uint32_t near_node = neg ? link : T.cur + 1;
+            uint32_t far_node = neg ? T.cur + 1 : link;
+            if (hit && !leaf) { // near child first, far child on the stack (bvh.rs:493-504)
+                stack[T.sp * stride] = far_node;
+                ++T.sp;
+                T.cur = near_node;
+            } else if (hit && leaf && count != 0u) {
+                trav_open_leaf(T, link, meta);
             } else {
                 trav_pop(P, T, stack, stride);
             }
         }
-        if (T.in_leaf && T.li >= T.le) { trav_pop(P, T, stack, stride); continue; } // empty leaf (nprims as u16 == 0)
+        }
+        if (T.in_leaf && T.li >= T.le) { LG_POP(); continue; } // empty leaf (nprims as u16 == 0)
         // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
         if (T.in_leaf && T.mesh) {
-            if (T.tri.kz == 0) mesh_leaf<0, STATS>(P, T, anyhit, best, cnt);
-            else if (T.tri.kz == 1) mesh_leaf<1, STATS>(P, T, anyhit, best, cnt);
-            else mesh_leaf<2, STATS>(P, T, anyhit, best, cnt);
-            if (!T.done) trav_pop(P, T, stack, stride); // may open the next (already box-tested) leaf
+            if (!FAST && LG_TRI_PER_LEAF) T.tri = tri_setup(T.ray); // fat reference leaves amortise the three divides
+            if (T.tri.kz == 0) mesh_leaf<0, STATS, FAST>(P, T, anyhit, best, cnt);
+            else if (T.tri.kz == 1) mesh_leaf<1, STATS, FAST>(P, T, anyhit, best, cnt);
+            else mesh_leaf<2, STATS, FAST>(P, T, anyhit, best, cnt);
+            if (!T.done) LG_POP(); // may open the next (already box-tested) leaf
             else T.in_leaf = false;
         } else if (T.in_leaf) {
-            uint32_t nref = P.primref[T.li];
-            LeafRec nrec = load_rec(P, T.li);
             while (T.in_leaf) {
-                const uint32_t ref = nref;
-                const LeafRec r = nrec;
+                const uint32_t ref = P.primref[T.li];
                 ++T.li;
-                {   // prefetch the next slot (clamped to this leaf: always valid)
-                    uint32_t nx = T.li < T.le ? T.li : T.le - 1u;
-                    nref = P.primref[nx];
-                    nrec = load_rec(P, nx);
-                }
                 uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
                 bool accepted = false;
                 double t = 0.0;
                 if (kind == PK_SPHERE) {
                     if (STATS) cnt.spheres++;
                     bool inside;
-                    t = sphere_t_a(T.ray, T.dd, V3{rec_f64(r.a.x, r.a.y), rec_f64(r.a.z, r.a.w), rec_f64(r.b.x, r.b.y)}, rec_f64(r.b.z, r.b.w), inside);
+                    DSphere sp = P.spheres[idx];
+                    t = sphere_t(T.ray, V3{sp.cx, sp.cy, sp.cz}, sp.r, inside);
                     accepted = !(t < 0.0) && !(t >= best.t);
                 } else if (kind == PK_CUBOID) {
                     if (STATS) cnt.cuboids++;
-                    double mn[3] = {rec_f64(r.a.x, r.a.y), rec_f64(r.a.z, r.a.w), rec_f64(r.b.x, r.b.y)};
-                    double mx[3] = {rec_f64(r.b.z, r.b.w), rec_f64(r.c.x, r.c.y), rec_f64(r.c.z, r.c.w)};
+                    DCuboid cb = P.cuboids[idx];
+                    double mn[3] = {cb.mn[0], cb.mn[1], cb.mn[2]}, mx[3] = {cb.mx[0], cb.mx[1], cb.mx[2]};
                     V3 d0, d1;
                     if (cuboid_hit<false>(mn, mx, T.ray, t, d0, d1)) accepted = !(t >= best.t);
                 } else if (kind == PK_ACCEL) {
                     // nested BVHAccel (Group / Mesh): save this level, re-express the ray (bvh.rs:462)
                     stack[T.sp * stride] = T.li; stack[(T.sp + 1) * stride] = T.le; stack[(T.sp + 2) * stride] = T.base;
                     T.sp += 3; T.base = T.sp;
-                    trav_set_level(P, T, idx, ray_to_local(P.accels[idx].minv, T.ray));
+                    trav_set_level<FAST>(P, T, idx, ray_to_local(P.accels[idx].minv, T.ray));
                     if (STATS) cnt.entries++;
-                    trav_enter_root<STATS>(P, T, cnt);
+                    trav_enter_root<STATS, FAST>(P, T, cnt);
                     break;
                 } else { // a triangle outside a mesh accel cannot be built by the scene API; kept for completeness
                     if (STATS) cnt.triangles++;
@@ -465,11 +561,12 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
                     TriHit h;
                     if (triangle_t(load_f3(P.vpos, vi[0]), load_f3(P.vpos, vi[1]), load_f3(P.vpos, vi[2]), T.ray, h)) { t = h.t; accepted = !(t >= best.t); }
                 }
+                if (FAST && !accepted && t == best.t && best.ref != NO_HIT && kind != PK_ACCEL) T.tie = true; // equal t: visit order decides
                 if (accepted) {
                     best.t = t; best.ref = ref; best.accel = T.accel;
                     if (anyhit && t < 1.0) { T.done = true; T.in_leaf = false; break; } // occluded: point.rs:49 only asks isect.t < 1.0
                 }
-                if (T.li >= T.le) { trav_pop(P, T, stack, stride); break; } // a popped leaf restarts phase B (fresh prefetch)
+                if (T.li >= T.le) { LG_POP(); break; } // a popped leaf restarts phase B (fresh prefetch)
             }
         }
         // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
@@ -480,12 +577,14 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
                 T.base = stack[(T.sp - 1) * stride]; T.le = stack[(T.sp - 2) * stride]; T.li = stack[(T.sp - 3) * stride];
                 T.sp -= 3;
                 uint32_t parent = (uint32_t)P.accels[T.accel].parent;
-                trav_set_level(P, T, parent, local_ray(P, wray, parent));
+                trav_set_level<FAST>(P, T, parent, local_ray(P, wray, parent));
                 if (T.li < T.le) T.in_leaf = true;
-                else trav_pop(P, T, stack, stride);
+                else LG_POP();
             }
         }
     }
+    tie = T.tie;
+#undef LG_POP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -634,7 +733,7 @@ struct Shade {
 };
 
 // BSDF::f (bsdf.rs:73-92) with the BxDF list of Material::scattering (material/*.rs) inlined
-__device__ __forceinline__ V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo, V3 wi) {
+__device__ LG_BSDF_INLINE V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo, V3 wi) {
 #if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 3 /* timing only: constant BSDF */
     return V3{m.p[0], m.p[1], m.p[2]} * dot(wo, wi) * dot(sh.ns, sh.ss);
 #endif
@@ -767,7 +866,7 @@ extern __shared__ uint32_t lds_stack[];
 // Shading frame of a hit from the ray that found it (resolve_hit + SurfaceInteraction::from,
 // surface.rs:158-183).  Pure function of (ray, best): recomputed after each shadow traversal
 // instead of being kept in registers across it, which is what lets 4-5 waves share a SIMD.
-__device__ __forceinline__ void shade_frame(const DParams &P, const Ray &ray, const Best &best, Shade &sh) {
+__device__ LG_SHADE_INLINE void shade_frame(const DParams &P, const Ray &ray, const Best &best, Shade &sh) {
     Isect is;
     sh.mat = resolve_hit(P, ray, best, is);
     sh.wo = -normalize(ray.d);
@@ -813,7 +912,7 @@ __device__ __forceinline__ void stash_get(const DParams &P, unsigned long long g
     sh.ts = cross(sh.ns, sh.ss);
 }
 
-template <bool STATS>
+template <bool STATS, bool FAST>
 __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(const DParams P) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -886,7 +985,13 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
 #if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 2 /* timing only: shadow rays are not traced */
                 if (shadow_job) { b.t = INFINITY; b.ref = NO_HIT; b.accel = 0; } else
 #endif
-                traverse<STATS>(P, tray, shadow_job, stack, stride, b, cnt);
+                {
+                    bool tie = false;
+                    traverse<STATS, FAST>(P, tray, shadow_job, stack, stride, b, cnt, tie);
+                    // fast mode: exact ties in t are decided by the reference's visit order -> re-trace this ray with it.
+                    // (an occluded any-hit ray needs no re-trace: the answer "some t < 1 exists" is order-independent)
+                    if (FAST && tie && !(shadow_job && b.t < 1.0)) traverse<STATS, false>(P, tray, shadow_job, stack, stride, b, cnt, tie);
+                }
                 bool have_value = false, need_shade = false, visible = false;
 #if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 1 /* timing only: primary traversal, nothing else */
                 value = V3{b.t, (double)b.ref, (double)b.accel}; have_value = true; (void)need_shade; (void)visible;
@@ -920,7 +1025,11 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
                         shade_frame(P, pray, pbest, sh);
                         if (P.nlights > 0) stash_put(P, gtid, sh);
                     } else {
+#ifdef LG_NO_STASH
+                        shade_frame(P, pray, pbest, sh);
+#else
                         stash_get(P, gtid, sh, pray);
+#endif
                     }
                     const DMaterial m = P.materials[sh.mat];
                     V3 n = sh.ns;
@@ -1125,20 +1234,30 @@ __global__ void math_kernel(int op, size_t n, const double *a, const double *b, 
 // ------------------------------------------------------------------------------------------
 // host-callable launchers (used by capi.cpp)
 // ------------------------------------------------------------------------------------------
-hipError_t launch_trace(const DParams &P, bool stats, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
-    size_t lds = (size_t)stack_depth * 256u * sizeof(uint32_t);
-    if (stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(256), lds, stream, P);
-    else hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(256), lds, stream, P);
+hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
+    size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
+    if (fast) {
+        if (stats) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+    } else {
+        if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+    }
     return hipGetLastError();
 }
-hipError_t trace_occupancy(uint32_t stack_depth, int *blocks_per_cu) {
-    size_t lds = (size_t)stack_depth * 256u * sizeof(uint32_t);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false>, 256, lds);
+hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu) {
+    size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
+    if (fast) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, true>, LG_BLOCK, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, false>, LG_BLOCK, lds);
 }
 hipError_t trace_set_lds_limit(size_t bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const void *fns[4] = {reinterpret_cast<const void *>(trace_kernel<false, false>), reinterpret_cast<const void *>(trace_kernel<true, false>),
+                          reinterpret_cast<const void *>(trace_kernel<false, true>), reinterpret_cast<const void *>(trace_kernel<true, true>)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 hipError_t launch_kat(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d, double *out,
                       hipStream_t stream) {

@@ -160,6 +160,42 @@ def test_gpu_matches_oracle(name):
     assert np.all(np.abs(grad - orad) <= tol)
 
 
+# ---- opt-in fast mode: must reproduce the parity path's bytes and radiance bits ------------------
+@pytest.mark.parametrize("name", list(MID))
+def test_fast_mode_matches_parity_mode(name):
+    builder, w, h = MID[name]
+    acc = G.Accel(builder(G))
+    film = G.Film(w, h)
+    G.capture_subset(0, 1, acc, film)
+    rad = G.capture_radiance(acc, w, h)
+    st = G.capture_stats(acc, w, h)
+    G.set_mode(acc, True)
+    ffilm = G.Film(w, h)
+    G.capture_subset(0, 1, acc, ffilm)
+    frad = G.capture_radiance(acc, w, h)
+    fst = G.capture_stats(acc, w, h)
+    assert np.array_equal(ffilm.pixels(), film.pixels())
+    assert np.array_equal(bits(frad), bits(rad))
+    for key in ("primary_rays", "shadow_rays", "secondary_rays", "hits"):
+        assert fst[key] == st[key]
+
+
+def test_fast_mode_full_size_films_are_identical():
+    import torch
+    cases = [(S.spheres_scene, 4096), (lambda api: S.mesh_scene(api, 224, 224, "glass"), 2048),
+             (lambda api: S.mixed_scene(api), 2048), (lambda api: S.kitchen_sink_scene(api, "perspective", 3, 0), 1024)]
+    for builder, size in cases:
+        acc = G.Accel(builder(G))
+        a = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
+        b = torch.zeros_like(a)
+        G.capture_rows_device(acc, size, size, 0, size, a.data_ptr(), row0=0)
+        G.synchronize(acc)
+        G.set_mode(acc, True)
+        G.capture_rows_device(acc, size, size, 0, size, b.data_ptr(), row0=0)
+        G.synchronize(acc)
+        assert torch.equal(a, b)
+
+
 # ---- driver semantics (lib.rs:55-162) -------------------------------------------------------
 def test_capture_subset_partitions_and_preserves_other_pixels():
     w, h = 96, 80

@@ -25,7 +25,8 @@ CONFIGS = [
 
 
 def main():
-    only = sys.argv[1:]
+    fast = "--fast" in sys.argv
+    only = [a for a in sys.argv[1:] if a != "--fast"]
     G.set_device(0)
     for name, build, size in CONFIGS:
         if only and not any(o in name for o in only):
@@ -34,6 +35,7 @@ def main():
         t0 = time.perf_counter()
         acc = G.Accel(scene)
         build_s = time.perf_counter() - t0
+        G.set_mode(acc, fast)
         film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
         stream = torch.cuda.current_stream().cuda_stream
         G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)
@@ -46,7 +48,7 @@ def main():
         ms = (time.perf_counter() - t0) / reps * 1e3
         st = G.capture_stats(acc, size, size)
         rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
-        print(json.dumps({"config": name, "ms": round(ms, 3), "Mrays_s": round(rays / ms / 1e3, 1), "rays": rays,
+        print(json.dumps({"config": name, "mode": "fast" if fast else "parity", "ms": round(ms, 3), "Mrays_s": round(rays / ms / 1e3, 1), "rays": rays,
                           "accel_build_s": round(build_s, 3), "info": G.accel_info(acc), "stats": st}), flush=True)
 
 
