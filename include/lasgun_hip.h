@@ -138,9 +138,20 @@ int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t
  * to mode 0 on every test scene and benchmark config, but not PROVEN identical. */
 int lg_accel_set_mode(const lg_accel *, int mode);
 
+/* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes without
+ * glass / mirror and with <= 32 lights run as a four-kernel streaming pipeline (primary traversal,
+ * shading frame, shadow traversal, shade) with per-pixel state in HBM when the launch covers at
+ * least 2^20 pixels; everything else -- and everything when 0 -- runs in the single persistent
+ * megakernel.  2 = use the pipeline for any size (tests). */
+int lg_accel_set_streaming(const lg_accel *, int enabled);
+
 /* Kernel timing with HIP events on the launch stream: enable, render, then read. */
 void lg_profile_enable(const lg_accel *, int enabled);
 int lg_profile_read(const lg_accel *, double *total_ms, uint64_t *launches); /* synchronises; resets the tally */
+/* Streaming pipeline only: per-kernel HIP-event time. kind 0 primary trace, 1 frame, 2 shadow trace, 3 shade. */
+int lg_profile_read_kinds(const lg_accel *, double ms[5], uint64_t launches[5]);
+/* lg_capture_stats restricted to one kind of traversal: 0 all, 1 closest-hit (primary/secondary), 2 shadow. */
+int lg_capture_stats_kind(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, int kind, lg_stats *out);
 
 /* Scene-structure introspection (tests) */
 int lg_accel_dump(const lg_accel *, const double **f, size_t *nf, const int64_t **i, size_t *ni);

@@ -33,10 +33,13 @@ _EXTRA = {
                                               _C.c_void_p, _C.c_void_p]),
     "accel_stream": (_C.c_void_p, [_C.c_void_p]),
     "accel_set_mode": (_C.c_int, [_C.c_void_p, _C.c_int]),
+    "accel_set_streaming": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
     "capture_radiance": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
     "capture_stats": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.POINTER(CStats)]),
     "profile_enable": (None, [_C.c_void_p, _C.c_int]),
+    "profile_read_kinds": (_C.c_int, [_C.c_void_p, _C.c_double * 5, _C.c_uint64 * 5]),
+    "capture_stats_kind": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_int, _C.POINTER(CStats)]),
     "profile_read": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.c_double), _C.POINTER(_C.c_uint64)]),
     "accel_info": (_C.c_int, [_C.c_void_p, _C.c_uint64 * 8]),
     "host_build_dump": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.POINTER(_C.c_double)), _C.POINTER(_C.c_size_t),
@@ -58,6 +61,10 @@ class HipApi(Api):
         """False = the reference traversal (parity path, default); True = the opt-in fast mode."""
         if self.call("accel_set_mode", accel.h, 1 if fast else 0):
             raise LasgunError(self.last_error())
+
+    def set_streaming(self, accel, enabled):
+        """True (default) = four-kernel streaming pipeline where the scene allows it; False = megakernel only."""
+        self.call("accel_set_streaming", accel.h, int(enabled) if enabled in (0, 1, 2) else (1 if enabled else 0))
 
     def set_device(self, device):
         if self.call("set_device", int(device)):
@@ -98,6 +105,21 @@ class HipApi(Api):
         if self.call("capture_stats", accel.h, w, h, y0, h if y1 is None else y1, _C.byref(s)):
             raise LasgunError(self.last_error())
         return s.as_dict()
+
+    def capture_stats_kind(self, accel, w, h, kind, y0=0, y1=None):
+        """Work counters of one kind of traversal: 1 = closest-hit (primary/secondary), 2 = shadow."""
+        s = CStats()
+        if self.call("capture_stats_kind", accel.h, w, h, y0, h if y1 is None else y1, int(kind), _C.byref(s)):
+            raise LasgunError(self.last_error())
+        return s.as_dict()
+
+    def profile_read_kinds(self, accel):
+        """Streaming pipeline: {kernel: (total ms, launches)} from HIP events around each kernel."""
+        ms = (_C.c_double * 5)(); n = (_C.c_uint64 * 5)()
+        if self.call("profile_read_kinds", accel.h, ms, n):
+            raise LasgunError(self.last_error())
+        names = ("stream_trace_kernel<primary>", "stream_frame_kernel", "stream_trace_kernel<shadow>", "stream_shade_kernel", "trace_kernel")
+        return {names[i]: (ms[i], int(n[i])) for i in range(5)}
 
     def profile_enable(self, accel, enabled=True):
         self.call("profile_enable", accel.h, 1 if enabled else 0)

@@ -15,6 +15,10 @@ namespace lg {
 // kernels.hip
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
 hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
+hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
+hipError_t launch_stream_frame(const DParams &P, hipStream_t stream);
+hipError_t launch_stream_shade(const DParams &P, hipStream_t stream);
+hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
 hipError_t trace_set_lds_limit(size_t bytes);
 hipError_t launch_kat(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d, double *out,
                       hipStream_t stream);
@@ -101,6 +105,12 @@ struct lg_accel {
     mutable DevBuf<uint32_t> tile_counter;
     mutable DevBuf<double> frames;
     mutable DevBuf<double> stash;
+    // streaming pipeline state (sized by work items of the largest launch so far)
+    mutable DevBuf<double> st_hit_t, st_frame, st_accum;
+    mutable DevBuf<uint32_t> st_hit_ref, st_hit_accel, st_vis;
+    mutable bool streaming = true; // use the streaming pipeline when the scene allows it
+    mutable unsigned long long streaming_min_items = 1ull << 20;
+    uint32_t stream_blocks = 1, stream_blocks_fast = 1;
     mutable DevBuf<DStats> stats;
     mutable DevBuf<uint8_t> staging;    // device film for host-film captures
     mutable DevBuf<double> staging_rad;
@@ -113,9 +123,13 @@ struct lg_accel {
     uint64_t device_bytes = 0;
     mutable bool profiling = false;
     mutable bool fast = false; // opt-in fast traversal mode (lg_accel_set_mode)
+    bool fast_available = true;
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    // streaming pipeline, per kernel kind: 0 primary trace, 1 frame, 2 shadow trace, 3 shade; 4 = megakernel
+    mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> kind_events[5];
     ~lg_accel() {
         for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto &v : kind_events) for (auto &e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -148,6 +162,52 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
 // Enqueue one render on `stream`.  Caller holds a.mtx.
 static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t stream) {
     if (P.ntiles == 0) return;
+    // ---- streaming pipeline: no glass / mirror (no recursion), <= 32 lights, not the counting variant
+    // and enough work to amortise 4 launches per supersample (below ~1 Mpixel the megakernel wins: measured)
+    if (a.streaming && !stats && !a.flat.has_specular && P.nlights <= 32 && (unsigned long long)P.ntiles * 64ull >= a.streaming_min_items) {
+        const uint32_t nsamples = P.ss_root * P.ss_root;
+        P.n_items = (unsigned long long)P.ntiles * 64ull;
+        size_t n = (size_t)P.n_items;
+        if (a.st_hit_t.n < n) {
+            HIP_TRY(hipDeviceSynchronize());
+            a.st_hit_t.alloc(n); a.st_hit_ref.alloc(n); a.st_hit_accel.alloc(n); a.st_vis.alloc(n);
+            a.st_frame.alloc(n * STASH_DOUBLES);
+        }
+        if (nsamples > 1 && a.st_accum.n < 3 * n) { HIP_TRY(hipDeviceSynchronize()); a.st_accum.alloc(3 * n); }
+        P.hit_t = a.st_hit_t.p; P.hit_ref = a.st_hit_ref.p; P.hit_accel = a.st_hit_accel.p; P.vis = a.st_vis.p;
+        P.frame = a.st_frame.p; P.accum = a.st_accum.p;
+        uint32_t cap = a.fast ? a.stream_blocks_fast : a.stream_blocks;
+        uint32_t blocks = (P.ntiles + 3u) / 4u;
+        if (blocks > cap) blocks = cap;
+        uint32_t depth = a.fast ? a.stack_depth_fast : a.stack_depth;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (a.profiling) {
+            HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+            HIP_TRY(hipEventRecord(e0, stream));
+        }
+        auto timed = [&](int kind, auto &&launch) { // HIP events around ONE kernel on its launch stream
+            hipEvent_t k0 = nullptr, k1 = nullptr;
+            if (a.profiling) { HIP_TRY(hipEventCreate(&k0)); HIP_TRY(hipEventCreate(&k1)); HIP_TRY(hipEventRecord(k0, stream)); }
+            HIP_TRY(launch());
+            if (a.profiling) { HIP_TRY(hipEventRecord(k1, stream)); a.kind_events[kind].emplace_back(k0, k1); }
+        };
+        for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
+            P.sample_index = sidx;
+            HIP_TRY(hipMemsetAsync(a.tile_counter.p, 0, sizeof(uint32_t), stream));
+            timed(0, [&] { return launch_stream_trace(P, a.fast, false, blocks, depth, stream); });
+            timed(1, [&] { return launch_stream_frame(P, stream); });
+            if (P.nlights > 0) {
+                HIP_TRY(hipMemsetAsync(a.tile_counter.p, 0, sizeof(uint32_t), stream));
+                timed(2, [&] { return launch_stream_trace(P, a.fast, true, blocks, depth, stream); });
+            }
+            timed(3, [&] { return launch_stream_shade(P, stream); });
+        }
+        if (a.profiling) {
+            HIP_TRY(hipEventRecord(e1, stream));
+            a.events.emplace_back(e0, e1);
+        }
+        return;
+    }
     uint32_t cap = a.fast ? a.max_blocks_fast : a.max_blocks;
     uint32_t blocks = (P.ntiles + 3u) / 4u;
     if (blocks > cap) blocks = cap;
@@ -378,8 +438,12 @@ lg_accel *lg_accel_from(const lg_scene *s) {
         a->stack_depth = f.max_stack + 2;
         // the fast kernel falls back to the reference traversal on exact ties, so its stack must hold either
         a->stack_depth_fast = (f.max_stack > f.max_stack_fast ? f.max_stack : f.max_stack_fast) + 2;
+        const size_t LDS_MAX = 160 * 1024;
+        if ((size_t)a->stack_depth * 256 * 4 > LDS_MAX)
+            throw Error("BVH too deep for the LDS traversal stack (" + std::to_string(a->stack_depth) + " entries per lane; the reference panics beyond 64 per level, bvh.rs:497)");
+        a->fast_available = (size_t)a->stack_depth_fast * 256 * 4 <= LDS_MAX;
+        if (!a->fast_available) a->stack_depth_fast = a->stack_depth;
         size_t lds = (size_t)a->stack_depth_fast * 256 * 4;
-        if (lds > 160 * 1024) throw Error("BVH too deep for the LDS traversal stack (" + std::to_string(a->stack_depth_fast) + " entries per lane)");
         if (lds > 64 * 1024) HIP_TRY(trace_set_lds_limit(lds));
         int per_cu = 0, cus = 0;
         HIP_TRY(trace_occupancy(a->stack_depth, false, &per_cu));
@@ -391,6 +455,11 @@ lg_accel *lg_accel_from(const lg_scene *s) {
         if (per_cu < 1) per_cu = 1;
         a->max_blocks = (uint32_t)(per_cu * cus);
         a->max_blocks_fast *= (uint32_t)cus;
+        int sp = 0, spf = 0;
+        HIP_TRY(stream_trace_occupancy(a->stack_depth, false, &sp));
+        HIP_TRY(stream_trace_occupancy(a->stack_depth_fast, true, &spf));
+        a->stream_blocks = (uint32_t)((sp < 1 ? 1 : sp) * cus);
+        a->stream_blocks_fast = (uint32_t)((spf < 1 ? 1 : spf) * cus);
     });
     if (rc) { delete a; return nullptr; }
     return a;
@@ -492,7 +561,15 @@ int lg_capture_radiance(size_t k, size_t n, const lg_accel *a, uint32_t w, uint3
         HIP_TRY(hipStreamSynchronize(a->stream));
     });
 }
+static int capture_stats_impl(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t filter, lg_stats *out);
 int lg_capture_stats(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, lg_stats *out) {
+    return capture_stats_impl(a, w, h, y0, y1, 0u, out);
+}
+int lg_capture_stats_kind(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, int kind, lg_stats *out) {
+    if (kind < 0 || kind > 2) return fail("kind: 0 all, 1 closest-hit traversals, 2 shadow traversals");
+    return capture_stats_impl(a, w, h, y0, y1, (uint32_t)kind, out);
+}
+static int capture_stats_impl(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t filter, lg_stats *out) {
     return guarded([&] {
         if (y1 > h || y0 > y1) throw Error("bad row range");
         std::lock_guard<std::mutex> g(a->mtx);
@@ -500,6 +577,7 @@ int lg_capture_stats(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uin
         DParams P = base_params(*a, w, h);
         set_rect(P, 0, y0, w, y1);
         P.out_row0 = y0;
+        P.stats_filter = filter;
         enqueue(*a, P, true, a->stream);
         DStats s;
         HIP_TRY(hipMemcpyAsync(&s, a->stats.p, sizeof s, hipMemcpyDeviceToHost, a->stream));
@@ -509,9 +587,16 @@ int lg_capture_stats(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uin
     });
 }
 
+int lg_accel_set_streaming(const lg_accel *a, int enabled) {
+    std::lock_guard<std::mutex> g(a->mtx);
+    a->streaming = enabled != 0;
+    a->streaming_min_items = enabled == 2 ? 0ull : (1ull << 20); // 2 = force it even for tiny launches (tests)
+    return 0;
+}
 int lg_accel_set_mode(const lg_accel *a, int mode) {
     if (mode != 0 && mode != 1) return fail("mode must be 0 (reference traversal) or 1 (fast)");
     std::lock_guard<std::mutex> g(a->mtx);
+    if (mode == 1 && !a->fast_available) return fail("fast mode unavailable: its tree is too deep for the LDS stack");
     a->fast = mode == 1;
     return 0;
 }
@@ -536,6 +621,23 @@ int lg_profile_read(const lg_accel *a, double *total_ms, uint64_t *launches) {
     });
 }
 
+int lg_profile_read_kinds(const lg_accel *a, double ms[5], uint64_t launches[5]) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> g(a->mtx);
+        for (int k = 0; k < 5; ++k) {
+            double total = 0.0;
+            for (auto &e : a->kind_events[k]) {
+                HIP_TRY(hipEventSynchronize(e.second));
+                float t = 0.f;
+                HIP_TRY(hipEventElapsedTime(&t, e.first, e.second));
+                total += t;
+                (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+            }
+            ms[k] = total; launches[k] = a->kind_events[k].size();
+            a->kind_events[k].clear();
+        }
+    });
+}
 int lg_accel_dump(const lg_accel *a, const double **f, size_t *nf, const int64_t **i, size_t *ni) {
     *f = a->flat.dump_f.data(); *nf = a->flat.dump_f.size();
     *i = a->flat.dump_i.data(); *ni = a->flat.dump_i.size();

@@ -152,6 +152,17 @@ struct DParams {
     unsigned long long frame_threads;
     double *stash;         // [STASH_DOUBLES][nthreads]: shading frame parked across the shadow traversals
     DStats *stats;
+    // ---- streaming pipeline (scenes without glass / mirror): per-work-item state in HBM, SoA,
+    // indexed by the dense work index widx = tile * 64 + lane
+    unsigned long long n_items; // ntiles * 64
+    double *hit_t;              // [n_items] closest t of the primary ray (+inf = miss)
+    uint32_t *hit_ref;          // [n_items] primref of the hit (NO_HIT = miss)
+    uint32_t *hit_accel;        // [n_items]
+    double *frame;              // [STASH_DOUBLES][n_items] shading frame of the hit
+    uint32_t *vis;              // [n_items] bit l set <=> light l is visible from the hit
+    double *accum;              // [3][n_items] running sum over the pixel's samples (integrate.rs:17-18)
+    uint32_t sample_index;      // which supersample this pass renders
+    uint32_t stats_filter;      // counting variant: 0 = all traversals, 1 = closest-hit (primary/secondary) only, 2 = shadow only
 };
 
 } // namespace lg

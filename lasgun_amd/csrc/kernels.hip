@@ -30,6 +30,9 @@
 #include "dscene.h"
 #include "trig.h"
 
+#ifndef LG_TRAV_WAVES_PER_SIMD
+#define LG_TRAV_WAVES_PER_SIMD 4 // register budget of the streaming pipeline's traversal kernels
+#endif
 #ifndef LG_TRI_PER_LEAF
 #define LG_TRI_PER_LEAF 1 // reference traversal: shear setup per fat leaf, not held in registers across the traversal (measured faster)
 #endif
@@ -987,10 +990,15 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
 #endif
                 {
                     bool tie = false;
+                    Counters before = cnt;
                     traverse<STATS, FAST>(P, tray, shadow_job, stack, stride, b, cnt, tie);
                     // fast mode: exact ties in t are decided by the reference's visit order -> re-trace this ray with it.
                     // (an occluded any-hit ray needs no re-trace: the answer "some t < 1 exists" is order-independent)
                     if (FAST && tie && !(shadow_job && b.t < 1.0)) traverse<STATS, false>(P, tray, shadow_job, stack, stride, b, cnt, tie);
+                    if (STATS && P.stats_filter != 0u && (P.stats_filter == 2u) != shadow_job) { // not the kind being counted
+                        cnt.nodes = before.nodes; cnt.spheres = before.spheres; cnt.cuboids = before.cuboids;
+                        cnt.triangles = before.triangles; cnt.entries = before.entries;
+                    }
                 }
                 bool have_value = false, need_shade = false, visible = false;
 #if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 1 /* timing only: primary traversal, nothing else */
@@ -1163,6 +1171,191 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
 }
 
 // ------------------------------------------------------------------------------------------
+// Streaming pipeline: the same li() for scenes WITHOUT glass / mirror (no recursion), cut into
+// four kernels so that traversal (wants occupancy, ~100 VGPRs, spill-free) and shading (wants
+// registers: trig, microfacet, Fresnel) each get their own register allocation.  Per work item
+// (pixel) the state between kernels lives in HBM, SoA, indexed by widx = tile * 64 + lane:
+//   K1 primary   camera ray -> closest hit                      -> hit_t / hit_ref / hit_accel
+//   K2 frame     shade_frame(ray, hit)                           -> frame[13][n]
+//   K3 shadow    one any-hit traversal per light from frame.p    -> vis bits
+//   K4 shade     lights in order, ambient, sample sum, Img::set  -> film
+// Every f64 is produced by the same expressions as in the megakernel; only their placement in
+// kernels differs.  Up to 32 lights; scenes with more use the megakernel.
+// ------------------------------------------------------------------------------------------
+struct Pixel {
+    uint32_t x, y, vy;
+    bool active;
+};
+__device__ __forceinline__ Pixel pixel_of(const DParams &P, uint32_t tile, uint32_t lane) {
+    Pixel px;
+    if (P.mode == 0) {
+        uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+        px.x = P.x0 + tx * 8u + (lane & 7u);
+        px.vy = P.y0 + ty * 8u + (lane >> 3);
+        px.active = px.x < P.x1 && px.vy < P.y1;
+        px.y = P.ilv_n > 1u ? ((px.vy / P.ilv_b) * P.ilv_n + P.ilv_r) * P.ilv_b + px.vy % P.ilv_b : px.vy;
+    } else {
+        unsigned long long i = (unsigned long long)tile * 64ull + lane;
+        px.active = i < P.sub_count;
+        unsigned long long off = P.sub_k + i * P.sub_n;
+        px.x = (uint32_t)(off % P.w);
+        px.y = (uint32_t)(off / P.w);
+        px.vy = px.y;
+    }
+    return px;
+}
+// Camera::sample for sample `sidx` of pixel (x, y) (camera.rs:113-146)
+__device__ __forceinline__ Ray camera_ray(const DParams &P, uint32_t x, uint32_t y, uint32_t sidx) {
+    double img_plane_height = P.image_plane_height;
+    double img_plane_width = img_plane_height * P.aspect;
+    double pixel_size = img_plane_height * P.hinv;
+    double sample_separation = P.ss_distance * pixel_size;
+    double sox = ((double)x * P.winv - 0.5) * img_plane_width;
+    double soy = (0.5 - (double)(y + 1u) * P.hinv) * img_plane_height;
+    V3 cam_o = P.cam_origin + ((soy * P.pixel_separation) * P.cam_up) + ((sox * P.pixel_separation) * P.cam_aux);
+    V3 cam_d = P.cam_view + (soy * P.cam_up) + (sox * P.cam_aux);
+    V3 updiff = P.cam_up * sample_separation;
+    V3 auxdiff = P.cam_aux * sample_separation;
+    V3 halfdiff = updiff * 0.5 + auxdiff * 0.5;
+    const uint32_t dim = P.ss_root;
+    uint32_t si = sidx / dim, sj = sidx % dim;
+    V3 dd = cam_d + ((double)sj * updiff) + ((double)si * auxdiff) + halfdiff;
+    return ray_new(cam_o, dd);
+}
+
+// K1 / K3: persistent traversal kernels (tile counter, per-lane LDS stack)
+template <bool FAST, bool SHADOW>
+__global__ void __launch_bounds__(LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_trace_kernel(const DParams P) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t *stack = lds_stack + tid;
+    constexpr uint32_t stride = LG_BLOCK;
+    Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (;;) {
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+        if (tile >= P.ntiles) break; // every wave reaches this exit
+        Pixel px = pixel_of(P, tile, lane);
+        if (!px.active) continue;
+        const unsigned long long widx = (unsigned long long)tile * 64ull + lane;
+        if (!SHADOW) {
+            Ray ray = camera_ray(P, px.x, px.y, P.sample_index);
+            Best b;
+            bool tie = false;
+            traverse<false, FAST>(P, ray, false, stack, stride, b, cnt, tie);
+            if (FAST && tie) traverse<false, false>(P, ray, false, stack, stride, b, cnt, tie);
+            P.hit_t[widx] = b.t; P.hit_ref[widx] = b.ref; P.hit_accel[widx] = b.accel;
+        } else {
+            if (P.hit_ref[widx] == NO_HIT) continue;
+            const unsigned long long n = P.n_items;
+            // interaction.p + p_err, recomputed from the parked frame exactly as stash_get does
+            V3 praw{P.frame[0 * n + widx], P.frame[1 * n + widx], P.frame[2 * n + widx]};
+            V3 ng{P.frame[3 * n + widx], P.frame[4 * n + widx], P.frame[5 * n + widx]};
+            const double err = 2.220446049250313e-16 * 65536.0;
+            V3 hit_p = praw + ng * err;
+            uint32_t vis = 0;
+            for (uint32_t l = 0; l < P.nlights; ++l) {
+                const DLight L = P.lights[l];
+                Ray sray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
+                Best b;
+                bool tie = false;
+                traverse<false, FAST>(P, sray, true, stack, stride, b, cnt, tie);
+                if (FAST && tie && !(b.t < 1.0)) traverse<false, false>(P, sray, true, stack, stride, b, cnt, tie);
+                if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
+            }
+            P.vis[widx] = vis;
+        }
+    }
+}
+
+// K2: shading frame of every hit (one thread per work item, no LDS)
+__global__ void __launch_bounds__(LG_BLOCK) stream_frame_kernel(const DParams P) {
+    const unsigned long long widx = (unsigned long long)blockIdx.x * LG_BLOCK + threadIdx.x;
+    if (widx >= P.n_items) return;
+    Pixel px = pixel_of(P, (uint32_t)(widx >> 6), (uint32_t)(widx & 63u));
+    if (!px.active) return;
+    Best b;
+    b.t = P.hit_t[widx]; b.ref = P.hit_ref[widx]; b.accel = P.hit_accel[widx];
+    if (b.ref == NO_HIT) return;
+    Ray ray = camera_ray(P, px.x, px.y, P.sample_index);
+    Shade sh;
+    shade_frame(P, ray, b, sh);
+    const unsigned long long n = P.n_items;
+    double *f = P.frame + widx;
+    f[0 * n] = sh.praw.x; f[1 * n] = sh.praw.y; f[2 * n] = sh.praw.z;
+    f[3 * n] = sh.ng.x; f[4 * n] = sh.ng.y; f[5 * n] = sh.ng.z;
+    f[6 * n] = sh.ns.x; f[7 * n] = sh.ns.y; f[8 * n] = sh.ns.z;
+    f[9 * n] = sh.ss.x; f[10 * n] = sh.ss.y; f[11 * n] = sh.ss.z;
+    f[12 * n] = (double)sh.mat;
+}
+
+// K4: li() of a non-specular hit from the parked frame and the visibility bits, then the
+// per-pixel sample sum and Img::set (integrate.rs:16-80, img.rs:46-67)
+__global__ void __launch_bounds__(LG_BLOCK) stream_shade_kernel(const DParams P) {
+    const unsigned long long widx = (unsigned long long)blockIdx.x * LG_BLOCK + threadIdx.x;
+    if (widx >= P.n_items) return;
+    Pixel px = pixel_of(P, (uint32_t)(widx >> 6), (uint32_t)(widx & 63u));
+    if (!px.active) return;
+    Ray ray = camera_ray(P, px.x, px.y, P.sample_index);
+    V3 value;
+    if (P.hit_ref[widx] == NO_HIT) {
+        value = background(P, normalize(ray.d)); // integrate.rs:26-28
+    } else {
+        const unsigned long long n = P.n_items;
+        const double *f = P.frame + widx;
+        Shade sh;
+        V3 p{f[0 * n], f[1 * n], f[2 * n]};
+        sh.ng = V3{f[3 * n], f[4 * n], f[5 * n]};
+        sh.ns = V3{f[6 * n], f[7 * n], f[8 * n]};
+        sh.ss = V3{f[9 * n], f[10 * n], f[11 * n]};
+        sh.mat = (int32_t)f[12 * n];
+        sh.wo = -normalize(ray.d);
+        const double err = 2.220446049250313e-16 * 65536.0;
+        V3 p_err = sh.ng * err;
+        sh.praw = p; sh.p = p + p_err; sh.pm = p - p_err;
+        sh.ts = cross(sh.ns, sh.ss);
+        const DMaterial m = P.materials[sh.mat];
+        const uint32_t vis = P.vis[widx];
+        V3 nrm = sh.ns;
+        V3 output = vzero();
+        for (uint32_t l = 0; l < P.nlights; ++l) { // integrate.rs:47-66
+            if (!((vis >> l) & 1u)) continue;
+            const DLight L = P.lights[l];
+            V3 wi = V3{L.pos[0], L.pos[1], L.pos[2]} - sh.p;
+            double d = magnitude(wi);
+            double f_att = L.falloff[0] + L.falloff[1] * d + L.falloff[2] * d * d;
+            if (f_att == 0.0) continue;
+            wi = normalize(wi);
+            double wi_dot_n = dot(wi, nrm);
+            V3 fr = bsdf_f(m, sh, sh.wo, wi);
+            V3 li_col{L.intensity[0], L.intensity[1], L.intensity[2]};
+            output = output + (mul_ew(PI * li_col, fr) * wi_dot_n / f_att);
+        }
+        output = output + mul_ew(P.ambient, bsdf_f(m, sh, sh.wo, nrm)); // integrate.rs:67
+        value = output + vzero() + vzero();                              // integrate.rs:79 (no specular children)
+    }
+    // integrate(): color = sum over samples, then * weight
+    const uint32_t nsamples = P.ss_root * P.ss_root;
+    V3 color = vzero();
+    if (P.sample_index > 0) color = V3{P.accum[widx], P.accum[P.n_items + widx], P.accum[2 * P.n_items + widx]};
+    color = color + value;
+    if (P.sample_index + 1 < nsamples) {
+        P.accum[widx] = color.x; P.accum[P.n_items + widx] = color.y; P.accum[2 * P.n_items + widx] = color.z;
+        return;
+    }
+    const double weight = 1. / (double)nsamples;
+    color = color * weight;
+    unsigned long long pix = (unsigned long long)(px.vy - P.out_row0) * P.w + px.x;
+    if (P.out_rgba) {
+        uint32_t rgba = to_byte(color.x) | (to_byte(color.y) << 8) | (to_byte(color.z) << 16) | (255u << 24);
+        reinterpret_cast<uint32_t *>(P.out_rgba)[pix] = rgba;
+    }
+    if (P.out_radiance) {
+        P.out_radiance[3 * pix] = color.x; P.out_radiance[3 * pix + 1] = color.y; P.out_radiance[3 * pix + 2] = color.z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // known-answer / arithmetic probe kernels (one thread; test hooks of the C ABI)
 // ------------------------------------------------------------------------------------------
 // kind 0 sphere (cx,cy,cz,r), 1 cuboid (min,max), 2 every triangle of a mesh in order.
@@ -1245,14 +1438,53 @@ hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks
     }
     return hipGetLastError();
 }
+hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
+    size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
+    if (fast) {
+        if (shadow) hipLaunchKernelGGL((stream_trace_kernel<true, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((stream_trace_kernel<true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+    } else {
+        if (shadow) hipLaunchKernelGGL((stream_trace_kernel<false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((stream_trace_kernel<false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_stream_frame(const DParams &P, hipStream_t stream) {
+    uint32_t blocks = (uint32_t)((P.n_items + LG_BLOCK - 1) / LG_BLOCK);
+    hipLaunchKernelGGL(stream_frame_kernel, dim3(blocks), dim3(LG_BLOCK), 0, stream, P);
+    return hipGetLastError();
+}
+hipError_t launch_stream_shade(const DParams &P, hipStream_t stream) {
+    uint32_t blocks = (uint32_t)((P.n_items + LG_BLOCK - 1) / LG_BLOCK);
+    hipLaunchKernelGGL(stream_shade_kernel, dim3(blocks), dim3(LG_BLOCK), 0, stream, P);
+    return hipGetLastError();
+}
+hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu) {
+    size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
+    int a = 0, b = 0;
+    hipError_t e;
+    if (fast) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<true, false>, LG_BLOCK, lds);
+        if (e != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<true, true>, LG_BLOCK, lds);
+    } else {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<false, false>, LG_BLOCK, lds);
+        if (e != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<false, true>, LG_BLOCK, lds);
+    }
+    *blocks_per_cu = a < b ? a : b;
+    return e;
+}
 hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu) {
     size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
     if (fast) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, true>, LG_BLOCK, lds);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, false>, LG_BLOCK, lds);
 }
 hipError_t trace_set_lds_limit(size_t bytes) {
-    const void *fns[4] = {reinterpret_cast<const void *>(trace_kernel<false, false>), reinterpret_cast<const void *>(trace_kernel<true, false>),
-                          reinterpret_cast<const void *>(trace_kernel<false, true>), reinterpret_cast<const void *>(trace_kernel<true, true>)};
+    const void *fns[8] = {reinterpret_cast<const void *>(trace_kernel<false, false>), reinterpret_cast<const void *>(trace_kernel<true, false>),
+                          reinterpret_cast<const void *>(trace_kernel<false, true>), reinterpret_cast<const void *>(trace_kernel<true, true>),
+                          reinterpret_cast<const void *>(stream_trace_kernel<false, false>), reinterpret_cast<const void *>(stream_trace_kernel<false, true>),
+                          reinterpret_cast<const void *>(stream_trace_kernel<true, false>), reinterpret_cast<const void *>(stream_trace_kernel<true, true>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;

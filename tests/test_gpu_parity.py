@@ -196,6 +196,25 @@ def test_fast_mode_full_size_films_are_identical():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["spheres_512", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "ragged_5x131", "one_pixel"])
+def test_streaming_pipeline_and_megakernel_agree(name):
+    """The two kernel organisations (and both traversal modes under each) give the same bytes and bits."""
+    builder, w, h = MID[name]
+    acc = G.Accel(builder(G))
+    outs = []
+    for streaming in (2, 0):  # 2 = streaming pipeline forced even for small films, 0 = megakernel
+        for fast in (False, True):
+            G.set_streaming(acc, streaming)
+            G.set_mode(acc, fast)
+            film = G.Film(w, h)
+            G.capture_subset(0, 1, acc, film)
+            sub = G.Film.new_with_output(w, h, np.full((h, w, 4), 7, np.uint8))
+            G.capture_subset(1, 3, acc, sub)
+            outs.append((film.pixels(), bits(G.capture_radiance(acc, w, h)), sub.pixels()))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+
+
 # ---- driver semantics (lib.rs:55-162) -------------------------------------------------------
 def test_capture_subset_partitions_and_preserves_other_pixels():
     w, h = 96, 80
