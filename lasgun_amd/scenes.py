@@ -321,3 +321,104 @@ def kitchen_sink_scene(api, camera="perspective", recursion=2, supersampling=1):
     g4.swap_backface(); g4.swap_backface()  # toggles twice: off
     root.add_group(g4)
     return scene
+
+
+def random_scene(api, seed):
+    """Seeded random scene for fuzz parity: every primitive / material / transform / camera feature,
+    plus deliberately DUPLICATED primitives and touching boxes so that exact ties in t occur (the
+    reference resolves them by visit order, bvh.rs:481-488)."""
+    rng = SplitMix64(0xF00D0000 + seed)
+    u = rng.uniform
+
+    def pick(n):
+        return min(int(rng.next_f64() * n), n - 1)
+
+    def col(lo=0.0, hi=1.0):
+        return [u(lo, hi), u(lo, hi), u(lo, hi)]
+
+    M = api.Material
+
+    def material():
+        k = pick(7)
+        if k == 0:
+            return M.matte(col(), 0.0)
+        if k == 1:
+            return M.matte(col(), u(5.0, 60.0))
+        if k == 2:
+            return M.plastic(col(), col(0.2, 0.9), u(0.05, 0.6))
+        if k == 3:
+            return M.plastic([0.0, 0.0, 0.0], col(0.2, 0.9), u(0.05, 0.6))
+        if k == 4:
+            return M.metal(col(0.1, 1.5), col(1.5, 4.0), u(0.05, 0.5), u(0.05, 0.5))
+        if k == 5:
+            return M.glass(col(0.3, 1.0), col(0.3, 1.0), u(1.1, 1.8))
+        return M.mirror(col(0.2, 0.9))
+
+    scene = api.Scene.new()
+    scene.set_ambient_light(col(0.0, 0.3))
+    if pick(2):
+        scene.set_radial_background(col(), col(), u(0.2, 1.0))
+    else:
+        scene.set_solid_background(col(0.0, 0.5))
+    scene.set_max_recursion_depth(pick(4))
+    cam = scene.set_orthographic_camera(u(6.0, 10.0)) if pick(4) == 0 else scene.set_perspective_camera(u(35.0, 70.0))
+    cam.look_at([u(-2, 2), u(-1, 3), u(7, 10)], [u(-0.5, 0.5), u(-0.5, 0.5), 0.0], [u(-0.2, 0.2), 1.0, u(-0.2, 0.2)])
+    cam.set_supersampling(pick(2))
+    for _ in range(1 + pick(3)):
+        fall = [[1.0, 0.0, 0.0], [0.5, 0.05, 0.0], [0.3, 0.02, 0.01]][pick(3)]
+        scene.add_point_light([u(-6, 6), u(2, 8), u(-2, 8)], col(0.3, 1.0), fall)
+    meshes = [scene.parse_obj(PLANE_OBJ), scene.parse_obj(quad_obj_with_uv()), scene.parse_obj(torus_obj(8 + pick(8), 6 + pick(6), normals=True))]
+    scene.set_mesh_smoothing(False)
+    meshes.append(scene.parse_obj(torus_obj(7, 5, normals=True)))
+    scene.set_mesh_smoothing(True)
+
+    def fill(agg, n, allow_group, depth):
+        for _ in range(n):
+            k = pick(10)
+            c = [u(-3, 3), u(-2, 2), u(-3, 3)]
+            if k <= 3:
+                agg.add_sphere(c, u(0.2, 1.0), material())
+            elif k == 4:  # the same sphere twice: an exact tie in t between two primitives
+                m1, m2, r = material(), material(), u(0.3, 0.8)
+                agg.add_sphere(c, r, m1)
+                agg.add_sphere(c, r, m2)
+            elif k == 5:
+                agg.add_cube(c, u(0.3, 1.2), material())
+            elif k == 6:  # two boxes sharing a face
+                d = u(0.4, 1.0)
+                agg.add_box(c, [c[0] + d, c[1] + d, c[2] + d], material())
+                agg.add_box([c[0] + d, c[1], c[2]], [c[0] + 2 * d, c[1] + d, c[2] + d], material())
+            elif k == 7:
+                mi = pick(len(meshes))
+                g = api.Aggregate.new()
+                g.translate(c).scale(u(0.5, 1.5), u(0.5, 1.5), u(0.5, 1.5))
+                if pick(2):
+                    g.add_obj_of(meshes[mi], material())
+                else:
+                    g.add_obj(meshes[mi])
+                agg.add_group(g)
+            elif allow_group and depth < 3:
+                g = api.Aggregate.new()
+                t = pick(5)
+                if t == 0:
+                    g.rotate_x(u(-90, 90))
+                elif t == 1:
+                    g.rotate_y(u(-90, 90))
+                elif t == 2:
+                    g.rotate_z(u(-90, 90))
+                elif t == 3:
+                    g.rotate(u(-90, 90), [0.48, 0.6, 0.64])
+                g.translate([u(-2, 2), u(-1, 1), u(-2, 2)])
+                if pick(3) == 0:
+                    g.swap_backface()
+                fill(g, 2 + pick(4), True, depth + 1)
+                agg.add_group(g)
+            else:
+                agg.add_sphere(c, u(0.2, 0.7), material())
+
+    root = scene.root
+    if pick(3) == 0:
+        root.rotate_y(u(-20, 20))
+    root.add_sphere([0.0, -103.0, 0.0], 100.0, material())
+    fill(root, 6 + pick(30), True, 0)
+    return scene
