@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (tiles staged through host memory)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="world size 1 through the N>1 code path (process group, interleaved tile, async gather): RCCL rehearsal on a 1-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,8 +97,10 @@ def main():
     dev = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev)
     G.set_device(dev)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":  # RCCL over xGMI
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
@@ -108,14 +112,16 @@ def main():
     t0 = time.perf_counter()
     acc = G.Accel(scene)  # host HLBVH build + flatten + upload (outside the timed region, reported below)
     accel_build_s = time.perf_counter() - t0
+    if os.environ.get("LASGUN_NO_LDS_SCENE"):  # A/B: traversal kernels read the scene tables through L1/L2 instead of LDS
+        G.set_lds_scene(acc, False)
     stream = torch.cuda.current_stream().cuda_stream
     BLOCK_ROWS = 64
-    balanced = world > 1 and interleave_ok(world, h, BLOCK_ROWS)
+    balanced = multi and interleave_ok(world, h, BLOCK_ROWS)
     y0, y1 = row_tile(rank, world, h)
     if balanced:
         # rank r renders the 64-row blocks {r, r+N, r+2N, ...} (even load) into a compact tile; the
         # gather of frame k overlaps the render of frame k+1 (two tile buffers)
-        ig = InterleavedGather(w, h, rank, world, BLOCK_ROWS, "cuda" if args.backend == "nccl" else "cpu")
+        ig = InterleavedGather(w, h, rank, world, BLOCK_ROWS, "cuda" if args.backend == "nccl" else "cpu", always_gather=True)
         cuda_tile = torch.zeros((h // world, w, 4), dtype=torch.uint8, device="cuda")
 
         def step():
@@ -135,7 +141,7 @@ def main():
 
         def step():
             G.capture_rows_device(acc, w, h, y0, y1, tile.data_ptr(), stream=stream)
-            if args.backend == "gloo" and world > 1:
+            if args.backend == "gloo" and multi:
                 last[0] = gather_tiles(tile.cpu(), w, h, rank, world)
             else:
                 last[0] = gather_tiles(tile, w, h, rank, world)
@@ -145,7 +151,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,7 +183,7 @@ def main():
     rdev = "cuda" if args.backend == "nccl" else "cpu"
     vec = torch.tensor([st[k] for k in keys] + [0], dtype=torch.float64, device=rdev)
     tmax = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64, device=rdev)
-    if world > 1:
+    if multi:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total = {k: int(v) for k, v in zip(keys, vec.tolist())}
@@ -193,7 +199,7 @@ def main():
         G.capture(scene, film)
         e2e_ms = (time.perf_counter() - t0) * 1e3
 
-    if rank == 0 and world > 1 and os.environ.get("LASGUN_BENCH_VERIFY"):
+    if rank == 0 and multi and os.environ.get("LASGUN_BENCH_VERIFY"):
         ref = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
         G.capture_rows_device(acc, w, h, 0, h, ref.data_ptr(), row0=0, stream=stream)
         torch.cuda.synchronize()
@@ -273,10 +279,10 @@ def main():
         }
         if fast_info is not None:
             out["fast_mode"] = fast_info
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.force_dist:
             out["cpu_baseline"] = cpu_baseline(w, h)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

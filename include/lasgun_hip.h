@@ -145,6 +145,13 @@ int lg_accel_set_mode(const lg_accel *, int mode);
  * megakernel.  2 = use the pipeline for any size (tests). */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
 
+/* LDS-resident scene (streaming pipeline, reference traversal): when the scene's node, primref,
+ * sphere and cuboid tables fit beside 1024 per-lane stacks in one CU's 160 KB of LDS, the two
+ * traversal kernels run as one 1024-lane workgroup per CU that copies those tables into LDS once
+ * and walks them there (same records, same arithmetic, same bytes out).  On by default; returns
+ * 1 when the accel's scene qualifies, 0 when it does not (the setting is then without effect). */
+int lg_accel_set_lds_scene(const lg_accel *, int enabled);
+
 /* Kernel timing with HIP events on the launch stream: enable, render, then read. */
 void lg_profile_enable(const lg_accel *, int enabled);
 int lg_profile_read(const lg_accel *, double *total_ms, uint64_t *launches); /* synchronises; resets the tally */

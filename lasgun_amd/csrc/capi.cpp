@@ -2,6 +2,7 @@
 // kernel launches.  No torch types, no C++ exceptions across the boundary, no CPU render path.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -20,6 +21,7 @@ hipError_t launch_stream_frame(const DParams &P, hipStream_t stream);
 hipError_t launch_stream_shade(const DParams &P, hipStream_t stream);
 hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
 hipError_t trace_set_lds_limit(size_t bytes);
+hipError_t stream_trace_ldss_prepare(size_t bytes);
 hipError_t launch_kat(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d, double *out,
                       hipStream_t stream);
 hipError_t launch_kat_si(V3 o, V3 d, double t, V3 dpdu, V3 dpdv, double *out, hipStream_t stream);
@@ -111,6 +113,11 @@ struct lg_accel {
     mutable bool streaming = true; // use the streaming pipeline when the scene allows it
     mutable unsigned long long streaming_min_items = 1ull << 20;
     uint32_t stream_blocks = 1, stream_blocks_fast = 1;
+    // LDS-resident scene (reference tree only): the tables in their LDS layout, when they fit beside the stacks
+    DevBuf<uint32_t> lds_image;
+    uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_node_stride = 0, lds_prim_off = 0, lds_sph_off = 0, lds_sph_stride = 0, lds_cub_off = 0;
+    uint32_t ldss_blocks = 0;         // one 1024-lane workgroup per CU; 0 = variant unavailable for this scene
+    mutable bool lds_scene = true;    // lg_accel_set_lds_scene
     mutable DevBuf<DStats> stats;
     mutable DevBuf<uint8_t> staging;    // device film for host-film captures
     mutable DevBuf<double> staging_rad;
@@ -180,6 +187,12 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         uint32_t blocks = (P.ntiles + 3u) / 4u;
         if (blocks > cap) blocks = cap;
         uint32_t depth = a.fast ? a.stack_depth_fast : a.stack_depth;
+        if (!a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS
+            P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
+            P.lds_node_off = a.lds_node_off; P.lds_node_stride = a.lds_node_stride; P.lds_prim_off = a.lds_prim_off;
+            P.lds_sph_off = a.lds_sph_off; P.lds_sph_stride = a.lds_sph_stride; P.lds_cub_off = a.lds_cub_off;
+            blocks = a.ldss_blocks;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (a.profiling) {
             HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -460,6 +473,57 @@ lg_accel *lg_accel_from(const lg_scene *s) {
         HIP_TRY(stream_trace_occupancy(a->stack_depth_fast, true, &spf));
         a->stream_blocks = (uint32_t)((sp < 1 ? 1 : sp) * cus);
         a->stream_blocks_fast = (uint32_t)((spf < 1 ? 1 : spf) * cus);
+        // LDS-resident scene: the REFERENCE tree's nodes (56 of 64 bytes, padded to 80 when that fits),
+        // its primrefs, the spheres (padded to 48 when that fits) and cuboids, behind 1024 per-lane
+        // stacks, all within one CU's LDS.  The flat tables interleave reference and fast trees per
+        // accel, so the image renumbers the reference trees compactly (DAccel::lnode_base / lprim_base).
+        {
+            FlatScene &fm = a->flat;
+            std::vector<uint32_t> nb, pb; // start offsets of every tree / primref run, both kinds
+            for (const DAccel &A : fm.accels) { nb.push_back(A.node_base); nb.push_back(A.fnode_base); pb.push_back(A.prim_base); pb.push_back(A.fprim_base); }
+            std::sort(nb.begin(), nb.end()); nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+            std::sort(pb.begin(), pb.end()); pb.erase(std::unique(pb.begin(), pb.end()), pb.end());
+            auto extent = [](const std::vector<uint32_t> &starts, uint32_t b, size_t total) {
+                auto it = std::upper_bound(starts.begin(), starts.end(), b);
+                return (uint32_t)((it == starts.end() ? total : (size_t)*it) - b);
+            };
+            std::vector<std::pair<uint32_t, uint32_t>> nruns, pruns; // (global base, compact base) of each reference tree, once
+            uint32_t nn = 0, np = 0;
+            for (DAccel &A : fm.accels) {
+                auto fn = std::find_if(nruns.begin(), nruns.end(), [&](auto &r) { return r.first == A.node_base; });
+                if (fn == nruns.end()) { nruns.emplace_back(A.node_base, nn); A.lnode_base = nn; nn += extent(nb, A.node_base, fm.nodes.size()); }
+                else A.lnode_base = fn->second;
+                auto fp = std::find_if(pruns.begin(), pruns.end(), [&](auto &r) { return r.first == A.prim_base; });
+                if (fp == pruns.end()) { pruns.emplace_back(A.prim_base, np); A.lprim_base = np; np += extent(pb, A.prim_base, fm.primref.size()); }
+                else A.lprim_base = fp->second;
+            }
+            const size_t stack_bytes = (size_t)a->stack_depth * 1024 * 4;
+            const size_t ns = fm.spheres.size(), nc = fm.cuboids.size();
+            const size_t prim16 = ((size_t)np + 3) / 4;
+            for (int attempt = 0; attempt < 3 && !a->ldss_blocks; ++attempt) {
+                const uint32_t nstride = attempt == 0 ? 5u : 4u, sstride = attempt < 2 ? 3u : 2u;
+                size_t n16 = (size_t)nn * nstride + prim16 + ns * sstride + nc * 3;
+                if (stack_bytes + n16 * 16 > LDS_MAX) continue;
+                std::vector<uint32_t> img(n16 * 4, 0u);
+                a->lds_node_off = 0; a->lds_node_stride = nstride;
+                for (auto &r : nruns)
+                    for (uint32_t i = 0, e = extent(nb, r.first, fm.nodes.size()); i < e; ++i)
+                        std::memcpy(&img[((size_t)(r.second + i) * nstride) * 4], &fm.nodes[r.first + i], 56);
+                a->lds_prim_off = nn * nstride;
+                for (auto &r : pruns)
+                    for (uint32_t i = 0, e = extent(pb, r.first, fm.primref.size()); i < e; ++i)
+                        img[(size_t)a->lds_prim_off * 4 + r.second + i] = fm.primref[r.first + i];
+                a->lds_sph_off = a->lds_prim_off + (uint32_t)prim16; a->lds_sph_stride = sstride;
+                for (size_t i = 0; i < ns; ++i) std::memcpy(&img[((size_t)a->lds_sph_off + i * sstride) * 4], &fm.spheres[i], 32);
+                a->lds_cub_off = a->lds_sph_off + (uint32_t)(ns * sstride);
+                for (size_t i = 0; i < nc; ++i) std::memcpy(&img[((size_t)a->lds_cub_off + i * 3) * 4], &fm.cuboids[i], 48);
+                a->lds_image.upload(img);
+                a->lds_image_n16 = (uint32_t)n16;
+                HIP_TRY(stream_trace_ldss_prepare(stack_bytes + n16 * 16));
+                a->ldss_blocks = (uint32_t)cus;
+            }
+            a->accels.upload(fm.accels); // again, now with the compact bases
+        }
     });
     if (rc) { delete a; return nullptr; }
     return a;
@@ -587,6 +651,11 @@ static int capture_stats_impl(const lg_accel *a, uint32_t w, uint32_t h, uint32_
     });
 }
 
+int lg_accel_set_lds_scene(const lg_accel *a, int enabled) {
+    std::lock_guard<std::mutex> lk(a->mtx);
+    a->lds_scene = enabled != 0;
+    return a->ldss_blocks ? 1 : 0; // 1: the scene's tables fit in LDS (the variant exists for this accel)
+}
 int lg_accel_set_streaming(const lg_accel *a, int enabled) {
     std::lock_guard<std::mutex> g(a->mtx);
     a->streaming = enabled != 0;

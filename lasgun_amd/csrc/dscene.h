@@ -90,6 +90,9 @@ struct alignas(16) DAccel {
     uint32_t chain[MAX_CHAIN];
     uint32_t fnode_base; // the optional fast tree (binned SAH, <= 4 primitives per leaf) over the SAME primitives
     uint32_t fprim_base;
+    uint32_t lnode_base; // reference tree again, in the compact numbering of the LDS-resident scene image (DParams::lds_image)
+    uint32_t lprim_base;
+    uint32_t pad[2];
 };
 
 struct DStats { // per-launch counters (stats kernel variant only)
@@ -162,6 +165,15 @@ struct DParams {
     uint32_t *vis;              // [n_items] bit l set <=> light l is visible from the hit
     double *accum;              // [3][n_items] running sum over the pixel's samples (integrate.rs:17-18)
     uint32_t sample_index;      // which supersample this pass renders
+    // ---- LDS-resident scene (scenes whose node / primref / sphere / cuboid tables fit beside the
+    // stacks in the CU's 160 KB): `lds_image` holds those tables in their LDS layout; offsets and
+    // strides are in 16-byte units from the start of the image
+    const void *lds_image;
+    uint32_t lds_image_n16;
+    uint32_t lds_node_off, lds_node_stride; // DNode without its pad: 4 or 5 units per node
+    uint32_t lds_prim_off;                  // primref[] as dwords from here
+    uint32_t lds_sph_off, lds_sph_stride;   // DSphere: 2 or 3 units per sphere
+    uint32_t lds_cub_off;                   // DCuboid: 3 units per cuboid
     uint32_t stats_filter;      // counting variant: 0 = all traversals, 1 = closest-hit (primary/secondary) only, 2 = shadow only
 };
 

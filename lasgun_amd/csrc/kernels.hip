@@ -296,6 +296,72 @@ __device__ __forceinline__ Ray local_ray(const DParams &P, const Ray &wray, uint
     return r;
 }
 
+// ---- scene table access: HBM/L2 tables, or (LDSS) the copy a 1024-lane workgroup holds in LDS.
+// Lanes of a wave read DIFFERENT records, 56 bytes per node visit: through the vector L1 that is
+// 64 B/clk per CU and the traversal kernels were bound by it as much as by VALU issue; the LDS
+// delivers 256 B/clk per CU at a third of the latency.  Records are padded to 80 B (nodes) and
+// 48 B (spheres) so that 16 consecutive records start in 16 different bank groups.
+struct NodeRec {
+    double bmin[3], bmax[3];
+    uint32_t link, meta;
+};
+__device__ __forceinline__ double u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+template <bool LDSS>
+__device__ __forceinline__ NodeRec load_node(const DParams &P, const uint4 *scn, uint32_t idx) {
+    NodeRec n;
+    if (LDSS) {
+        const uint4 *q = scn + (P.lds_node_off + idx * P.lds_node_stride);
+        uint4 a = q[0], b = q[1], c = q[2];
+        uint2 d = *reinterpret_cast<const uint2 *>(q + 3);
+        n.bmin[0] = u2d(a.x, a.y); n.bmin[1] = u2d(a.z, a.w); n.bmin[2] = u2d(b.x, b.y);
+        n.bmax[0] = u2d(b.z, b.w); n.bmax[1] = u2d(c.x, c.y); n.bmax[2] = u2d(c.z, c.w);
+        n.link = d.x; n.meta = d.y;
+    } else {
+        // one 64-byte record = four 16-byte loads from a single line, all issued before the slab test
+        const DNode *nd = P.nodes + idx;
+        n.bmin[0] = nd->bmin[0]; n.bmin[1] = nd->bmin[1]; n.bmin[2] = nd->bmin[2];
+        n.bmax[0] = nd->bmax[0]; n.bmax[1] = nd->bmax[1]; n.bmax[2] = nd->bmax[2];
+        n.link = nd->link; n.meta = nd->meta;
+    }
+    return n;
+}
+template <bool LDSS>
+__device__ __forceinline__ void load_node_link(const DParams &P, const uint4 *scn, uint32_t idx, uint32_t &link, uint32_t &meta) {
+    if (LDSS) {
+        uint2 d = *reinterpret_cast<const uint2 *>(scn + (P.lds_node_off + idx * P.lds_node_stride + 3u));
+        link = d.x; meta = d.y;
+    } else {
+        const DNode *nd = P.nodes + idx;
+        link = nd->link; meta = nd->meta;
+    }
+}
+template <bool LDSS>
+__device__ __forceinline__ uint32_t load_primref(const DParams &P, const uint4 *scn, uint32_t i) {
+    if (LDSS) return reinterpret_cast<const uint32_t *>(scn + P.lds_prim_off)[i];
+    return P.primref[i];
+}
+template <bool LDSS>
+__device__ __forceinline__ DSphere load_sphere(const DParams &P, const uint4 *scn, uint32_t idx) {
+    if (LDSS) {
+        const uint4 *q = scn + (P.lds_sph_off + idx * P.lds_sph_stride);
+        uint4 a = q[0], b = q[1];
+        return DSphere{u2d(a.x, a.y), u2d(a.z, a.w), u2d(b.x, b.y), u2d(b.z, b.w)};
+    }
+    return P.spheres[idx];
+}
+template <bool LDSS>
+__device__ __forceinline__ DCuboid load_cuboid(const DParams &P, const uint4 *scn, uint32_t idx) {
+    if (LDSS) {
+        const uint4 *q = scn + (P.lds_cub_off + idx * 3u);
+        uint4 a = q[0], b = q[1], c = q[2];
+        DCuboid cb;
+        cb.mn[0] = u2d(a.x, a.y); cb.mn[1] = u2d(a.z, a.w); cb.mn[2] = u2d(b.x, b.y);
+        cb.mx[0] = u2d(b.z, b.w); cb.mx[1] = u2d(c.x, c.y); cb.mx[2] = u2d(c.z, c.w);
+        return cb;
+    }
+    return P.cuboids[idx];
+}
+
 struct Best {
     double t;
     uint32_t ref;   // primref of the closest accepted primitive, NO_HIT if none
@@ -321,15 +387,17 @@ struct Trav {
     bool tie;            // fast mode: two primitives produced exactly the same t
     uint32_t negmask;    // bit a set <=> dinv[a] < 0 (dir_is_neg, bvh.rs:463)
     bool mesh;           // current accel is a triangle mesh (every leaf slot is a triangle)
+    uint32_t soup_delta; // LDS-resident scene: leaf_soup slot = compact primref index + this
     TriSetup tri;        // valid while `mesh`
 };
-template <bool FAST>
+template <bool FAST, bool LDSS = false>
 __device__ __forceinline__ void trav_set_level(const DParams &P, Trav &T, uint32_t accel, const Ray &local) {
     const DAccel *A = P.accels + accel;
     T.accel = accel;
     T.ray = local;
-    T.node_base = FAST ? A->fnode_base : A->node_base;
-    T.prim_base = FAST ? A->fprim_base : A->prim_base;
+    T.node_base = LDSS ? A->lnode_base : FAST ? A->fnode_base : A->node_base;
+    T.prim_base = LDSS ? A->lprim_base : FAST ? A->fprim_base : A->prim_base;
+    T.soup_delta = LDSS ? A->prim_base - A->lprim_base : 0u;
     T.negmask = (local.dinv.x < 0.0 ? 1u : 0u) | (local.dinv.y < 0.0 ? 2u : 0u) | (local.dinv.z < 0.0 ? 4u : 0u);
     T.mesh = (A->flags & AF_MESH) != 0u;
     if (T.mesh && (FAST || !LG_TRI_PER_LEAF)) T.tri = tri_setup(local);
@@ -348,16 +416,17 @@ __device__ __forceinline__ double rec_f32(uint32_t w) { return (double)__uint_as
 
 // One fat mesh leaf [li, le): the reference's leaf loop (bvh.rs:483-488) specialised for
 // triangles, streaming the leaf-ordered records one slot ahead of the test.
-template <int KZ, bool STATS, bool FAST>
-__device__ __forceinline__ void mesh_leaf(const DParams &P, Trav &T, bool anyhit, Best &best, Counters &cnt) {
+template <int KZ, bool STATS, bool FAST, bool LDSS>
+__device__ __forceinline__ void mesh_leaf(const DParams &P, const uint4 *scn, Trav &T, bool anyhit, Best &best, Counters &cnt) {
     const V3 o = T.ray.o;
     const double sx = T.tri.sx, sy = T.tri.sy, sz = T.tri.sz;
     uint32_t li = T.li;
     const uint32_t le = T.le, last = le - 1u;
-    LeafRec cur = load_rec(P, li);
+    const uint32_t sd = LDSS ? T.soup_delta : 0u;
+    LeafRec cur = load_rec(P, li + sd);
     for (; li < le; ++li) {
         LeafRec r = cur;
-        cur = load_rec(P, li < last ? li + 1u : last); // prefetch the next slot (clamped: always a valid slot)
+        cur = load_rec(P, (li < last ? li + 1u : last) + sd); // prefetch the next slot (clamped: always a valid slot)
         V3 p0{rec_f32(r.a.x), rec_f32(r.a.y), rec_f32(r.a.z)}, p1{rec_f32(r.a.w), rec_f32(r.b.x), rec_f32(r.b.y)},
             p2{rec_f32(r.b.z), rec_f32(r.b.w), rec_f32(r.c.x)};
         if (STATS) cnt.triangles++;
@@ -365,7 +434,7 @@ __device__ __forceinline__ void mesh_leaf(const DParams &P, Trav &T, bool anyhit
         if (!triangle_t_pre<KZ>(p0, p1, p2, o, sx, sy, sz, h)) continue;
         if (FAST && h.t == best.t && best.ref != NO_HIT) T.tie = true; // equal t: the reference's visit order decides
         if (h.t >= best.t) continue;
-        best.t = h.t; best.ref = P.primref[li]; best.accel = T.accel;
+        best.t = h.t; best.ref = load_primref<LDSS>(P, scn, li); best.accel = T.accel;
         if (anyhit && h.t < 1.0) { T.done = true; break; } // point.rs:49
     }
     T.li = le;
@@ -380,14 +449,16 @@ __device__ __forceinline__ void trav_open_leaf(Trav &T, uint32_t link, uint32_t 
 }
 // leave the current node / leaf: next pending (already box-tested) child of this accel level,
 // or flag the level as exhausted
-__device__ __forceinline__ void trav_pop(const DParams &P, Trav &T, uint32_t *stack, uint32_t stride) {
+template <bool LDSS>
+__device__ __forceinline__ void trav_pop(const DParams &P, const uint4 *scn, Trav &T, uint32_t *stack, uint32_t stride) {
     T.in_leaf = false;
     if (T.sp != T.base) {
         --T.sp;
         uint32_t e = stack[T.sp * stride];
         if (e & STACK_LEAF) {
-            const DNode *nd = P.nodes + (T.node_base + (e & ~STACK_LEAF));
-            trav_open_leaf(T, nd->link, nd->meta);
+            uint32_t link, meta;
+            load_node_link<LDSS>(P, scn, T.node_base + (e & ~STACK_LEAF), link, meta);
+            trav_open_leaf(T, link, meta);
         } else {
             T.cur = e;
         }
@@ -445,13 +516,14 @@ __device__ __forceinline__ void trav_pop_fast(const DParams &P, Trav &T, uint32_
     }
 }
 
-template <bool STATS, bool FAST>
+template <bool STATS, bool FAST, bool LDSS = false>
 __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, bool anyhit, uint32_t *stack, uint32_t stride,
-                                         Best &best, Counters &cnt, bool &tie) {
-#define LG_POP() do { if (FAST) trav_pop_fast(P, T, stack, stride, prune_limit(best.t, anyhit)); else trav_pop(P, T, stack, stride); } while (0)
+                                         Best &best, Counters &cnt, bool &tie, const uint4 *scn = nullptr) {
+    static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
+#define LG_POP() do { if (FAST) trav_pop_fast(P, T, stack, stride, prune_limit(best.t, anyhit)); else trav_pop<LDSS>(P, scn, T, stack, stride); } while (0)
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
     Trav T;
-    trav_set_level<FAST>(P, T, 0u, ray_to_local(P.accels->minv, wray));
+    trav_set_level<FAST, LDSS>(P, T, 0u, ray_to_local(P.accels->minv, wray));
     T.sp = 0; T.base = 0; T.li = 0; T.le = 0; T.done = false; T.level_done = false; T.tie = false;
     if (STATS) cnt.entries++;
     trav_enter_root<STATS, FAST>(P, T, cnt);
@@ -497,15 +569,12 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
         } else {
         // reference traversal, one node per step (bvh.rs:471-505)
         while (!T.in_leaf && !T.level_done) {
-            const DNode *nd = P.nodes + (T.node_base + T.cur);
-            // one 64-byte record = four 16-byte loads from a single line, all issued before the
-            // slab test; link/meta are decoded branch-free so the compiler cannot sink their load
-            // behind the hit test (that would put a second memory latency on the critical path)
-            double bmin[3] = {nd->bmin[0], nd->bmin[1], nd->bmin[2]};
-            double bmax[3] = {nd->bmax[0], nd->bmax[1], nd->bmax[2]};
-            uint32_t link = nd->link, meta = nd->meta;
+            // link/meta are decoded branch-free so the compiler cannot sink their load behind the
+            // hit test (that would put a second memory latency on the critical path)
+            const NodeRec nd = load_node<LDSS>(P, scn, T.node_base + T.cur);
+            const uint32_t link = nd.link, meta = nd.meta;
             if (STATS) cnt.nodes++;
-            bool hit = slab_intersects(bmin, bmax, T.ray);
+            bool hit = slab_intersects(nd.bmin, nd.bmax, T.ray);
             bool leaf = (meta & NODE_LEAF) != 0u;
             uint32_t count = meta & 0xFFFFu;
             bool neg = ((T.negmask >> (meta & 3u)) & 1u) != 0u; // dir_is_neg[axis] (bvh.rs:463,496)
@@ -518,7 +587,7 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
             } else if (hit && leaf && count != 0u) {
                 trav_open_leaf(T, link, meta);
             } else {
-                trav_pop(P, T, stack, stride);
+                trav_pop<LDSS>(P, scn, T, stack, stride);
             }
         }
         }
@@ -526,14 +595,14 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
         // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
         if (T.in_leaf && T.mesh) {
             if (!FAST && LG_TRI_PER_LEAF) T.tri = tri_setup(T.ray); // fat reference leaves amortise the three divides
-            if (T.tri.kz == 0) mesh_leaf<0, STATS, FAST>(P, T, anyhit, best, cnt);
-            else if (T.tri.kz == 1) mesh_leaf<1, STATS, FAST>(P, T, anyhit, best, cnt);
-            else mesh_leaf<2, STATS, FAST>(P, T, anyhit, best, cnt);
+            if (T.tri.kz == 0) mesh_leaf<0, STATS, FAST, LDSS>(P, scn, T, anyhit, best, cnt);
+            else if (T.tri.kz == 1) mesh_leaf<1, STATS, FAST, LDSS>(P, scn, T, anyhit, best, cnt);
+            else mesh_leaf<2, STATS, FAST, LDSS>(P, scn, T, anyhit, best, cnt);
             if (!T.done) LG_POP(); // may open the next (already box-tested) leaf
             else T.in_leaf = false;
         } else if (T.in_leaf) {
             while (T.in_leaf) {
-                const uint32_t ref = P.primref[T.li];
+                const uint32_t ref = load_primref<LDSS>(P, scn, T.li);
                 ++T.li;
                 uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
                 bool accepted = false;
@@ -541,12 +610,12 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
                 if (kind == PK_SPHERE) {
                     if (STATS) cnt.spheres++;
                     bool inside;
-                    DSphere sp = P.spheres[idx];
+                    DSphere sp = load_sphere<LDSS>(P, scn, idx);
                     t = sphere_t(T.ray, V3{sp.cx, sp.cy, sp.cz}, sp.r, inside);
                     accepted = !(t < 0.0) && !(t >= best.t);
                 } else if (kind == PK_CUBOID) {
                     if (STATS) cnt.cuboids++;
-                    DCuboid cb = P.cuboids[idx];
+                    DCuboid cb = load_cuboid<LDSS>(P, scn, idx);
                     double mn[3] = {cb.mn[0], cb.mn[1], cb.mn[2]}, mx[3] = {cb.mx[0], cb.mx[1], cb.mx[2]};
                     V3 d0, d1;
                     if (cuboid_hit<false>(mn, mx, T.ray, t, d0, d1)) accepted = !(t >= best.t);
@@ -554,7 +623,7 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
                     // nested BVHAccel (Group / Mesh): save this level, re-express the ray (bvh.rs:462)
                     stack[T.sp * stride] = T.li; stack[(T.sp + 1) * stride] = T.le; stack[(T.sp + 2) * stride] = T.base;
                     T.sp += 3; T.base = T.sp;
-                    trav_set_level<FAST>(P, T, idx, ray_to_local(P.accels[idx].minv, T.ray));
+                    trav_set_level<FAST, LDSS>(P, T, idx, ray_to_local(P.accels[idx].minv, T.ray));
                     if (STATS) cnt.entries++;
                     trav_enter_root<STATS, FAST>(P, T, cnt);
                     break;
@@ -580,7 +649,7 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
                 T.base = stack[(T.sp - 1) * stride]; T.le = stack[(T.sp - 2) * stride]; T.li = stack[(T.sp - 3) * stride];
                 T.sp -= 3;
                 uint32_t parent = (uint32_t)P.accels[T.accel].parent;
-                trav_set_level<FAST>(P, T, parent, local_ray(P, wray, parent));
+                trav_set_level<FAST, LDSS>(P, T, parent, local_ray(P, wray, parent));
                 if (T.li < T.le) T.in_leaf = true;
                 else LG_POP();
             }
@@ -864,7 +933,7 @@ __device__ __forceinline__ V3 frame_get3(const DParams &P, uint32_t depth, int f
     return V3{frame_at(P, depth, field, g), frame_at(P, depth, field + 1, g), frame_at(P, depth, field + 2, g)};
 }
 
-extern __shared__ uint32_t lds_stack[];
+extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
 
 // Shading frame of a hit from the ray that found it (resolve_hit + SurfaceInteraction::from,
 // surface.rs:158-183).  Pure function of (ray, best): recomputed after each shadow traversal
@@ -1224,11 +1293,23 @@ __device__ __forceinline__ Ray camera_ray(const DParams &P, uint32_t x, uint32_t
 }
 
 // K1 / K3: persistent traversal kernels (tile counter, per-lane LDS stack)
-template <bool FAST, bool SHADOW>
-__global__ void __launch_bounds__(LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_trace_kernel(const DParams P) {
+// LDSS: one 1024-lane workgroup per CU (still 4 waves per SIMD) that first copies the scene's
+// node / primref / sphere / cuboid tables into LDS behind the stacks; its waves then pull tiles
+// independently exactly like the 256-lane form.
+#define LG_LDSS_BLOCK 1024
+template <bool FAST, bool SHADOW, bool LDSS>
+__global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_trace_kernel(const DParams P) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t *stack = lds_stack + tid;
-    constexpr uint32_t stride = LG_BLOCK;
+    constexpr uint32_t stride = LDSS ? LG_LDSS_BLOCK : LG_BLOCK;
+    const uint4 *scn = nullptr;
+    if (LDSS) {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_stack + P.stack_depth * stride);
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.lds_image);
+        for (uint32_t i = tid; i < P.lds_image_n16; i += stride) dst[i] = src[i];
+        __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling tiles
+        scn = dst;
+    }
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
         uint32_t tile = 0;
@@ -1242,7 +1323,7 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_trace
             Ray ray = camera_ray(P, px.x, px.y, P.sample_index);
             Best b;
             bool tie = false;
-            traverse<false, FAST>(P, ray, false, stack, stride, b, cnt, tie);
+            traverse<false, FAST, LDSS>(P, ray, false, stack, stride, b, cnt, tie, scn);
             if (FAST && tie) traverse<false, false>(P, ray, false, stack, stride, b, cnt, tie);
             P.hit_t[widx] = b.t; P.hit_ref[widx] = b.ref; P.hit_accel[widx] = b.accel;
         } else {
@@ -1259,7 +1340,7 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_trace
                 Ray sray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
                 Best b;
                 bool tie = false;
-                traverse<false, FAST>(P, sray, true, stack, stride, b, cnt, tie);
+                traverse<false, FAST, LDSS>(P, sray, true, stack, stride, b, cnt, tie, scn);
                 if (FAST && tie && !(b.t < 1.0)) traverse<false, false>(P, sray, true, stack, stride, b, cnt, tie);
                 if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
             }
@@ -1439,15 +1520,31 @@ hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks
     return hipGetLastError();
 }
 hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
+    if (P.lds_image && !fast) { // LDS-resident scene: `blocks` = one workgroup per CU
+        size_t lds = (size_t)P.stack_depth * LG_LDSS_BLOCK * sizeof(uint32_t) + (size_t)P.lds_image_n16 * 16u;
+        if (shadow) hipLaunchKernelGGL((stream_trace_kernel<false, true, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((stream_trace_kernel<false, false, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
+        return hipGetLastError();
+    }
     size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
     if (fast) {
-        if (shadow) hipLaunchKernelGGL((stream_trace_kernel<true, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-        else hipLaunchKernelGGL((stream_trace_kernel<true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        if (shadow) hipLaunchKernelGGL((stream_trace_kernel<true, true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((stream_trace_kernel<true, false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     } else {
-        if (shadow) hipLaunchKernelGGL((stream_trace_kernel<false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-        else hipLaunchKernelGGL((stream_trace_kernel<false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        if (shadow) hipLaunchKernelGGL((stream_trace_kernel<false, true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((stream_trace_kernel<false, false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     }
     return hipGetLastError();
+}
+// LDS-resident scene variant: raise the dynamic-LDS limit of its two kernels to `bytes`
+hipError_t stream_trace_ldss_prepare(size_t bytes) {
+    const void *fns[2] = {reinterpret_cast<const void *>(stream_trace_kernel<false, false, true>),
+                          reinterpret_cast<const void *>(stream_trace_kernel<false, true, true>)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 hipError_t launch_stream_frame(const DParams &P, hipStream_t stream) {
     uint32_t blocks = (uint32_t)((P.n_items + LG_BLOCK - 1) / LG_BLOCK);
@@ -1464,13 +1561,13 @@ hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_p
     int a = 0, b = 0;
     hipError_t e;
     if (fast) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<true, false>, LG_BLOCK, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<true, false, false>, LG_BLOCK, lds);
         if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<true, true>, LG_BLOCK, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<true, true, false>, LG_BLOCK, lds);
     } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<false, false>, LG_BLOCK, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<false, false, false>, LG_BLOCK, lds);
         if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<false, true>, LG_BLOCK, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<false, true, false>, LG_BLOCK, lds);
     }
     *blocks_per_cu = a < b ? a : b;
     return e;
@@ -1483,8 +1580,8 @@ hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu) 
 hipError_t trace_set_lds_limit(size_t bytes) {
     const void *fns[8] = {reinterpret_cast<const void *>(trace_kernel<false, false>), reinterpret_cast<const void *>(trace_kernel<true, false>),
                           reinterpret_cast<const void *>(trace_kernel<false, true>), reinterpret_cast<const void *>(trace_kernel<true, true>),
-                          reinterpret_cast<const void *>(stream_trace_kernel<false, false>), reinterpret_cast<const void *>(stream_trace_kernel<false, true>),
-                          reinterpret_cast<const void *>(stream_trace_kernel<true, false>), reinterpret_cast<const void *>(stream_trace_kernel<true, true>)};
+                          reinterpret_cast<const void *>(stream_trace_kernel<false, false, false>), reinterpret_cast<const void *>(stream_trace_kernel<false, true, false>),
+                          reinterpret_cast<const void *>(stream_trace_kernel<true, false, false>), reinterpret_cast<const void *>(stream_trace_kernel<true, true, false>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;

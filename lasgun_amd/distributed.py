@@ -74,9 +74,10 @@ class InterleavedGather:
     frame k overlaps the render of frame k+1 (separate streams; `tile()` hands out the buffer to
     render into after making the current stream wait for the gather that last read it)."""
 
-    def __init__(self, width, height, rank, world, block_rows, device, group=None):
+    def __init__(self, width, height, rank, world, block_rows, device, group=None, always_gather=False):
         assert interleave_ok(world, height, block_rows)
         self.w, self.h, self.rank, self.world, self.b, self.group = width, height, rank, world, block_rows, group
+        self.collective = world > 1 or always_gather  # always_gather: run the collective even at world size 1 (rehearsal)
         self.rows = height // world
         self.tiles = [torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(2)]
         self.pending = [None, None]
@@ -98,7 +99,7 @@ class InterleavedGather:
         """Start the gather of the tile handed out by the last tile() call."""
         i = self.k % 2
         self.k += 1
-        if self.world == 1:
+        if not self.collective:
             return
         glist = [self.recv[r] for r in range(self.world)] if self.rank == 0 else None
         self.pending[i] = dist.gather(self.tiles[i], gather_list=glist, dst=0, group=self.group, async_op=True)
@@ -111,7 +112,7 @@ class InterleavedGather:
                 self.pending[i] = None
         if self.rank != 0:
             return None
-        if self.world == 1:
+        if not self.collective:
             return self.tiles[(self.k - 1) % 2]
         g = self.h // (self.b * self.world)
         self.out.view(g, self.world, self.b, self.w, 4).copy_(

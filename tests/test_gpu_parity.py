@@ -221,6 +221,28 @@ def test_streaming_pipeline_and_megakernel_agree(name):
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
 
 
+@pytest.mark.parametrize("name", ["spheres_512", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "ragged_5x131", "one_pixel"])
+def test_lds_resident_scene_matches_global_tables(name):
+    """Streaming traversal kernels with the scene tables in LDS (1024-lane workgroups) vs in HBM/L2."""
+    builder, w, h = MID[name]
+    acc = G.Accel(builder(G))
+    G.set_streaming(acc, 2)
+    outs = []
+    for lds in (True, False):
+        fits = G.set_lds_scene(acc, lds)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        sub = G.Film.new_with_output(w, h, np.full((h, w, 4), 7, np.uint8))
+        G.capture_subset(2, 5, acc, sub)
+        outs.append((film.pixels(), bits(G.capture_radiance(acc, w, h)), sub.pixels()))
+    assert fits or name == "mixed_128", "these scenes are small enough for the LDS variant"
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
+    ofilm = oracle().Film(w, h)
+    o = oracle()
+    o.capture_subset_mt(0, 1, o.Accel(builder(o)), ofilm, 16)
+    assert np.array_equal(outs[0][0], ofilm.pixels())
+
+
 # ---- fuzz parity: seeded random scenes with duplicated / touching primitives (exact ties in t) ----
 @pytest.mark.parametrize("seed", list(range(32)))
 def test_random_scene_parity(seed):
@@ -382,3 +404,20 @@ def test_headline_4096_properties():
     # (4) ray accounting: every primary ray is counted, one shadow ray per hit and light
     st = G.capture_stats(acc, w, h)
     assert st["primary_rays"] == w * h and st["shadow_rays"] == st["hits"] and st["secondary_rays"] == 0
+
+
+def test_bench_multi_gpu_path_over_rccl_world1():
+    """bench.py's N>1 code path (RCCL process group, interleaved tile, async gather overlapped with the
+    next frame, all_reduce of counters) at world size 1: the gathered film must equal the plain film."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LASGUN_BENCH_VERIFY="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--size", "1024", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "verify: gathered 1-rank film == single-GPU film" in p.stderr
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["primary"] == 1024 * 1024
