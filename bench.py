@@ -41,6 +41,21 @@ def algorithmic_bytes(st):
             + BYTES_PIXEL * st["primary_rays"])
 
 
+# The resource that actually binds the traversal kernels is f64 VALU issue (the scene is cache / LDS
+# resident).  Unfused f64 operations the reference's algorithm needs per test, lower bounds (miss paths):
+# slab test 26 (cuboid.rs:104-121), sphere 26 up to the discriminant test (sphere.rs:30-69), cuboid 26,
+# triangle 36 up to the edge-function signs (triangle.rs:186-230), accel entry 2 x (36 + 3 divisions).
+# Peak: 256 CUs x 4 SIMDs x 16 f64 lanes x 2.4 GHz = 39.3 T unfused ops/s (-ffp-contract=off is part of
+# the parity contract, so an FMA's second flop is not available).
+FLOPS_NODE, FLOPS_SPHERE, FLOPS_CUBOID, FLOPS_TRI, FLOPS_ACCEL_ENTRY = 26, 26, 26, 36, 78
+VALU_F64_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+
+
+def algorithmic_flops(st):
+    return (FLOPS_NODE * st["nodes_tested"] + FLOPS_SPHERE * st["spheres_tested"] + FLOPS_CUBOID * st["cuboids_tested"]
+            + FLOPS_TRI * st["triangles_tested"] + FLOPS_ACCEL_ENTRY * st["accel_entries"])
+
+
 def cpu_baseline(width, height, target_seconds=15.0):
     """Time the CPU oracle on a bounded strided sample {k + i*n} of the same frame (all host cores)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -112,8 +127,8 @@ def main():
     t0 = time.perf_counter()
     acc = G.Accel(scene)  # host HLBVH build + flatten + upload (outside the timed region, reported below)
     accel_build_s = time.perf_counter() - t0
-    if os.environ.get("LASGUN_NO_LDS_SCENE"):  # A/B: traversal kernels read the scene tables through L1/L2 instead of LDS
-        G.set_lds_scene(acc, False)
+    # LASGUN_NO_LDS_SCENE=1 (A/B): the traversal kernels read the scene tables through L1/L2 instead of LDS
+    lds_scene = G.set_lds_scene(acc, not os.environ.get("LASGUN_NO_LDS_SCENE")) and not os.environ.get("LASGUN_NO_LDS_SCENE")
     stream = torch.cuda.current_stream().cuda_stream
     BLOCK_ROWS = 64
     balanced = multi and interleave_ok(world, h, BLOCK_ROWS)
@@ -248,9 +263,12 @@ def main():
             dst = dict(dst)
             dst["primary_rays"] = 0  # the RGBA write belongs to the shade kernel, not to a traversal kernel
             my_bytes = algorithmic_bytes(dst)
-            kernel_name = "lg::" + dom.replace("<primary>", "<false, false>").replace("<shadow>", "<false, true>")
+            tail = ", true>" if lds_scene else ", false>"  # third template argument: scene tables resident in LDS
+            kernel_name = "lg::" + dom.replace("<primary>", "<false, false" + tail).replace("<shadow>", "<false, true" + tail)
+            dom_flops = algorithmic_flops(dst)
         else:  # megakernel (scenes with glass / mirror, small films)
             dom_ms, my_bytes, kernel_name, per_kernel = frame_ms, algorithmic_bytes(st), "lg::trace_kernel<false, false>", {"trace_kernel": frame_ms}
+            dom_flops = algorithmic_flops(st)
         achieved = my_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         try:  # HBM bytes of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB)
@@ -274,8 +292,11 @@ def main():
                          "traffic": traffic, "kernel": kernel_name, "kernel_ms_avg": dom_ms,
                          "algorithmic_bytes_per_launch": my_bytes,
                          "frame_device_ms": frame_ms, "kernels_ms_avg": per_kernel,
-                         "note": "algorithmic bytes = node/primitive records the traversal demands (DESIGN.md); the 160 KB scene is L2-resident, "
-                                 "so they are served from cache (frac can exceed 1) and the binding resources are f64 VALU issue and L2 latency"},
+                         "scene_tables": "LDS" if lds_scene else "L1/L2",
+                         "valu_f64": {"achieved": dom_flops / (dom_ms * 1e-3) / 1e12, "peak": VALU_F64_PEAK_TOPS, "unit": "T unfused f64 ops/s",
+                                      "frac": dom_flops / (dom_ms * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS, "algorithmic_flops_per_launch": dom_flops},
+                         "note": "algorithmic bytes = node/primitive records the traversal demands (DESIGN.md); the 160 KB scene is resident in "
+                                 "LDS / L2, so they never reach HBM (frac exceeds 1); the binding resource is f64 VALU issue: see valu_f64"},
         }
         if fast_info is not None:
             out["fast_mode"] = fast_info

@@ -12,7 +12,7 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/p
 timeout -k 10 300 python tools/bench_configs.py > $O/configs_parity.jsonl 2>/dev/null
 timeout -k 10 300 python tools/bench_configs.py --fast > $O/configs_fast.jsonl 2>/dev/null
 {
-  echo "# per-launch counters of lg::trace_kernel<false,false> (4096^2, config 3); one row per counter, median over dispatches"
-  for d in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_tcc; do f=$(find $O/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && grep 'trace_kernel<false, false>' $f | awk -F, '{n=NF; gsub(/"/,"",$(n-3)); print $(n-3), $(n-2)}' | sort | awk '{a[$1]=a[$1]" "$2} END{for(k in a) print k, a[k]}' | sort; done
+  echo "# per-launch counters of lg::stream_trace_kernel<false,true,true> (shadow traversal, LDS-resident scene) (4096^2, config 3); one row per counter, median over dispatches"
+  for d in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_tcc; do f=$(find $O/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && grep "stream_trace_kernel<false, true, true>" $f | awk -F, '{n=NF; gsub(/"/,"",$(n-3)); print $(n-3), $(n-2)}' | sort | awk '{a[$1]=a[$1]" "$2} END{for(k in a) print k, a[k]}' | sort; done
 } > $O/pmc_summary.txt
 cat $O/pmc_summary.txt; tail -1 $O/pytest_gpu.log; tail -1 $O/bench.log | cut -c1-400
