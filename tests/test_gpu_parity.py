@@ -406,6 +406,28 @@ def test_headline_4096_properties():
     assert st["primary_rays"] == w * h and st["shadow_rays"] == st["hits"] and st["secondary_rays"] == 0
 
 
+def test_headline_4096_full_frame_vs_oracle():
+    """The headline claim literally: the whole 4096x4096 film of config 3, every byte, against the CPU
+    oracle (all host cores, capped at 64 threads), in every kernel organisation."""
+    import torch
+    w = h = 4096
+    o = oracle()
+    oacc = o.Accel(S.spheres_scene(o))
+    ofilm = o.Film(w, h)
+    nthreads = max(1, min(64, len(os.sched_getaffinity(0))))
+    o.capture_subset_mt(0, 1, oacc, ofilm, nthreads)
+    ref = ofilm.pixels()
+    acc = G.Accel(S.spheres_scene(G))
+    film = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    for streaming, lds, fast in ((1, True, False), (1, False, False), (0, True, False), (1, True, True)):
+        G.set_streaming(acc, streaming); G.set_lds_scene(acc, lds); G.set_mode(acc, fast)
+        film.zero_()
+        G.capture_rows_device(acc, w, h, 0, h, film.data_ptr(), row0=0)
+        G.synchronize(acc)
+        diff = int((film.cpu().numpy() != ref).sum())
+        assert diff == 0, (streaming, lds, fast, diff)
+
+
 def test_bench_multi_gpu_path_over_rccl_world1():
     """bench.py's N>1 code path (RCCL process group, interleaved tile, async gather overlapped with the
     next frame, all_reduce of counters) at world size 1: the gathered film must equal the plain film."""
