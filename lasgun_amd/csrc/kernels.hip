@@ -7,6 +7,14 @@
 // stack -> RGBA8.  All arithmetic is f64 in the reference's order of operations (vecmath.h);
 // compile with -ffp-contract=off.  No MFMA: this is branchy traversal, not a contraction.
 //
+// Kernels:
+//   trace_kernel<STATS, FAST>                 the whole of li() per lane (scenes with glass / mirror, small
+//                                             films, the counting variant)
+//   stream_trace_kernel<FAST, SHADOW, LDSS>   traversal only: primary closest-hit or per-light any-hit;
+//                                             LDSS = scene tables resident in LDS, one 1024-lane workgroup per CU
+//   stream_frame_kernel, stream_shade_kernel  hit -> shading frame; frame + visibility -> radiance -> RGBA8
+//   kat_kernel, kat_si_kernel, math_kernel    probes behind the test hooks of the C ABI
+//
 // What is restated from where (file:line under /root/reference):
 //   pixel loop / quantisation   src/lib.rs:110-162, src/img.rs:56-67
 //   camera rays                 src/camera.rs:113-146
@@ -32,18 +40,6 @@
 
 #ifndef LG_TRAV_WAVES_PER_SIMD
 #define LG_TRAV_WAVES_PER_SIMD 4 // register budget of the streaming pipeline's traversal kernels
-#endif
-#ifndef LG_TRI_PER_LEAF
-#define LG_TRI_PER_LEAF 1 // reference traversal: shear setup per fat leaf, not held in registers across the traversal (measured faster)
-#endif
-#ifndef LG_SHADE_INLINE
-#define LG_SHADE_INLINE __forceinline__
-#endif
-#ifndef LG_BSDF_INLINE
-#define LG_BSDF_INLINE __forceinline__
-#endif
-#ifndef LG_TRAVERSE_INLINE
-#define LG_TRAVERSE_INLINE __forceinline__
 #endif
 #define LG_BLOCK 256 // threads per workgroup; also the per-entry stride (in dwords) of the LDS stacks
 #ifndef LG_WAVES_PER_SIMD
@@ -400,7 +396,7 @@ __device__ __forceinline__ void trav_set_level(const DParams &P, Trav &T, uint32
     T.soup_delta = LDSS ? A->prim_base - A->lprim_base : 0u;
     T.negmask = (local.dinv.x < 0.0 ? 1u : 0u) | (local.dinv.y < 0.0 ? 2u : 0u) | (local.dinv.z < 0.0 ? 4u : 0u);
     T.mesh = (A->flags & AF_MESH) != 0u;
-    if (T.mesh && (FAST || !LG_TRI_PER_LEAF)) T.tri = tri_setup(local);
+    if (T.mesh && FAST) T.tri = tri_setup(local); // reference traversal: per fat leaf instead (fewer live registers, measured faster)
 }
 
 // leaf-ordered 48-byte geometry records: three 16-byte loads per slot
@@ -517,7 +513,7 @@ __device__ __forceinline__ void trav_pop_fast(const DParams &P, Trav &T, uint32_
 }
 
 template <bool STATS, bool FAST, bool LDSS = false>
-__device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, bool anyhit, uint32_t *stack, uint32_t stride,
+__device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool anyhit, uint32_t *stack, uint32_t stride,
                                          Best &best, Counters &cnt, bool &tie, const uint4 *scn = nullptr) {
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
 #define LG_POP() do { if (FAST) trav_pop_fast(P, T, stack, stride, prune_limit(best.t, anyhit)); else trav_pop<LDSS>(P, scn, T, stack, stride); } while (0)
@@ -594,7 +590,7 @@ __device__ LG_TRAVERSE_INLINE void traverse(const DParams &P, const Ray &wray, b
         if (T.in_leaf && T.li >= T.le) { LG_POP(); continue; } // empty leaf (nprims as u16 == 0)
         // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
         if (T.in_leaf && T.mesh) {
-            if (!FAST && LG_TRI_PER_LEAF) T.tri = tri_setup(T.ray); // fat reference leaves amortise the three divides
+            if (!FAST) T.tri = tri_setup(T.ray); // fat reference leaves amortise the three divides
             if (T.tri.kz == 0) mesh_leaf<0, STATS, FAST, LDSS>(P, scn, T, anyhit, best, cnt);
             else if (T.tri.kz == 1) mesh_leaf<1, STATS, FAST, LDSS>(P, scn, T, anyhit, best, cnt);
             else mesh_leaf<2, STATS, FAST, LDSS>(P, scn, T, anyhit, best, cnt);
@@ -805,18 +801,12 @@ struct Shade {
 };
 
 // BSDF::f (bsdf.rs:73-92) with the BxDF list of Material::scattering (material/*.rs) inlined
-__device__ LG_BSDF_INLINE V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo, V3 wi) {
-#if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 3 /* timing only: constant BSDF */
-    return V3{m.p[0], m.p[1], m.p[2]} * dot(wo, wi) * dot(sh.ns, sh.ss);
-#endif
+__device__ __forceinline__ V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo, V3 wi) {
     bool reflect = dot(wi, sh.ng) * dot(wo, sh.ng) > 0.0;
     V3 wo_l{dot(wo, sh.ss), dot(wo, sh.ts), dot(wo, sh.ns)};
     V3 wi_l{dot(wi, sh.ss), dot(wi, sh.ts), dot(wi, sh.ns)};
     if (wo_l.z == 0.0) return vzero();
     V3 f = vzero();
-#ifdef LG_MATMASK
-    if (!((LG_MATMASK >> m.kind) & 1)) return f;
-#endif
     switch (m.kind) {
     case MAT_MATTE: { // matte.rs:18-26 -- REFLECTION | DIFFUSE
         if (reflect) {
@@ -833,7 +823,6 @@ __device__ LG_BSDF_INLINE V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo, 
         }
         break;
     }
-#if !defined(LG_MATMASK) || (LG_MATMASK & 4)
     case MAT_METAL: { // metal.rs:17-26
         if (reflect) {
             V3 eta{m.p[0], m.p[1], m.p[2]}, k{m.p[3], m.p[4], m.p[5]};
@@ -841,7 +830,6 @@ __device__ LG_BSDF_INLINE V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo, 
         }
         break;
     }
-#endif
     case MAT_GLASS: { // glass.rs:33-56: specular BxDFs evaluate to zero (bxdf/mod.rs:172)
         V3 kr{m.p[0], m.p[1], m.p[2]}, kt{m.p[3], m.p[4], m.p[5]};
         if (reflect && vne(kr, vzero())) f = f + vzero();
@@ -938,7 +926,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
 // Shading frame of a hit from the ray that found it (resolve_hit + SurfaceInteraction::from,
 // surface.rs:158-183).  Pure function of (ray, best): recomputed after each shadow traversal
 // instead of being kept in registers across it, which is what lets 4-5 waves share a SIMD.
-__device__ LG_SHADE_INLINE void shade_frame(const DParams &P, const Ray &ray, const Best &best, Shade &sh) {
+__device__ __forceinline__ void shade_frame(const DParams &P, const Ray &ray, const Best &best, Shade &sh) {
     Isect is;
     sh.mat = resolve_hit(P, ray, best, is);
     sh.wo = -normalize(ray.d);
@@ -1054,9 +1042,6 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
             Ray tray = pray;         // the ray handed to the traversal
             for (;;) {
                 Best b;
-#if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 2 /* timing only: shadow rays are not traced */
-                if (shadow_job) { b.t = INFINITY; b.ref = NO_HIT; b.accel = 0; } else
-#endif
                 {
                     bool tie = false;
                     Counters before = cnt;
@@ -1070,10 +1055,6 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
                     }
                 }
                 bool have_value = false, need_shade = false, visible = false;
-#if defined(LG_EXPERIMENT) && LG_EXPERIMENT == 1 /* timing only: primary traversal, nothing else */
-                value = V3{b.t, (double)b.ref, (double)b.accel}; have_value = true; (void)need_shade; (void)visible;
-                if (false)
-#endif
                 if (!shadow_job) {
                     if (b.ref == NO_HIT) {
                         value = background(P, normalize(pray.d)); // integrate.rs:26-28
@@ -1102,11 +1083,7 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
                         shade_frame(P, pray, pbest, sh);
                         if (P.nlights > 0) stash_put(P, gtid, sh);
                     } else {
-#ifdef LG_NO_STASH
-                        shade_frame(P, pray, pbest, sh);
-#else
                         stash_get(P, gtid, sh, pray);
-#endif
                     }
                     const DMaterial m = P.materials[sh.mat];
                     V3 n = sh.ns;
@@ -1137,11 +1114,7 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
                     // specular children (integrate.rs:69-77,82-132)
                     bool has_r = false, has_t = false;
                     Sample sr, st;
-#if defined(LG_MATMASK) && !(LG_MATMASK & 24)
-                    if (false) {
-#else
                     if (depth < P.recursion && (m.kind == MAT_GLASS || m.kind == MAT_MIRROR)) {
-#endif
                         if (sample_specular_transmission(m, sh, st))
                             has_t = !(st.pdf <= 0.0 || veq(st.spectrum, vzero()) || fabs(dot(st.wi, sh.ns)) == 0.0);
                         if (sample_specular_reflection(m, sh, sr))
