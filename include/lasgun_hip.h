@@ -139,10 +139,11 @@ int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t
 int lg_accel_set_mode(const lg_accel *, int mode);
 
 /* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes without
- * glass / mirror and with <= 32 lights run as a four-kernel streaming pipeline (primary traversal,
- * shading frame, shadow traversal, shade) with per-pixel state in HBM when the launch covers at
- * least 2^20 pixels; everything else -- and everything when 0 -- runs in the single persistent
- * megakernel.  2 = use the pipeline for any size (tests). */
+ * glass / mirror, with <= 32 lights and with at least 128 spheres / boxes (where node and sphere
+ * tests dominate a ray) run as a four-kernel streaming pipeline (primary traversal, shading
+ * frame, shadow traversal, shade) with per-pixel state in HBM when the launch covers at least
+ * 2^19..2^23 pixels (by scene kind); everything else -- and everything when 0 -- runs in the
+ * single persistent megakernel.  2 = use the pipeline wherever it is possible (tests). */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
 
 /* LDS-resident scene (streaming pipeline, reference traversal): when the scene's node, primref,

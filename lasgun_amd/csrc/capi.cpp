@@ -111,7 +111,11 @@ struct lg_accel {
     mutable DevBuf<double> st_hit_t, st_frame, st_accum;
     mutable DevBuf<uint32_t> st_hit_ref, st_hit_accel, st_vis;
     mutable bool streaming = true; // use the streaming pipeline when the scene allows it
-    mutable unsigned long long streaming_min_items = 1ull << 20;
+    mutable bool streaming_forced = false; // lg_accel_set_streaming(2): ignore the two criteria below (tests)
+    // the pipeline pays for its per-pixel state traffic only where node / sphere / box traversal dominates a
+    // ray's cost (tools/threshold_sweep.py): set from the scene by lg_accel_from
+    bool streaming_pays = false;
+    unsigned long long streaming_min_items = 1ull << 20;
     uint32_t stream_blocks = 1, stream_blocks_fast = 1;
     // LDS-resident scene (reference tree only): the tables in their LDS layout, when they fit beside the stacks
     DevBuf<uint32_t> lds_image;
@@ -171,7 +175,8 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     if (P.ntiles == 0) return;
     // ---- streaming pipeline: no glass / mirror (no recursion), <= 32 lights, not the counting variant
     // and enough work to amortise 4 launches per supersample (below ~1 Mpixel the megakernel wins: measured)
-    if (a.streaming && !stats && !a.flat.has_specular && P.nlights <= 32 && (unsigned long long)P.ntiles * 64ull >= a.streaming_min_items) {
+    if (a.streaming && !stats && !a.flat.has_specular && P.nlights <= 32 &&
+        (a.streaming_forced || (a.streaming_pays && (unsigned long long)P.ntiles * 64ull >= a.streaming_min_items))) {
         const uint32_t nsamples = P.ss_root * P.ss_root;
         P.n_items = (unsigned long long)P.ntiles * 64ull;
         size_t n = (size_t)P.n_items;
@@ -524,6 +529,16 @@ lg_accel *lg_accel_from(const lg_scene *s) {
             }
             a->accels.upload(fm.accels); // again, now with the compact bases
         }
+        // Which organisation is the default (measured, tools/threshold_sweep.py): the megakernel unless the scene has
+        // enough spheres / boxes that BVH-node and sphere tests dominate a ray (>= 128: from ~45 node + primitive tests
+        // per ray on, the traversal kernels' lower register pressure outweighs ~360 B of per-pixel state traffic);
+        // scenes that also carry a big mesh have long, uneven tiles and need more of them per wave to balance.
+        {
+            size_t big_mesh = 0;
+            for (const auto &m : s->s.meshes) if (m && m->tri.size() / 3 > big_mesh) big_mesh = m->tri.size() / 3;
+            a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 128;
+            a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : a->ldss_blocks ? (1ull << 19) : (1ull << 20);
+        }
     });
     if (rc) { delete a; return nullptr; }
     return a;
@@ -659,7 +674,7 @@ int lg_accel_set_lds_scene(const lg_accel *a, int enabled) {
 int lg_accel_set_streaming(const lg_accel *a, int enabled) {
     std::lock_guard<std::mutex> g(a->mtx);
     a->streaming = enabled != 0;
-    a->streaming_min_items = enabled == 2 ? 0ull : (1ull << 20); // 2 = force it even for tiny launches (tests)
+    a->streaming_forced = enabled == 2; // 2 = use it whatever the scene and the launch size (tests)
     return 0;
 }
 int lg_accel_set_mode(const lg_accel *a, int mode) {
