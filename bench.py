@@ -210,9 +210,11 @@ def main():
     e2e_ms = None
     if rank == 0 and world == 1:
         film = G.Film(w, h)
-        t0 = time.perf_counter()
-        G.capture(scene, film)
-        e2e_ms = (time.perf_counter() - t0) * 1e3
+        e2e_ms = float("inf")
+        for _ in range(3):  # best of 3: the first call also pays the first touch of the 64 MiB host film
+            t0 = time.perf_counter()
+            G.capture(scene, film)
+            e2e_ms = min(e2e_ms, (time.perf_counter() - t0) * 1e3)
 
     if rank == 0 and multi and os.environ.get("LASGUN_BENCH_VERIFY"):
         ref = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")

@@ -154,6 +154,28 @@ class HipApi(Api):
         return dict(zip(keys, [int(v) for v in out]))
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so and load it by
+    file name; liblasgun_hip.so asks for the soname libamdhip64.so.7.  If this library is loaded first it
+    binds to the system runtime and a later `import torch` brings a SECOND runtime into the process, which
+    then finds no GPU.  Loading torch's copy first (when a torch wheel with a bundled runtime is installed;
+    torch itself is not imported) makes both resolve to the same object, whichever is imported first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    bundled = _os.path.join(_os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if _os.path.exists(bundled):
+        _C.CDLL(bundled, mode=_C.RTLD_GLOBAL)
+
+
+_share_torch_hip_runtime()
 api = HipApi(_C.CDLL(LIB_PATH), "lg_", _EXTRA)
 
 # reference-shaped names at package level: `from lasgun_amd import Scene, Material, capture`

@@ -428,6 +428,23 @@ def test_headline_4096_full_frame_vs_oracle():
         assert diff == 0, (streaming, lds, fast, diff)
 
 
+def test_library_first_then_torch_share_one_hip_runtime():
+    """Importing lasgun_amd (and rendering) BEFORE torch must leave torch able to use the GPU: the package
+    preloads the HIP runtime bundled with the torch wheel so the process never holds two runtimes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import lasgun_amd as la\n"
+            "G = la.api; f = G.Film(64, 64); G.capture(la.scenes.readme_scene(G), f)\n"
+            "import torch\n"
+            "t = torch.zeros((64, 64, 4), dtype=torch.uint8, device='cuda')\n"
+            "acc = G.Accel(la.scenes.readme_scene(G)); G.capture_rows_device(acc, 64, 64, 0, 64, t.data_ptr(), row0=0); G.synchronize(acc)\n"
+            "assert (t.cpu().numpy() == f.pixels()).all(); print('shared runtime ok')\n") % root
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "shared runtime ok" in p.stdout, p.stderr[-2000:]
+
+
 def test_bench_multi_gpu_path_over_rccl_world1():
     """bench.py's N>1 code path (RCCL process group, interleaved tile, async gather overlapped with the
     next frame, all_reduce of counters) at world size 1: the gathered film must equal the plain film."""
