@@ -383,6 +383,7 @@ struct Trav {
     bool tie;            // fast mode: two primitives produced exactly the same t
     uint32_t negmask;    // bit a set <=> dinv[a] < 0 (dir_is_neg, bvh.rs:463)
     bool mesh;           // current accel is a triangle mesh (every leaf slot is a triangle)
+    double dd;           // dot(ray.d, ray.d) (reference traversal only)
     uint32_t soup_delta; // LDS-resident scene: leaf_soup slot = compact primref index + this
     TriSetup tri;        // valid while `mesh`
 };
@@ -391,6 +392,7 @@ __device__ __forceinline__ void trav_set_level(const DParams &P, Trav &T, uint32
     const DAccel *A = P.accels + accel;
     T.accel = accel;
     T.ray = local;
+    if (!FAST) T.dd = dot(local.d, local.d);
     T.node_base = LDSS ? A->lnode_base : FAST ? A->fnode_base : A->node_base;
     T.prim_base = LDSS ? A->lprim_base : FAST ? A->fprim_base : A->prim_base;
     T.soup_delta = LDSS ? A->prim_base - A->lprim_base : 0u;
@@ -607,7 +609,9 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
                     if (STATS) cnt.spheres++;
                     bool inside;
                     DSphere sp = load_sphere<LDSS>(P, scn, idx);
-                    t = sphere_t(T.ray, V3{sp.cx, sp.cy, sp.cz}, sp.r, inside);
+                    // d.d once per accel level in the reference traversal (39 sphere tests per ray in config 3: +0.7 %);
+                    // the fast traversal tests few spheres and is better off with the two registers (measured)
+                    t = FAST ? sphere_t(T.ray, V3{sp.cx, sp.cy, sp.cz}, sp.r, inside) : sphere_t_a(T.ray, T.dd, V3{sp.cx, sp.cy, sp.cz}, sp.r, inside);
                     accepted = !(t < 0.0) && !(t >= best.t);
                 } else if (kind == PK_CUBOID) {
                     if (STATS) cnt.cuboids++;
