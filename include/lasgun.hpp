@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <vector>
 #include <utility>
 
 #include "lasgun_hip.h"
@@ -162,6 +163,11 @@ class Accel { // `Accel::from(&scene)`: borrows the scene, which must outlive it
     lg_accel *h_;
 };
 
+// GPU-side counterpart of `scene.threads`: the devices capture() / render() split a host film over
+// (empty = every visible device); see lg_set_devices.
+inline void set_devices(const std::vector<int> &ids = {}) {
+    if (lg_set_devices(ids.data(), (int)ids.size())) throw Error(lg_last_error());
+}
 inline void capture(const Scene &scene, Film &film) { // lib.rs:55
     if (lg_capture(scene.handle(), film.handle())) throw Error(lg_last_error());
 }

@@ -60,7 +60,7 @@ void lg_scene_set_radial_background(lg_scene *, const double inner[3], const dou
 void lg_scene_set_ambient_light(lg_scene *, const double color[3]);                           /* scene.rs:87 */
 void lg_scene_set_mesh_smoothing(lg_scene *, int enabled);                                    /* scene.rs:91 */
 void lg_scene_set_max_recursion_depth(lg_scene *, uint32_t max_depth);                        /* scene.rs:95 */
-void lg_scene_set_threads(lg_scene *, size_t threads);                                        /* scene.rs:99 (ignored by the GPU path) */
+void lg_scene_set_threads(lg_scene *, size_t threads);                                        /* scene.rs:99: caps the devices of lg_set_devices */
 void lg_scene_add_point_light(lg_scene *, const double position[3], const double intensity[3], const double falloff[3]); /* :103 */
 int lg_scene_parse_obj(lg_scene *, const char *text, size_t len, uint32_t *out_ref);          /* scene.rs:120 -> Result */
 int lg_scene_load_obj(lg_scene *, const char *path, uint32_t *out_ref);                       /* scene.rs:127 -> Result */
@@ -105,8 +105,16 @@ typedef struct lg_stats { /* deterministic work counters of one render (stats ke
         accel_entries, hits;
 } lg_stats;
 
-int lg_set_device(int device);      /* HIP device used by this process (default 0) */
+int lg_set_device(int device);      /* HIP device new accels are created on (default 0) */
 int lg_device_count(void);
+/* Devices a host-film lg_capture / lg_render is split over, one host thread per device -- the counterpart
+ * of the reference's split over `scene.threads` CPU threads (lib.rs:58-104): count == 0 selects every visible
+ * device; a non-zero `scene.threads` caps how many of them are used.  Each device renders the 64-row blocks
+ * {r, r+n, ...} of the film (contiguous row tiles when the height is not a multiple of 64*n) from its own copy
+ * of the scene and copies them straight into the host film; there is no inter-device traffic.  Until this is
+ * called, lg_capture uses the one device of lg_set_device.  An index may repeat (its shares then run
+ * concurrently on that device).  lg_accel handles stay bound to the device they were created on. */
+int lg_set_devices(const int *device_ids, int count);
 
 /* Render image rows [y0, y1) of a width x height film straight into DEVICE memory, no host copy:
  * dev_rgba[0] is pixel (0, row0) of the image.  `hip_stream` is the hipStream_t to enqueue on,

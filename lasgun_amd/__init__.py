@@ -25,6 +25,7 @@ if not _os.path.exists(LIB_PATH):
 _EXTRA = {
     "set_device": (_C.c_int, [_C.c_int]),
     "device_count": (_C.c_int, []),
+    "set_devices": (_C.c_int, [_C.POINTER(_C.c_int), _C.c_int]),
     "capture_rows_device": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32,
                                        _C.c_void_p, _C.c_void_p]),
     "capture_subset_device": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p,
@@ -74,6 +75,13 @@ class HipApi(Api):
 
     def set_device(self, device):
         if self.call("set_device", int(device)):
+            raise LasgunError(self.last_error())
+
+    def set_devices(self, ids=None):
+        """Devices a host-film `capture` / `render` is split over (None or [] = every visible device)."""
+        ids = list(ids or [])
+        arr = (_C.c_int * max(len(ids), 1))(*ids)
+        if self.call("set_devices", arr, len(ids)):
             raise LasgunError(self.last_error())
 
     def device_count(self):

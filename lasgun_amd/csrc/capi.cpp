@@ -7,6 +7,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lasgun_hip.h"
@@ -32,6 +33,7 @@ using namespace lg;
 
 static thread_local std::string tl_error;
 static int g_device = 0;
+static std::vector<int> g_devices; // lg_set_devices: the devices a host-film lg_capture is split over (empty = g_device)
 
 static int fail(const std::string &msg) {
     tl_error = msg;
@@ -43,15 +45,16 @@ static int fail(const std::string &msg) {
         if (_e != hipSuccess) throw Error(std::string(#expr) + ": " + hipGetErrorString(_e));                           \
     } while (0)
 
-static void use_device() {
+static void use_device(int dev) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
         throw Error("no HIP device available: liblasgun_hip has no CPU fallback (hipGetDeviceCount: " +
                     std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")");
-    if (g_device >= n) throw Error("device index out of range");
-    HIP_TRY(hipSetDevice(g_device));
+    if (dev < 0 || dev >= n) throw Error("device index out of range");
+    HIP_TRY(hipSetDevice(dev));
 }
+static void use_device() { use_device(g_device); }
 
 template <class T> struct DevBuf {
     T *p = nullptr;
@@ -89,6 +92,7 @@ struct lg_film {
 
 struct lg_accel {
     const Scene *scene = nullptr;
+    int device = 0; // the HIP device this accel's tables and launches live on
     FlatScene flat;
     DevBuf<DNode> nodes;
     DevBuf<DNode2> nodes2;
@@ -428,19 +432,34 @@ int lg_set_device(int device) {
     g_device = device;
     return guarded([] { use_device(); });
 }
+int lg_set_devices(const int *ids, int count) {
+    return guarded([&] {
+        if (count < 0 || (count > 0 && !ids)) throw Error("bad device list");
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error("no HIP device available: liblasgun_hip has no CPU fallback");
+        std::vector<int> v;
+        if (count == 0) for (int i = 0; i < n; ++i) v.push_back(i); // 0 ids = every visible device
+        for (int i = 0; i < count; ++i) {
+            if (ids[i] < 0 || ids[i] >= n) throw Error("device index out of range");
+            v.push_back(ids[i]); // an index may repeat: its shares then run concurrently on that device
+        }
+        g_devices = v;
+    });
+}
 int lg_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
 
-lg_accel *lg_accel_from(const lg_scene *s) {
+static lg_accel *accel_from_on(const lg_scene *s, int device) {
     lg_accel *a = nullptr;
     int rc = guarded([&] {
         a = new lg_accel();
         a->scene = &s->s;
+        a->device = device;
         flatten_scene(s->s, a->flat); // host HLBVH build + flatten (throws on what the reference would panic on)
-        use_device();
+        use_device(device);
         const FlatScene &f = a->flat;
         a->nodes.upload(f.nodes); a->nodes2.upload(f.nodes2); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
@@ -469,7 +488,7 @@ lg_accel *lg_accel_from(const lg_scene *s) {
         HIP_TRY(trace_occupancy(a->stack_depth_fast, true, &per_cu_fast));
         if (per_cu_fast < 1) per_cu_fast = 1;
         a->max_blocks_fast = (uint32_t)per_cu_fast;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g_device));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         if (per_cu < 1) per_cu = 1;
         a->max_blocks = (uint32_t)(per_cu * cus);
         a->max_blocks_fast *= (uint32_t)cus;
@@ -543,6 +562,7 @@ lg_accel *lg_accel_from(const lg_scene *s) {
     if (rc) { delete a; return nullptr; }
     return a;
 }
+lg_accel *lg_accel_from(const lg_scene *s) { return accel_from_on(s, g_device); }
 void lg_accel_free(lg_accel *a) {
     if (!a) return;
     if (a->stream) (void)hipStreamSynchronize(a->stream);
@@ -557,7 +577,7 @@ int lg_capture_rows_device(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y
     return guarded([&] {
         if (y1 > h || y0 > y1 || row0 > y0) throw Error("bad row range");
         std::lock_guard<std::mutex> g(a->mtx);
-        use_device();
+        use_device(a->device);
         DParams P = base_params(*a, w, h);
         set_rect(P, 0, y0, w, y1);
         P.out_row0 = row0;
@@ -569,7 +589,7 @@ int lg_capture_interleaved_device(const lg_accel *a, uint32_t w, uint32_t h, uin
     return guarded([&] {
         if (n == 0 || r >= n || block_rows == 0 || h % (block_rows * n) != 0) throw Error("height must be a multiple of block_rows * n");
         std::lock_guard<std::mutex> g(a->mtx);
-        use_device();
+        use_device(a->device);
         DParams P = base_params(*a, w, h);
         set_rect(P, 0, 0, w, h / n); // virtual rows of the compact tile
         P.ilv_n = n; P.ilv_r = r; P.ilv_b = block_rows;
@@ -582,7 +602,7 @@ int lg_capture_subset_device(size_t k, size_t n, const lg_accel *a, uint32_t w, 
     return guarded([&] {
         if (n == 0) throw Error("n must be > 0");
         std::lock_guard<std::mutex> g(a->mtx);
-        use_device();
+        use_device(a->device);
         DParams P = base_params(*a, w, h);
         if (n == 1 && k == 0) set_rect(P, 0, 0, w, h);
         else set_subset(P, k, n, w, h);
@@ -598,7 +618,7 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) { //
         size_t bytes = (size_t)film->w * film->h * 4;
         {
             std::lock_guard<std::mutex> g(a->mtx);
-            use_device();
+            use_device(a->device);
             if (a->staging.n < bytes) { HIP_TRY(hipStreamSynchronize(a->stream)); a->staging.alloc(bytes); }
             // pixels outside the subset must keep their current value (lib.rs:152)
             if (!(n == 1 && k == 0)) HIP_TRY(hipMemcpyAsync(a->staging.p, film->px, bytes, hipMemcpyHostToDevice, a->stream));
@@ -609,12 +629,66 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) { //
         HIP_TRY(hipStreamSynchronize(a->stream));
     });
 }
-int lg_capture(const lg_scene *s, lg_film *film) { // lib.rs:55-104: the BVH is (re)built inside every capture
-    lg_accel *a = lg_accel_from(s);
+// One device's share of a multi-device capture: rows of `film` rendered on `device` and copied home.
+// With `block_rows` > 0 the share is the 64-row blocks {r, r+n, ...} (even load, one D2H copy per block);
+// otherwise the contiguous row tile r of n.
+static int capture_share(const lg_scene *s, lg_film *film, int device, uint32_t n, uint32_t r, uint32_t block_rows) {
+    lg_accel *a = accel_from_on(s, device);
     if (!a) return 1;
-    int rc = lg_capture_subset(0, 1, a, film);
+    const uint32_t w = film->w, h = film->h;
+    int rc = guarded([&] {
+        use_device(device);
+        const size_t row_bytes = (size_t)w * 4;
+        if (block_rows) {
+            const uint32_t rows = h / n;
+            a->staging.alloc((size_t)rows * row_bytes);
+            if (lg_capture_interleaved_device(a, w, h, block_rows, n, r, a->staging.p, (void *)a->stream)) throw Error(tl_error);
+            for (uint32_t g = 0; g < rows / block_rows; ++g) { // block g of the compact tile is image block g*n + r
+                const size_t src = (size_t)g * block_rows * row_bytes, dst = ((size_t)g * n + r) * block_rows * row_bytes;
+                HIP_TRY(hipMemcpyAsync(film->px + dst, a->staging.p + src, (size_t)block_rows * row_bytes, hipMemcpyDeviceToHost, a->stream));
+            }
+        } else {
+            const uint32_t base = h / n, rem = h % n;
+            const uint32_t y0 = r * base + (r < rem ? r : rem), y1 = y0 + base + (r < rem ? 1u : 0u);
+            if (y1 > y0) {
+                a->staging.alloc((size_t)(y1 - y0) * row_bytes);
+                if (lg_capture_rows_device(a, w, h, y0, y1, y0, a->staging.p, (void *)a->stream)) throw Error(tl_error);
+                HIP_TRY(hipMemcpyAsync(film->px + (size_t)y0 * row_bytes, a->staging.p, (size_t)(y1 - y0) * row_bytes, hipMemcpyDeviceToHost, a->stream));
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(a->stream));
+    });
     lg_accel_free(a);
     return rc;
+}
+
+int lg_capture(const lg_scene *s, lg_film *film) { // lib.rs:55-104: the BVH is (re)built inside every capture
+    // The reference splits the film over `scene.threads` CPU threads (0 = all cores, lib.rs:58-62); here the
+    // film is split over the devices chosen with lg_set_devices (default: the one current device), capped by
+    // `scene.threads` when that is non-zero.  Pixels are independent, so the film is the same for any split.
+    std::vector<int> devs = g_devices;
+    if (s->s.threads != 0 && devs.size() > s->s.threads) devs.resize(s->s.threads);
+    if (devs.size() <= 1) {
+        lg_accel *a = accel_from_on(s, devs.empty() ? g_device : devs[0]);
+        if (!a) return 1;
+        int rc = lg_capture_subset(0, 1, a, film);
+        lg_accel_free(a);
+        return rc;
+    }
+    const uint32_t n = (uint32_t)devs.size();
+    const uint32_t block_rows = film->h % (64u * n) == 0 ? 64u : 0u;
+    std::vector<int> rcs(n, 0);
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> workers;
+    for (uint32_t r = 0; r < n; ++r)
+        workers.emplace_back([&, r] { // one host thread per device, like the reference's one thread per core
+            rcs[r] = capture_share(s, film, devs[r], n, r, block_rows);
+            if (rcs[r]) errs[r] = tl_error;
+        });
+    for (auto &t : workers) t.join();
+    for (uint32_t r = 0; r < n; ++r)
+        if (rcs[r]) return fail("device " + std::to_string(devs[r]) + ": " + errs[r]);
+    return 0;
 }
 lg_film *lg_render(const lg_scene *s, uint32_t w, uint32_t h) { // lib.rs:46-50
     lg_film *f = lg_film_new(w, h);
@@ -626,7 +700,7 @@ int lg_capture_radiance(size_t k, size_t n, const lg_accel *a, uint32_t w, uint3
     return guarded([&] {
         if (n == 0) throw Error("n must be > 0");
         std::lock_guard<std::mutex> g(a->mtx);
-        use_device();
+        use_device(a->device);
         size_t count = (size_t)w * h * 3;
         if (a->staging_rad.n < count) { HIP_TRY(hipStreamSynchronize(a->stream)); a->staging_rad.alloc(count); }
         HIP_TRY(hipMemcpyAsync(a->staging_rad.p, rgb, count * 8, hipMemcpyHostToDevice, a->stream));
@@ -652,7 +726,7 @@ static int capture_stats_impl(const lg_accel *a, uint32_t w, uint32_t h, uint32_
     return guarded([&] {
         if (y1 > h || y0 > y1) throw Error("bad row range");
         std::lock_guard<std::mutex> g(a->mtx);
-        use_device();
+        use_device(a->device);
         DParams P = base_params(*a, w, h);
         set_rect(P, 0, y0, w, y1);
         P.out_row0 = y0;

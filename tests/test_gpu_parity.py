@@ -428,6 +428,28 @@ def test_headline_4096_full_frame_vs_oracle():
         assert diff == 0, (streaming, lds, fast, diff)
 
 
+@pytest.mark.parametrize("devices, w, h, threads", [([0, 0], 160, 256, 0), ([0, 0, 0], 131, 200, 0), ([0, 0, 0, 0], 96, 512, 2), ([], 64, 128, 0)])
+def test_host_film_capture_split_over_devices(devices, w, h, threads):
+    """lg_capture split over the devices of lg_set_devices (one host thread each; an index may repeat, which is
+    how a 1-GPU box exercises the split): same film as the single-device capture, for interleaved 64-row blocks
+    (height % (64 n) == 0), contiguous row tiles otherwise, and with `scene.threads` capping the device count."""
+    def build():
+        sc = S.kitchen_sink_scene(G)
+        sc.set_threads(threads)
+        return sc
+    try:
+        G.set_devices([0])
+        one = G.Film(w, h)
+        G.capture(build(), one)
+        G.set_devices(devices)
+        many = G.Film.new_with_output(w, h, np.full((h, w, 4), 9, np.uint8))
+        G.capture(build(), many)
+        assert np.array_equal(one.pixels(), many.pixels())
+        assert np.array_equal(G.render(build(), (w, h)).pixels(), one.pixels())
+    finally:
+        G.set_devices([0])
+
+
 def test_library_first_then_torch_share_one_hip_runtime():
     """Importing lasgun_amd (and rendering) BEFORE torch must leave torch able to use the GPU: the package
     preloads the HIP runtime bundled with the torch wheel so the process never holds two runtimes."""
