@@ -127,6 +127,8 @@ def main():
     t0 = time.perf_counter()
     acc = G.Accel(scene)  # host HLBVH build + flatten + upload (outside the timed region, reported below)
     accel_build_s = time.perf_counter() - t0
+    if os.environ.get("LASGUN_PACKET"):  # A/B: one tree walk per wavefront
+        G.set_packet(acc, os.environ["LASGUN_PACKET"] == "1")
     # LASGUN_NO_LDS_SCENE=1 (A/B): the traversal kernels read the scene tables through L1/L2 instead of LDS
     lds_scene = G.set_lds_scene(acc, not os.environ.get("LASGUN_NO_LDS_SCENE")) and not os.environ.get("LASGUN_NO_LDS_SCENE")
     stream = torch.cuda.current_stream().cuda_stream

@@ -161,6 +161,14 @@ int lg_accel_set_streaming(const lg_accel *, int enabled);
  * 1 when the accel's scene qualifies, 0 when it does not (the setting is then without effect). */
 int lg_accel_set_lds_scene(const lg_accel *, int enabled);
 
+/* Packet traversal (streaming pipeline, reference traversal): the 64 rays of a wavefront (an 8x8 pixel
+ * tile, or its hit points towards one light) walk the reference tree ONCE together -- uniform node /
+ * primitive fetches, one per-wave stack of (node, lane mask), near child by a vote of the lanes that hit
+ * the node -- instead of 64 private walks.  Every lane sees exactly the reference's candidate set and
+ * arithmetic; lanes that meet an exact tie in t (where the reference's visiting order decides) are
+ * re-traced privately.  Same bytes out. */
+int lg_accel_set_packet(const lg_accel *, int enabled);
+
 /* Kernel timing with HIP events on the launch stream: enable, render, then read. */
 void lg_profile_enable(const lg_accel *, int enabled);
 int lg_profile_read(const lg_accel *, double *total_ms, uint64_t *launches); /* synchronises; resets the tally */

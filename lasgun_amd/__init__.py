@@ -36,6 +36,7 @@ _EXTRA = {
     "accel_set_mode": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_streaming": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_lds_scene": (_C.c_int, [_C.c_void_p, _C.c_int]),
+    "accel_set_packet": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
     "capture_radiance": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
     "capture_stats": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.POINTER(CStats)]),
@@ -67,6 +68,10 @@ class HipApi(Api):
     def set_streaming(self, accel, enabled):
         """True (default) = four-kernel streaming pipeline where the scene allows it; False = megakernel only."""
         self.call("accel_set_streaming", accel.h, int(enabled) if enabled in (0, 1, 2) else (1 if enabled else 0))
+
+    def set_packet(self, accel, enabled):
+        """One tree walk per wavefront (packet traversal) in the streaming traversal kernels."""
+        self.call("accel_set_packet", accel.h, 1 if enabled else 0)
 
     def set_lds_scene(self, accel, enabled):
         """Scene tables resident in LDS for the streaming traversal kernels (default on); returns

@@ -17,7 +17,9 @@ namespace lg {
 // kernels.hip
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
 hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
-hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
+hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, bool fixup, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
+hipError_t launch_stream_packet(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream);
+hipError_t stream_packet_occupancy(uint32_t stack_depth, int *blocks_per_cu);
 hipError_t launch_stream_frame(const DParams &P, hipStream_t stream);
 hipError_t launch_stream_shade(const DParams &P, hipStream_t stream);
 hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
@@ -113,7 +115,7 @@ struct lg_accel {
     mutable DevBuf<double> stash;
     // streaming pipeline state (sized by work items of the largest launch so far)
     mutable DevBuf<double> st_hit_t, st_frame, st_accum;
-    mutable DevBuf<uint32_t> st_hit_ref, st_hit_accel, st_vis;
+    mutable DevBuf<uint32_t> st_hit_ref, st_hit_accel, st_vis, st_tie_flag, st_tie_tiles;
     mutable bool streaming = true; // use the streaming pipeline when the scene allows it
     mutable bool streaming_forced = false; // lg_accel_set_streaming(2): ignore the two criteria below (tests)
     // the pipeline pays for its per-pixel state traffic only where node / sphere / box traversal dominates a
@@ -125,7 +127,12 @@ struct lg_accel {
     DevBuf<uint32_t> lds_image;
     uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_node_stride = 0, lds_prim_off = 0, lds_sph_off = 0, lds_sph_stride = 0, lds_cub_off = 0;
     uint32_t ldss_blocks = 0;         // one 1024-lane workgroup per CU; 0 = variant unavailable for this scene
+    uint32_t packet_blocks = 1;       // grid of the 256-lane packet kernels
+    uint32_t cus = 1;                 // compute units of the accel's device
+    DevBuf<uint32_t> pk_image;        // the packet organisation's LDS image (nodes, primrefs, leaf records), when it fits
+    uint32_t pk_image_n16 = 0, pk_prim_off = 0, pk_soup_off = 0;
     mutable bool lds_scene = true;    // lg_accel_set_lds_scene
+    mutable bool packet = false;      // lg_accel_set_packet: one tree walk per wavefront in the streaming traversal kernels
     mutable DevBuf<DStats> stats;
     mutable DevBuf<uint8_t> staging;    // device film for host-film captures
     mutable DevBuf<double> staging_rad;
@@ -213,15 +220,38 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
             HIP_TRY(launch());
             if (a.profiling) { HIP_TRY(hipEventRecord(k1, stream)); a.kind_events[kind].emplace_back(k0, k1); }
         };
+#ifdef LG_PKT_STATS
+        P.stats = a.stats.p;
+#endif
+        const bool packet = a.packet && !a.fast; // one tree walk per wavefront, then a fix-up pass over the lanes that met a tie
+        uint32_t pblocks = blocks, fblocks = 1;
+        if (packet) {
+            if (a.st_tie_flag.n < n || a.st_tie_tiles.n < P.ntiles) { HIP_TRY(hipDeviceSynchronize()); a.st_tie_flag.alloc(n); a.st_tie_tiles.alloc(P.ntiles); }
+            P.tie_flag = a.st_tie_flag.p; P.tie_tiles = a.st_tie_tiles.p;
+            if (a.lds_scene && a.pk_image_n16) { // the packet image fits in LDS: one 1024-lane workgroup per CU
+                P.pk_image = a.pk_image.p; P.pk_image_n16 = a.pk_image_n16; P.pk_prim_off = a.pk_prim_off; P.pk_soup_off = a.pk_soup_off;
+                pblocks = a.cus;
+            } else {
+                pblocks = (P.ntiles + 3u) / 4u;
+                if (pblocks > a.packet_blocks) pblocks = a.packet_blocks;
+            }
+            fblocks = (P.ntiles + 3u) / 4u; if (fblocks > 256u) fblocks = 256u;
+        }
+        auto trace = [&](bool shadow) {
+            if (!packet) {
+                HIP_TRY(hipMemsetAsync(a.tile_counter.p, 0, sizeof(uint32_t), stream));
+                return launch_stream_trace(P, a.fast, shadow, false, blocks, depth, stream);
+            }
+            HIP_TRY(hipMemsetAsync(a.tile_counter.p, 0, 3 * sizeof(uint32_t), stream));
+            hipError_t e = launch_stream_packet(P, shadow, pblocks, stream);
+            if (e != hipSuccess) return e;
+            return launch_stream_trace(P, false, shadow, true, fblocks, depth, stream);
+        };
         for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
             P.sample_index = sidx;
-            HIP_TRY(hipMemsetAsync(a.tile_counter.p, 0, sizeof(uint32_t), stream));
-            timed(0, [&] { return launch_stream_trace(P, a.fast, false, blocks, depth, stream); });
+            timed(0, [&] { return trace(false); });
             timed(1, [&] { return launch_stream_frame(P, stream); });
-            if (P.nlights > 0) {
-                HIP_TRY(hipMemsetAsync(a.tile_counter.p, 0, sizeof(uint32_t), stream));
-                timed(2, [&] { return launch_stream_trace(P, a.fast, true, blocks, depth, stream); });
-            }
+            if (P.nlights > 0) timed(2, [&] { return trace(true); });
             timed(3, [&] { return launch_stream_shade(P, stream); });
         }
         if (a.profiling) {
@@ -465,7 +495,7 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
         a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
         a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
-        a->tile_counter.alloc(1);
+        a->tile_counter.alloc(4);
         a->stats.alloc(1);
         a->device_bytes = f.nodes.size() * (sizeof(DNode) + sizeof(DNode2)) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
                           f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 + f.leaf_soup.size() * sizeof(DLeafRec) +
@@ -497,6 +527,10 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
         HIP_TRY(stream_trace_occupancy(a->stack_depth_fast, true, &spf));
         a->stream_blocks = (uint32_t)((sp < 1 ? 1 : sp) * cus);
         a->stream_blocks_fast = (uint32_t)((spf < 1 ? 1 : spf) * cus);
+        int pk = 0;
+        HIP_TRY(stream_packet_occupancy(a->stack_depth, &pk));
+        a->packet_blocks = (uint32_t)((pk < 1 ? 1 : pk) * cus);
+        a->cus = (uint32_t)cus;
         // LDS-resident scene: the REFERENCE tree's nodes (56 of 64 bytes, padded to 80 when that fits),
         // its primrefs, the spheres (padded to 48 when that fits) and cuboids, behind 1024 per-lane
         // stacks, all within one CU's LDS.  The flat tables interleave reference and fast trees per
@@ -521,7 +555,7 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
                 if (fp == pruns.end()) { pruns.emplace_back(A.prim_base, np); A.lprim_base = np; np += extent(pb, A.prim_base, fm.primref.size()); }
                 else A.lprim_base = fp->second;
             }
-            const size_t stack_bytes = (size_t)a->stack_depth * 1024 * 4;
+            const size_t stack_bytes = (size_t)a->stack_depth * 1024 * 4; // per-lane stacks (the packet form needs 64x less)
             const size_t ns = fm.spheres.size(), nc = fm.cuboids.size();
             const size_t prim16 = ((size_t)np + 3) / 4;
             for (int attempt = 0; attempt < 3 && !a->ldss_blocks; ++attempt) {
@@ -543,8 +577,28 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
                 for (size_t i = 0; i < nc; ++i) std::memcpy(&img[((size_t)a->lds_cub_off + i * 3) * 4], &fm.cuboids[i], 48);
                 a->lds_image.upload(img);
                 a->lds_image_n16 = (uint32_t)n16;
-                HIP_TRY(stream_trace_ldss_prepare(stack_bytes + n16 * 16));
+                HIP_TRY(stream_trace_ldss_prepare(LDS_MAX));
                 a->ldss_blocks = (uint32_t)cus;
+            }
+            {   // packet image: [nodes, 4 units each][primrefs][leaf records, 3 units per slot], behind 16 per-wave stacks
+                const size_t wave_stacks = (size_t)a->stack_depth * 16 * 16;
+                const size_t n16 = (size_t)nn * 4 + prim16 + (size_t)np * 3;
+                if (wave_stacks + n16 * 16 <= LDS_MAX) {
+                    std::vector<uint32_t> img(n16 * 4, 0u);
+                    for (auto &r : nruns)
+                        for (uint32_t i = 0, e = extent(nb, r.first, fm.nodes.size()); i < e; ++i)
+                            std::memcpy(&img[(size_t)(r.second + i) * 16], &fm.nodes[r.first + i], 56);
+                    a->pk_prim_off = nn * 4u;
+                    a->pk_soup_off = a->pk_prim_off + (uint32_t)prim16;
+                    for (auto &r : pruns)
+                        for (uint32_t i = 0, e = extent(pb, r.first, fm.primref.size()); i < e; ++i) {
+                            img[(size_t)a->pk_prim_off * 4 + r.second + i] = fm.primref[r.first + i];
+                            std::memcpy(&img[((size_t)a->pk_soup_off + (size_t)(r.second + i) * 3) * 4], &fm.leaf_soup[r.first + i], 48);
+                        }
+                    a->pk_image.upload(img);
+                    a->pk_image_n16 = (uint32_t)n16;
+                    HIP_TRY(stream_trace_ldss_prepare(LDS_MAX));
+                }
             }
             a->accels.upload(fm.accels); // again, now with the compact bases
         }
@@ -745,6 +799,11 @@ int lg_accel_set_lds_scene(const lg_accel *a, int enabled) {
     a->lds_scene = enabled != 0;
     return a->ldss_blocks ? 1 : 0; // 1: the scene's tables fit in LDS (the variant exists for this accel)
 }
+int lg_accel_set_packet(const lg_accel *a, int enabled) {
+    std::lock_guard<std::mutex> lk(a->mtx);
+    a->packet = enabled != 0;
+    return 0;
+}
 int lg_accel_set_streaming(const lg_accel *a, int enabled) {
     std::lock_guard<std::mutex> g(a->mtx);
     a->streaming = enabled != 0;
@@ -865,3 +924,14 @@ int lg_math_eval(int op, size_t n, const double *a, const double *b, double *out
 }
 
 } // extern "C"
+
+#ifdef LG_PKT_STATS
+extern "C" int lg_debug_stats(const lg_accel *a, int clear, unsigned long long *out9) { // analysis builds only
+    return guarded([&] {
+        use_device(a->device);
+        HIP_TRY(hipDeviceSynchronize());
+        if (clear) HIP_TRY(hipMemset(a->stats.p, 0, sizeof(DStats)));
+        else HIP_TRY(hipMemcpy(out9, a->stats.p, sizeof(DStats), hipMemcpyDeviceToHost));
+    });
+}
+#endif

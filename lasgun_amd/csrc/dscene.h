@@ -150,7 +150,7 @@ struct DParams {
     uint32_t out_row0; // row of the image stored at out_rgba[0] (0 for a full film, y0 for a row tile)
     uint8_t *out_rgba;
     double *out_radiance; // optional f64 RGB, same addressing as out_rgba (3 doubles per pixel)
-    uint32_t *tile_counter;
+    uint32_t *tile_counter;   // [0] next tile, [1] number of tiles listed in tie_tiles, [2] next listed tile (fix-up pass)
     double *frames;        // [recursion][FRAME_DOUBLES][nthreads]
     unsigned long long frame_threads;
     double *stash;         // [STASH_DOUBLES][nthreads]: shading frame parked across the shadow traversals
@@ -165,6 +165,9 @@ struct DParams {
     uint32_t *vis;              // [n_items] bit l set <=> light l is visible from the hit
     double *accum;              // [3][n_items] running sum over the pixel's samples (integrate.rs:17-18)
     uint32_t sample_index;      // which supersample this pass renders
+    // packet organisation: lanes whose packet walk met an exact tie in t (or a NaN t) are re-traced privately
+    uint32_t *tie_flag;         // [n_items] bit l: light l (shadow pass) / bit 0 (primary pass)
+    uint32_t *tie_tiles;        // [ntiles] tiles with at least one flagged lane
     // ---- LDS-resident scene (scenes whose node / primref / sphere / cuboid tables fit beside the
     // stacks in the CU's 160 KB): `lds_image` holds those tables in their LDS layout; offsets and
     // strides are in 16-byte units from the start of the image
@@ -174,6 +177,10 @@ struct DParams {
     uint32_t lds_prim_off;                  // primref[] as dwords from here
     uint32_t lds_sph_off, lds_sph_stride;   // DSphere: 2 or 3 units per sphere
     uint32_t lds_cub_off;                   // DCuboid: 3 units per cuboid
+    // the packet organisation's image (uniform reads: nothing to pad): nodes at 4 units from 0, primref[] as dwords
+    // from pk_prim_off, one 3-unit leaf record per primref slot from pk_soup_off
+    const void *pk_image;
+    uint32_t pk_image_n16, pk_prim_off, pk_soup_off;
     uint32_t stats_filter;      // counting variant: 0 = all traversals, 1 = closest-hit (primary/secondary) only, 2 = shadow only
 };
 

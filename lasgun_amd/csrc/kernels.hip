@@ -10,8 +10,10 @@
 // Kernels:
 //   trace_kernel<STATS, FAST>                 the whole of li() per lane (scenes with glass / mirror, small
 //                                             films, the counting variant)
-//   stream_trace_kernel<FAST, SHADOW, LDSS>   traversal only: primary closest-hit or per-light any-hit;
-//                                             LDSS = scene tables resident in LDS, one 1024-lane workgroup per CU
+//   stream_trace_kernel<FAST, SHADOW, LDSS, FIXUP>  traversal only: primary closest-hit or per-light any-hit;
+//                                             LDSS = scene tables resident in LDS, one 1024-lane workgroup per CU;
+//                                             FIXUP = re-trace the lanes the packet pass flagged
+//   stream_packet_kernel<SHADOW, LDSS>        the same two passes with ONE tree walk per wavefront (opt-in)
 //   stream_frame_kernel, stream_shade_kernel  hit -> shading frame; frame + visibility -> radiance -> RGBA8
 //   kat_kernel, kat_si_kernel, math_kernel    probes behind the test hooks of the C ABI
 //
@@ -660,6 +662,250 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
 }
 
 // ------------------------------------------------------------------------------------------
+// Packet traversal (streaming pipeline, reference tree): ONE walk per wavefront.
+//
+// The 64 rays of an 8x8 tile (primary) or of its hit points towards one light (shadow) visit
+// almost the same nodes.  Instead of 64 private walks -- private node fetches, private stacks,
+// private near/far selects -- the wave walks the UNION of its lanes' node sets once: the node and
+// primitive records are fetched with wave-uniform addresses (one request, broadcast), the stack
+// is one small per-wave array of (node, lane mask) in LDS, the near child is chosen by a vote of
+// the lanes that hit the node (ballot + popcount on dir_is_neg[axis], bvh.rs:496), and a lane
+// simply drops out of the mask at a node whose box it misses.
+//
+// Exactness.  A lane takes part in a primitive test iff every box on the path from the root to
+// that leaf passed ITS OWN slab test -- exactly the reference's candidate set for that ray, since
+// the reference never culls by t (cuboid.rs:120) -- and every test is the same arithmetic on the
+// same operands.  The closest hit is the minimum of the accepted t over that set, which does not
+// depend on the visiting order except (a) between candidates with exactly equal t, where the
+// reference keeps the first one it visits, and (b) after a NaN t, which the reference's
+// comparisons accept and which then accepts everything after it.  Both are detected per lane
+// (`tie`) and that lane is re-traced with its private reference-order walk.  An occluded any-hit
+// ray needs no re-trace: "some accepted t < 1 exists" is order-independent (NaN aside, as in
+// the private walk).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ bool lane_in(unsigned long long m, uint32_t lane) { return ((m >> lane) & 1ull) != 0ull; }
+constexpr uint32_t PKT_ENTRY = 4u; // dwords per wave-stack entry: {a, b, mask lo, mask hi}
+
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    return (unsigned long long)uni((uint32_t)v) | ((unsigned long long)uni((uint32_t)(v >> 32)) << 32);
+}
+// Records of the packet walk.  LDSS: the packet image in LDS (DParams::pk_*: nodes at 64-byte stride, primrefs,
+// then one 48-byte leaf record per primref slot, all in the compact numbering of DAccel::lnode_base / lprim_base;
+// every lane reads the SAME address, so there is nothing to pad against bank conflicts).  Otherwise the same
+// tables in HBM / L2, again with wave-uniform addresses: one request per record and wave.
+template <bool LDSS>
+__device__ __forceinline__ NodeRec pkt_node(const DParams &P, const uint4 *scn, uint32_t idx) {
+    if (!LDSS) return load_node<false>(P, nullptr, idx);
+    NodeRec n;
+    const uint4 *q = scn + idx * 4u;
+    uint4 a = q[0], b = q[1], c = q[2];
+    uint2 d = *reinterpret_cast<const uint2 *>(q + 3);
+    n.bmin[0] = u2d(a.x, a.y); n.bmin[1] = u2d(a.z, a.w); n.bmin[2] = u2d(b.x, b.y);
+    n.bmax[0] = u2d(b.z, b.w); n.bmax[1] = u2d(c.x, c.y); n.bmax[2] = u2d(c.z, c.w);
+    n.link = d.x; n.meta = d.y;
+    return n;
+}
+struct SlotRec { // one leaf slot: its primref and its 48-byte geometry record
+    uint32_t ref;
+    LeafRec g;
+};
+template <bool LDSS>
+__device__ __forceinline__ SlotRec pkt_slot(const DParams &P, const uint4 *scn, uint32_t slot) {
+    SlotRec r;
+    if (LDSS) {
+        r.ref = reinterpret_cast<const uint32_t *>(scn + P.pk_prim_off)[slot];
+        const uint4 *q = scn + (P.pk_soup_off + slot * 3u);
+        r.g = LeafRec{q[0], q[1], q[2]};
+    } else {
+        r.ref = P.primref[slot];
+        r.g = load_rec(P, slot);
+    }
+    return r;
+}
+// The wave-uniform state lives in plain locals and every value that comes back from memory goes through
+// readfirstlane, so that the compiler keeps it in SGPRs and branches on it with scalar branches.  (No
+// by-reference lambdas here: state that round-trips through a private-memory capture is treated as divergent.)
+#define PKT_SET_LEVEL(ACC, LOCAL)                                                                                      \
+    do {                                                                                                               \
+        const DAccel *A_ = P.accels + (ACC);                                                                           \
+        accel = (ACC);                                                                                                 \
+        ray = (LOCAL);                                                                                                 \
+        dd = dot(ray.d, ray.d);                                                                                        \
+        node_base = uni(LDSS ? A_->lnode_base : A_->node_base);                                                        \
+        prim_base = uni(LDSS ? A_->lprim_base : A_->prim_base);                                                        \
+        mesh = (uni(A_->flags) & AF_MESH) != 0u;                                                                       \
+        negbits = (ray.dinv.x < 0.0 ? 1u : 0u) | (ray.dinv.y < 0.0 ? 2u : 0u) | (ray.dinv.z < 0.0 ? 4u : 0u);          \
+    } while (0)
+/* every lane stores the same four words to the same address: one LDS write, no exec juggling */
+#define PKT_PUSH(SP, A, B, M)                                                                                          \
+    do {                                                                                                               \
+        *reinterpret_cast<uint4 *>(ws + (SP) * PKT_ENTRY) = uint4{(A), (B), (uint32_t)(M), (uint32_t)((M) >> 32)};     \
+    } while (0)
+#define PKT_MASK(SP) ((unsigned long long)uni(ws[(SP) * PKT_ENTRY + 2u]) | ((unsigned long long)uni(ws[(SP) * PKT_ENTRY + 3u]) << 32))
+// one candidate of this lane: tie / NaN bookkeeping, acceptance, any-hit exit
+#define PKT_CANDIDATE(VALID, T, REF)                                                                                   \
+    do {                                                                                                               \
+        if (VALID) {                                                                                                   \
+            const double t_ = (T);                                                                                     \
+            if ((t_ == best.t && best.ref != NO_HIT) || t_ != t_) tie = true;                                          \
+            if (!(t_ >= best.t)) {                                                                                     \
+                best.t = t_; best.ref = (REF); best.accel = accel;                                                     \
+                if (anyhit && t_ < 1.0) alive = false; /* point.rs:49 */                                               \
+            }                                                                                                          \
+        }                                                                                                              \
+    } while (0)
+
+template <bool LDSS>
+__device__ __forceinline__ void traverse_packet(const DParams &P, const uint4 *scn, const Ray &wray, bool alive, const bool anyhit,
+                                                uint32_t *ws, const uint32_t lane, Best &best, bool &tie) {
+    best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
+    tie = false;
+    unsigned long long alive_m = __ballot(alive);
+    if (alive_m == 0ull) return;
+    // ---- level state: wave-uniform except the rays
+    uint32_t accel = 0u, node_base = 0u, prim_base = 0u;
+    bool mesh = false;
+    Ray ray;
+    double dd = 0.0;
+    uint32_t negbits = 0u;                 // per lane: bit a set <=> dinv[a] < 0 (dir_is_neg, bvh.rs:463)
+    PKT_SET_LEVEL(0u, ray_to_local(P.accels->minv, wray));
+    uint32_t sp = 0u, base = 0u;           // wave stack, in entries
+    uint32_t cur = 0u;                     // node to visit ...
+    unsigned long long m = alive_m;        // ... by these lanes
+    bool have = true;                      // (cur, m) is pending
+    uint32_t li = 0u, le = 0u;             // leaf cursor (slots of this level's numbering) ...
+    unsigned long long lm = 0ull;          // ... and the lanes inside the leaf
+    bool leaf_open = false;
+    for (;;) {
+        // ---- phase A: interior nodes, one record fetch and one slab test per step for the whole wave
+        // (readfirstlane pins: no-ops in hardware terms, they tell the compiler this state is wave-uniform)
+        have = uni((uint32_t)have) != 0u; leaf_open = uni((uint32_t)leaf_open) != 0u;
+        sp = uni(sp); base = uni(base); accel = uni(accel); node_base = uni(node_base); prim_base = uni(prim_base);
+        alive_m = uni64(alive_m);
+        while (have) {
+            cur = uni(cur); m = uni64(m); sp = uni(sp);
+            have = false;
+            m &= alive_m;
+            if (m == 0ull) break;
+            const NodeRec nd = pkt_node<LDSS>(P, scn, node_base + cur);
+            const uint32_t link = uni(nd.link), meta = uni(nd.meta);
+            const bool inside_box = slab_intersects(nd.bmin, nd.bmax, ray); // every lane computes it: no exec juggling
+            const unsigned long long hm = __ballot(inside_box) & m;
+            if (hm == 0ull) break;
+            if (meta & NODE_LEAF) {
+                const uint32_t count = meta & 0xFFFFu;
+                if (count != 0u) { li = prim_base + link; le = li + count; lm = hm; leaf_open = true; } // nprims as u16 == 0: nothing
+                break;
+            }
+            const unsigned long long ng = __ballot(((negbits >> (meta & 3u)) & 1u) != 0u); // dir_is_neg[axis] of every lane
+            const bool neg_first = 2 * __popcll(hm & ng) > __popcll(hm); // the vote: most lanes' near child first (bvh.rs:496)
+            const uint32_t near_node = neg_first ? link : cur + 1u, far_node = neg_first ? cur + 1u : link;
+            PKT_PUSH(sp, far_node, 0u, hm);
+            ++sp;
+            cur = near_node; m = hm; have = true;
+        }
+        // ---- phase B: the leaf's slots li .. le for the lanes lm, in order[] sequence, one slot ahead
+        if (leaf_open) {
+            leaf_open = false;
+            li = uni(li); le = uni(le); lm = uni64(lm);
+            lm &= alive_m;
+            if (lm != 0ull) {
+                TriSetup tri{2, 0.0, 0.0, 0.0};
+                unsigned long long kz0 = 0ull, kz1 = 0ull, kz2 = 0ull;
+                if (mesh) { // shear constants and dominant axis per fat leaf (as the private walk does)
+                    tri = tri_setup(ray);
+                    kz0 = __ballot(tri.kz == 0); kz1 = __ballot(tri.kz == 1); kz2 = __ballot(tri.kz == 2);
+                }
+                const uint32_t last = le - 1u;
+                SlotRec nxt = pkt_slot<LDSS>(P, scn, li);
+                while (li < le) {
+                    li = uni(li); lm = uni64(lm);
+                    const SlotRec s = nxt;
+                    const uint32_t slot = li;
+                    ++li;
+                    nxt = pkt_slot<LDSS>(P, scn, li < last ? li : last); // prefetch (clamped: always a valid slot)
+                    const uint32_t ref = uni(s.ref);
+                    const uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
+                    const bool in = lane_in(lm, lane);
+                    (void)slot;
+                    if (kind == PK_TRIANGLE) {
+                        const V3 p0{rec_f32(s.g.a.x), rec_f32(s.g.a.y), rec_f32(s.g.a.z)}, p1{rec_f32(s.g.a.w), rec_f32(s.g.b.x), rec_f32(s.g.b.y)},
+                            p2{rec_f32(s.g.b.z), rec_f32(s.g.b.w), rec_f32(s.g.c.x)};
+                        TriHit h;
+                        if (mesh) { // the permutation is a per-ray property: one pass per dominant axis present among the leaf's lanes
+                            if ((lm & kz0) != 0ull) { if (lane_in(lm & kz0, lane)) { const bool ok = triangle_t_pre<0>(p0, p1, p2, ray.o, tri.sx, tri.sy, tri.sz, h); PKT_CANDIDATE(ok, h.t, ref); } }
+                            if ((lm & kz1) != 0ull) { if (lane_in(lm & kz1, lane)) { const bool ok = triangle_t_pre<1>(p0, p1, p2, ray.o, tri.sx, tri.sy, tri.sz, h); PKT_CANDIDATE(ok, h.t, ref); } }
+                            if ((lm & kz2) != 0ull) { if (lane_in(lm & kz2, lane)) { const bool ok = triangle_t_pre<2>(p0, p1, p2, ray.o, tri.sx, tri.sy, tri.sz, h); PKT_CANDIDATE(ok, h.t, ref); } }
+                        } else if (in) { // a triangle outside a mesh accel cannot be built by the scene API; kept for completeness
+                            const bool ok = triangle_t(p0, p1, p2, ray, h);
+                            PKT_CANDIDATE(ok, h.t, ref);
+                        }
+                    } else if (kind == PK_SPHERE) {
+                        const V3 cen{rec_f64(s.g.a.x, s.g.a.y), rec_f64(s.g.a.z, s.g.a.w), rec_f64(s.g.b.x, s.g.b.y)};
+                        const double rad = rec_f64(s.g.b.z, s.g.b.w);
+                        // the discriminant for every lane first; the roots (sqrt, two divides) only if some lane of the leaf needs them
+                        const V3 l = ray.o - cen;
+                        const double b = 2.0 * dot(ray.d, l);
+                        const double c = dot(l, l) - rad * rad;
+                        const double disc = b * b - 4.0 * dd * c;
+                        const bool need = in && (dd == 0.0 || !(disc < 0.0));
+                        if (__ballot(need) != 0ull) {
+                            if (need) {
+                                bool inside;
+                                const double t = sphere_t_a(ray, dd, cen, rad, inside);
+                                PKT_CANDIDATE(!(t < 0.0), t, ref);
+                            }
+                        }
+                    } else if (kind == PK_CUBOID) {
+                        if (in) {
+                            double mn[3] = {rec_f64(s.g.a.x, s.g.a.y), rec_f64(s.g.a.z, s.g.a.w), rec_f64(s.g.b.x, s.g.b.y)};
+                            double mx[3] = {rec_f64(s.g.b.z, s.g.b.w), rec_f64(s.g.c.x, s.g.c.y), rec_f64(s.g.c.z, s.g.c.w)};
+                            V3 d0, d1;
+                            double t = 0.0;
+                            const bool ok = cuboid_hit<false>(mn, mx, ray, t, d0, d1);
+                            PKT_CANDIDATE(ok, t, ref);
+                        }
+                    } else { // PK_ACCEL -- nested BVHAccel: every lane of the leaf enters it (bvh.rs:483-488, 462)
+                        PKT_PUSH(sp, li, le, lm);
+                        PKT_PUSH(sp + 1u, base, 0u, 0ull);
+                        sp += 2u; base = sp;
+                        PKT_SET_LEVEL(idx, ray_to_local(P.accels[idx].minv, ray));
+                        cur = 0u; m = lm; have = true;
+                        break;
+                    }
+                    if (anyhit) {
+                        alive_m = __ballot(alive);
+                        lm &= alive_m;
+                        if (lm == 0ull) break;
+                    }
+                }
+            }
+        }
+        // ---- phase C: next pending (node, mask) of this level, or back to the parent's leaf
+        if (!have) {
+            if (sp != base) {
+                --sp;
+                cur = uni(ws[sp * PKT_ENTRY]); m = PKT_MASK(sp);
+                have = true;
+            } else {
+                if (accel == 0u) break;
+                sp -= 2u;                  // level frame: {li, le, leaf mask} {previous base}
+                li = uni(ws[sp * PKT_ENTRY]); le = uni(ws[sp * PKT_ENTRY + 1u]); lm = PKT_MASK(sp);
+                base = uni(ws[(sp + 1u) * PKT_ENTRY]);
+                const uint32_t parent = uni((uint32_t)P.accels[accel].parent);
+                PKT_SET_LEVEL(parent, local_ray(P, wray, parent)); // recomputed, bit-identical to the first computation
+                leaf_open = li < le;
+            }
+        }
+    }
+}
+#undef PKT_SET_LEVEL
+#undef PKT_PUSH
+#undef PKT_MASK
+#undef PKT_CANDIDATE
+
+// ------------------------------------------------------------------------------------------
 // hit resolution: the winning primitive's RayIntersection carried back to world space
 // (primitive intersect, then bvh.rs:509-519 / transform.rs:243-264 for every accel on the way up)
 // ------------------------------------------------------------------------------------------
@@ -1273,9 +1519,12 @@ __device__ __forceinline__ Ray camera_ray(const DParams &P, uint32_t x, uint32_t
 // LDSS: one 1024-lane workgroup per CU (still 4 waves per SIMD) that first copies the scene's
 // node / primref / sphere / cuboid tables into LDS behind the stacks; its waves then pull tiles
 // independently exactly like the 256-lane form.
+// FIXUP: the second pass of the packet organisation -- only the tiles listed in P.tie_tiles, and in
+// them only the lanes (and lights) flagged in P.tie_flag, are re-traced with the private walk.
 #define LG_LDSS_BLOCK 1024
-template <bool FAST, bool SHADOW, bool LDSS>
+template <bool FAST, bool SHADOW, bool LDSS, bool FIXUP>
 __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_trace_kernel(const DParams P) {
+    static_assert(!(FAST && FIXUP), "ties of the packet walk are resolved by the reference walk");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t *stack = lds_stack + tid;
     constexpr uint32_t stride = LDSS ? LG_LDSS_BLOCK : LG_BLOCK;
@@ -1290,12 +1539,24 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
         uint32_t tile = 0;
-        if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
-        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-        if (tile >= P.ntiles) break; // every wave reaches this exit
+        if (FIXUP) {
+            if (lane == 0) tile = atomicAdd(P.tile_counter + 2, 1u);
+            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+            if (tile >= P.tile_counter[1]) break; // number of listed tiles (written by the packet pass); every wave reaches this exit
+            tile = P.tie_tiles[tile];
+        } else {
+            if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
+            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+            if (tile >= P.ntiles) break; // every wave reaches this exit
+        }
         Pixel px = pixel_of(P, tile, lane);
         if (!px.active) continue;
         const unsigned long long widx = (unsigned long long)tile * 64ull + lane;
+        uint32_t redo = 0xFFFFFFFFu; // FIXUP: bit l = light l (shadow) / bit 0 (primary) must be re-traced
+        if (FIXUP) {
+            redo = P.tie_flag[widx];
+            if (redo == 0u) continue;
+        }
         if (!SHADOW) {
             Ray ray = camera_ray(P, px.x, px.y, P.sample_index);
             Best b;
@@ -1311,8 +1572,9 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             V3 ng{P.frame[3 * n + widx], P.frame[4 * n + widx], P.frame[5 * n + widx]};
             const double err = 2.220446049250313e-16 * 65536.0;
             V3 hit_p = praw + ng * err;
-            uint32_t vis = 0;
+            uint32_t vis = FIXUP ? P.vis[widx] : 0u;
             for (uint32_t l = 0; l < P.nlights; ++l) {
+                if (FIXUP && !((redo >> l) & 1u)) continue;
                 const DLight L = P.lights[l];
                 Ray sray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
                 Best b;
@@ -1320,9 +1582,70 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
                 traverse<false, FAST, LDSS>(P, sray, true, stack, stride, b, cnt, tie, scn);
                 if (FAST && tie && !(b.t < 1.0)) traverse<false, false>(P, sray, true, stack, stride, b, cnt, tie);
                 if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
+                else if (FIXUP) vis &= ~(1u << l);
             }
             P.vis[widx] = vis;
         }
+    }
+}
+
+// K1' / K3': the packet organisation of the same two traversal passes -- one tree walk per wavefront
+// (traverse_packet).  Lanes whose walk met an exact tie (or a NaN t) get their bit set in P.tie_flag and
+// their tile appended to P.tie_tiles; the FIXUP form of stream_trace_kernel re-traces just those.
+// LDS: [per-wave stacks][scene image (LDSS)].
+template <bool SHADOW, bool LDSS>
+__global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_packet_kernel(const DParams P) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    constexpr uint32_t block = LDSS ? LG_LDSS_BLOCK : LG_BLOCK;
+    uint32_t *ws = lds_stack + (tid >> 6) * P.stack_depth * PKT_ENTRY; // this wave's stack
+    const uint4 *scn = nullptr;
+    if (LDSS) {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_stack + (block / 64u) * P.stack_depth * PKT_ENTRY);
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.pk_image);
+        for (uint32_t i = tid; i < P.pk_image_n16; i += block) dst[i] = src[i];
+        __syncthreads();
+        scn = dst;
+    }
+    for (;;) {
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+        if (tile >= P.ntiles) break; // every wave reaches this exit
+        // all 64 lanes stay together; lanes without a pixel (or without a hit) are dead from the start
+        const Pixel px = pixel_of(P, tile, lane);
+        const unsigned long long widx = (unsigned long long)tile * 64ull + lane;
+        uint32_t ties = 0u;
+        if (!SHADOW) {
+            const Ray ray = camera_ray(P, px.x, px.y, P.sample_index);
+            Best b;
+            bool tie = false;
+            traverse_packet<LDSS>(P, scn, ray, px.active, false, ws, lane, b, tie);
+            if (px.active) { P.hit_t[widx] = b.t; P.hit_ref[widx] = b.ref; P.hit_accel[widx] = b.accel; }
+            ties = px.active && tie ? 1u : 0u;
+        } else {
+            const bool has = px.active && P.hit_ref[widx] != NO_HIT;
+            const unsigned long long n = P.n_items;
+            V3 hit_p = vzero();
+            if (has) {
+                V3 praw{P.frame[0 * n + widx], P.frame[1 * n + widx], P.frame[2 * n + widx]};
+                V3 ng{P.frame[3 * n + widx], P.frame[4 * n + widx], P.frame[5 * n + widx]};
+                const double err = 2.220446049250313e-16 * 65536.0;
+                hit_p = praw + ng * err;
+            }
+            uint32_t vis = 0;
+            for (uint32_t l = 0; l < P.nlights; ++l) {
+                const DLight L = P.lights[l];
+                const Ray sray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
+                Best b;
+                bool tie = false;
+                traverse_packet<LDSS>(P, scn, sray, has, true, ws, lane, b, tie);
+                if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
+                if (has && tie && !(b.t < 1.0)) ties |= 1u << l; // an occluded ray's answer is order-independent
+            }
+            if (has) P.vis[widx] = vis;
+        }
+        if (px.active) P.tie_flag[widx] = ties;
+        if (__ballot(ties != 0u) != 0ull && lane == 0u) P.tie_tiles[atomicAdd(P.tile_counter + 1, 1u)] = tile;
     }
 }
 
@@ -1496,27 +1819,44 @@ hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks
     }
     return hipGetLastError();
 }
-hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
-    if (P.lds_image && !fast) { // LDS-resident scene: `blocks` = one workgroup per CU
-        size_t lds = (size_t)P.stack_depth * LG_LDSS_BLOCK * sizeof(uint32_t) + (size_t)P.lds_image_n16 * 16u;
-        if (shadow) hipLaunchKernelGGL((stream_trace_kernel<false, true, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
-        else hipLaunchKernelGGL((stream_trace_kernel<false, false, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
-        return hipGetLastError();
-    }
-    size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
-    if (fast) {
-        if (shadow) hipLaunchKernelGGL((stream_trace_kernel<true, true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-        else hipLaunchKernelGGL((stream_trace_kernel<true, false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-    } else {
-        if (shadow) hipLaunchKernelGGL((stream_trace_kernel<false, true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-        else hipLaunchKernelGGL((stream_trace_kernel<false, false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-    }
+hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, bool fixup, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
+    const bool ldss = P.lds_image && !fast && !fixup; // LDS-resident scene: `blocks` = one workgroup per CU (the rare fix-up pass reads L1/L2)
+    const uint32_t block = ldss ? LG_LDSS_BLOCK : LG_BLOCK;
+    const uint32_t depth = fast ? stack_depth : P.stack_depth;
+    size_t lds = (size_t)depth * block * sizeof(uint32_t) + (ldss ? (size_t)P.lds_image_n16 * 16u : 0u);
+#define LG_LAUNCH(F, S, L, X) hipLaunchKernelGGL((stream_trace_kernel<F, S, L, X>), dim3(blocks), dim3(block), lds, stream, P)
+    if (fast) { if (shadow) LG_LAUNCH(true, true, false, false); else LG_LAUNCH(true, false, false, false); }
+    else if (ldss) { if (shadow) LG_LAUNCH(false, true, true, false); else LG_LAUNCH(false, false, true, false); }
+    else if (fixup) { if (shadow) LG_LAUNCH(false, true, false, true); else LG_LAUNCH(false, false, false, true); }
+    else { if (shadow) LG_LAUNCH(false, true, false, false); else LG_LAUNCH(false, false, false, false); }
+#undef LG_LAUNCH
     return hipGetLastError();
 }
-// LDS-resident scene variant: raise the dynamic-LDS limit of its two kernels to `bytes`
+hipError_t launch_stream_packet(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream) {
+    const bool ldss = P.pk_image != nullptr;
+    const uint32_t block = ldss ? LG_LDSS_BLOCK : LG_BLOCK;
+    size_t lds = (size_t)(block / 64u) * P.stack_depth * PKT_ENTRY * sizeof(uint32_t) + (ldss ? (size_t)P.pk_image_n16 * 16u : 0u);
+    if (ldss) { if (shadow) hipLaunchKernelGGL((stream_packet_kernel<true, true>), dim3(blocks), dim3(block), lds, stream, P);
+                else hipLaunchKernelGGL((stream_packet_kernel<false, true>), dim3(blocks), dim3(block), lds, stream, P); }
+    else { if (shadow) hipLaunchKernelGGL((stream_packet_kernel<true, false>), dim3(blocks), dim3(block), lds, stream, P);
+           else hipLaunchKernelGGL((stream_packet_kernel<false, false>), dim3(blocks), dim3(block), lds, stream, P); }
+    return hipGetLastError();
+}
+hipError_t stream_packet_occupancy(uint32_t stack_depth, int *blocks_per_cu) { // the 256-lane form (scene in L1/L2)
+    size_t lds = (size_t)(LG_BLOCK / 64u) * stack_depth * PKT_ENTRY * sizeof(uint32_t);
+    int a = 0, b = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_packet_kernel<false, false>, LG_BLOCK, lds);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_packet_kernel<true, false>, LG_BLOCK, lds);
+    *blocks_per_cu = a < b ? a : b;
+    return e;
+}
+// raise the dynamic-LDS limit of the LDS-resident-scene variants to `bytes`
 hipError_t stream_trace_ldss_prepare(size_t bytes) {
-    const void *fns[2] = {reinterpret_cast<const void *>(stream_trace_kernel<false, false, true>),
-                          reinterpret_cast<const void *>(stream_trace_kernel<false, true, true>)};
+    const void *fns[4] = {reinterpret_cast<const void *>(stream_trace_kernel<false, false, true, false>),
+                          reinterpret_cast<const void *>(stream_trace_kernel<false, true, true, false>),
+                          reinterpret_cast<const void *>(stream_packet_kernel<false, true>),
+                          reinterpret_cast<const void *>(stream_packet_kernel<true, true>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
@@ -1538,13 +1878,13 @@ hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_p
     int a = 0, b = 0;
     hipError_t e;
     if (fast) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<true, false, false>, LG_BLOCK, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<true, false, false, false>, LG_BLOCK, lds);
         if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<true, true, false>, LG_BLOCK, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<true, true, false, false>, LG_BLOCK, lds);
     } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<false, false, false>, LG_BLOCK, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<false, false, false, false>, LG_BLOCK, lds);
         if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<false, true, false>, LG_BLOCK, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<false, true, false, false>, LG_BLOCK, lds);
     }
     *blocks_per_cu = a < b ? a : b;
     return e;
@@ -1557,8 +1897,8 @@ hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu) 
 hipError_t trace_set_lds_limit(size_t bytes) {
     const void *fns[8] = {reinterpret_cast<const void *>(trace_kernel<false, false>), reinterpret_cast<const void *>(trace_kernel<true, false>),
                           reinterpret_cast<const void *>(trace_kernel<false, true>), reinterpret_cast<const void *>(trace_kernel<true, true>),
-                          reinterpret_cast<const void *>(stream_trace_kernel<false, false, false>), reinterpret_cast<const void *>(stream_trace_kernel<false, true, false>),
-                          reinterpret_cast<const void *>(stream_trace_kernel<true, false, false>), reinterpret_cast<const void *>(stream_trace_kernel<true, true, false>)};
+                          reinterpret_cast<const void *>(stream_trace_kernel<false, false, false, false>), reinterpret_cast<const void *>(stream_trace_kernel<false, true, false, false>),
+                          reinterpret_cast<const void *>(stream_trace_kernel<true, false, false, false>), reinterpret_cast<const void *>(stream_trace_kernel<true, true, false, false>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;

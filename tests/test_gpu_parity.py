@@ -243,6 +243,31 @@ def test_lds_resident_scene_matches_global_tables(name):
     assert np.array_equal(outs[0][0], ofilm.pixels())
 
 
+@pytest.mark.parametrize("name", ["spheres_512", "spheres_seed7_300", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "mesh_plastic_flat_128", "ragged_5x131", "one_pixel"])
+def test_packet_traversal_matches_private_walks(name):
+    """One tree walk per wavefront (lane masks, vote on the near child, tie lanes re-traced) vs 64 private
+    walks: same bytes, same radiance bits, with the scene tables in LDS and in HBM/L2; and vs the oracle."""
+    if name not in MID:
+        pytest.skip("no such scene")
+    builder, w, h = MID[name]
+    acc = G.Accel(builder(G))
+    G.set_streaming(acc, 2)
+    outs = []
+    for packet, lds in ((False, True), (True, True), (True, False)):
+        G.set_packet(acc, packet); G.set_lds_scene(acc, lds)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        sub = G.Film.new_with_output(w, h, np.full((h, w, 4), 7, np.uint8))
+        G.capture_subset(2, 5, acc, sub)
+        outs.append((film.pixels(), bits(G.capture_radiance(acc, w, h)), sub.pixels()))
+    for o_ in outs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], o_))
+    o = oracle()
+    ofilm = o.Film(w, h)
+    o.capture_subset_mt(0, 1, o.Accel(builder(o)), ofilm, 16)
+    assert np.array_equal(outs[1][0], ofilm.pixels())
+
+
 # ---- fuzz parity: seeded random scenes with duplicated / touching primitives (exact ties in t) ----
 @pytest.mark.parametrize("seed", list(range(32)))
 def test_random_scene_parity(seed):
@@ -262,14 +287,14 @@ def test_random_scene_parity(seed):
     finally:
         o.set_trig_mode(0)
     acc = G.Accel(S.random_scene(G, seed))
-    for streaming in (0, 2):
-        for fast in (False, True):
-            G.set_streaming(acc, streaming)
-            G.set_mode(acc, fast)
-            film = G.Film(w, h)
-            G.capture_subset(0, 1, acc, film)
-            assert np.array_equal(film.pixels(), ofilm.pixels()), (seed, streaming, fast)
-            assert np.array_equal(bits(G.capture_radiance(acc, w, h)), bits(orad)), (seed, streaming, fast)
+    for streaming, fast, packet in ((0, False, False), (0, True, False), (2, False, False), (2, True, False), (2, False, True)):
+        G.set_streaming(acc, streaming)
+        G.set_mode(acc, fast)
+        G.set_packet(acc, packet)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        assert np.array_equal(film.pixels(), ofilm.pixels()), (seed, streaming, fast, packet)
+        assert np.array_equal(bits(G.capture_radiance(acc, w, h)), bits(orad)), (seed, streaming, fast, packet)
 
 
 # ---- driver semantics (lib.rs:55-162) -------------------------------------------------------
@@ -419,13 +444,14 @@ def test_headline_4096_full_frame_vs_oracle():
     ref = ofilm.pixels()
     acc = G.Accel(S.spheres_scene(G))
     film = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
-    for streaming, lds, fast in ((1, True, False), (1, False, False), (0, True, False), (1, True, True)):
-        G.set_streaming(acc, streaming); G.set_lds_scene(acc, lds); G.set_mode(acc, fast)
+    for streaming, lds, fast, packet in ((1, True, False, False), (1, False, False, False), (0, True, False, False), (1, True, True, False),
+                                         (1, True, False, True), (1, False, False, True)):
+        G.set_streaming(acc, streaming); G.set_lds_scene(acc, lds); G.set_mode(acc, fast); G.set_packet(acc, packet)
         film.zero_()
         G.capture_rows_device(acc, w, h, 0, h, film.data_ptr(), row0=0)
         G.synchronize(acc)
         diff = int((film.cpu().numpy() != ref).sum())
-        assert diff == 0, (streaming, lds, fast, diff)
+        assert diff == 0, (streaming, lds, fast, packet, diff)
 
 
 @pytest.mark.parametrize("devices, w, h, threads", [([0, 0], 160, 256, 0), ([0, 0, 0], 131, 200, 0), ([0, 0, 0, 0], 96, 512, 2), ([], 64, 128, 0)])

@@ -18,11 +18,11 @@ for seed in range(a, b):
     of = o.Film(w, h); o.capture_subset_mt(0, 1, oacc, of, 16)
     o.set_trig_mode(1); orad = o.capture_radiance(oacc, w, h, nthreads=16); o.set_trig_mode(0)
     acc = G.Accel(S.random_scene(G, seed))
-    for streaming in (0, 2):
-        for fast in (False, True):
-            G.set_streaming(acc, streaming); G.set_mode(acc, fast)
+    for streaming, fast, packet in ((0, False, False), (0, True, False), (2, False, False), (2, True, False), (2, False, True)):
+        if True:
+            G.set_streaming(acc, streaming); G.set_mode(acc, fast); G.set_packet(acc, packet)
             f = G.Film(w, h); G.capture_subset(0, 1, acc, f)
             r = G.capture_radiance(acc, w, h)
             if not (np.array_equal(f.pixels(), of.pixels()) and np.array_equal(bits(r), bits(orad))):
-                bad += 1; print("MISMATCH seed", seed, "streaming", streaming, "fast", fast, int((f.pixels() != of.pixels()).sum()), "bytes", flush=True)
+                bad += 1; print("MISMATCH seed", seed, "streaming", streaming, "fast", fast, "packet", packet, int((f.pixels() != of.pixels()).sum()), "bytes", flush=True)
 print("seeds", a, b, "mismatches", bad, "skipped (unbuildable in the reference)", skipped)
