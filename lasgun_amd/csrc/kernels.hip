@@ -360,6 +360,16 @@ __device__ __forceinline__ DCuboid load_cuboid(const DParams &P, const uint4 *sc
     return P.cuboids[idx];
 }
 
+// the same ray from the ROOT accel's local ray (chain[0] already applied): the continuation of the same
+// sequence of transforms, so bit-identical to local_ray() -- and one transform cheaper per call
+__device__ __forceinline__ Ray level_ray(const DParams &P, V3 root_o, V3 root_d, uint32_t accel) {
+    const DAccel *a = P.accels + accel;
+    uint32_t n = a->nchain;
+    Ray r = ray_new(root_o, root_d);
+    for (uint32_t i = 1; i < n; ++i) r = ray_to_local(P.accels[a->chain[i]].minv, r);
+    return r;
+}
+
 struct Best {
     double t;
     uint32_t ref;   // primref of the closest accepted primitive, NO_HIT if none
@@ -523,7 +533,10 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
 #define LG_POP() do { if (FAST) trav_pop_fast(P, T, stack, stride, prune_limit(best.t, anyhit)); else trav_pop<LDSS>(P, scn, T, stack, stride); } while (0)
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
     Trav T;
-    trav_set_level<FAST, LDSS>(P, T, 0u, ray_to_local(P.accels->minv, wray));
+    // the world ray is not kept: everything below the root is derived from the root accel's local ray
+    const Ray root = ray_to_local(P.accels->minv, wray);
+    const V3 root_o = root.o, root_d = root.d;
+    trav_set_level<FAST, LDSS>(P, T, 0u, root);
     T.sp = 0; T.base = 0; T.li = 0; T.le = 0; T.done = false; T.level_done = false; T.tie = false;
     if (STATS) cnt.entries++;
     trav_enter_root<STATS, FAST>(P, T, cnt);
@@ -651,7 +664,7 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
                 T.base = stack[(T.sp - 1) * stride]; T.le = stack[(T.sp - 2) * stride]; T.li = stack[(T.sp - 3) * stride];
                 T.sp -= 3;
                 uint32_t parent = (uint32_t)P.accels[T.accel].parent;
-                trav_set_level<FAST, LDSS>(P, T, parent, local_ray(P, wray, parent));
+                trav_set_level<FAST, LDSS>(P, T, parent, level_ray(P, root_o, root_d, parent));
                 if (T.li < T.le) T.in_leaf = true;
                 else LG_POP();
             }
@@ -769,7 +782,9 @@ __device__ __forceinline__ void traverse_packet(const DParams &P, const uint4 *s
     Ray ray;
     double dd = 0.0;
     uint32_t negbits = 0u;                 // per lane: bit a set <=> dinv[a] < 0 (dir_is_neg, bvh.rs:463)
-    PKT_SET_LEVEL(0u, ray_to_local(P.accels->minv, wray));
+    const Ray root = ray_to_local(P.accels->minv, wray); // the world ray is not kept (see level_ray)
+    const V3 root_o = root.o, root_d = root.d;
+    PKT_SET_LEVEL(0u, root);
     uint32_t sp = 0u, base = 0u;           // wave stack, in entries
     uint32_t cur = 0u;                     // node to visit ...
     unsigned long long m = alive_m;        // ... by these lanes
@@ -894,7 +909,7 @@ __device__ __forceinline__ void traverse_packet(const DParams &P, const uint4 *s
                 li = uni(ws[sp * PKT_ENTRY]); le = uni(ws[sp * PKT_ENTRY + 1u]); lm = PKT_MASK(sp);
                 base = uni(ws[(sp + 1u) * PKT_ENTRY]);
                 const uint32_t parent = uni((uint32_t)P.accels[accel].parent);
-                PKT_SET_LEVEL(parent, local_ray(P, wray, parent)); // recomputed, bit-identical to the first computation
+                PKT_SET_LEVEL(parent, level_ray(P, root_o, root_d, parent)); // recomputed, bit-identical to the first computation
                 leaf_open = li < le;
             }
         }
