@@ -267,7 +267,7 @@ def main():
             dst = dict(dst)
             dst["primary_rays"] = 0  # the RGBA write belongs to the shade kernel, not to a traversal kernel
             my_bytes = algorithmic_bytes(dst)
-            tail = ", true>" if lds_scene else ", false>"  # third template argument: scene tables resident in LDS
+            tail = ", true, false>" if lds_scene else ", false, false>"  # <FAST, SHADOW, scene tables resident in LDS, FIXUP>
             kernel_name = "lg::" + dom.replace("<primary>", "<false, false" + tail).replace("<shadow>", "<false, true" + tail)
             dom_flops = algorithmic_flops(dst)
         else:  # megakernel (scenes with glass / mirror, small films)

@@ -11,8 +11,17 @@ rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/pmc_tcc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_tcc.log 2>&1
 timeout -k 10 300 python tools/bench_configs.py > $O/configs_parity.jsonl 2>/dev/null
 timeout -k 10 300 python tools/bench_configs.py --fast > $O/configs_fast.jsonl 2>/dev/null
-{
-  echo "# per-launch counters of lg::stream_trace_kernel<false,true,true> (shadow traversal, LDS-resident scene) (4096^2, config 3); one row per counter, median over dispatches"
-  for d in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_tcc; do f=$(find $O/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && grep "stream_trace_kernel<false, true, true>" $f | awk -F, '{n=NF; gsub(/"/,"",$(n-3)); print $(n-3), $(n-2)}' | sort | awk '{a[$1]=a[$1]" "$2} END{for(k in a) print k, a[k]}' | sort; done
-} > $O/pmc_summary.txt
+python3 - "$O" > $O/pmc_summary.txt <<'PY'
+import csv, glob, collections, sys
+K = "stream_trace_kernel<false, true, true, false>"
+print("# per-launch counters of lg::%s (shadow traversal, scene tables in LDS; 4096^2, config 3): every dispatch's value" % K)
+for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_tcc"):
+    for f in glob.glob("%s/%s/**/*counter_collection.csv" % (sys.argv[1], d), recursive=True):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if K in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(r["Counter_Value"])
+        for c, v in sorted(acc.items()):
+            print(c, " ".join(v))
+PY
 cat $O/pmc_summary.txt; tail -1 $O/pytest_gpu.log; tail -1 $O/bench.log | cut -c1-400
