@@ -237,6 +237,37 @@ def mixed_scene(api, nspheres=1024, nu=224, nv=224, supersampling=0):
     return scene
 
 
+def instanced_scene(api, nu=24, nv=16, supersampling=0):
+    """No glass / mirror (so every kernel organisation applies): one torus mesh instanced three times under
+    different transforms and materials (the instances share BVH nodes and primrefs on the device), nested two
+    groups deep, next to boxes, spheres and two lights."""
+    scene = api.Scene.new()
+    _cornell_shell(api, scene, supersampling)
+    scene.add_point_light([-1.2, 1.2, 1.5], [0.4, 0.4, 0.5], [1.0, 0.0, 0.1])
+    M = api.Material
+    mesh = scene.parse_obj(torus_obj(nu, nv, normals=True))
+    outer = api.Aggregate.new()
+    outer.translate([0.1, -0.2, 0.0])
+    for k, (mat, tr, rot) in enumerate([(M.plastic([0.9, 0.3, 0.2], [0.5, 0.7, 0.5], 0.2), [-0.9, -0.6, 0.2], 20.0),
+                                        (M.matte([0.3, 0.8, 0.4], 25.0), [0.8, 0.1, -0.3], 75.0),
+                                        (M.metal([0.2, 0.9, 1.1], [3.9, 2.4, 2.2], 0.15, 0.1), [0.0, 0.9, 0.4], 140.0)]):
+        g = api.Aggregate.new()
+        g.scale(0.55 + 0.1 * k, 0.55, 0.55)
+        g.rotate_x(rot)
+        g.rotate_z(15.0 * k)
+        g.translate(tr)
+        g.add_obj_of(mesh, mat)
+        if k == 1:
+            g.add_sphere([0.0, 0.0, 0.0], 0.25, M.plastic([0.2, 0.2, 0.9], [0.5, 0.5, 0.5], 0.3))
+        outer.add_group(g)
+    outer.add_cube([-0.3, -1.6, -0.9], 0.5, M.matte([0.8, 0.8, 0.2], 0.0))
+    scene.root.add_group(outer)
+    scene.root.add_box([1.0, -1.9, -1.0], [1.6, -1.2, -0.2], M.plastic([0.7, 0.4, 0.8], [0.4, 0.4, 0.4], 0.4))
+    for i in range(40):
+        scene.root.add_sphere([-1.6 + 0.08 * i, -1.7 + 0.02 * (i % 7), 1.2 - 0.05 * i], 0.06 + 0.002 * (i % 5), M.matte([0.6, 0.6, 0.6], 0.0))
+    return scene
+
+
 def quad_obj_with_uv():
     """A unit quad given as ONE 4-vertex polygon (only its first three vertices are used,
     src/shape/triangle.rs:41-53) plus two triangles, with vt and vn on every vertex."""

@@ -133,6 +133,7 @@ MID = {
     "mesh_glass_128": (lambda api: S.mesh_scene(api, 64, 64, "glass"), 128, 128),
     "mesh_plastic_flat_128": (lambda api: S.mesh_scene(api, 48, 48, "plastic", smoothing=False), 128, 96),
     "mixed_128": (lambda api: S.mixed_scene(api, 256, 48, 48), 128, 128),
+    "instanced_mesh_176": (S.instanced_scene, 176, 144),
     "kitchen_sink_persp": (lambda api: S.kitchen_sink_scene(api, "perspective"), 192, 160),
     "kitchen_sink_ortho": (lambda api: S.kitchen_sink_scene(api, "orthographic", recursion=4, supersampling=0), 160, 120),
     "kitchen_sink_rec0": (lambda api: S.kitchen_sink_scene(api, "perspective", recursion=0, supersampling=2), 96, 72),
@@ -202,7 +203,7 @@ def test_fast_mode_full_size_films_are_identical():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("name", ["spheres_512", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "ragged_5x131", "one_pixel"])
+@pytest.mark.parametrize("name", ["spheres_512", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "instanced_mesh_176", "ragged_5x131", "one_pixel"])
 def test_streaming_pipeline_and_megakernel_agree(name):
     """The two kernel organisations (and both traversal modes under each) give the same bytes and bits."""
     builder, w, h = MID[name]
@@ -221,7 +222,7 @@ def test_streaming_pipeline_and_megakernel_agree(name):
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
 
 
-@pytest.mark.parametrize("name", ["spheres_512", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "ragged_5x131", "one_pixel"])
+@pytest.mark.parametrize("name", ["spheres_512", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "instanced_mesh_176", "ragged_5x131", "one_pixel"])
 def test_lds_resident_scene_matches_global_tables(name):
     """Streaming traversal kernels with the scene tables in LDS (1024-lane workgroups) vs in HBM/L2."""
     builder, w, h = MID[name]
@@ -243,7 +244,7 @@ def test_lds_resident_scene_matches_global_tables(name):
     assert np.array_equal(outs[0][0], ofilm.pixels())
 
 
-@pytest.mark.parametrize("name", ["spheres_512", "spheres_seed7_300", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "mesh_plastic_flat_128", "ragged_5x131", "one_pixel"])
+@pytest.mark.parametrize("name", ["spheres_512", "spheres_seed7_300", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "instanced_mesh_176", "mesh_plastic_flat_128", "ragged_5x131", "one_pixel"])
 def test_packet_traversal_matches_private_walks(name):
     """One tree walk per wavefront (lane masks, vote on the near child, tie lanes re-traced) vs 64 private
     walks: same bytes, same radiance bits, with the scene tables in LDS and in HBM/L2; and vs the oracle."""
