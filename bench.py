@@ -252,7 +252,7 @@ def main():
         # roofline of the DOMINANT kernel of this rank's frame
         frame_ms = kernel_ms / max(launches, 1)
         per_kernel = {k: v[0] / v[1] for k, v in kinds.items() if v[1] > 0}
-        if per_kernel:  # streaming pipeline: K1 primary trace, K2 frame, K3 shadow trace, K4 shade
+        if per_kernel:  # streaming pipeline: K1 primary trace (+ shading frame), K2 shadow trace, K3 shade
             dom = max(per_kernel, key=per_kernel.get)
             dom_ms = per_kernel[dom]
             kind = 2 if "shadow" in dom else 1

@@ -20,7 +20,6 @@ hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
 hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, bool fixup, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
 hipError_t launch_stream_packet(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream);
 hipError_t stream_packet_occupancy(uint32_t stack_depth, int *blocks_per_cu);
-hipError_t launch_stream_frame(const DParams &P, hipStream_t stream);
 hipError_t launch_stream_shade(const DParams &P, hipStream_t stream);
 hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
 hipError_t trace_set_lds_limit(size_t bytes);
@@ -250,7 +249,6 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
             P.sample_index = sidx;
             timed(0, [&] { return trace(false); });
-            timed(1, [&] { return launch_stream_frame(P, stream); });
             if (P.nlights > 0) timed(2, [&] { return trace(true); });
             timed(3, [&] { return launch_stream_shade(P, stream); });
         }
