@@ -148,7 +148,7 @@ int lg_accel_set_mode(const lg_accel *, int mode);
 
 /* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes without
  * glass / mirror, with <= 32 lights and with at least 128 spheres / boxes (where node and sphere
- * tests dominate a ray) run as a four-kernel streaming pipeline (primary traversal, shading
+ * tests dominate a ray) run as a three-kernel streaming pipeline (primary traversal + shading
  * frame, shadow traversal, shade) with per-pixel state in HBM when the launch covers at least
  * 2^19..2^23 pixels (by scene kind); everything else -- and everything when 0 -- runs in the
  * single persistent megakernel.  2 = use the pipeline wherever it is possible (tests). */

@@ -66,7 +66,7 @@ class HipApi(Api):
             raise LasgunError(self.last_error())
 
     def set_streaming(self, accel, enabled):
-        """True (default) = four-kernel streaming pipeline where the scene allows it; False = megakernel only."""
+        """True (default) = three-kernel streaming pipeline where the scene allows it; False = megakernel only."""
         self.call("accel_set_streaming", accel.h, int(enabled) if enabled in (0, 1, 2) else (1 if enabled else 0))
 
     def set_packet(self, accel, enabled):
