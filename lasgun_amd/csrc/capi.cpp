@@ -113,8 +113,8 @@ struct lg_accel {
     mutable DevBuf<double> frames;
     mutable DevBuf<double> stash;
     // streaming pipeline state (sized by work items of the largest launch so far)
-    mutable DevBuf<double> st_hit_t, st_frame, st_accum;
-    mutable DevBuf<uint32_t> st_hit_ref, st_hit_accel, st_vis, st_tie_flag, st_tie_tiles;
+    mutable DevBuf<double> st_frame, st_accum;
+    mutable DevBuf<uint32_t> st_hit_ref, st_vis, st_tie_flag, st_tie_tiles;
     mutable bool streaming = true; // use the streaming pipeline when the scene allows it
     mutable bool streaming_forced = false; // lg_accel_set_streaming(2): ignore the two criteria below (tests)
     // the pipeline pays for its per-pixel state traffic only where node / sphere / box traversal dominates a
@@ -190,13 +190,13 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         const uint32_t nsamples = P.ss_root * P.ss_root;
         P.n_items = (unsigned long long)P.ntiles * 64ull;
         size_t n = (size_t)P.n_items;
-        if (a.st_hit_t.n < n) {
+        if (a.st_hit_ref.n < n) {
             HIP_TRY(hipDeviceSynchronize());
-            a.st_hit_t.alloc(n); a.st_hit_ref.alloc(n); a.st_hit_accel.alloc(n); a.st_vis.alloc(n);
+            a.st_hit_ref.alloc(n); a.st_vis.alloc(n);
             a.st_frame.alloc(n * STASH_DOUBLES);
         }
         if (nsamples > 1 && a.st_accum.n < 3 * n) { HIP_TRY(hipDeviceSynchronize()); a.st_accum.alloc(3 * n); }
-        P.hit_t = a.st_hit_t.p; P.hit_ref = a.st_hit_ref.p; P.hit_accel = a.st_hit_accel.p; P.vis = a.st_vis.p;
+        P.hit_ref = a.st_hit_ref.p; P.vis = a.st_vis.p;
         P.frame = a.st_frame.p; P.accum = a.st_accum.p;
         uint32_t cap = a.fast ? a.stream_blocks_fast : a.stream_blocks;
         uint32_t blocks = (P.ntiles + 3u) / 4u;

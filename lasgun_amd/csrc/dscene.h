@@ -158,9 +158,7 @@ struct DParams {
     // ---- streaming pipeline (scenes without glass / mirror): per-work-item state in HBM, SoA,
     // indexed by the dense work index widx = tile * 64 + lane
     unsigned long long n_items; // ntiles * 64
-    double *hit_t;              // [n_items] closest t of the primary ray (+inf = miss)
     uint32_t *hit_ref;          // [n_items] primref of the hit (NO_HIT = miss)
-    uint32_t *hit_accel;        // [n_items]
     double *frame;              // [STASH_DOUBLES][n_items] shading frame of the hit
     uint32_t *vis;              // [n_items] bit l set <=> light l is visible from the hit
     double *accum;              // [3][n_items] running sum over the pixel's samples (integrate.rs:17-18)

@@ -1483,7 +1483,7 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
 // three kernels so that traversal (wants occupancy, 128 VGPRs) and shading (wants registers: trig,
 // microfacet, Fresnel) each get their own register allocation.  Per work item (pixel) the state
 // between kernels lives in HBM, SoA, indexed by widx = tile * 64 + lane:
-//   K1 primary   camera ray -> closest hit -> shade_frame           -> hit_t / hit_ref / hit_accel, frame[13][n]
+//   K1 primary   camera ray -> closest hit -> shade_frame           -> hit_ref, frame[13][n]
 //   K2 shadow    one any-hit traversal per light from frame.p       -> vis bits
 //   K3 shade     lights in order, ambient, sample sum, Img::set     -> film
 // (the shading frame used to be a kernel of its own between K1 and K2; see park_frame)
@@ -1595,7 +1595,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             bool tie = false;
             traverse<false, FAST, LDSS>(P, ray, false, stack, stride, b, cnt, tie, scn);
             if (FAST && tie) traverse<false, false>(P, ray, false, stack, stride, b, cnt, tie);
-            P.hit_t[widx] = b.t; P.hit_ref[widx] = b.ref; P.hit_accel[widx] = b.accel;
+            P.hit_ref[widx] = b.ref; // (t and the accel instance are consumed by park_frame right here)
             park_frame(P, widx, ray, b);
         } else {
             if (P.hit_ref[widx] == NO_HIT) continue;
@@ -1653,7 +1653,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             Best b;
             bool tie = false;
             traverse_packet<LDSS>(P, scn, ray, px.active, false, ws, lane, b, tie);
-            if (px.active) { P.hit_t[widx] = b.t; P.hit_ref[widx] = b.ref; P.hit_accel[widx] = b.accel; }
+            if (px.active) P.hit_ref[widx] = b.ref;
             ties = px.active && tie ? 1u : 0u;
             if (px.active && !tie) park_frame(P, widx, ray, b); // a tie lane's frame comes from the fix-up pass
         } else {
