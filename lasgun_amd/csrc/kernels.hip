@@ -1683,9 +1683,9 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
     }
 }
 
-// K3: li() of a non-specular hit from the parked frame and the visibility bits, then the
+// K3: li() of a non-specular hit from the parked frame and the visibility bits, then the (3 waves/SIMD: measured best)
 // per-pixel sample sum and Img::set (integrate.rs:16-80, img.rs:46-67)
-__global__ void __launch_bounds__(LG_BLOCK) stream_shade_kernel(const DParams P) {
+__global__ void __launch_bounds__(LG_BLOCK, 3) stream_shade_kernel(const DParams P) {
     const unsigned long long widx = (unsigned long long)blockIdx.x * LG_BLOCK + threadIdx.x;
     if (widx >= P.n_items) return;
     Pixel px = pixel_of(P, (uint32_t)(widx >> 6), (uint32_t)(widx & 63u));
