@@ -147,16 +147,16 @@ int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t
 int lg_accel_set_mode(const lg_accel *, int mode);
 
 /* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes without
- * glass / mirror, with <= 32 lights and with at least 128 spheres / boxes (where node and sphere
+ * glass / mirror, with <= 32 lights and with at least 512 spheres / boxes (where node and sphere
  * tests dominate a ray) run as a three-kernel streaming pipeline (primary traversal + shading
  * frame, shadow traversal, shade) with per-pixel state in HBM when the launch covers at least
- * 2^19..2^23 pixels (by scene kind); everything else -- and everything when 0 -- runs in the
+ * 2^20 pixels (2^23 when the scene carries a big mesh); everything else -- and everything when 0 -- runs in the
  * single persistent megakernel.  2 = use the pipeline wherever it is possible (tests). */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
 
-/* LDS-resident scene (streaming pipeline, reference traversal): when the scene's node, primref,
- * sphere and cuboid tables fit beside 1024 per-lane stacks in one CU's 160 KB of LDS, the two
- * traversal kernels run as one 1024-lane workgroup per CU that copies those tables into LDS once
+/* LDS-resident scene (reference traversal; streaming pipeline and megakernel): when the scene's node,
+ * primref, sphere and cuboid tables fit beside 1024 per-lane stacks in one CU's 160 KB of LDS, the
+ * kernels that traverse run as one 1024-lane workgroup per CU that copies those tables into LDS once
  * and walks them there (same records, same arithmetic, same bytes out).  On by default; returns
  * 1 when the accel's scene qualifies, 0 when it does not (the setting is then without effect). */
 int lg_accel_set_lds_scene(const lg_accel *, int enabled);

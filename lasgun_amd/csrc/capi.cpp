@@ -262,6 +262,13 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     uint32_t blocks = (P.ntiles + 3u) / 4u;
     if (blocks > cap) blocks = cap;
     uint32_t maxb = a.max_blocks > a.max_blocks_fast ? a.max_blocks : a.max_blocks_fast;
+    if (!stats && !a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS: one 1024-lane workgroup per CU
+        P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
+        P.lds_node_off = a.lds_node_off; P.lds_node_stride = a.lds_node_stride; P.lds_prim_off = a.lds_prim_off;
+        P.lds_sph_off = a.lds_sph_off; P.lds_sph_stride = a.lds_sph_stride; P.lds_cub_off = a.lds_cub_off;
+        blocks = a.ldss_blocks;
+    }
+    if (maxb < a.ldss_blocks * 4u) maxb = a.ldss_blocks * 4u; // per-lane slots below: 1024 lanes per LDS-scene workgroup
     // Whitted frames: one slot per resident lane and recursion level, only for glass / mirror scenes
     if (a.flat.has_specular && P.recursion > 0) {
         unsigned long long threads = (unsigned long long)maxb * 256ull;
@@ -601,14 +608,15 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
             a->accels.upload(fm.accels); // again, now with the compact bases
         }
         // Which organisation is the default (measured, tools/threshold_sweep.py): the megakernel unless the scene has
-        // enough spheres / boxes that BVH-node and sphere tests dominate a ray (>= 128: from ~45 node + primitive tests
-        // per ray on, the traversal kernels' lower register pressure outweighs ~360 B of per-pixel state traffic);
-        // scenes that also carry a big mesh have long, uneven tiles and need more of them per wave to balance.
+        // so many spheres / boxes that BVH-node and sphere tests dominate a ray (>= 512: with the scene tables in LDS
+        // the megakernel keeps up to ~50 node + primitive tests per ray; beyond that the traversal kernels' lower
+        // register pressure outweighs the per-pixel state traffic); scenes that also carry a big mesh have long,
+        // uneven tiles and need more of them per wave to balance.
         {
             size_t big_mesh = 0;
             for (const auto &m : s->s.meshes) if (m && m->tri.size() / 3 > big_mesh) big_mesh = m->tri.size() / 3;
-            a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 128;
-            a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : a->ldss_blocks ? (1ull << 19) : (1ull << 20);
+            a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512;
+            a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 20);
         }
     });
     if (rc) { delete a; return nullptr; }

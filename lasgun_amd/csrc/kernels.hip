@@ -1238,13 +1238,25 @@ __device__ __forceinline__ void stash_get(const DParams &P, unsigned long long g
     sh.ts = cross(sh.ns, sh.ss);
 }
 
-template <bool STATS, bool FAST>
-__global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(const DParams P) {
+#define LG_LDSS_BLOCK 1024
+// LDSS (reference traversal only): one 1024-lane workgroup per CU with the scene's node / primref / sphere /
+// cuboid tables copied into LDS behind the stacks (see load_node); otherwise 256-lane workgroups and L1/L2.
+template <bool STATS, bool FAST, bool LDSS>
+__global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(const DParams P) {
+    static_assert(!(FAST && LDSS) && !(STATS && LDSS), "LDS-resident scene: plain reference traversal only");
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + tid;
-    uint32_t *stack = lds_stack + tid; // entry i at stack[i * LG_BLOCK]: bank = tid % 32 for every i
-    constexpr uint32_t stride = LG_BLOCK;
+    uint32_t *stack = lds_stack + tid; // entry i at stack[i * stride]: bank = tid % 32 for every i
+    constexpr uint32_t stride = LDSS ? LG_LDSS_BLOCK : LG_BLOCK;
+    const uint4 *scn = nullptr;
+    if (LDSS) {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_stack + P.stack_depth * stride);
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.lds_image);
+        for (uint32_t i = tid; i < P.lds_image_n16; i += stride) dst[i] = src[i];
+        __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling tiles
+        scn = dst;
+    }
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (;;) {
@@ -1311,7 +1323,7 @@ __global__ void __launch_bounds__(LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(cons
                 {
                     bool tie = false;
                     Counters before = cnt;
-                    traverse<STATS, FAST>(P, tray, shadow_job, stack, stride, b, cnt, tie);
+                    traverse<STATS, FAST, LDSS>(P, tray, shadow_job, stack, stride, b, cnt, tie, scn);
                     // fast mode: exact ties in t are decided by the reference's visit order -> re-trace this ray with it.
                     // (an occluded any-hit ray needs no re-trace: the answer "some t < 1 exists" is order-independent)
                     if (FAST && tie && !(shadow_job && b.t < 1.0)) traverse<STATS, false>(P, tray, shadow_job, stack, stride, b, cnt, tie);
@@ -1553,7 +1565,6 @@ __device__ __forceinline__ void park_frame(const DParams &P, unsigned long long 
 // independently exactly like the 256-lane form.
 // FIXUP: the second pass of the packet organisation -- only the tiles listed in P.tie_tiles, and in
 // them only the lanes (and lights) flagged in P.tie_flag, are re-traced with the private walk.
-#define LG_LDSS_BLOCK 1024
 template <bool FAST, bool SHADOW, bool LDSS, bool FIXUP>
 __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_trace_kernel(const DParams P) {
     static_assert(!(FAST && FIXUP), "ties of the packet walk are resolved by the reference walk");
@@ -1822,13 +1833,18 @@ __global__ void math_kernel(int op, size_t n, const double *a, const double *b, 
 // host-callable launchers (used by capi.cpp)
 // ------------------------------------------------------------------------------------------
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
+    if (P.lds_image && !stats && !fast) { // LDS-resident scene: `blocks` = one 1024-lane workgroup per CU
+        size_t lds = (size_t)P.stack_depth * LG_LDSS_BLOCK * sizeof(uint32_t) + (size_t)P.lds_image_n16 * 16u;
+        hipLaunchKernelGGL((trace_kernel<false, false, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
+        return hipGetLastError();
+    }
     size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
     if (fast) {
-        if (stats) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-        else hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        if (stats) hipLaunchKernelGGL((trace_kernel<true, true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((trace_kernel<false, true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     } else {
-        if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        if (stats) hipLaunchKernelGGL((trace_kernel<true, false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((trace_kernel<false, false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     }
     return hipGetLastError();
 }
@@ -1866,7 +1882,8 @@ hipError_t stream_packet_occupancy(uint32_t stack_depth, int *blocks_per_cu) { /
 }
 // raise the dynamic-LDS limit of the LDS-resident-scene variants to `bytes`
 hipError_t stream_trace_ldss_prepare(size_t bytes) {
-    const void *fns[4] = {reinterpret_cast<const void *>(stream_trace_kernel<false, false, true, false>),
+    const void *fns[5] = {reinterpret_cast<const void *>(trace_kernel<false, false, true>),
+                          reinterpret_cast<const void *>(stream_trace_kernel<false, false, true, false>),
                           reinterpret_cast<const void *>(stream_trace_kernel<false, true, true, false>),
                           reinterpret_cast<const void *>(stream_packet_kernel<false, true>),
                           reinterpret_cast<const void *>(stream_packet_kernel<true, true>)};
@@ -1899,12 +1916,12 @@ hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_p
 }
 hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu) {
     size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
-    if (fast) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, true>, LG_BLOCK, lds);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, false>, LG_BLOCK, lds);
+    if (fast) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, true, false>, LG_BLOCK, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, false, false>, LG_BLOCK, lds);
 }
 hipError_t trace_set_lds_limit(size_t bytes) {
-    const void *fns[8] = {reinterpret_cast<const void *>(trace_kernel<false, false>), reinterpret_cast<const void *>(trace_kernel<true, false>),
-                          reinterpret_cast<const void *>(trace_kernel<false, true>), reinterpret_cast<const void *>(trace_kernel<true, true>),
+    const void *fns[8] = {reinterpret_cast<const void *>(trace_kernel<false, false, false>), reinterpret_cast<const void *>(trace_kernel<true, false, false>),
+                          reinterpret_cast<const void *>(trace_kernel<false, true, false>), reinterpret_cast<const void *>(trace_kernel<true, true, false>),
                           reinterpret_cast<const void *>(stream_trace_kernel<false, false, false, false>), reinterpret_cast<const void *>(stream_trace_kernel<false, true, false, false>),
                           reinterpret_cast<const void *>(stream_trace_kernel<true, false, false, false>), reinterpret_cast<const void *>(stream_trace_kernel<true, true, false, false>)};
     for (const void *f : fns) {
