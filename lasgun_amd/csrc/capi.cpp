@@ -124,7 +124,7 @@ struct lg_accel {
     uint32_t stream_blocks = 1, stream_blocks_fast = 1;
     // LDS-resident scene (reference tree only): the tables in their LDS layout, when they fit beside the stacks
     DevBuf<uint32_t> lds_image;
-    uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_node_stride = 0, lds_prim_off = 0, lds_sph_off = 0, lds_sph_stride = 0, lds_cub_off = 0;
+    uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_prim_off = 0, lds_sph_off = 0, lds_cub_off = 0;
     uint32_t ldss_blocks = 0;         // one 1024-lane workgroup per CU; 0 = variant unavailable for this scene
     uint32_t packet_blocks = 1;       // grid of the 256-lane packet kernels
     uint32_t cus = 1;                 // compute units of the accel's device
@@ -204,8 +204,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         uint32_t depth = a.fast ? a.stack_depth_fast : a.stack_depth;
         if (!a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS
             P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
-            P.lds_node_off = a.lds_node_off; P.lds_node_stride = a.lds_node_stride; P.lds_prim_off = a.lds_prim_off;
-            P.lds_sph_off = a.lds_sph_off; P.lds_sph_stride = a.lds_sph_stride; P.lds_cub_off = a.lds_cub_off;
+            P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_sph_off = a.lds_sph_off; P.lds_cub_off = a.lds_cub_off;
             blocks = a.ldss_blocks;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -264,8 +263,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     uint32_t maxb = a.max_blocks > a.max_blocks_fast ? a.max_blocks : a.max_blocks_fast;
     if (!stats && !a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS: one 1024-lane workgroup per CU
         P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
-        P.lds_node_off = a.lds_node_off; P.lds_node_stride = a.lds_node_stride; P.lds_prim_off = a.lds_prim_off;
-        P.lds_sph_off = a.lds_sph_off; P.lds_sph_stride = a.lds_sph_stride; P.lds_cub_off = a.lds_cub_off;
+        P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_sph_off = a.lds_sph_off; P.lds_cub_off = a.lds_cub_off;
         blocks = a.ldss_blocks;
     }
     if (maxb < a.ldss_blocks * 4u) maxb = a.ldss_blocks * 4u; // per-lane slots below: 1024 lanes per LDS-scene workgroup
@@ -563,27 +561,28 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
             const size_t stack_bytes = (size_t)a->stack_depth * 1024 * 4; // per-lane stacks (the packet form needs 64x less)
             const size_t ns = fm.spheres.size(), nc = fm.cuboids.size();
             const size_t prim16 = ((size_t)np + 3) / 4;
-            for (int attempt = 0; attempt < 3 && !a->ldss_blocks; ++attempt) {
-                const uint32_t nstride = attempt == 0 ? 5u : 4u, sstride = attempt < 2 ? 3u : 2u;
+            {
+                const uint32_t nstride = LDS_NODE_STRIDE, sstride = LDS_SPH_STRIDE;
                 size_t n16 = (size_t)nn * nstride + prim16 + ns * sstride + nc * 3;
-                if (stack_bytes + n16 * 16 > LDS_MAX) continue;
-                std::vector<uint32_t> img(n16 * 4, 0u);
-                a->lds_node_off = 0; a->lds_node_stride = nstride;
-                for (auto &r : nruns)
-                    for (uint32_t i = 0, e = extent(nb, r.first, fm.nodes.size()); i < e; ++i)
-                        std::memcpy(&img[((size_t)(r.second + i) * nstride) * 4], &fm.nodes[r.first + i], 56);
-                a->lds_prim_off = nn * nstride;
-                for (auto &r : pruns)
-                    for (uint32_t i = 0, e = extent(pb, r.first, fm.primref.size()); i < e; ++i)
-                        img[(size_t)a->lds_prim_off * 4 + r.second + i] = fm.primref[r.first + i];
-                a->lds_sph_off = a->lds_prim_off + (uint32_t)prim16; a->lds_sph_stride = sstride;
-                for (size_t i = 0; i < ns; ++i) std::memcpy(&img[((size_t)a->lds_sph_off + i * sstride) * 4], &fm.spheres[i], 32);
-                a->lds_cub_off = a->lds_sph_off + (uint32_t)(ns * sstride);
-                for (size_t i = 0; i < nc; ++i) std::memcpy(&img[((size_t)a->lds_cub_off + i * 3) * 4], &fm.cuboids[i], 48);
-                a->lds_image.upload(img);
-                a->lds_image_n16 = (uint32_t)n16;
-                HIP_TRY(stream_trace_ldss_prepare(LDS_MAX));
-                a->ldss_blocks = (uint32_t)cus;
+                if (stack_bytes + n16 * 16 <= LDS_MAX) {
+                    std::vector<uint32_t> img(n16 * 4, 0u);
+                    a->lds_node_off = 0;
+                    for (auto &r : nruns)
+                        for (uint32_t i = 0, e = extent(nb, r.first, fm.nodes.size()); i < e; ++i)
+                            std::memcpy(&img[((size_t)(r.second + i) * nstride) * 4], &fm.nodes[r.first + i], 56);
+                    a->lds_prim_off = nn * nstride;
+                    for (auto &r : pruns)
+                        for (uint32_t i = 0, e = extent(pb, r.first, fm.primref.size()); i < e; ++i)
+                            img[(size_t)a->lds_prim_off * 4 + r.second + i] = fm.primref[r.first + i];
+                    a->lds_sph_off = a->lds_prim_off + (uint32_t)prim16;
+                    for (size_t i = 0; i < ns; ++i) std::memcpy(&img[((size_t)a->lds_sph_off + i * sstride) * 4], &fm.spheres[i], 32);
+                    a->lds_cub_off = a->lds_sph_off + (uint32_t)(ns * sstride);
+                    for (size_t i = 0; i < nc; ++i) std::memcpy(&img[((size_t)a->lds_cub_off + i * 3) * 4], &fm.cuboids[i], 48);
+                    a->lds_image.upload(img);
+                    a->lds_image_n16 = (uint32_t)n16;
+                    HIP_TRY(stream_trace_ldss_prepare(LDS_MAX));
+                    a->ldss_blocks = (uint32_t)cus;
+                }
             }
             {   // packet image: [nodes, 4 units each][primrefs][leaf records, 3 units per slot], behind 16 per-wave stacks
                 const size_t wave_stacks = (size_t)a->stack_depth * 16 * 16;

@@ -309,7 +309,7 @@ template <bool LDSS>
 __device__ __forceinline__ NodeRec load_node(const DParams &P, const uint4 *scn, uint32_t idx) {
     NodeRec n;
     if (LDSS) {
-        const uint4 *q = scn + (P.lds_node_off + idx * P.lds_node_stride);
+        const uint4 *q = scn + (P.lds_node_off + idx * LDS_NODE_STRIDE); // compile-time stride: shift + add, no quarter-rate multiply
         uint4 a = q[0], b = q[1], c = q[2];
         uint2 d = *reinterpret_cast<const uint2 *>(q + 3);
         n.bmin[0] = u2d(a.x, a.y); n.bmin[1] = u2d(a.z, a.w); n.bmin[2] = u2d(b.x, b.y);
@@ -327,7 +327,7 @@ __device__ __forceinline__ NodeRec load_node(const DParams &P, const uint4 *scn,
 template <bool LDSS>
 __device__ __forceinline__ void load_node_link(const DParams &P, const uint4 *scn, uint32_t idx, uint32_t &link, uint32_t &meta) {
     if (LDSS) {
-        uint2 d = *reinterpret_cast<const uint2 *>(scn + (P.lds_node_off + idx * P.lds_node_stride + 3u));
+        uint2 d = *reinterpret_cast<const uint2 *>(scn + (P.lds_node_off + idx * LDS_NODE_STRIDE + 3u));
         link = d.x; meta = d.y;
     } else {
         const DNode *nd = P.nodes + idx;
@@ -342,7 +342,7 @@ __device__ __forceinline__ uint32_t load_primref(const DParams &P, const uint4 *
 template <bool LDSS>
 __device__ __forceinline__ DSphere load_sphere(const DParams &P, const uint4 *scn, uint32_t idx) {
     if (LDSS) {
-        const uint4 *q = scn + (P.lds_sph_off + idx * P.lds_sph_stride);
+        const uint4 *q = scn + (P.lds_sph_off + idx * LDS_SPH_STRIDE);
         uint4 a = q[0], b = q[1];
         return DSphere{u2d(a.x, a.y), u2d(a.z, a.w), u2d(b.x, b.y), u2d(b.z, b.w)};
     }
