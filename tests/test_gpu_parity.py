@@ -269,6 +269,39 @@ def test_packet_traversal_matches_private_walks(name):
     assert np.array_equal(outs[1][0], ofilm.pixels())
 
 
+@pytest.mark.parametrize("nlights, w, h", [(3, 160, 96), (32, 96, 64), (33, 96, 64), (40, 64, 64)])
+def test_many_lights(nlights, w, h):
+    """One any-hit pass per light; 32 lights is the last count the streaming pipeline's visibility word holds,
+    from 33 on the megakernel takes over whatever the setting."""
+    def build(api):
+        sc = S.spheres_scene(api, 600)
+        for i in range(nlights - 1):
+            sc.add_point_light([-1.5 + 3.0 * i / max(nlights - 1, 1), 1.5, 1.0 - 0.05 * i], [0.05, 0.04, 0.06], [1.0, 0.0, 0.05])
+        return sc
+    o = oracle()
+    ofilm = o.Film(w, h)
+    o.capture_subset_mt(0, 1, o.Accel(build(o)), ofilm, 16)
+    acc = G.Accel(build(G))
+    for streaming, packet in ((0, False), (2, False), (2, True)):
+        G.set_streaming(acc, streaming); G.set_packet(acc, packet)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        assert np.array_equal(film.pixels(), ofilm.pixels()), (streaming, packet)
+
+
+@pytest.mark.parametrize("w, h", [(4096, 1), (1, 777), (3, 3), (8192, 2)])
+def test_extreme_film_shapes(w, h):
+    o = oracle()
+    ofilm = o.Film(w, h)
+    o.capture_subset_mt(0, 1, o.Accel(S.cornell_scene(o, "plastic")), ofilm, 16)
+    acc = G.Accel(S.cornell_scene(G, "plastic"))
+    for streaming in (0, 2):
+        G.set_streaming(acc, streaming)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        assert np.array_equal(film.pixels(), ofilm.pixels()), streaming
+
+
 # ---- fuzz parity: seeded random scenes with duplicated / touching primitives (exact ties in t) ----
 @pytest.mark.parametrize("seed", list(range(32)))
 def test_random_scene_parity(seed):
