@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -108,13 +109,19 @@ struct lg_accel {
     DevBuf<DAccel> accels;
     DevBuf<DMaterial> materials;
     DevBuf<DLight> lights;
-    // launch resources (mutable: a `const lg_accel*` render call still enqueues work)
-    mutable DevBuf<uint32_t> tile_counter;
-    mutable DevBuf<double> frames;
-    mutable DevBuf<double> stash;
-    // streaming pipeline state (sized by work items of the largest launch so far)
-    mutable DevBuf<double> st_frame, st_accum;
-    mutable DevBuf<uint32_t> st_hit_ref, st_vis, st_tie_flag, st_tie_tiles;
+    // launch resources (mutable: a `const lg_accel*` render call still enqueues work).  Everything a launch
+    // scribbles on lives in a per-STREAM context, so launches of one accel on different streams (frame k+1's
+    // primary pass filling the tail of frame k's shadow pass) do not share tile counters or per-pixel state.
+    struct LaunchCtx {
+        hipStream_t key = nullptr;
+        unsigned long long last_use = 0;
+        DevBuf<uint32_t> tile_counter;                         // [0] next tile, [1] listed ties, [2] next listed tile
+        DevBuf<double> frames, stash;                          // megakernel: Whitted frame stack, parked shading frame
+        DevBuf<double> st_frame, st_accum;                     // streaming pipeline state (sized by the largest launch so far)
+        DevBuf<uint32_t> st_hit_ref, st_vis, st_tie_flag, st_tie_tiles;
+    };
+    mutable std::vector<std::unique_ptr<LaunchCtx>> ctxs;
+    mutable unsigned long long ctx_clock = 0;
     mutable bool streaming = true; // use the streaming pipeline when the scene allows it
     mutable bool streaming_forced = false; // lg_accel_set_streaming(2): ignore the two criteria below (tests)
     // the pipeline pays for its per-pixel state traffic only where node / sphere / box traversal dominates a
@@ -155,6 +162,27 @@ struct lg_accel {
     }
 };
 
+// The launch context of `stream` (at most four are kept; the least recently used one is recycled after a
+// device-wide synchronise).  Caller holds a.mtx and has made the accel's device current.
+static lg_accel::LaunchCtx &ctx_for(const lg_accel &a, hipStream_t stream) {
+    for (auto &c : a.ctxs)
+        if (c->key == stream) { c->last_use = ++a.ctx_clock; return *c; }
+    lg_accel::LaunchCtx *c = nullptr;
+    if (a.ctxs.size() < 4) {
+        a.ctxs.emplace_back(new lg_accel::LaunchCtx());
+        c = a.ctxs.back().get();
+        c->tile_counter.alloc(4);
+        HIP_TRY(hipMemset(c->tile_counter.p, 0, 4 * sizeof(uint32_t)));
+    } else {
+        c = a.ctxs[0].get();
+        for (auto &x : a.ctxs) if (x->last_use < c->last_use) c = x.get();
+        HIP_TRY(hipDeviceSynchronize()); // nothing may still be using the recycled buffers
+    }
+    c->key = stream;
+    c->last_use = ++a.ctx_clock;
+    return *c;
+}
+
 // ------------------------------------------------------------------------------------------
 static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     const Scene &s = *a.scene;
@@ -176,13 +204,14 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     P.ambient = s.ambient;
     P.w = w; P.h = h;
     P.winv = 1. / (double)w; P.hinv = 1. / (double)h; P.aspect = (double)w / (double)h; // film.rs:40-42
-    P.tile_counter = a.tile_counter.p;
     return P;
 }
 
 // Enqueue one render on `stream`.  Caller holds a.mtx.
 static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t stream) {
     if (P.ntiles == 0) return;
+    lg_accel::LaunchCtx &c = ctx_for(a, stream);
+    P.tile_counter = c.tile_counter.p;
     // ---- streaming pipeline: no glass / mirror (no recursion), <= 32 lights, not the counting variant
     // and enough work to amortise 4 launches per supersample (below ~1 Mpixel the megakernel wins: measured)
     if (a.streaming && !stats && !a.flat.has_specular && P.nlights <= 32 &&
@@ -190,14 +219,14 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         const uint32_t nsamples = P.ss_root * P.ss_root;
         P.n_items = (unsigned long long)P.ntiles * 64ull;
         size_t n = (size_t)P.n_items;
-        if (a.st_hit_ref.n < n) {
+        if (c.st_hit_ref.n < n) {
             HIP_TRY(hipDeviceSynchronize());
-            a.st_hit_ref.alloc(n); a.st_vis.alloc(n);
-            a.st_frame.alloc(n * STASH_DOUBLES);
+            c.st_hit_ref.alloc(n); c.st_vis.alloc(n);
+            c.st_frame.alloc(n * STASH_DOUBLES);
         }
-        if (nsamples > 1 && a.st_accum.n < 3 * n) { HIP_TRY(hipDeviceSynchronize()); a.st_accum.alloc(3 * n); }
-        P.hit_ref = a.st_hit_ref.p; P.vis = a.st_vis.p;
-        P.frame = a.st_frame.p; P.accum = a.st_accum.p;
+        if (nsamples > 1 && c.st_accum.n < 3 * n) { HIP_TRY(hipDeviceSynchronize()); c.st_accum.alloc(3 * n); }
+        P.hit_ref = c.st_hit_ref.p; P.vis = c.st_vis.p;
+        P.frame = c.st_frame.p; P.accum = c.st_accum.p;
         uint32_t cap = a.fast ? a.stream_blocks_fast : a.stream_blocks;
         uint32_t blocks = (P.ntiles + 3u) / 4u;
         if (blocks > cap) blocks = cap;
@@ -224,8 +253,8 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         const bool packet = a.packet && !a.fast; // one tree walk per wavefront, then a fix-up pass over the lanes that met a tie
         uint32_t pblocks = blocks, fblocks = 1;
         if (packet) {
-            if (a.st_tie_flag.n < n || a.st_tie_tiles.n < P.ntiles) { HIP_TRY(hipDeviceSynchronize()); a.st_tie_flag.alloc(n); a.st_tie_tiles.alloc(P.ntiles); }
-            P.tie_flag = a.st_tie_flag.p; P.tie_tiles = a.st_tie_tiles.p;
+            if (c.st_tie_flag.n < n || c.st_tie_tiles.n < P.ntiles) { HIP_TRY(hipDeviceSynchronize()); c.st_tie_flag.alloc(n); c.st_tie_tiles.alloc(P.ntiles); }
+            P.tie_flag = c.st_tie_flag.p; P.tie_tiles = c.st_tie_tiles.p;
             if (a.lds_scene && a.pk_image_n16) { // the packet image fits in LDS: one 1024-lane workgroup per CU
                 P.pk_image = a.pk_image.p; P.pk_image_n16 = a.pk_image_n16; P.pk_prim_off = a.pk_prim_off; P.pk_soup_off = a.pk_soup_off;
                 pblocks = a.cus;
@@ -237,10 +266,10 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         }
         auto trace = [&](bool shadow) {
             if (!packet) {
-                HIP_TRY(hipMemsetAsync(a.tile_counter.p, 0, sizeof(uint32_t), stream));
+                HIP_TRY(hipMemsetAsync(c.tile_counter.p, 0, sizeof(uint32_t), stream));
                 return launch_stream_trace(P, a.fast, shadow, false, blocks, depth, stream);
             }
-            HIP_TRY(hipMemsetAsync(a.tile_counter.p, 0, 3 * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(c.tile_counter.p, 0, 3 * sizeof(uint32_t), stream));
             hipError_t e = launch_stream_packet(P, shadow, pblocks, stream);
             if (e != hipSuccess) return e;
             return launch_stream_trace(P, false, shadow, true, fblocks, depth, stream);
@@ -271,28 +300,28 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     if (a.flat.has_specular && P.recursion > 0) {
         unsigned long long threads = (unsigned long long)maxb * 256ull;
         size_t need = (size_t)threads * P.recursion * FRAME_DOUBLES;
-        if (a.frames.n < need) {
+        if (c.frames.n < need) {
             HIP_TRY(hipDeviceSynchronize()); // (re)allocation: nothing may still use the old buffer
-            a.frames.alloc(need);
+            c.frames.alloc(need);
         }
-        P.frames = a.frames.p;
+        P.frames = c.frames.p;
         P.frame_threads = threads;
     }
     if (P.nlights > 0) { // shading frame parked across the shadow traversals
         unsigned long long threads = (unsigned long long)maxb * 256ull;
         size_t need = (size_t)threads * STASH_DOUBLES;
-        if (a.stash.n < need) {
+        if (c.stash.n < need) {
             HIP_TRY(hipDeviceSynchronize()); // (re)allocation: nothing may still use the old buffer
-            a.stash.alloc(need);
+            c.stash.alloc(need);
         }
-        P.stash = a.stash.p;
+        P.stash = c.stash.p;
         P.frame_threads = threads;
     }
     if (stats) {
         P.stats = a.stats.p;
         HIP_TRY(hipMemsetAsync(a.stats.p, 0, sizeof(DStats), stream));
     }
-    HIP_TRY(hipMemsetAsync(a.tile_counter.p, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(c.tile_counter.p, 0, sizeof(uint32_t), stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (a.profiling) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -498,7 +527,6 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
         a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
         a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
-        a->tile_counter.alloc(4);
         a->stats.alloc(1);
         a->device_bytes = f.nodes.size() * (sizeof(DNode) + sizeof(DNode2)) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
                           f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 + f.leaf_soup.size() * sizeof(DLeafRec) +

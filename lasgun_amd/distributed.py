@@ -71,8 +71,10 @@ def interleaved_rows(rank, world, height, block_rows):
 
 class InterleavedGather:
     """One RCCL gather per frame of compact interleaved tiles, double-buffered so that the gather of
-    frame k overlaps the render of frame k+1 (separate streams; `tile()` hands out the buffer to
-    render into after making the current stream wait for the gather that last read it)."""
+    frame k overlaps the render of frame k+1 (`tile()` hands out the buffer to render into after
+    making the CURRENT stream wait for the gather that last read it; `submit()` orders the gather
+    after whatever the current stream has enqueued).  Callers that alternate two render streams
+    (bench.py) call both inside `with torch.cuda.stream(s)`."""
 
     def __init__(self, width, height, rank, world, block_rows, device, group=None, always_gather=False):
         assert interleave_ok(world, height, block_rows)
