@@ -70,19 +70,21 @@ def interleaved_rows(rank, world, height, block_rows):
 
 
 class InterleavedGather:
-    """One RCCL gather per frame of compact interleaved tiles, double-buffered so that the gather of
-    frame k overlaps the render of frame k+1 (`tile()` hands out the buffer to render into after
+    """One RCCL gather per frame of compact interleaved tiles, multi-buffered so that the gather of
+    frame k overlaps the renders of the following frames (`tile()` hands out the buffer to render into after
     making the CURRENT stream wait for the gather that last read it; `submit()` orders the gather
     after whatever the current stream has enqueued).  Callers that alternate two render streams
     (bench.py) call both inside `with torch.cuda.stream(s)`."""
 
-    def __init__(self, width, height, rank, world, block_rows, device, group=None, always_gather=False):
+    def __init__(self, width, height, rank, world, block_rows, device, group=None, always_gather=False, buffers=3):
         assert interleave_ok(world, height, block_rows)
         self.w, self.h, self.rank, self.world, self.b, self.group = width, height, rank, world, block_rows, group
         self.collective = world > 1 or always_gather  # always_gather: run the collective even at world size 1 (rehearsal)
         self.rows = height // world
-        self.tiles = [torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(2)]
-        self.pending = [None, None]
+        # three tile buffers: the gather of frame k may take until frame k+3's render wants its buffer back
+        self.nbuf = max(2, int(buffers))
+        self.tiles = [torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(self.nbuf)]
+        self.pending = [None] * self.nbuf
         self.k = 0
         self.recv = None
         self.out = None
@@ -91,7 +93,7 @@ class InterleavedGather:
             self.out = torch.empty((height, width, 4), dtype=torch.uint8, device=device)
 
     def tile(self):
-        i = self.k % 2
+        i = self.k % self.nbuf
         if self.pending[i] is not None:
             self.pending[i].wait()  # stream-level wait: the buffer is free again
             self.pending[i] = None
@@ -99,7 +101,7 @@ class InterleavedGather:
 
     def submit(self):
         """Start the gather of the tile handed out by the last tile() call."""
-        i = self.k % 2
+        i = self.k % self.nbuf
         self.k += 1
         if not self.collective:
             return
@@ -108,14 +110,14 @@ class InterleavedGather:
 
     def finish(self):
         """Wait for outstanding gathers; on rank 0 return the assembled (height, width, 4) film."""
-        for i in range(2):
+        for i in range(self.nbuf):
             if self.pending[i] is not None:
                 self.pending[i].wait()
                 self.pending[i] = None
         if self.rank != 0:
             return None
         if not self.collective:
-            return self.tiles[(self.k - 1) % 2]
+            return self.tiles[(self.k - 1) % self.nbuf]
         g = self.h // (self.b * self.world)
         self.out.view(g, self.world, self.b, self.w, 4).copy_(
             self.recv.view(self.world, g, self.b, self.w, 4).permute(1, 0, 2, 3, 4))
