@@ -137,7 +137,7 @@ class HipApi(Api):
         ms = (_C.c_double * 5)(); n = (_C.c_uint64 * 5)()
         if self.call("profile_read_kinds", accel.h, ms, n):
             raise LasgunError(self.last_error())
-        names = ("stream_trace_kernel<primary>", "stream_frame_kernel", "stream_trace_kernel<shadow>", "stream_shade_kernel", "trace_kernel")
+        names = ("stream_trace_kernel<primary>", "(unused)", "stream_trace_kernel<shadow>", "stream_shade_kernel", "trace_kernel")
         return {names[i]: (ms[i], int(n[i])) for i in range(5)}
 
     def profile_enable(self, accel, enabled=True):

@@ -1559,7 +1559,7 @@ __device__ __forceinline__ void park_frame(const DParams &P, unsigned long long 
     f[12 * n] = (double)sh.mat;
 }
 
-// K1 / K3: persistent traversal kernels (tile counter, per-lane LDS stack)
+// K1 / K2: persistent traversal kernels (tile counter, per-lane LDS stack)
 // LDSS: one 1024-lane workgroup per CU (still 4 waves per SIMD) that first copies the scene's
 // node / primref / sphere / cuboid tables into LDS behind the stacks; its waves then pull tiles
 // independently exactly like the 256-lane form.
@@ -1633,7 +1633,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
     }
 }
 
-// K1' / K3': the packet organisation of the same two traversal passes -- one tree walk per wavefront
+// K1' / K2': the packet organisation of the same two traversal passes -- one tree walk per wavefront
 // (traverse_packet).  Lanes whose walk met an exact tie (or a NaN t) get their bit set in P.tie_flag and
 // their tile appended to P.tie_tiles; the FIXUP form of stream_trace_kernel re-traces just those.
 // LDS: [per-wave stacks][scene image (LDSS)].
@@ -1694,8 +1694,8 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
     }
 }
 
-// K3: li() of a non-specular hit from the parked frame and the visibility bits, then the (3 waves/SIMD: measured best)
-// per-pixel sample sum and Img::set (integrate.rs:16-80, img.rs:46-67)
+// K3: li() of a non-specular hit from the parked frame and the visibility bits, then the per-pixel
+// sample sum and Img::set (integrate.rs:16-80, img.rs:46-67).  3 waves per SIMD: measured best (0.97 -> 0.87 ms).
 __global__ void __launch_bounds__(LG_BLOCK, 3) stream_shade_kernel(const DParams P) {
     const unsigned long long widx = (unsigned long long)blockIdx.x * LG_BLOCK + threadIdx.x;
     if (widx >= P.n_items) return;
