@@ -172,7 +172,8 @@ int lg_accel_set_packet(const lg_accel *, int enabled);
 /* Kernel timing with HIP events on the launch stream: enable, render, then read. */
 void lg_profile_enable(const lg_accel *, int enabled);
 int lg_profile_read(const lg_accel *, double *total_ms, uint64_t *launches); /* synchronises; resets the tally */
-/* Streaming pipeline only: per-kernel HIP-event time. kind 0 primary trace, 1 frame, 2 shadow trace, 3 shade. */
+/* Streaming pipeline: per-kernel HIP-event time.  kind 0 primary trace (+ shading frame; with the packet organisation
+ * also its fix-up launch), 1 unused, 2 shadow trace, 3 shade; 4 = the megakernel. */
 int lg_profile_read_kinds(const lg_accel *, double ms[5], uint64_t launches[5]);
 /* lg_capture_stats restricted to one kind of traversal: 0 all, 1 closest-hit (primary/secondary), 2 shadow. */
 int lg_capture_stats_kind(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, int kind, lg_stats *out);
