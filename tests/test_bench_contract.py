@@ -1,0 +1,40 @@
+"""The committed bench line (profiles/r01_final_bench.json, produced by `python bench.py` on the GPU box) carries
+every field of the driver's contract; BASELINE.json's metric string is the one bench.py prints."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r01_final_bench.json")) as f:
+        rows = [l for l in f.read().splitlines() if l.startswith("{")]
+    return json.loads(rows[-1])
+
+
+def test_bench_line_has_the_contract_fields():
+    d = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == "f64" and d["unit"] == "Mrays/s" and d["value"] > 100.0  # north-star floor: 100 Mrays/s
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+
+
+def test_bench_metric_is_baselines_metric():
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    want = base["metric"].replace("×", "x")
+    assert _line()["metric"] == want
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert want in src
