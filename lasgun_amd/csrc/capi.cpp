@@ -131,12 +131,11 @@ struct lg_accel {
     uint32_t stream_blocks = 1, stream_blocks_fast = 1;
     // LDS-resident scene (reference tree only): the tables in their LDS layout, when they fit beside the stacks
     DevBuf<uint32_t> lds_image;
-    uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_prim_off = 0, lds_sph_off = 0, lds_cub_off = 0;
+    uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_prim_off = 0, lds_soup_off = 0;
     uint32_t ldss_blocks = 0;         // one 1024-lane workgroup per CU; 0 = variant unavailable for this scene
     uint32_t packet_blocks = 1;       // grid of the 256-lane packet kernels
     uint32_t cus = 1;                 // compute units of the accel's device
-    DevBuf<uint32_t> pk_image;        // the packet organisation's LDS image (nodes, primrefs, leaf records), when it fits
-    uint32_t pk_image_n16 = 0, pk_prim_off = 0, pk_soup_off = 0;
+    bool packet_lds = false;          // the image fits beside the (64x smaller) per-wave stacks of the packet kernels
     mutable bool lds_scene = true;    // lg_accel_set_lds_scene
     mutable bool packet = false;      // lg_accel_set_packet: one tree walk per wavefront in the streaming traversal kernels
     mutable DevBuf<DStats> stats;
@@ -233,7 +232,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         uint32_t depth = a.fast ? a.stack_depth_fast : a.stack_depth;
         if (!a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS
             P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
-            P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_sph_off = a.lds_sph_off; P.lds_cub_off = a.lds_cub_off;
+            P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off;
             blocks = a.ldss_blocks;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -255,8 +254,9 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         if (packet) {
             if (c.st_tie_flag.n < n || c.st_tie_tiles.n < P.ntiles) { HIP_TRY(hipDeviceSynchronize()); c.st_tie_flag.alloc(n); c.st_tie_tiles.alloc(P.ntiles); }
             P.tie_flag = c.st_tie_flag.p; P.tie_tiles = c.st_tie_tiles.p;
-            if (a.lds_scene && a.pk_image_n16) { // the packet image fits in LDS: one 1024-lane workgroup per CU
-                P.pk_image = a.pk_image.p; P.pk_image_n16 = a.pk_image_n16; P.pk_prim_off = a.pk_prim_off; P.pk_soup_off = a.pk_soup_off;
+            if (a.lds_scene && a.packet_lds) { // the image fits in LDS: one 1024-lane workgroup per CU
+                P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
+                P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off;
                 pblocks = a.cus;
             } else {
                 pblocks = (P.ntiles + 3u) / 4u;
@@ -292,7 +292,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     uint32_t maxb = a.max_blocks > a.max_blocks_fast ? a.max_blocks : a.max_blocks_fast;
     if (!stats && !a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS: one 1024-lane workgroup per CU
         P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
-        P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_sph_off = a.lds_sph_off; P.lds_cub_off = a.lds_cub_off;
+        P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off;
         blocks = a.ldss_blocks;
     }
     if (maxb < a.ldss_blocks * 4u) maxb = a.ldss_blocks * 4u; // per-lane slots below: 1024 lanes per LDS-scene workgroup
@@ -578,59 +578,44 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
             };
             std::vector<std::pair<uint32_t, uint32_t>> nruns, pruns; // (global base, compact base) of each reference tree, once
             uint32_t nn = 0, np = 0;
-            for (DAccel &A : fm.accels) {
+            // compact numbering: the non-mesh accels first (their slots get a leaf record in the image), then the meshes
+            uint32_t np_soup = 0; // slots of the non-mesh accels
+            for (int pass = 0; pass < 2; ++pass) {
+              if (pass == 1) np_soup = np;
+              for (DAccel &A : fm.accels) {
+                if (((A.flags & AF_MESH) != 0u) != (pass == 1)) continue;
                 auto fn = std::find_if(nruns.begin(), nruns.end(), [&](auto &r) { return r.first == A.node_base; });
                 if (fn == nruns.end()) { nruns.emplace_back(A.node_base, nn); A.lnode_base = nn; nn += extent(nb, A.node_base, fm.nodes.size()); }
                 else A.lnode_base = fn->second;
                 auto fp = std::find_if(pruns.begin(), pruns.end(), [&](auto &r) { return r.first == A.prim_base; });
                 if (fp == pruns.end()) { pruns.emplace_back(A.prim_base, np); A.lprim_base = np; np += extent(pb, A.prim_base, fm.primref.size()); }
                 else A.lprim_base = fp->second;
+              }
             }
-            const size_t stack_bytes = (size_t)a->stack_depth * 1024 * 4; // per-lane stacks (the packet form needs 64x less)
-            const size_t ns = fm.spheres.size(), nc = fm.cuboids.size();
+            const size_t stack_bytes = (size_t)a->stack_depth * 1024 * 4; // per-lane stacks of the private walks
+            const size_t wave_stacks = (size_t)a->stack_depth * 16 * 16;  // per-wave stacks of the packet walk
             const size_t prim16 = ((size_t)np + 3) / 4;
-            {
-                const uint32_t nstride = LDS_NODE_STRIDE, sstride = LDS_SPH_STRIDE;
-                size_t n16 = (size_t)nn * nstride + prim16 + ns * sstride + nc * 3;
-                if (stack_bytes + n16 * 16 <= LDS_MAX) {
-                    std::vector<uint32_t> img(n16 * 4, 0u);
-                    a->lds_node_off = 0;
-                    for (auto &r : nruns)
-                        for (uint32_t i = 0, e = extent(nb, r.first, fm.nodes.size()); i < e; ++i)
-                            std::memcpy(&img[((size_t)(r.second + i) * nstride) * 4], &fm.nodes[r.first + i], 56);
-                    a->lds_prim_off = nn * nstride;
-                    for (auto &r : pruns)
-                        for (uint32_t i = 0, e = extent(pb, r.first, fm.primref.size()); i < e; ++i)
-                            img[(size_t)a->lds_prim_off * 4 + r.second + i] = fm.primref[r.first + i];
-                    a->lds_sph_off = a->lds_prim_off + (uint32_t)prim16;
-                    for (size_t i = 0; i < ns; ++i) std::memcpy(&img[((size_t)a->lds_sph_off + i * sstride) * 4], &fm.spheres[i], 32);
-                    a->lds_cub_off = a->lds_sph_off + (uint32_t)(ns * sstride);
-                    for (size_t i = 0; i < nc; ++i) std::memcpy(&img[((size_t)a->lds_cub_off + i * 3) * 4], &fm.cuboids[i], 48);
-                    a->lds_image.upload(img);
-                    a->lds_image_n16 = (uint32_t)n16;
-                    HIP_TRY(stream_trace_ldss_prepare(LDS_MAX));
-                    a->ldss_blocks = (uint32_t)cus;
-                }
-            }
-            {   // packet image: [nodes, 4 units each][primrefs][leaf records, 3 units per slot], behind 16 per-wave stacks
-                const size_t wave_stacks = (size_t)a->stack_depth * 16 * 16;
-                const size_t n16 = (size_t)nn * 4 + prim16 + (size_t)np * 3;
-                if (wave_stacks + n16 * 16 <= LDS_MAX) {
-                    std::vector<uint32_t> img(n16 * 4, 0u);
-                    for (auto &r : nruns)
-                        for (uint32_t i = 0, e = extent(nb, r.first, fm.nodes.size()); i < e; ++i)
-                            std::memcpy(&img[(size_t)(r.second + i) * 16], &fm.nodes[r.first + i], 56);
-                    a->pk_prim_off = nn * 4u;
-                    a->pk_soup_off = a->pk_prim_off + (uint32_t)prim16;
-                    for (auto &r : pruns)
-                        for (uint32_t i = 0, e = extent(pb, r.first, fm.primref.size()); i < e; ++i) {
-                            img[(size_t)a->pk_prim_off * 4 + r.second + i] = fm.primref[r.first + i];
-                            std::memcpy(&img[((size_t)a->pk_soup_off + (size_t)(r.second + i) * 3) * 4], &fm.leaf_soup[r.first + i], 48);
-                        }
-                    a->pk_image.upload(img);
-                    a->pk_image_n16 = (uint32_t)n16;
-                    HIP_TRY(stream_trace_ldss_prepare(LDS_MAX));
-                }
+            // image: [nodes, LDS_NODE_STRIDE units each][primrefs][leaf records, 3 units per slot]
+            const size_t n16 = (size_t)nn * LDS_NODE_STRIDE + prim16 + (size_t)np_soup * 3;
+            if (wave_stacks + n16 * 16 <= LDS_MAX) {
+                std::vector<uint32_t> img(n16 * 4, 0u);
+                a->lds_node_off = 0;
+                for (auto &r : nruns)
+                    for (uint32_t i = 0, e = extent(nb, r.first, fm.nodes.size()); i < e; ++i)
+                        std::memcpy(&img[((size_t)(r.second + i) * LDS_NODE_STRIDE) * 4], &fm.nodes[r.first + i], 56);
+                a->lds_prim_off = nn * LDS_NODE_STRIDE;
+                a->lds_soup_off = a->lds_prim_off + (uint32_t)prim16;
+                for (auto &r : pruns)
+                    for (uint32_t i = 0, e = extent(pb, r.first, fm.primref.size()); i < e; ++i) {
+                        img[(size_t)a->lds_prim_off * 4 + r.second + i] = fm.primref[r.first + i];
+                        if (r.second + i < np_soup)
+                            std::memcpy(&img[((size_t)a->lds_soup_off + (size_t)(r.second + i) * 3) * 4], &fm.leaf_soup[r.first + i], 48);
+                    }
+                a->lds_image.upload(img);
+                a->lds_image_n16 = (uint32_t)n16;
+                HIP_TRY(stream_trace_ldss_prepare(LDS_MAX));
+                a->packet_lds = true;
+                if (stack_bytes + n16 * 16 <= LDS_MAX) a->ldss_blocks = (uint32_t)cus;
             }
             a->accels.upload(fm.accels); // again, now with the compact bases
         }

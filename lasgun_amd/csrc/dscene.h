@@ -30,9 +30,9 @@ constexpr uint32_t PRIM_INDEX_MASK = 0x3FFFFFFFu;
 constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
 constexpr int MAX_CHAIN = 8;      // scene-graph nesting levels (root = 1)
 constexpr uint32_t NODE_LEAF = 0x80000000u;
-// LDS-resident scene image: record strides in 16-byte units.  80-byte nodes and 48-byte spheres make 16 consecutive
-// records start in 16 different bank groups; compile-time constants so that indexing is a shift and an add.
-constexpr uint32_t LDS_NODE_STRIDE = 5u, LDS_SPH_STRIDE = 3u;
+// LDS-resident scene image: node stride in 16-byte units.  80-byte nodes (and the 48-byte leaf records) make 16
+// consecutive records start in 16 different bank groups; a compile-time constant so that indexing is a shift and an add.
+constexpr uint32_t LDS_NODE_STRIDE = 5u;
 
 struct alignas(64) DNode {
     double bmin[3];
@@ -176,12 +176,7 @@ struct DParams {
     uint32_t lds_image_n16;
     uint32_t lds_node_off;                  // DNode without its pad, LDS_NODE_STRIDE units per node
     uint32_t lds_prim_off;                  // primref[] as dwords from here
-    uint32_t lds_sph_off;                   // DSphere, LDS_SPH_STRIDE units per sphere
-    uint32_t lds_cub_off;                   // DCuboid: 3 units per cuboid
-    // the packet organisation's image (uniform reads: nothing to pad): nodes at 4 units from 0, primref[] as dwords
-    // from pk_prim_off, one 3-unit leaf record per primref slot from pk_soup_off
-    const void *pk_image;
-    uint32_t pk_image_n16, pk_prim_off, pk_soup_off;
+    uint32_t lds_soup_off;                  // one 3-unit (48-byte) leaf record per primref slot
     uint32_t stats_filter;      // counting variant: 0 = all traversals, 1 = closest-hit (primary/secondary) only, 2 = shadow only
 };
 

@@ -298,8 +298,9 @@ __device__ __forceinline__ Ray local_ray(const DParams &P, const Ray &wray, uint
 // ---- scene table access: HBM/L2 tables, or (LDSS) the copy a 1024-lane workgroup holds in LDS.
 // Lanes of a wave read DIFFERENT records, 56 bytes per node visit: through the vector L1 that is
 // 64 B/clk per CU and the traversal kernels were bound by it as much as by VALU issue; the LDS
-// delivers 256 B/clk per CU at a third of the latency.  Records are padded to 80 B (nodes) and
-// 48 B (spheres) so that 16 consecutive records start in 16 different bank groups.
+// delivers 256 B/clk per CU at a third of the latency.  Image: nodes padded to 80 B, primrefs, and one 48-byte
+// leaf record per primref slot (sphere c, r / cuboid min, max / triangle positions): 16 consecutive records of
+// either kind start in 16 different bank groups.
 struct NodeRec {
     double bmin[3], bmax[3];
     uint32_t link, meta;
@@ -339,19 +340,21 @@ __device__ __forceinline__ uint32_t load_primref(const DParams &P, const uint4 *
     if (LDSS) return reinterpret_cast<const uint32_t *>(scn + P.lds_prim_off)[i];
     return P.primref[i];
 }
+// LDSS: the geometry comes from the leaf-ordered record of the SLOT (same index as its primref), not from the
+// per-kind table: the primref and its geometry are fetched side by side instead of one after the other
 template <bool LDSS>
-__device__ __forceinline__ DSphere load_sphere(const DParams &P, const uint4 *scn, uint32_t idx) {
+__device__ __forceinline__ DSphere load_sphere(const DParams &P, const uint4 *scn, uint32_t idx, uint32_t slot) {
     if (LDSS) {
-        const uint4 *q = scn + (P.lds_sph_off + idx * LDS_SPH_STRIDE);
+        const uint4 *q = scn + (P.lds_soup_off + slot * 3u);
         uint4 a = q[0], b = q[1];
         return DSphere{u2d(a.x, a.y), u2d(a.z, a.w), u2d(b.x, b.y), u2d(b.z, b.w)};
     }
     return P.spheres[idx];
 }
 template <bool LDSS>
-__device__ __forceinline__ DCuboid load_cuboid(const DParams &P, const uint4 *scn, uint32_t idx) {
+__device__ __forceinline__ DCuboid load_cuboid(const DParams &P, const uint4 *scn, uint32_t idx, uint32_t slot) {
     if (LDSS) {
-        const uint4 *q = scn + (P.lds_cub_off + idx * 3u);
+        const uint4 *q = scn + (P.lds_soup_off + slot * 3u);
         uint4 a = q[0], b = q[1], c = q[2];
         DCuboid cb;
         cb.mn[0] = u2d(a.x, a.y); cb.mn[1] = u2d(a.z, a.w); cb.mn[2] = u2d(b.x, b.y);
@@ -396,8 +399,8 @@ struct Trav {
     bool tie;            // fast mode: two primitives produced exactly the same t
     uint32_t negmask;    // bit a set <=> dinv[a] < 0 (dir_is_neg, bvh.rs:463)
     bool mesh;           // current accel is a triangle mesh (every leaf slot is a triangle)
+    uint32_t soup_delta; // LDS-resident scene: leaf_soup slot (global numbering) = compact slot + this; mesh records stay in HBM/L2
     double dd;           // dot(ray.d, ray.d) (reference traversal only)
-    uint32_t soup_delta; // LDS-resident scene: leaf_soup slot = compact primref index + this
     TriSetup tri;        // valid while `mesh`
 };
 template <bool FAST, bool LDSS = false>
@@ -433,7 +436,7 @@ __device__ __forceinline__ void mesh_leaf(const DParams &P, const uint4 *scn, Tr
     const double sx = T.tri.sx, sy = T.tri.sy, sz = T.tri.sz;
     uint32_t li = T.li;
     const uint32_t le = T.le, last = le - 1u;
-    const uint32_t sd = LDSS ? T.soup_delta : 0u;
+    const uint32_t sd = LDSS ? T.soup_delta : 0u; // triangle records are streamed from HBM / L2 in either form
     LeafRec cur = load_rec(P, li + sd);
     for (; li < le; ++li) {
         LeafRec r = cur;
@@ -624,14 +627,14 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
                 if (kind == PK_SPHERE) {
                     if (STATS) cnt.spheres++;
                     bool inside;
-                    DSphere sp = load_sphere<LDSS>(P, scn, idx);
+                    DSphere sp = load_sphere<LDSS>(P, scn, idx, T.li - 1u);
                     // d.d once per accel level in the reference traversal (39 sphere tests per ray in config 3: +0.7 %);
                     // the fast traversal tests few spheres and is better off with the two registers (measured)
                     t = FAST ? sphere_t(T.ray, V3{sp.cx, sp.cy, sp.cz}, sp.r, inside) : sphere_t_a(T.ray, T.dd, V3{sp.cx, sp.cy, sp.cz}, sp.r, inside);
                     accepted = !(t < 0.0) && !(t >= best.t);
                 } else if (kind == PK_CUBOID) {
                     if (STATS) cnt.cuboids++;
-                    DCuboid cb = load_cuboid<LDSS>(P, scn, idx);
+                    DCuboid cb = load_cuboid<LDSS>(P, scn, idx, T.li - 1u);
                     double mn[3] = {cb.mn[0], cb.mn[1], cb.mn[2]}, mx[3] = {cb.mx[0], cb.mx[1], cb.mx[2]};
                     V3 d0, d1;
                     if (cuboid_hit<false>(mn, mx, T.ray, t, d0, d1)) accepted = !(t >= best.t);
@@ -704,33 +707,25 @@ constexpr uint32_t PKT_ENTRY = 4u; // dwords per wave-stack entry: {a, b, mask l
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
     return (unsigned long long)uni((uint32_t)v) | ((unsigned long long)uni((uint32_t)(v >> 32)) << 32);
 }
-// Records of the packet walk.  LDSS: the packet image in LDS (DParams::pk_*: nodes at 64-byte stride, primrefs,
-// then one 48-byte leaf record per primref slot, all in the compact numbering of DAccel::lnode_base / lprim_base;
-// every lane reads the SAME address, so there is nothing to pad against bank conflicts).  Otherwise the same
-// tables in HBM / L2, again with wave-uniform addresses: one request per record and wave.
+// Records of the packet walk: the same LDS image as the private walks (every lane reads the SAME address here,
+// so its padding is irrelevant), or the tables in HBM / L2 with wave-uniform addresses: one request per record and wave.
 template <bool LDSS>
-__device__ __forceinline__ NodeRec pkt_node(const DParams &P, const uint4 *scn, uint32_t idx) {
-    if (!LDSS) return load_node<false>(P, nullptr, idx);
-    NodeRec n;
-    const uint4 *q = scn + idx * 4u;
-    uint4 a = q[0], b = q[1], c = q[2];
-    uint2 d = *reinterpret_cast<const uint2 *>(q + 3);
-    n.bmin[0] = u2d(a.x, a.y); n.bmin[1] = u2d(a.z, a.w); n.bmin[2] = u2d(b.x, b.y);
-    n.bmax[0] = u2d(b.z, b.w); n.bmax[1] = u2d(c.x, c.y); n.bmax[2] = u2d(c.z, c.w);
-    n.link = d.x; n.meta = d.y;
-    return n;
-}
+__device__ __forceinline__ NodeRec pkt_node(const DParams &P, const uint4 *scn, uint32_t idx) { return load_node<LDSS>(P, scn, idx); }
 struct SlotRec { // one leaf slot: its primref and its 48-byte geometry record
     uint32_t ref;
     LeafRec g;
 };
 template <bool LDSS>
-__device__ __forceinline__ SlotRec pkt_slot(const DParams &P, const uint4 *scn, uint32_t slot) {
+__device__ __forceinline__ SlotRec pkt_slot(const DParams &P, const uint4 *scn, uint32_t slot, bool mesh, uint32_t soup_delta) {
     SlotRec r;
     if (LDSS) {
-        r.ref = reinterpret_cast<const uint32_t *>(scn + P.pk_prim_off)[slot];
-        const uint4 *q = scn + (P.pk_soup_off + slot * 3u);
-        r.g = LeafRec{q[0], q[1], q[2]};
+        r.ref = reinterpret_cast<const uint32_t *>(scn + P.lds_prim_off)[slot];
+        if (mesh) { // triangle records are not part of the LDS image
+            r.g = load_rec(P, slot + soup_delta);
+        } else {
+            const uint4 *q = scn + (P.lds_soup_off + slot * 3u);
+            r.g = LeafRec{q[0], q[1], q[2]};
+        }
     } else {
         r.ref = P.primref[slot];
         r.g = load_rec(P, slot);
@@ -748,6 +743,7 @@ __device__ __forceinline__ SlotRec pkt_slot(const DParams &P, const uint4 *scn, 
         dd = dot(ray.d, ray.d);                                                                                        \
         node_base = uni(LDSS ? A_->lnode_base : A_->node_base);                                                        \
         prim_base = uni(LDSS ? A_->lprim_base : A_->prim_base);                                                        \
+        soup_delta = uni(LDSS ? A_->prim_base - A_->lprim_base : 0u);                                                  \
         mesh = (uni(A_->flags) & AF_MESH) != 0u;                                                                       \
         negbits = (ray.dinv.x < 0.0 ? 1u : 0u) | (ray.dinv.y < 0.0 ? 2u : 0u) | (ray.dinv.z < 0.0 ? 4u : 0u);          \
     } while (0)
@@ -778,7 +774,7 @@ __device__ __forceinline__ void traverse_packet(const DParams &P, const uint4 *s
     unsigned long long alive_m = __ballot(alive);
     if (alive_m == 0ull) return;
     // ---- level state: wave-uniform except the rays
-    uint32_t accel = 0u, node_base = 0u, prim_base = 0u;
+    uint32_t accel = 0u, node_base = 0u, prim_base = 0u, soup_delta = 0u;
     bool mesh = false;
     Ray ray;
     double dd = 0.0;
@@ -834,13 +830,13 @@ __device__ __forceinline__ void traverse_packet(const DParams &P, const uint4 *s
                     kz0 = __ballot(tri.kz == 0); kz1 = __ballot(tri.kz == 1); kz2 = __ballot(tri.kz == 2);
                 }
                 const uint32_t last = le - 1u;
-                SlotRec nxt = pkt_slot<LDSS>(P, scn, li);
+                SlotRec nxt = pkt_slot<LDSS>(P, scn, li, mesh, soup_delta);
                 while (li < le) {
                     li = uni(li); lm = uni64(lm);
                     const SlotRec s = nxt;
                     const uint32_t slot = li;
                     ++li;
-                    nxt = pkt_slot<LDSS>(P, scn, li < last ? li : last); // prefetch (clamped: always a valid slot)
+                    nxt = pkt_slot<LDSS>(P, scn, li < last ? li : last, mesh, soup_delta); // prefetch (clamped: always a valid slot)
                     const uint32_t ref = uni(s.ref);
                     const uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
                     const bool in = lane_in(lm, lane);
@@ -1645,8 +1641,8 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
     const uint4 *scn = nullptr;
     if (LDSS) {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_stack + (block / 64u) * P.stack_depth * PKT_ENTRY);
-        const uint4 *src = reinterpret_cast<const uint4 *>(P.pk_image);
-        for (uint32_t i = tid; i < P.pk_image_n16; i += block) dst[i] = src[i];
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.lds_image);
+        for (uint32_t i = tid; i < P.lds_image_n16; i += block) dst[i] = src[i];
         __syncthreads();
         scn = dst;
     }
@@ -1862,9 +1858,9 @@ hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, bool fi
     return hipGetLastError();
 }
 hipError_t launch_stream_packet(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream) {
-    const bool ldss = P.pk_image != nullptr;
+    const bool ldss = P.lds_image != nullptr;
     const uint32_t block = ldss ? LG_LDSS_BLOCK : LG_BLOCK;
-    size_t lds = (size_t)(block / 64u) * P.stack_depth * PKT_ENTRY * sizeof(uint32_t) + (ldss ? (size_t)P.pk_image_n16 * 16u : 0u);
+    size_t lds = (size_t)(block / 64u) * P.stack_depth * PKT_ENTRY * sizeof(uint32_t) + (ldss ? (size_t)P.lds_image_n16 * 16u : 0u);
     if (ldss) { if (shadow) hipLaunchKernelGGL((stream_packet_kernel<true, true>), dim3(blocks), dim3(block), lds, stream, P);
                 else hipLaunchKernelGGL((stream_packet_kernel<false, true>), dim3(blocks), dim3(block), lds, stream, P); }
     else { if (shadow) hipLaunchKernelGGL((stream_packet_kernel<true, false>), dim3(blocks), dim3(block), lds, stream, P);
