@@ -142,8 +142,10 @@ int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t
 /* Traversal mode of an accel.  0 (default) = the reference's own traversal over the reference's
  * own BVH: the parity path.  1 = opt-in FAST mode: a binned-SAH BVH (<= 4 primitives per leaf)
  * over the same primitives, front-to-back with pruning beyond the best hit; same primitive tests
- * and arithmetic, exact ties in t re-traced with the reference traversal.  Verified byte-identical
- * to mode 0 on every test scene and benchmark config, but not PROVEN identical. */
+ * and arithmetic.  Its winner is put to the reference tree's own box tests (leaf to root, through every
+ * nested accel); a winner that fails them, or an exact tie in t, re-traces the ray with the reference
+ * traversal.  Verified byte-identical to mode 0 on every test, benchmark config, fuzz and adversarial
+ * scene; its two rounding margins are argued, not PROVEN. */
 int lg_accel_set_mode(const lg_accel *, int mode);
 
 /* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes without
@@ -185,6 +187,12 @@ void lg_aggregate_get_transform(lg_aggregate *, double m[16], double minv[16]);
 /* Host-only HLBVH build + flatten of a scene, no device needed: structure dump + counts
  * (nodes, primrefs, spheres, cuboids, triangles, accels, max_stack, has_specular). */
 int lg_host_build_dump(const lg_scene *, const double **f, size_t *nf, const int64_t **i, size_t *ni, uint64_t info[8]);
+
+/* One pixel traced by a single lane (sample 0): out = { t, primref, accel instance, number of lights, then per light
+ * the shadow ray's { t, primref }, then the shadow rays' origin (3) } -- primref is 4294967295 for "no hit"; out_len >=
+ * 7 + 2 * lights.  `fast` selects the traversal mode.
+ * A debugging / test hook: it is how a film difference is traced back to the ray that caused it. */
+int lg_trace_pixel(const lg_accel *, uint32_t width, uint32_t height, uint32_t x, uint32_t y, int fast, double *out, size_t out_len);
 
 /* Known-answer and arithmetic probes: run the DEVICE intersectors / math on one thread. */
 int lg_kat_intersect(int kind, const double *params, const char *obj_text, size_t obj_len, const double origin[3],

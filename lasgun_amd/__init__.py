@@ -45,6 +45,7 @@ _EXTRA = {
     "capture_stats_kind": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_int, _C.POINTER(CStats)]),
     "profile_read": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.c_double), _C.POINTER(_C.c_uint64)]),
     "accel_info": (_C.c_int, [_C.c_void_p, _C.c_uint64 * 8]),
+    "trace_pixel": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_int, _C.POINTER(_C.c_double), _C.c_size_t]),
     "host_build_dump": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.POINTER(_C.c_double)), _C.POINTER(_C.c_size_t),
                                    _C.POINTER(_C.POINTER(_C.c_int64)), _C.POINTER(_C.c_size_t), _C.c_uint64 * 8]),
 }
@@ -81,6 +82,16 @@ class HipApi(Api):
     def set_device(self, device):
         if self.call("set_device", int(device)):
             raise LasgunError(self.last_error())
+
+    def trace_pixel(self, accel, w, h, x, y, fast=False, max_lights=64):
+        """{"t", "ref", "accel", "shadow": [(t, ref), ...]} of pixel (x, y), sample 0 (debugging / test hook)."""
+        n = 7 + 2 * max_lights
+        out = (_C.c_double * n)()
+        if self.call("trace_pixel", accel.h, int(w), int(h), int(x), int(y), 1 if fast else 0, out, n):
+            raise LasgunError(self.last_error())
+        nl = int(out[3])
+        return {"t": out[0], "ref": int(out[1]), "accel": int(out[2]), "shadow": [(out[4 + 2 * l], int(out[5 + 2 * l])) for l in range(nl)],
+                "shadow_origin": [out[4 + 2 * nl], out[5 + 2 * nl], out[6 + 2 * nl]]}
 
     def set_devices(self, ids=None):
         """Devices a host-film `capture` / `render` is split over (None or [] = every visible device)."""

@@ -29,6 +29,7 @@ hipError_t launch_kat(int kind, const double *params, const float *vpos, const u
                       hipStream_t stream);
 hipError_t launch_kat_si(V3 o, V3 d, double t, V3 dpdu, V3 dpdv, double *out, hipStream_t stream);
 hipError_t launch_math(int op, size_t n, const double *a, const double *b, double *out, hipStream_t stream);
+hipError_t launch_trace_pixel(const DParams &P, bool fast, uint32_t stack_depth, uint32_t x, uint32_t y, double *out, hipStream_t stream);
 } // namespace lg
 
 using namespace lg;
@@ -106,6 +107,7 @@ struct lg_accel {
     DevBuf<uint32_t> tri_v, tri_n, tri_t;
     DevBuf<float> vpos, vnorm, vtex;
     DevBuf<DLeafRec> leaf_soup;
+    DevBuf<uint32_t> node_parent, sphere_ref_leaf, cuboid_ref_leaf, tri_ref_leaf, accel_ref_leaf;
     DevBuf<DAccel> accels;
     DevBuf<DMaterial> materials;
     DevBuf<DLight> lights;
@@ -188,7 +190,8 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     DParams P{};
     P.nodes = a.nodes.p; P.nodes2 = a.nodes2.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
     P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
-    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.accels = a.accels.p; P.materials = a.materials.p;
+    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.node_parent = a.node_parent.p; P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
+    P.tri_ref_leaf = a.tri_ref_leaf.p; P.accel_ref_leaf = a.accel_ref_leaf.p; P.accels = a.accels.p; P.materials = a.materials.p;
     P.lights = a.lights.p;
     P.nlights = (uint32_t)a.flat.lights.size();
     P.recursion = s.recursion;
@@ -525,7 +528,8 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
         const FlatScene &f = a->flat;
         a->nodes.upload(f.nodes); a->nodes2.upload(f.nodes2); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
-        a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
+        a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->node_parent.upload(f.node_parent); a->sphere_ref_leaf.upload(f.sphere_ref_leaf); a->cuboid_ref_leaf.upload(f.cuboid_ref_leaf);
+        a->tri_ref_leaf.upload(f.tri_ref_leaf); a->accel_ref_leaf.upload(f.accel_ref_leaf); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
         a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
         a->stats.alloc(1);
         a->device_bytes = f.nodes.size() * (sizeof(DNode) + sizeof(DNode2)) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
@@ -927,6 +931,23 @@ int lg_kat_surface_interaction(const double o[3], const double d[3], double t, c
         dout.alloc(3);
         HIP_TRY(launch_kat_si(V3{o[0], o[1], o[2]}, V3{d[0], d[1], d[2]}, t, V3{dpdu[0], dpdu[1], dpdu[2]}, V3{dpdv[0], dpdv[1], dpdv[2]}, dout.p, nullptr));
         HIP_TRY(hipMemcpy(out_ng, dout.p, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+int lg_trace_pixel(const lg_accel *a, uint32_t w, uint32_t h, uint32_t x, uint32_t y, int fast, double *out, size_t out_len) {
+    return guarded([&] {
+        if (x >= w || y >= h) throw Error("pixel outside the film");
+        std::lock_guard<std::mutex> g(a->mtx);
+        use_device(a->device);
+        const size_t need = 7 + 2 * a->flat.lights.size();
+        if (out_len < need) throw Error("output too small: 7 + 2 * lights doubles");
+        if (fast && !a->fast_available) throw Error("fast mode unavailable for this scene");
+        DParams P = base_params(*a, w, h);
+        DevBuf<double> dout;
+        dout.alloc(need);
+        HIP_TRY(hipMemset(dout.p, 0, need * sizeof(double)));
+        HIP_TRY(launch_trace_pixel(P, fast != 0, fast ? a->stack_depth_fast : a->stack_depth, x, y, dout.p, a->stream));
+        HIP_TRY(hipMemcpyAsync(out, dout.p, need * sizeof(double), hipMemcpyDeviceToHost, a->stream));
+        HIP_TRY(hipStreamSynchronize(a->stream));
     });
 }
 int lg_math_eval(int op, size_t n, const double *a, const double *b, double *out) {

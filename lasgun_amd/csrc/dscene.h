@@ -123,6 +123,9 @@ struct DParams {
     const float *vnorm;
     const float *vtex;
     const DLeafRec *leaf_soup; // slot j <-> primref[j]
+    // fast mode's candidate check (host.h): reference-tree parents; reference leaf of every sphere / cuboid / triangle / accel
+    const uint32_t *node_parent;
+    const uint32_t *sphere_ref_leaf, *cuboid_ref_leaf, *tri_ref_leaf, *accel_ref_leaf;
     const DAccel *accels;
     const DMaterial *materials;
     const DLight *lights;

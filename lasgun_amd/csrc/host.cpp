@@ -617,6 +617,43 @@ struct Flattener {
         }
     }
 
+    // parents of the reference tree just appended at node_base (fast mode's candidate check walks leaf -> root)
+    void record_parents(const BuiltBVH &bvh, uint32_t node_base) {
+        out.node_parent.resize(out.nodes.size(), NO_HIT);
+        for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+            const LinNode &n = bvh.nodes[i];
+            if (n.leaf) continue;
+            out.node_parent[node_base + i + 1] = (uint32_t)i;
+            out.node_parent[node_base + n.c] = (uint32_t)i;
+        }
+    }
+    // reference leaf of every primitive (NO_HIT for primitives the reference never tests: beyond a leaf's u16 count)
+    static std::vector<uint32_t> ref_leaf_of_prims(const BuiltBVH &bvh, size_t nprims) {
+        std::vector<uint32_t> leaf(nprims, NO_HIT);
+        for (size_t i = 0; i < bvh.nodes.size(); ++i) {
+            const LinNode &n = bvh.nodes[i];
+            if (!n.leaf) continue;
+            for (uint32_t k = 0; k < (n.c & 0xFFFFu); ++k) leaf[bvh.order[n.a + k]] = (uint32_t)i;
+        }
+        return leaf;
+    }
+    // boxes of the fast tree: the primitive boxes pushed out by 1e-9 of the accel's extent, so that a ray the reference
+    // tree lets through to a primitive (its leaf boxes are unions, hence looser) is not lost at a tight fast-tree box
+    // by a rounding-sized margin; what the looser boxes let through in excess is removed by the candidate check
+    static std::vector<Bounds> inflated(const std::vector<Bounds> &pb) {
+        double ext = 0.0;
+        for (const Bounds &b : pb)
+            for (int a = 0; a < 3; ++a) {
+                double lo = std::fabs(comp(b.min, a)), hi = std::fabs(comp(b.max, a));
+                if (std::isfinite(lo) && lo > ext) ext = lo;
+                if (std::isfinite(hi) && hi > ext) ext = hi;
+            }
+        const double e = ext * 1e-9 + 1e-300;
+        std::vector<Bounds> r = pb;
+        for (Bounds &b : r) { b.min = b.min - V3{e, e, e}; b.max = b.max + V3{e, e, e}; }
+        return r;
+    }
+
     void dump(const BuiltBVH &bvh, bool has_mat, bool swap, const Transform &t) {
         auto &f = out.dump_f; auto &i = out.dump_i;
         i.push_back((int64_t)bvh.nodes.size()); i.push_back((int64_t)bvh.order.size());
@@ -661,6 +698,10 @@ struct Flattener {
         }
         mt.bvh = Builder(pb, nf).run();
         append_nodes(mt.bvh, mt.node_base);
+        record_parents(mt.bvh, mt.node_base);
+        const std::vector<uint32_t> ref_leaf = ref_leaf_of_prims(mt.bvh, nf);
+        out.tri_ref_leaf.resize((size_t)mt.tri_base + nf, NO_HIT);
+        for (size_t f = 0; f < nf; ++f) out.tri_ref_leaf[mt.tri_base + f] = ref_leaf[f];
         mt.prim_base = (uint32_t)out.primref.size();
         out.leaf_soup.resize(mt.prim_base, DLeafRec{}); // keep slot j of the soup aligned with primref[j]
         for (uint32_t o : mt.bvh.order) {
@@ -677,7 +718,8 @@ struct Flattener {
         std::vector<uint32_t> refs(mt.bvh.order.size(), 0);
         mt.max_stack = stack_need(mt.bvh.nodes, refs, [](uint32_t) { return 0u; });
         {   // fast tree over the same triangles
-            BuiltBVH fb = FastBuilder(pb).run();
+            const std::vector<Bounds> pbf = inflated(pb);
+            BuiltBVH fb = FastBuilder(pbf).run();
             append_nodes(fb, mt.fnode_base);
             mt.fprim_base = (uint32_t)out.primref.size();
             out.leaf_soup.resize(mt.fprim_base, DLeafRec{});
@@ -792,6 +834,17 @@ struct Flattener {
         BuiltBVH bvh = Builder(pb, n).run();
         uint32_t node_base;
         append_nodes(bvh, node_base);
+        record_parents(bvh, node_base);
+        const std::vector<uint32_t> ref_leaf = ref_leaf_of_prims(bvh, n);
+        out.accel_ref_leaf.resize(out.accels.size(), NO_HIT);
+        out.sphere_ref_leaf.resize(out.spheres.size(), NO_HIT);
+        out.cuboid_ref_leaf.resize(out.cuboids.size(), NO_HIT);
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t kind = ref[i] >> 30, idx = ref[i] & PRIM_INDEX_MASK;
+            if (kind == PK_ACCEL) out.accel_ref_leaf[idx] = ref_leaf[i];
+            else if (kind == PK_SPHERE) out.sphere_ref_leaf[idx] = ref_leaf[i];
+            else if (kind == PK_CUBOID) out.cuboid_ref_leaf[idx] = ref_leaf[i];
+        }
         uint32_t prim_base = (uint32_t)out.primref.size();
         std::vector<uint32_t> extra_in_order(bvh.order.size());
         out.leaf_soup.resize(prim_base, DLeafRec{});
@@ -805,7 +858,8 @@ struct Flattener {
         need = stack_need(bvh.nodes, extra_in_order, [](uint32_t e) { return e; });
         bound = b_transform(agg.transform.m, bvh.nodes[0].b);
         {   // fast tree over the same primitives (child accels included as primitives)
-            BuiltBVH fb = FastBuilder(pb).run();
+            const std::vector<Bounds> pbf = inflated(pb);
+            BuiltBVH fb = FastBuilder(pbf).run();
             uint32_t fnode_base;
             append_nodes(fb, fnode_base);
             uint32_t fprim_base = (uint32_t)out.primref.size();
@@ -845,6 +899,11 @@ void flatten_scene(const Scene &scene, FlatScene &out) {
     out.max_stack = need;
     out.max_stack_fast = fneed;
     out.leaf_soup.resize(out.primref.size(), DLeafRec{});
+    out.sphere_ref_leaf.resize(out.spheres.size(), NO_HIT);
+    out.cuboid_ref_leaf.resize(out.cuboids.size(), NO_HIT);
+    out.tri_ref_leaf.resize(out.tri_v.size() / 3, NO_HIT);
+    out.node_parent.resize(out.nodes.size(), NO_HIT);
+    out.accel_ref_leaf.resize(out.accels.size(), NO_HIT);
     for (const Light &l : scene.lights) {
         DLight d;
         std::memcpy(d.pos, l.pos, sizeof d.pos);

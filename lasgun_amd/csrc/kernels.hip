@@ -69,7 +69,7 @@ __device__ __forceinline__ bool slab_intersects(const double bmin[3], const doub
 }
 
 // the same test, also handing back its tnear (used by the fast mode's front-to-back pruning)
-__device__ __forceinline__ bool slab_intersects_t(const double bmin[3], const double bmax[3], const Ray &r, double &tnear_out) {
+__device__ __forceinline__ bool slab_intersects_t(const double bmin[3], const double bmax[3], const Ray &r, double &tnear_out, double &tfar_out) {
     double t1 = (bmin[0] - r.o.x) * r.dinv.x, t2 = (bmax[0] - r.o.x) * r.dinv.x;
     double tnear = fmax_(-INFINITY, fmin_(t1, t2));
     double tfar = fmin_(INFINITY, fmax_(t1, t2));
@@ -79,7 +79,7 @@ __device__ __forceinline__ bool slab_intersects_t(const double bmin[3], const do
     t1 = (bmin[2] - r.o.z) * r.dinv.z; t2 = (bmax[2] - r.o.z) * r.dinv.z;
     tnear = fmax_(tnear, fmin_(t1, t2));
     tfar = fmin_(tfar, fmax_(t1, t2));
-    tnear_out = tnear;
+    tnear_out = tnear; tfar_out = tfar;
     return tnear <= tfar && tfar > 0.0;
 }
 
@@ -380,6 +380,39 @@ struct Best {
     uint32_t accel; // accel instance it was hit in
 };
 
+// ---- fast mode's candidate check ----------------------------------------------------------------
+// The fast tree finds primitives quickly, but WHICH primitives a ray is tested against is the reference
+// tree's decision: the reference tests a primitive iff every box from its root down to the primitive's
+// leaf passes the slab test (and likewise for every nested accel on the way up), and near a box face that
+// decision is made by the last bit.  The fast walk's WINNER therefore counts only after the same boxes
+// have been put to the same test, leaf to root, level by level: one check per ray with a hit, after the
+// walk.  A winner that fails it -- like an exact tie -- sends the ray to the reference walk.  (If the
+// winner passes, it is the reference's winner: the fast walk tests every primitive the reference tests
+// and hits -- its boxes are the same primitive boxes, pushed out by 1e-9 of the accel's extent -- so
+// nothing the reference accepts is closer, and the winner is one of the reference's candidates.)
+__device__ __forceinline__ bool ref_path_hit(const DParams &P, uint32_t node_base, uint32_t leaf, const Ray &ray) {
+    uint32_t n = leaf;
+    if (n == NO_HIT) return false; // a primitive beyond its leaf's u16 count: the reference never reaches it
+    for (;;) {
+        const NodeRec nd = load_node<false>(P, nullptr, node_base + n);
+        if (!slab_intersects(nd.bmin, nd.bmax, ray)) return false;
+        n = P.node_parent[node_base + n];
+        if (n == NO_HIT) return true;
+    }
+}
+__device__ __forceinline__ bool ref_candidate(const DParams &P, const Ray &wray, const Best &best) {
+    const uint32_t kind = best.ref >> 30, idx = best.ref & PRIM_INDEX_MASK;
+    const uint32_t leaf = kind == PK_SPHERE ? P.sphere_ref_leaf[idx] : kind == PK_CUBOID ? P.cuboid_ref_leaf[idx] : P.tri_ref_leaf[idx];
+    uint32_t a = best.accel;
+    if (!ref_path_hit(P, P.accels[a].node_base, leaf, local_ray(P, wray, a))) return false;
+    while (a != 0u) {
+        const uint32_t parent = (uint32_t)P.accels[a].parent;
+        if (!ref_path_hit(P, P.accels[parent].node_base, P.accel_ref_leaf[a], local_ray(P, wray, parent))) return false;
+        a = parent;
+    }
+    return true;
+}
+
 // BVHAccel::intersect over the whole nested scene graph (bvh.rs:461-522), one lane = one ray.
 // `stack` is this lane's LDS stack: entry i lives at stack[i * stride].
 //
@@ -499,9 +532,9 @@ __device__ __forceinline__ void trav_enter_root(const DParams &P, Trav &T, Count
 // <= 4 primitives per leaf, visiting the child with the smaller slab tnear first and skipping
 // children whose tnear lies beyond the current best hit (closest) or beyond the light (any-hit).
 // Pending children carry their tnear (as a float rounded down) so they can be skipped at pop time.
-// The candidate set differs from the reference's only by primitives that cannot win unless a
-// computed t is off by more than the margin below; exact ties in t (where the reference's visit
-// order decides) are detected and those rays are re-traced with the reference traversal.
+// Exact ties in t (where the reference's visit order decides) are detected, and the walk's winner is
+// put to the reference tree's own box tests afterwards (ref_candidate); either sends the ray to the
+// reference traversal.
 __device__ __forceinline__ double prune_limit(double tbest, bool anyhit) {
     double lim = anyhit ? 1.0 : tbest;
     return lim + 1e-5 * (fabs(lim) + 1.0); // +inf stays +inf
@@ -557,9 +590,12 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
             uint32_t axis = nd->axis, second = nd->second;
             if (STATS) cnt.nodes += 2;
             if (FAST) {
-                double tn0, tn1;
-                bool hit0 = slab_intersects_t(b0min, b0max, T.ray, tn0);
-                bool hit1 = slab_intersects_t(b1min, b1max, T.ray, tn1);
+                double tn0, tn1, tf0, tf1;
+                bool hit0 = slab_intersects_t(b0min, b0max, T.ray, tn0, tf0);
+                bool hit1 = slab_intersects_t(b1min, b1max, T.ray, tn1, tf1);
+                // a primitive's computed t can undershoot its box's tnear by the error of its own formula: for a sphere
+                // the quadratic's cancellation, ~sqrt(eps) of the distance to its centre, which lies inside the box
+                tn0 -= 4e-8 * fabs(tf0); tn1 -= 4e-8 * fabs(tf1);
                 double limit = prune_limit(best.t, anyhit);
                 hit0 = hit0 && !(tn0 > limit);
                 hit1 = hit1 && !(tn1 > limit);
@@ -675,6 +711,11 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
         }
     }
     tie = T.tie;
+    // fast walk: a winner the reference tree would not have tested is handled like a tie (re-trace with the reference walk)
+    // (the hit is dropped as well, so that an any-hit caller does not take it for a valid occluder and skip the re-trace)
+    if (FAST && !tie && best.ref != NO_HIT && !(anyhit && !(best.t < 1.0)) && !ref_candidate(P, wray, best)) {
+        tie = true; best.t = INFINITY; best.ref = NO_HIT;
+    }
 #undef LG_POP
 }
 
@@ -1806,6 +1847,32 @@ __global__ void kat_si_kernel(V3 o, V3 d, double t, V3 dpdu, V3 dpdv, double *ou
     (void)o; (void)t;
     out[0] = ng.x; out[1] = ng.y; out[2] = ng.z;
 }
+// One pixel, traced by lane 0 with the private walk (test hook lg_trace_pixel): the primary hit, then for each
+// light the shadow ray's result.  out = { t, primref, accel, nlights, then per light: t, primref; then the shadow rays' origin }.
+template <bool FAST>
+__global__ void trace_pixel_kernel(const DParams P, uint32_t x, uint32_t y, double *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t *stack = lds_stack;
+    Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const Ray ray = camera_ray(P, x, y, 0u);
+    Best b;
+    bool tie = false;
+    traverse<false, FAST>(P, ray, false, stack, 1u, b, cnt, tie);
+    if (FAST && tie) traverse<false, false>(P, ray, false, stack, 1u, b, cnt, tie);
+    out[0] = b.t; out[1] = (double)b.ref; out[2] = (double)b.accel; out[3] = (double)P.nlights;
+    if (b.ref == NO_HIT) return;
+    Shade sh;
+    shade_frame(P, ray, b, sh);
+    for (uint32_t l = 0; l < P.nlights; ++l) {
+        const DLight L = P.lights[l];
+        const Ray sray = ray_new(sh.p, V3{L.pos[0], L.pos[1], L.pos[2]} - sh.p);
+        Best sb;
+        traverse<false, FAST>(P, sray, true, stack, 1u, sb, cnt, tie);
+        if (FAST && tie && !(sb.t < 1.0)) traverse<false, false>(P, sray, true, stack, 1u, sb, cnt, tie);
+        out[4 + 2 * l] = sb.t; out[5 + 2 * l] = (double)sb.ref;
+    }
+    out[4 + 2 * P.nlights] = sh.p.x; out[5 + 2 * P.nlights] = sh.p.y; out[6 + 2 * P.nlights] = sh.p.z; // origin of the shadow rays
+}
 __global__ void math_kernel(int op, size_t n, const double *a, const double *b, double *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1933,6 +2000,12 @@ hipError_t launch_kat(int kind, const double *params, const float *vpos, const u
 }
 hipError_t launch_kat_si(V3 o, V3 d, double t, V3 dpdu, V3 dpdv, double *out, hipStream_t stream) {
     hipLaunchKernelGGL(kat_si_kernel, dim3(1), dim3(64), 0, stream, o, d, t, dpdu, dpdv, out);
+    return hipGetLastError();
+}
+hipError_t launch_trace_pixel(const DParams &P, bool fast, uint32_t stack_depth, uint32_t x, uint32_t y, double *out, hipStream_t stream) {
+    size_t lds = (size_t)stack_depth * sizeof(uint32_t) + 64;
+    if (fast) hipLaunchKernelGGL((trace_pixel_kernel<true>), dim3(1), dim3(64), lds, stream, P, x, y, out);
+    else hipLaunchKernelGGL((trace_pixel_kernel<false>), dim3(1), dim3(64), lds, stream, P, x, y, out);
     return hipGetLastError();
 }
 hipError_t launch_math(int op, size_t n, const double *a, const double *b, double *out, hipStream_t stream) {

@@ -302,6 +302,30 @@ def test_extreme_film_shapes(w, h):
         assert np.array_equal(film.pixels(), ofilm.pixels()), streaming
 
 
+def test_fast_mode_adversarial_scenes():
+    """Scenes built against fast mode's margins (wall-sized spheres, lights a hair from a surface, needle boxes, twin
+    spheres); seeds 75 and 375 differed by one pixel each before the fast walk's winner was put to the reference tree's
+    own box tests (a shadow ray leaving a giant sphere 3e-11 above its box)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "tools", "fast_adversarial.py")).read().split("a, b = int(sys.argv[1])")[0]
+    ns = {"__file__": os.path.join(root, "tools", "fast_adversarial.py")}
+    exec(compile(src, "fast_adversarial", "exec"), ns)
+    w, h = 128, 96
+    for seed in (75, 375, 1, 2, 3, 4, 5, 6):
+        acc = G.Accel(ns["scene"](seed))
+        outs = []
+        for fast in (False, True):
+            G.set_mode(acc, fast)
+            film = G.Film(w, h)
+            G.capture_subset(0, 1, acc, film)
+            outs.append((film.pixels(), bits(G.capture_radiance(acc, w, h))))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), seed
+    # the trace hook that found the cause: the primary hit is a wall sphere in both modes
+    r0, r1 = G.trace_pixel(acc, w, h, 40, 50, False), G.trace_pixel(acc, w, h, 40, 50, True)
+    assert r0["ref"] == r1["ref"] and r0["t"] == r1["t"] and [s[1] for s in r0["shadow"]] != []
+
+
 # ---- fuzz parity: seeded random scenes with duplicated / touching primitives (exact ties in t) ----
 @pytest.mark.parametrize("seed", list(range(32)))
 def test_random_scene_parity(seed):
