@@ -191,7 +191,10 @@ int lg_host_build_dump(const lg_scene *, const double **f, size_t *nf, const int
 /* One pixel traced by a single lane (sample 0): out = { t, primref, accel instance, number of lights, then per light
  * the shadow ray's { t, primref }, then the shadow rays' origin (3) } -- primref is 4294967295 for "no hit"; out_len >=
  * 7 + 2 * lights.  `fast` selects the traversal mode.
- * A debugging / test hook: it is how a film difference is traced back to the ray that caused it. */
+ * With out_len >= 7 + 2 * lights + 16001 the event log of the primary ray's walk follows: a count, then up to 4000
+ * events of 4 doubles (code, a, b, c: node pairs / nodes visited, primitive tests, accel entries and returns; the codes
+ * are listed at lasgun_amd.HipApi.trace_pixel_log).  A debugging / test hook: it is how a film difference is traced
+ * back to the ray, and the ray to the box, that caused it. */
 int lg_trace_pixel(const lg_accel *, uint32_t width, uint32_t height, uint32_t x, uint32_t y, int fast, double *out, size_t out_len);
 
 /* Known-answer and arithmetic probes: run the DEVICE intersectors / math on one thread. */

@@ -83,6 +83,18 @@ class HipApi(Api):
         if self.call("set_device", int(device)):
             raise LasgunError(self.last_error())
 
+    def trace_pixel_log(self, accel, w, h, x, y, fast=False, nlights=1):
+        """trace_pixel plus the event log of the PRIMARY ray's walk: rows of (code, a, b, c) -- 1.xy fast node pair
+        (x/y = child boxes hit; a = accel*1e5 + node, b/c = tnear of the children), 2.x reference node, 3.x primitive
+        test (a = primref, b = t, c = accel; .1 = accepted), 4 / 4.5 accel entry, 5 return, 6 triangle accepted, 9 end."""
+        need = 7 + 2 * nlights
+        n = need + 1 + 4 * 4000
+        out = (_C.c_double * n)()
+        if self.call("trace_pixel", accel.h, int(w), int(h), int(x), int(y), 1 if fast else 0, out, n):
+            raise LasgunError(self.last_error())
+        cnt = int(out[need])
+        return [tuple(out[need + 1 + 4 * i + k] for k in range(4)) for i in range(cnt)]
+
     def trace_pixel(self, accel, w, h, x, y, fast=False, max_lights=64):
         """{"t", "ref", "accel", "shadow": [(t, ref), ...]} of pixel (x, y), sample 0 (debugging / test hook)."""
         n = 7 + 2 * max_lights

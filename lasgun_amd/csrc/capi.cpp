@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -153,6 +155,7 @@ struct lg_accel {
     mutable bool profiling = false;
     mutable bool fast = false; // opt-in fast traversal mode (lg_accel_set_mode)
     bool fast_available = true;
+    std::string fast_refusal = "fast mode unavailable: its tree is too deep for the LDS stack";
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     // streaming pipeline, per kernel kind: 0 primary trace, 1 frame, 2 shadow trace, 3 shade; 4 = megakernel
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> kind_events[5];
@@ -544,6 +547,22 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
         if ((size_t)a->stack_depth * 256 * 4 > LDS_MAX)
             throw Error("BVH too deep for the LDS traversal stack (" + std::to_string(a->stack_depth) + " entries per lane; the reference panics beyond 64 per level, bvh.rs:497)");
         a->fast_available = (size_t)a->stack_depth_fast * 256 * 4 <= LDS_MAX;
+        // The fast tree's tight boxes are only meaningful if every accel's `minv` (which moves the rays) really is the
+        // inverse of its `m` (which moved the boxes).  Transform3::rotate(theta, axis) takes the transpose for the inverse
+        // without normalising the axis (transform.rs:144-148), so a non-unit axis gives a pair that is not: the reference
+        // still renders *something* through its fat, overlapping leaves, and the reference traversal reproduces that
+        // bit for bit, but the fast mode is refused for such a scene.
+        for (const DAccel &A : f.accels) {
+            double worst = 0.0;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 4; ++c) {
+                    double v = (c == 3 ? A.m.c[3][r] : 0.0);
+                    for (int k = 0; k < 3; ++k) v += A.m.c[k][r] * (c == 3 ? A.minv.c[3][k] : A.minv.c[c][k]);
+                    const double want = (c < 3 && r == c) ? 1.0 : 0.0;
+                    if (!(std::fabs(v - want) <= worst)) worst = std::fabs(v - want);
+                }
+            if (!(worst <= 1e-9)) { a->fast_available = false; a->fast_refusal = "fast mode unavailable: an aggregate's transform and inverse do not match (rotate() about a non-unit axis?)"; }
+        }
         if (!a->fast_available) a->stack_depth_fast = a->stack_depth;
         size_t lds = (size_t)a->stack_depth_fast * 256 * 4;
         if (lds > 64 * 1024) HIP_TRY(trace_set_lds_limit(lds));
@@ -835,7 +854,7 @@ int lg_accel_set_streaming(const lg_accel *a, int enabled) {
 int lg_accel_set_mode(const lg_accel *a, int mode) {
     if (mode != 0 && mode != 1) return fail("mode must be 0 (reference traversal) or 1 (fast)");
     std::lock_guard<std::mutex> g(a->mtx);
-    if (mode == 1 && !a->fast_available) return fail("fast mode unavailable: its tree is too deep for the LDS stack");
+    if (mode == 1 && !a->fast_available) return fail(a->fast_refusal);
     a->fast = mode == 1;
     return 0;
 }
@@ -942,11 +961,14 @@ int lg_trace_pixel(const lg_accel *a, uint32_t w, uint32_t h, uint32_t x, uint32
         if (out_len < need) throw Error("output too small: 7 + 2 * lights doubles");
         if (fast && !a->fast_available) throw Error("fast mode unavailable for this scene");
         DParams P = base_params(*a, w, h);
-        DevBuf<double> dout;
+        DevBuf<double> dout, dlog;
         dout.alloc(need);
         HIP_TRY(hipMemset(dout.p, 0, need * sizeof(double)));
+        const size_t log_n = 1 + 4 * 4000;
+        if (out_len >= need + log_n) { dlog.alloc(log_n); HIP_TRY(hipMemset(dlog.p, 0, log_n * sizeof(double))); P.dbg_log = dlog.p; }
         HIP_TRY(launch_trace_pixel(P, fast != 0, fast ? a->stack_depth_fast : a->stack_depth, x, y, dout.p, a->stream));
         HIP_TRY(hipMemcpyAsync(out, dout.p, need * sizeof(double), hipMemcpyDeviceToHost, a->stream));
+        if (P.dbg_log) HIP_TRY(hipMemcpyAsync(out + need, dlog.p, log_n * sizeof(double), hipMemcpyDeviceToHost, a->stream));
         HIP_TRY(hipStreamSynchronize(a->stream));
     });
 }

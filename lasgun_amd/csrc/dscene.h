@@ -161,6 +161,7 @@ struct DParams {
     unsigned long long frame_threads;
     double *stash;         // [STASH_DOUBLES][nthreads]: shading frame parked across the shadow traversals
     DStats *stats;
+    double *dbg_log;       // lg_trace_pixel only (counting instantiations): [0] = entries used, then 4 doubles per event
     // ---- streaming pipeline (scenes without glass / mirror): per-work-item state in HBM, SoA,
     // indexed by the dense work index widx = tile * 64 + lane
     unsigned long long n_items; // ntiles * 64

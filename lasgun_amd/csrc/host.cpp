@@ -648,7 +648,11 @@ struct Flattener {
                 if (std::isfinite(lo) && lo > ext) ext = lo;
                 if (std::isfinite(hi) && hi > ext) ext = hi;
             }
+#ifdef LG_NO_INFLATE
+        const double e = 0.0 * ext;
+#else
         const double e = ext * 1e-9 + 1e-300;
+#endif
         std::vector<Bounds> r = pb;
         for (Bounds &b : r) { b.min = b.min - V3{e, e, e}; b.max = b.max + V3{e, e, e}; }
         return r;

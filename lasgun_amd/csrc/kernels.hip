@@ -279,6 +279,15 @@ __device__ __forceinline__ void triangle_full(const DParams &P, uint32_t tri, ui
 // ------------------------------------------------------------------------------------------
 // traversal
 // ------------------------------------------------------------------------------------------
+// event log of one traced ray (lg_trace_pixel, counting instantiations only): code, a, b, c
+__device__ __forceinline__ void dbg_event(const DParams &P, double code, double a, double b, double c) {
+    if (!P.dbg_log) return;
+    const uint32_t n = (uint32_t)P.dbg_log[0];
+    if (n >= 4000u) return;
+    double *e = P.dbg_log + 1 + 4 * (size_t)n;
+    e[0] = code; e[1] = a; e[2] = b; e[3] = c;
+    P.dbg_log[0] = (double)(n + 1u);
+}
 struct Counters {
     uint32_t primary, shadow, secondary, nodes, spheres, cuboids, triangles, entries, hits;
 };
@@ -482,6 +491,7 @@ __device__ __forceinline__ void mesh_leaf(const DParams &P, const uint4 *scn, Tr
         if (FAST && h.t == best.t && best.ref != NO_HIT) T.tie = true; // equal t: the reference's visit order decides
         if (h.t >= best.t) continue;
         best.t = h.t; best.ref = load_primref<LDSS>(P, scn, li); best.accel = T.accel;
+        if (STATS) dbg_event(P, 6.0, (double)best.ref, h.t, (double)T.accel);
         if (anyhit && h.t < 1.0) { T.done = true; break; } // point.rs:49
     }
     T.li = le;
@@ -536,6 +546,9 @@ __device__ __forceinline__ void trav_enter_root(const DParams &P, Trav &T, Count
 // put to the reference tree's own box tests afterwards (ref_candidate); either sends the ray to the
 // reference traversal.
 __device__ __forceinline__ double prune_limit(double tbest, bool anyhit) {
+#ifdef LG_FAST_NOPRUNE
+    return INFINITY;
+#endif
     double lim = anyhit ? 1.0 : tbest;
     return lim + 1e-5 * (fabs(lim) + 1.0); // +inf stays +inf
 }
@@ -597,6 +610,7 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
                 // the quadratic's cancellation, ~sqrt(eps) of the distance to its centre, which lies inside the box
                 tn0 -= 4e-8 * fabs(tf0); tn1 -= 4e-8 * fabs(tf1);
                 double limit = prune_limit(best.t, anyhit);
+                if (STATS) { dbg_event(P, 1.0 + (hit0 ? 0.1 : 0.0) + (hit1 ? 0.01 : 0.0), (double)T.accel * 100000.0 + (double)(T.node_base + T.cur), tn0, tn1); }
                 hit0 = hit0 && !(tn0 > limit);
                 hit1 = hit1 && !(tn1 > limit);
                 bool swap = hit1 && (!hit0 || tn1 < tn0); // nearer child first
@@ -628,6 +642,7 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
             const uint32_t link = nd.link, meta = nd.meta;
             if (STATS) cnt.nodes++;
             bool hit = slab_intersects(nd.bmin, nd.bmax, T.ray);
+            if (STATS) dbg_event(P, 2.0 + (hit ? 0.1 : 0.0), (double)T.accel * 100000.0 + (double)(T.node_base + T.cur), (double)nd.link, (double)nd.meta);
             bool leaf = (meta & NODE_LEAF) != 0u;
             uint32_t count = meta & 0xFFFFu;
             bool neg = ((T.negmask >> (meta & 3u)) & 1u) != 0u; // dir_is_neg[axis] (bvh.rs:463,496)
@@ -680,7 +695,9 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
                     T.sp += 3; T.base = T.sp;
                     trav_set_level<FAST, LDSS>(P, T, idx, ray_to_local(P.accels[idx].minv, T.ray));
                     if (STATS) cnt.entries++;
+                    if (STATS) dbg_event(P, 4.0, (double)idx, (double)T.sp, (double)T.base);
                     trav_enter_root<STATS, FAST>(P, T, cnt);
+                    if (STATS) dbg_event(P, 4.5, (double)idx, T.level_done ? 1.0 : 0.0, T.in_leaf ? 1.0 : 0.0);
                     break;
                 } else { // a triangle outside a mesh accel cannot be built by the scene API; kept for completeness
                     if (STATS) cnt.triangles++;
@@ -689,6 +706,7 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
                     if (triangle_t(load_f3(P.vpos, vi[0]), load_f3(P.vpos, vi[1]), load_f3(P.vpos, vi[2]), T.ray, h)) { t = h.t; accepted = !(t >= best.t); }
                 }
                 if (FAST && !accepted && t == best.t && best.ref != NO_HIT && kind != PK_ACCEL) T.tie = true; // equal t: visit order decides
+                if (STATS && kind != PK_ACCEL) dbg_event(P, 3.0 + (accepted ? 0.1 : 0.0), (double)ref, t, (double)T.accel);
                 if (accepted) {
                     best.t = t; best.ref = ref; best.accel = T.accel;
                     if (anyhit && t < 1.0) { T.done = true; T.in_leaf = false; break; } // occluded: point.rs:49 only asks isect.t < 1.0
@@ -703,6 +721,7 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
             else {
                 T.base = stack[(T.sp - 1) * stride]; T.le = stack[(T.sp - 2) * stride]; T.li = stack[(T.sp - 3) * stride];
                 T.sp -= 3;
+                if (STATS) dbg_event(P, 5.0, (double)T.accel, (double)T.li, (double)T.le);
                 uint32_t parent = (uint32_t)P.accels[T.accel].parent;
                 trav_set_level<FAST, LDSS>(P, T, parent, level_ray(P, root_o, root_d, parent));
                 if (T.li < T.le) T.in_leaf = true;
@@ -713,9 +732,11 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
     tie = T.tie;
     // fast walk: a winner the reference tree would not have tested is handled like a tie (re-trace with the reference walk)
     // (the hit is dropped as well, so that an any-hit caller does not take it for a valid occluder and skip the re-trace)
+#ifndef LG_NO_REFCHECK
     if (FAST && !tie && best.ref != NO_HIT && !(anyhit && !(best.t < 1.0)) && !ref_candidate(P, wray, best)) {
         tie = true; best.t = INFINITY; best.ref = NO_HIT;
     }
+#endif
 #undef LG_POP
 }
 
@@ -1857,8 +1878,9 @@ __global__ void trace_pixel_kernel(const DParams P, uint32_t x, uint32_t y, doub
     const Ray ray = camera_ray(P, x, y, 0u);
     Best b;
     bool tie = false;
-    traverse<false, FAST>(P, ray, false, stack, 1u, b, cnt, tie);
-    if (FAST && tie) traverse<false, false>(P, ray, false, stack, 1u, b, cnt, tie);
+    traverse<true, FAST>(P, ray, false, stack, 1u, b, cnt, tie);
+    if (P.dbg_log) dbg_event(P, 9.0, tie ? 1.0 : 0.0, b.t, (double)b.ref);
+    if (FAST && tie) traverse<true, false>(P, ray, false, stack, 1u, b, cnt, tie);
     out[0] = b.t; out[1] = (double)b.ref; out[2] = (double)b.accel; out[3] = (double)P.nlights;
     if (b.ref == NO_HIT) return;
     Shade sh;
