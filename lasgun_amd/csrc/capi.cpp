@@ -109,7 +109,7 @@ struct lg_accel {
     DevBuf<uint32_t> tri_v, tri_n, tri_t;
     DevBuf<float> vpos, vnorm, vtex;
     DevBuf<DLeafRec> leaf_soup;
-    DevBuf<uint32_t> node_parent, sphere_ref_leaf, cuboid_ref_leaf, tri_ref_leaf, accel_ref_leaf;
+    DevBuf<uint32_t> sphere_ref_leaf, cuboid_ref_leaf, tri_ref_leaf, accel_ref_leaf;
     DevBuf<DAccel> accels;
     DevBuf<DMaterial> materials;
     DevBuf<DLight> lights;
@@ -193,7 +193,7 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     DParams P{};
     P.nodes = a.nodes.p; P.nodes2 = a.nodes2.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
     P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
-    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.node_parent = a.node_parent.p; P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
+    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
     P.tri_ref_leaf = a.tri_ref_leaf.p; P.accel_ref_leaf = a.accel_ref_leaf.p; P.accels = a.accels.p; P.materials = a.materials.p;
     P.lights = a.lights.p;
     P.nlights = (uint32_t)a.flat.lights.size();
@@ -531,7 +531,7 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
         const FlatScene &f = a->flat;
         a->nodes.upload(f.nodes); a->nodes2.upload(f.nodes2); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
-        a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->node_parent.upload(f.node_parent); a->sphere_ref_leaf.upload(f.sphere_ref_leaf); a->cuboid_ref_leaf.upload(f.cuboid_ref_leaf);
+        a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->sphere_ref_leaf.upload(f.sphere_ref_leaf); a->cuboid_ref_leaf.upload(f.cuboid_ref_leaf);
         a->tri_ref_leaf.upload(f.tri_ref_leaf); a->accel_ref_leaf.upload(f.accel_ref_leaf); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
         a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
         a->stats.alloc(1);

@@ -39,7 +39,8 @@ struct alignas(64) DNode {
     double bmax[3];
     uint32_t link; // leaf: offset of its first primref (relative to the accel's prim_base); interior: second child (relative to node_base)
     uint32_t meta; // leaf: NODE_LEAF | nprims (u16, bvh.rs:440) ; interior: split axis
-    uint32_t pad[2];
+    uint32_t parent; // reference trees: the parent node (relative to node_base), NO_HIT at the root -- fast mode's candidate check walks leaf -> root
+    uint32_t pad;
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
@@ -123,8 +124,7 @@ struct DParams {
     const float *vnorm;
     const float *vtex;
     const DLeafRec *leaf_soup; // slot j <-> primref[j]
-    // fast mode's candidate check (host.h): reference-tree parents; reference leaf of every sphere / cuboid / triangle / accel
-    const uint32_t *node_parent;
+    // fast mode's candidate check (host.h): reference leaf of every sphere / cuboid / triangle / accel (parents: DNode::parent)
     const uint32_t *sphere_ref_leaf, *cuboid_ref_leaf, *tri_ref_leaf, *accel_ref_leaf;
     const DAccel *accels;
     const DMaterial *materials;

@@ -619,12 +619,12 @@ struct Flattener {
 
     // parents of the reference tree just appended at node_base (fast mode's candidate check walks leaf -> root)
     void record_parents(const BuiltBVH &bvh, uint32_t node_base) {
-        out.node_parent.resize(out.nodes.size(), NO_HIT);
+        for (size_t i = 0; i < bvh.nodes.size(); ++i) out.nodes[node_base + i].parent = NO_HIT;
         for (size_t i = 0; i < bvh.nodes.size(); ++i) {
             const LinNode &n = bvh.nodes[i];
             if (n.leaf) continue;
-            out.node_parent[node_base + i + 1] = (uint32_t)i;
-            out.node_parent[node_base + n.c] = (uint32_t)i;
+            out.nodes[node_base + i + 1].parent = (uint32_t)i;
+            out.nodes[node_base + n.c].parent = (uint32_t)i;
         }
     }
     // reference leaf of every primitive (NO_HIT for primitives the reference never tests: beyond a leaf's u16 count)
@@ -906,7 +906,6 @@ void flatten_scene(const Scene &scene, FlatScene &out) {
     out.sphere_ref_leaf.resize(out.spheres.size(), NO_HIT);
     out.cuboid_ref_leaf.resize(out.cuboids.size(), NO_HIT);
     out.tri_ref_leaf.resize(out.tri_v.size() / 3, NO_HIT);
-    out.node_parent.resize(out.nodes.size(), NO_HIT);
     out.accel_ref_leaf.resize(out.accels.size(), NO_HIT);
     for (const Light &l : scene.lights) {
         DLight d;

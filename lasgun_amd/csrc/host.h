@@ -118,7 +118,6 @@ struct FlatScene {
     std::vector<DLeafRec> leaf_soup; // one per primref slot
     // fast mode's candidate check: a hit found through the fast tree counts only if the REFERENCE tree would have tested
     // that primitive for this ray, i.e. if every box on its root-to-leaf path in the reference tree passes the slab test
-    std::vector<uint32_t> node_parent;    // per node of a reference tree: its parent (relative to node_base), NO_HIT at the root
     std::vector<uint32_t> sphere_ref_leaf, cuboid_ref_leaf, tri_ref_leaf; // per primitive: the leaf of ITS accel's reference tree holding it
     std::vector<uint32_t> accel_ref_leaf; // per accel: the leaf of its parent's reference tree that holds it (NO_HIT for the root)
     std::vector<DAccel> accels;

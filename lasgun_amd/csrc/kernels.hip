@@ -403,9 +403,10 @@ __device__ __forceinline__ bool ref_path_hit(const DParams &P, uint32_t node_bas
     uint32_t n = leaf;
     if (n == NO_HIT) return false; // a primitive beyond its leaf's u16 count: the reference never reaches it
     for (;;) {
-        const NodeRec nd = load_node<false>(P, nullptr, node_base + n);
-        if (!slab_intersects(nd.bmin, nd.bmax, ray)) return false;
-        n = P.node_parent[node_base + n];
+        const DNode *nd = P.nodes + (node_base + n);
+        const double bmin[3] = {nd->bmin[0], nd->bmin[1], nd->bmin[2]}, bmax[3] = {nd->bmax[0], nd->bmax[1], nd->bmax[2]};
+        n = nd->parent; // same 64-byte record: one fetch per step
+        if (!slab_intersects(bmin, bmax, ray)) return false;
         if (n == NO_HIT) return true;
     }
 }
