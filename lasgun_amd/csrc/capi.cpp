@@ -561,7 +561,10 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
                     const double want = (c < 3 && r == c) ? 1.0 : 0.0;
                     if (!(std::fabs(v - want) <= worst)) worst = std::fabs(v - want);
                 }
-            if (!(worst <= 1e-9)) { a->fast_available = false; a->fast_refusal = "fast mode unavailable: an aggregate's transform and inverse do not match (rotate() about a non-unit axis?)"; }
+            if (!(worst <= 1e-11)) { // two orders below the 1e-9 the fast tree's boxes are pushed out by
+                a->fast_available = false;
+                a->fast_refusal = "fast mode unavailable: an aggregate's transform and inverse do not match (rotate() about a non-unit axis?)";
+            }
         }
         if (!a->fast_available) a->stack_depth_fast = a->stack_depth;
         size_t lds = (size_t)a->stack_depth_fast * 256 * 4;
