@@ -552,6 +552,19 @@ def test_host_film_capture_split_over_devices(devices, w, h, threads):
         G.set_devices([0])
 
 
+def test_hooks_reject_bad_arguments():
+    acc = G.Accel(S.readme_scene(G))
+    with pytest.raises(la.LasgunError):
+        G.trace_pixel(acc, 64, 64, 64, 0)          # pixel outside the film
+    with pytest.raises(la.LasgunError):
+        G.set_devices([0, 99])                     # no such device
+    G.set_devices([0])
+    r = G.trace_pixel(acc, 64, 64, 32, 32)         # the sphere in the middle of the README scene
+    assert r["ref"] == 0 and r["accel"] == 0 and 0.0 < r["t"] < 1e3 and len(r["shadow"]) == 1
+    log = G.trace_pixel_log(acc, 64, 64, 32, 32, False, 1)
+    assert log and log[-1][0] == 9.0 and any(3.0 <= e[0] < 4.0 for e in log)
+
+
 def test_library_first_then_torch_share_one_hip_runtime():
     """Importing lasgun_amd (and rendering) BEFORE torch must leave torch able to use the GPU: the package
     preloads the HIP runtime bundled with the torch wheel so the process never holds two runtimes."""
