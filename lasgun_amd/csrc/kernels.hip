@@ -8,14 +8,15 @@
 // compile with -ffp-contract=off.  No MFMA: this is branchy traversal, not a contraction.
 //
 // Kernels:
-//   trace_kernel<STATS, FAST>                 the whole of li() per lane (scenes with glass / mirror, small
-//                                             films, the counting variant)
+//   trace_kernel<STATS, FAST, LDSS>           the whole of li() per lane (scenes with glass / mirror, light scenes,
+//                                             small films, the counting variant)
 //   stream_trace_kernel<FAST, SHADOW, LDSS, FIXUP>  traversal only: primary closest-hit or per-light any-hit;
 //                                             (the primary pass also parks the hit's shading frame);
 //                                             LDSS = scene tables resident in LDS, one 1024-lane workgroup per CU;
 //                                             FIXUP = re-trace the lanes the packet pass flagged
 //   stream_packet_kernel<SHADOW, LDSS>        the same two passes with ONE tree walk per wavefront (opt-in)
 //   stream_shade_kernel                       frame + visibility -> radiance -> RGBA8
+//   trace_pixel_kernel<FAST>                  one pixel by one lane, with an event log of the walk (lg_trace_pixel)
 //   kat_kernel, kat_si_kernel, math_kernel    probes behind the test hooks of the C ABI
 //
 // What is restated from where (file:line under /root/reference):
