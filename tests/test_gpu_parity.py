@@ -552,6 +552,40 @@ def test_host_film_capture_split_over_devices(devices, w, h, threads):
         G.set_devices([0])
 
 
+@pytest.mark.parametrize("gen", ["scene", "scene2"])
+def test_adversarial_scenes_match_the_oracle(gen):
+    """tools/fast_adversarial.py's generators (giant spheres, needle boxes, degenerate meshes, nested anisotropic groups,
+    non-unit rotation axes, distant / orthographic cameras) through the reference traversal, every kernel organisation,
+    against the CPU oracle: the reference's behaviour on ill-conditioned input is reproduced too."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "tools", "fast_adversarial.py")).read().split("a, b = int(sys.argv[1])")[0]
+    o = oracle()
+
+    def make(api):
+        ns = {"__file__": os.path.join(root, "tools", "fast_adversarial.py")}
+        exec(compile(src, "fast_adversarial", "exec"), ns)
+        ns["G"] = api; ns["M"] = api.Material
+        return ns
+    ns_g, ns_o = make(G), make(o)
+    w, h = 96, 72
+    for seed in (75, 375, 381, 589, 591, 11, 12, 13, 14, 15):
+        oacc = o.Accel(ns_o[gen](seed))
+        ofilm = o.Film(w, h)
+        o.capture_subset_mt(0, 1, oacc, ofilm, 16)
+        o.set_trig_mode(1)
+        try:
+            orad = o.capture_radiance(oacc, w, h, nthreads=16)
+        finally:
+            o.set_trig_mode(0)
+        acc = G.Accel(ns_g[gen](seed))
+        for streaming, packet in ((0, False), (2, False), (2, True)):
+            G.set_streaming(acc, streaming); G.set_packet(acc, packet)
+            film = G.Film(w, h)
+            G.capture_subset(0, 1, acc, film)
+            assert np.array_equal(film.pixels(), ofilm.pixels()), (seed, streaming, packet)
+            assert np.array_equal(bits(G.capture_radiance(acc, w, h)), bits(orad)), (seed, streaming, packet)
+
+
 def test_hooks_reject_bad_arguments():
     acc = G.Accel(S.readme_scene(G))
     with pytest.raises(la.LasgunError):
