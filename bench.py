@@ -30,14 +30,16 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy peak
-# algorithmic bytes per unit of traversal work (DESIGN.md "Roofline bookkeeping")
-BYTES_NODE, BYTES_SPHERE, BYTES_CUBOID, BYTES_TRI, BYTES_PRIMREF, BYTES_ACCEL_ENTRY, BYTES_PIXEL = 56, 32, 48, 48, 4, 96, 4
+# algorithmic bytes per unit of traversal work: SURVEY.md section 8(d)'s per-unit figures (restated in DESIGN.md
+# "Roofline bookkeeping"): 56 B per node whose bounds are tested, 32 B per sphere / 48 B per cuboid / 48 B per triangle
+# tested, 256 B (m, minv) per nested-BVH entry, 4 B material id per accepted closest hit, 4 B RGBA per primary ray.
+# (The +36 B of vertex normals per accepted smoothed-triangle hit is left out: it is not counted separately.)
+BYTES_NODE, BYTES_SPHERE, BYTES_CUBOID, BYTES_TRI, BYTES_ACCEL_ENTRY, BYTES_HIT, BYTES_PIXEL = 56, 32, 48, 48, 256, 4, 4
 
 
 def algorithmic_bytes(st):
-    prims = st["spheres_tested"] + st["cuboids_tested"] + st["triangles_tested"] + st["accel_entries"]
     return (BYTES_NODE * st["nodes_tested"] + BYTES_SPHERE * st["spheres_tested"] + BYTES_CUBOID * st["cuboids_tested"]
-            + BYTES_TRI * st["triangles_tested"] + BYTES_ACCEL_ENTRY * st["accel_entries"] + BYTES_PRIMREF * prims
+            + BYTES_TRI * st["triangles_tested"] + BYTES_ACCEL_ENTRY * st["accel_entries"] + BYTES_HIT * st["hits"]
             + BYTES_PIXEL * st["primary_rays"])
 
 
