@@ -262,7 +262,7 @@ def main():
             fms = (time.perf_counter() - t0) / 3 * 1e3
             fast_info = {"ms_per_step": fms, "value": rays / fms / 1e3, "unit": "Mrays/s",
                          "identical_to_reference_traversal": bool(torch.equal(ref_film, fast_film)),
-                         "note": "lg_accel_set_mode(1): binned-SAH tree + pruning; verified, not proven, identical (DESIGN.md)"}
+                         "note": "lg_accel_set_mode(1): binned-SAH tree + pruning, winner checked against the reference tree's boxes; verified, not proven, identical (DESIGN.md)"}
         finally:
             G.set_mode(acc, False)
 
