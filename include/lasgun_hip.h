@@ -145,7 +145,9 @@ int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t
  * and arithmetic.  Its winner is put to the reference tree's own box tests (leaf to root, through every
  * nested accel); a winner that fails them, or an exact tie in t, re-traces the ray with the reference
  * traversal.  Verified byte-identical to mode 0 on every test, benchmark config, fuzz and adversarial
- * scene; its two rounding margins are argued, not PROVEN. */
+ * scene; its two rounding margins are argued, not PROVEN.  The fast trees cost 5-10x the
+ * reference build, so lg_accel_from does not build them: the first lg_accel_set_mode(accel, 1) does (it
+ * synchronises the device and uploads the tables again; the Scene must still be alive, as for any use of the accel). */
 int lg_accel_set_mode(const lg_accel *, int mode);
 
 /* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes without

@@ -520,14 +520,13 @@ int lg_device_count(void) {
     return n;
 }
 
-static lg_accel *accel_from_on(const lg_scene *s, int device) {
-    lg_accel *a = nullptr;
-    int rc = guarded([&] {
-        a = new lg_accel();
-        a->scene = &s->s;
-        a->device = device;
-        flatten_scene(s->s, a->flat); // host HLBVH build + flatten (throws on what the reference would panic on)
-        use_device(device);
+// Host build (reference trees; with `with_fast` also the fast mode's), upload, and everything derived from the tables.
+// Called at creation without the fast trees -- they cost 5-10x the reference build and only mode 1 walks them -- and
+// once more, with them, by the first lg_accel_set_mode(accel, 1).
+static void build_and_upload(lg_accel *a, bool with_fast) {
+    a->ldss_blocks = 0; a->packet_lds = false; a->lds_image_n16 = 0; a->fast_available = true;
+        flatten_scene(*a->scene, a->flat, with_fast); // host HLBVH build + flatten (throws on what the reference would panic on)
+        use_device(a->device);
         const FlatScene &f = a->flat;
         a->nodes.upload(f.nodes); a->nodes2.upload(f.nodes2); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
@@ -538,7 +537,7 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
         a->device_bytes = f.nodes.size() * (sizeof(DNode) + sizeof(DNode2)) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
                           f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 + f.leaf_soup.size() * sizeof(DLeafRec) +
                           f.accels.size() * sizeof(DAccel) + f.materials.size() * sizeof(DMaterial);
-        HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+        if (!a->stream) HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
         // per-lane LDS stack: worst case of this scene graph, +2 guard entries
         a->stack_depth = f.max_stack + 2;
         // the fast kernel falls back to the reference traversal on exact ties, so its stack must hold either
@@ -575,7 +574,7 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
         HIP_TRY(trace_occupancy(a->stack_depth_fast, true, &per_cu_fast));
         if (per_cu_fast < 1) per_cu_fast = 1;
         a->max_blocks_fast = (uint32_t)per_cu_fast;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device));
         if (per_cu < 1) per_cu = 1;
         a->max_blocks = (uint32_t)(per_cu * cus);
         a->max_blocks_fast *= (uint32_t)cus;
@@ -652,10 +651,27 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
         // uneven tiles and need more of them per wave to balance.
         {
             size_t big_mesh = 0;
-            for (const auto &m : s->s.meshes) if (m && m->tri.size() / 3 > big_mesh) big_mesh = m->tri.size() / 3;
+            for (const auto &m : a->scene->meshes) if (m && m->tri.size() / 3 > big_mesh) big_mesh = m->tri.size() / 3;
             a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512;
             a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 20);
         }
+}
+
+// First request for the fast mode: build its trees now and upload the tables again.  Caller holds a->mtx.
+static void ensure_fast_trees(const lg_accel *a) {
+    if (a->flat.has_fast) return;
+    use_device(a->device);
+    HIP_TRY(hipDeviceSynchronize()); // nothing may still be reading the tables that are about to be replaced
+    build_and_upload(const_cast<lg_accel *>(a), true);
+}
+
+static lg_accel *accel_from_on(const lg_scene *s, int device) {
+    lg_accel *a = nullptr;
+    int rc = guarded([&] {
+        a = new lg_accel();
+        a->scene = &s->s;
+        a->device = device;
+        build_and_upload(a, false);
     });
     if (rc) { delete a; return nullptr; }
     return a;
@@ -857,6 +873,10 @@ int lg_accel_set_streaming(const lg_accel *a, int enabled) {
 int lg_accel_set_mode(const lg_accel *a, int mode) {
     if (mode != 0 && mode != 1) return fail("mode must be 0 (reference traversal) or 1 (fast)");
     std::lock_guard<std::mutex> g(a->mtx);
+    if (mode == 1) {
+        int rc = guarded([&] { ensure_fast_trees(a); });
+        if (rc) return rc;
+    }
     if (mode == 1 && !a->fast_available) return fail(a->fast_refusal);
     a->fast = mode == 1;
     return 0;
@@ -962,7 +982,8 @@ int lg_trace_pixel(const lg_accel *a, uint32_t w, uint32_t h, uint32_t x, uint32
         use_device(a->device);
         const size_t need = 7 + 2 * a->flat.lights.size();
         if (out_len < need) throw Error("output too small: 7 + 2 * lights doubles");
-        if (fast && !a->fast_available) throw Error("fast mode unavailable for this scene");
+        if (fast) ensure_fast_trees(a);
+        if (fast && !a->fast_available) throw Error(a->fast_refusal);
         DParams P = base_params(*a, w, h);
         DevBuf<double> dout, dlog;
         dout.alloc(need);

@@ -553,6 +553,7 @@ struct Flattener {
     const Scene &scene;
     FlatScene &out;
     std::vector<MeshTables> meshes;
+    bool with_fast = false;
 
     int32_t add_material(const Material &m) {
         DMaterial d{};
@@ -721,7 +722,7 @@ struct Flattener {
         mt.root_bounds = mt.bvh.nodes[0].b;
         std::vector<uint32_t> refs(mt.bvh.order.size(), 0);
         mt.max_stack = stack_need(mt.bvh.nodes, refs, [](uint32_t) { return 0u; });
-        {   // fast tree over the same triangles
+        if (with_fast) { // fast tree over the same triangles
             const std::vector<Bounds> pbf = inflated(pb);
             BuiltBVH fb = FastBuilder(pbf).run();
             append_nodes(fb, mt.fnode_base);
@@ -861,7 +862,8 @@ struct Flattener {
         out.accels[id].prim_base = prim_base;
         need = stack_need(bvh.nodes, extra_in_order, [](uint32_t e) { return e; });
         bound = b_transform(agg.transform.m, bvh.nodes[0].b);
-        {   // fast tree over the same primitives (child accels included as primitives)
+        fneed = 0;
+        if (with_fast) { // fast tree over the same primitives (child accels included as primitives)
             const std::vector<Bounds> pbf = inflated(pb);
             BuiltBVH fb = FastBuilder(pbf).run();
             uint32_t fnode_base;
@@ -892,9 +894,10 @@ struct Flattener {
 };
 } // namespace
 
-void flatten_scene(const Scene &scene, FlatScene &out) {
+void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     out = FlatScene();
-    Flattener fl{scene, out, {}};
+    Flattener fl{scene, out, {}, with_fast};
+    out.has_fast = with_fast;
     fl.meshes.resize(scene.meshes.size());
     out.default_material = fl.add_material(material_default());
     Bounds b;

@@ -127,10 +127,12 @@ struct FlatScene {
     uint32_t max_stack = 0;      // worst-case per-lane traversal stack entries
     uint32_t max_stack_fast = 0; // same for the fast tree (two words per pending child)
     bool has_specular = false;   // any glass / mirror material present
+    bool has_fast = false;       // the fast mode's trees are part of the tables
     // structure dump in the same format as the oracle's orc_accel_dump (build-parity tests)
     std::vector<double> dump_f;
     std::vector<int64_t> dump_i;
 };
-void flatten_scene(const Scene &scene, FlatScene &out); // throws Error
+// `with_fast`: also build the fast mode's trees (binned SAH; 5-10x the reference build's time): only when that mode is asked for
+void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast = false); // throws Error
 
 } // namespace lg
