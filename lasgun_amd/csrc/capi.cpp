@@ -61,24 +61,65 @@ static void use_device(int dev) {
 }
 static void use_device() { use_device(g_device); }
 
+// Device allocations of 1 MiB and more are recycled through a small per-process pool (at most 4 GiB parked per
+// device): capture() builds and drops an accel -- film staging, per-pixel state -- for every frame, like the
+// reference, and hipMalloc / hipFree of those buffers would otherwise cost about a millisecond of each frame.
+// Nothing relies on the contents of a fresh buffer: every buffer is written (kernel, memset or copy) before it is read.
+namespace {
+struct DevPool {
+    std::mutex mtx;
+    struct Block { int device; size_t bytes; void *p; };
+    std::vector<Block> parked;
+    size_t parked_bytes[64] = {0};
+    static constexpr size_t MIN_BYTES = 1u << 20, CAP = 4ull << 30;
+    void *take(int device, size_t bytes) {
+        std::lock_guard<std::mutex> g(mtx);
+        size_t best = parked.size();
+        for (size_t i = 0; i < parked.size(); ++i)
+            if (parked[i].device == device && parked[i].bytes >= bytes && parked[i].bytes <= bytes + bytes / 4 &&
+                (best == parked.size() || parked[i].bytes < parked[best].bytes)) best = i;
+        if (best == parked.size()) return nullptr;
+        void *p = parked[best].p;
+        parked_bytes[device & 63] -= parked[best].bytes;
+        parked.erase(parked.begin() + (long)best);
+        return p;
+    }
+    bool park(int device, size_t bytes, void *p) {
+        std::lock_guard<std::mutex> g(mtx);
+        if (bytes < MIN_BYTES || parked_bytes[device & 63] + bytes > CAP || parked.size() >= 64) return false;
+        parked.push_back(Block{device, bytes, p});
+        parked_bytes[device & 63] += bytes;
+        return true;
+    }
+};
+DevPool g_pool;
+} // namespace
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
-    void upload(const std::vector<T> &v) {
+    size_t bytes_ = 0; // capacity in bytes (what the pool is told)
+    int device_ = 0;
+    void obtain(size_t bytes) {
         release();
+        HIP_TRY(hipGetDevice(&device_));
+        bytes_ = bytes;
+        void *q = bytes >= DevPool::MIN_BYTES ? g_pool.take(device_, bytes) : nullptr;
+        if (!q) HIP_TRY(hipMalloc(&q, bytes));
+        p = (T *)q;
+    }
+    void upload(const std::vector<T> &v) {
+        obtain((v.size() ? v.size() : 1) * sizeof(T));
         n = v.size();
-        size_t bytes = (n ? n : 1) * sizeof(T);
-        HIP_TRY(hipMalloc((void **)&p, bytes));
         if (n) HIP_TRY(hipMemcpy(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice));
     }
     void alloc(size_t count) {
-        release();
+        obtain((count ? count : 1) * sizeof(T));
         n = count;
-        HIP_TRY(hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)));
     }
     void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
+        if (p && !g_pool.park(device_, bytes_, p)) (void)hipFree(p);
+        p = nullptr; n = 0; bytes_ = 0;
     }
     ~DevBuf() { release(); }
 };
@@ -679,7 +720,9 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
 lg_accel *lg_accel_from(const lg_scene *s) { return accel_from_on(s, g_device); }
 void lg_accel_free(lg_accel *a) {
     if (!a) return;
-    if (a->stream) (void)hipStreamSynchronize(a->stream);
+    // its buffers go back to the pool and may be handed out again at once: nothing on any stream may still use them
+    // (hipFree used to imply the same wait)
+    if (hipSetDevice(a->device) == hipSuccess) (void)hipDeviceSynchronize();
     delete a;
 }
 void *lg_accel_stream(const lg_accel *a) { return (void *)a->stream; }
