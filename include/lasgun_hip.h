@@ -136,6 +136,14 @@ int lg_accel_synchronize(const lg_accel *);    /* hipStreamSynchronize(lg_accel_
 /* f64 radiance before quantisation for subset (k, n); rgb = width*height*3 doubles on the HOST,
  * pixels outside the subset are left untouched. */
 int lg_capture_radiance(size_t k, size_t n, const lg_accel *, uint32_t width, uint32_t height, double *rgb);
+/* Any list of pixels (offset = y * width + x < width * height) of a width x height film; results are compact and in
+ * list order on the HOST: rgba_out[4*i..] and / or rgb_out[3*i..] (f64 radiance before quantisation) for offsets[i];
+ * either output may be NULL.  For samples and crops of films too large to move whole (tests, tooling). */
+int lg_capture_pixels(const lg_accel *, uint32_t width, uint32_t height, const uint64_t *offsets, size_t count,
+                      uint8_t *rgba_out, double *rgb_out);
+/* The crop [x0, x1) x [y0, y1) of a width x height film, compact and row-major on the HOST (either output may be NULL). */
+int lg_capture_rect(const lg_accel *, uint32_t width, uint32_t height, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                    uint8_t *rgba_out, double *rgb_out);
 /* Work counters for rendering rows [y0, y1) (runs the counting kernel variant once). */
 int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, lg_stats *out);
 

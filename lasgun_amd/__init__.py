@@ -39,6 +39,8 @@ _EXTRA = {
     "accel_set_packet": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
     "capture_radiance": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
+    "capture_pixels": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p, _C.c_size_t, _C.c_void_p, _C.c_void_p]),
+    "capture_rect": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_void_p, _C.c_void_p]),
     "capture_stats": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.POINTER(CStats)]),
     "profile_enable": (None, [_C.c_void_p, _C.c_int]),
     "profile_read_kinds": (_C.c_int, [_C.c_void_p, _C.c_double * 5, _C.c_uint64 * 5]),
@@ -141,6 +143,23 @@ class HipApi(Api):
         if self.call("capture_radiance", k, n, accel.h, w, h, rgb.ctypes.data):
             raise LasgunError(self.last_error())
         return rgb
+
+    def capture_pixels(self, accel, w, h, offsets, radiance=True):
+        """(rgba (n, 4) uint8, radiance (n, 3) float64 or None) of the pixels `offsets` (y * w + x), in list order."""
+        off = _np.ascontiguousarray(offsets, dtype=_np.uint64)
+        rgba = _np.zeros((off.size, 4), dtype=_np.uint8)
+        rad = _np.full((off.size, 3), _np.nan, dtype=_np.float64) if radiance else None
+        if self.call("capture_pixels", accel.h, w, h, off.ctypes.data, off.size, rgba.ctypes.data, rad.ctypes.data if radiance else None):
+            raise LasgunError(self.last_error())
+        return rgba, rad
+
+    def capture_rect(self, accel, w, h, x0, y0, x1, y1, radiance=True):
+        """(rgba (y1-y0, x1-x0, 4) uint8, radiance (y1-y0, x1-x0, 3) float64 or None) of a crop of the w x h film."""
+        rgba = _np.zeros((y1 - y0, x1 - x0, 4), dtype=_np.uint8)
+        rad = _np.full((y1 - y0, x1 - x0, 3), _np.nan, dtype=_np.float64) if radiance else None
+        if self.call("capture_rect", accel.h, w, h, x0, y0, x1, y1, rgba.ctypes.data, rad.ctypes.data if radiance else None):
+            raise LasgunError(self.last_error())
+        return rgba, rad
 
     def capture_stats(self, accel, w, h, y0=0, y1=None):
         s = CStats()

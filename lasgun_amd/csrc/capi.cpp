@@ -387,6 +387,7 @@ static void set_rect(DParams &P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t
     uint32_t tiles_y = (y1 - y0 + 7u) / 8u;
     P.ntiles = P.tiles_x * tiles_y;
     P.ilv_n = 1; P.ilv_r = 0; P.ilv_b = 1;
+    P.out_x0 = 0; P.out_pitch = P.w;
 }
 static void set_subset(DParams &P, size_t k, size_t n, uint32_t w, uint32_t h) {
     unsigned long long area = (unsigned long long)w * h;
@@ -769,20 +770,88 @@ int lg_capture_subset_device(size_t k, size_t n, const lg_accel *a, uint32_t w, 
     });
 }
 
-int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) { // lib.rs:110-162
+// capture_subset into a HOST film (lib.rs:110-162).  The reference calls this from n threads at once on one
+// Accel and one film (lib.rs:67-103: write-disjoint pixel sets), so concurrent calls must not disturb each other:
+// every call renders into a device buffer of its own -- the whole film for (0, 1), otherwise a COMPACT buffer of
+// just the subset's pixels, one word per work item -- and only the owned pixels {k + i*n} of the host film are
+// written.  Nothing is uploaded and no other pixel of the film is touched (lib.rs:152).
+int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) {
     return guarded([&] {
         if (n == 0) throw Error("n must be > 0");
-        size_t bytes = (size_t)film->w * film->h * 4;
+        const uint32_t w = film->w, h = film->h;
+        const unsigned long long area = (unsigned long long)w * h;
+        const bool whole = n == 1 && k == 0;
+        const unsigned long long count = whole ? area : (k < area ? (area - k + n - 1) / n : 0);
+        if (count == 0) return;
+        DevBuf<uint32_t> buf; // this call's own output (returned to the pool when the call ends)
         {
             std::lock_guard<std::mutex> g(a->mtx);
             use_device(a->device);
-            if (a->staging.n < bytes) { HIP_TRY(hipStreamSynchronize(a->stream)); a->staging.alloc(bytes); }
-            // pixels outside the subset must keep their current value (lib.rs:152)
-            if (!(n == 1 && k == 0)) HIP_TRY(hipMemcpyAsync(a->staging.p, film->px, bytes, hipMemcpyHostToDevice, a->stream));
+            buf.alloc((size_t)count);
+            DParams P = base_params(*a, w, h);
+            if (whole) set_rect(P, 0, 0, w, h);
+            else { set_subset(P, k, n, w, h); P.out_compact = 1; }
+            P.out_row0 = 0;
+            P.out_rgba = (uint8_t *)buf.p;
+            enqueue(*a, P, false, a->stream);
+            if (whole) HIP_TRY(hipMemcpyAsync(film->px, buf.p, (size_t)area * 4, hipMemcpyDeviceToHost, a->stream));
         }
-        if (lg_capture_subset_device(k, n, a, film->w, film->h, a->staging.p, (void *)a->stream)) throw Error(tl_error);
+        if (whole) { use_device(a->device); HIP_TRY(hipStreamSynchronize(a->stream)); return; }
+        std::vector<uint32_t> host((size_t)count);
+        use_device(a->device);
+        HIP_TRY(hipMemcpyAsync(host.data(), buf.p, (size_t)count * 4, hipMemcpyDeviceToHost, a->stream));
+        HIP_TRY(hipStreamSynchronize(a->stream));
+        uint8_t *px = film->px;
+        for (unsigned long long i = 0; i < count; ++i) std::memcpy(px + 4 * (k + i * n), &host[(size_t)i], 4);
+    });
+}
+// Any list of pixels of a width x height film (offset = y * width + x), results compact and in list order:
+// rgba_out[4*i ..] and/or rgb_out[3*i ..] (f64 radiance before quantisation) for offsets[i].  Test / tooling hook:
+// samples and crops of films too large to move whole.
+int lg_capture_pixels(const lg_accel *a, uint32_t w, uint32_t h, const uint64_t *offsets, size_t count, uint8_t *rgba_out, double *rgb_out) {
+    return guarded([&] {
+        if (count == 0) return;
+        if (!offsets) throw Error("offsets is NULL");
+        const unsigned long long area = (unsigned long long)w * h;
+        for (size_t i = 0; i < count; ++i) if (offsets[i] >= area) throw Error("pixel offset outside the film");
+        if (count > 0xFFFFFFFFull * 64ull) throw Error("too many pixels");
+        DevBuf<unsigned long long> list;
+        DevBuf<uint32_t> rgba;
+        DevBuf<double> rad;
         std::lock_guard<std::mutex> g(a->mtx);
-        HIP_TRY(hipMemcpyAsync(film->px, a->staging.p, bytes, hipMemcpyDeviceToHost, a->stream));
+        use_device(a->device);
+        list.alloc(count);
+        HIP_TRY(hipMemcpyAsync(list.p, offsets, count * 8, hipMemcpyHostToDevice, a->stream));
+        DParams P = base_params(*a, w, h);
+        P.mode = 2; P.pixel_list = list.p; P.sub_count = count; P.out_compact = 1;
+        P.ntiles = (uint32_t)((count + 63) / 64);
+        if (rgba_out) { rgba.alloc(count); P.out_rgba = (uint8_t *)rgba.p; }
+        if (rgb_out) { rad.alloc(count * 3); P.out_radiance = rad.p; }
+        enqueue(*a, P, false, a->stream);
+        if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rgba.p, count * 4, hipMemcpyDeviceToHost, a->stream));
+        if (rgb_out) HIP_TRY(hipMemcpyAsync(rgb_out, rad.p, count * 24, hipMemcpyDeviceToHost, a->stream));
+        HIP_TRY(hipStreamSynchronize(a->stream));
+    });
+}
+// The crop [x0, x1) x [y0, y1) of a width x height film, compact and row-major: rgba_out (x1-x0)*(y1-y0)*4 bytes and/or
+// rgb_out (x1-x0)*(y1-y0)*3 doubles on the HOST.
+int lg_capture_rect(const lg_accel *a, uint32_t w, uint32_t h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint8_t *rgba_out, double *rgb_out) {
+    return guarded([&] {
+        if (x1 > w || y1 > h || x0 > x1 || y0 > y1) throw Error("bad rectangle");
+        const size_t count = (size_t)(x1 - x0) * (y1 - y0);
+        if (count == 0) return;
+        DevBuf<uint32_t> rgba;
+        DevBuf<double> rad;
+        std::lock_guard<std::mutex> g(a->mtx);
+        use_device(a->device);
+        DParams P = base_params(*a, w, h);
+        set_rect(P, x0, y0, x1, y1);
+        P.out_row0 = y0; P.out_x0 = x0; P.out_pitch = x1 - x0;
+        if (rgba_out) { rgba.alloc(count); P.out_rgba = (uint8_t *)rgba.p; }
+        if (rgb_out) { rad.alloc(count * 3); P.out_radiance = rad.p; }
+        enqueue(*a, P, false, a->stream);
+        if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rgba.p, count * 4, hipMemcpyDeviceToHost, a->stream));
+        if (rgb_out) HIP_TRY(hipMemcpyAsync(rgb_out, rad.p, count * 24, hipMemcpyDeviceToHost, a->stream));
         HIP_TRY(hipStreamSynchronize(a->stream));
     });
 }

@@ -80,7 +80,7 @@ struct DLight {
     double pos[3], intensity[3], falloff[3];
 };
 
-enum AccelFlags : uint32_t { AF_SWAP_BACKFACE = 1, AF_MESH = 2, AF_HAS_N = 4, AF_HAS_UV = 8 };
+enum AccelFlags : uint32_t { AF_SWAP_BACKFACE = 1, AF_MESH = 2, AF_HAS_N = 4, AF_HAS_UV = 8, AF_IDENTITY = 16 /* minv is exactly the identity */ };
 
 struct alignas(16) DAccel {
     Affine m;    // 96 B
@@ -145,7 +145,7 @@ struct DParams {
     uint32_t w, h;
     double winv, hinv, aspect;
     // ---- work: either a rectangle of 8x8 tiles or a strided pixel subset (lib.rs:152)
-    uint32_t mode; // 0 = rectangle [x0,x1) x [y0,y1); 1 = subset {k + i*n}
+    uint32_t mode; // 0 = rectangle [x0,x1) x [y0,y1); 1 = subset {k + i*n}; 2 = the pixel offsets listed in pixel_list[0 .. sub_count)
     uint32_t x0, y0, x1, y1;
     uint32_t tiles_x;
     // row-block interleave for multi-GPU balance (mode 0): with ilv_n > 1 the rows [y0, y1) are
@@ -154,6 +154,10 @@ struct DParams {
     unsigned long long sub_k, sub_n, sub_count;
     uint32_t ntiles;
     uint32_t out_row0; // row of the image stored at out_rgba[0] (0 for a full film, y0 for a row tile)
+    uint32_t out_x0;   // mode 0: column of the image stored at out_rgba[0] (0 unless the output is a crop)
+    uint32_t out_pitch; // mode 0: pixels per row of the output buffer (w unless the output is a crop)
+    uint32_t out_compact; // modes 1, 2: work item i writes output element i (a compact buffer) instead of its pixel offset
+    const unsigned long long *pixel_list; // mode 2
     uint8_t *out_rgba;
     double *out_radiance; // optional f64 RGB, same addressing as out_rgba (3 doubles per pixel)
     uint32_t *tile_counter;   // [0] next tile, [1] number of tiles listed in tie_tiles, [2] next listed tile (fix-up pass)

@@ -741,6 +741,17 @@ struct Flattener {
         return mt;
     }
 
+    // minv is EXACTLY the identity (1.0 and +0.0 bit patterns): the traversal may then skip inverse_transform_ray
+    // for rays whose components are finite and not -0 (kernels.hip, enter_accel: the product is the same bits)
+    static bool affine_is_identity(const Affine &m) {
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 3; ++r) {
+                uint64_t bits;
+                std::memcpy(&bits, &m.c[c][r], 8);
+                if (bits != (c == r ? 0x3FF0000000000000ull : 0ull)) return false;
+            }
+        return true;
+    }
     void set_chain(DAccel &a, int32_t parent, uint32_t self) {
         a.parent = parent;
         if (parent < 0) { a.nchain = 1; a.chain[0] = self; return; }
@@ -762,7 +773,7 @@ struct Flattener {
         a.node_base = mt.node_base; a.prim_base = mt.prim_base;
         a.fnode_base = mt.fnode_base; a.fprim_base = mt.fprim_base;
         a.material = has_mat ? add_material(mat) : -1;
-        a.flags = AF_MESH | (mt.has_n ? AF_HAS_N : 0u) | (mt.has_uv ? AF_HAS_UV : 0u);
+        a.flags = AF_MESH | (mt.has_n ? AF_HAS_N : 0u) | (mt.has_uv ? AF_HAS_UV : 0u) | (affine_is_identity(a.minv) ? AF_IDENTITY : 0u);
         set_chain(a, parent, id);
         out.accels[id] = a;
         dump(mt.bvh, has_mat, false, idt);
@@ -779,7 +790,7 @@ struct Flattener {
             DAccel a{};
             a.m = to_affine(agg.transform.m); a.minv = to_affine(agg.transform.minv);
             a.material = -1;
-            a.flags = agg.swap_backface ? AF_SWAP_BACKFACE : 0u;
+            a.flags = (agg.swap_backface ? AF_SWAP_BACKFACE : 0u) | (affine_is_identity(a.minv) ? AF_IDENTITY : 0u);
             set_chain(a, parent, id);
             out.accels[id] = a;
         }

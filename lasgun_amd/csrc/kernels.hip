@@ -743,6 +743,214 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
 }
 
 // ------------------------------------------------------------------------------------------
+// Reference traversal, second formulation (the plain instantiations: no counters, no fast tree).
+//
+// Same walk, same visit order, same arithmetic as traverse<false, false> above -- what differs is how
+// the divergence is written down.  There the per-lane state is a handful of bools and the phases are
+// nested per-lane loops with breaks; hipcc turns every one of those into lane masks kept in SGPR pairs
+// and merged with s_and / s_andn2 / s_or triplets: 87 scalar and 86 vector instructions per node or
+// primitive step, of which 26 are the slab test.  Here
+//   * a lane's phase is ONE integer (ST_NODE / ST_LEAF / ST_LEVEL_DONE / ST_DONE);
+//   * every loop is WAVE-UNIFORM (`while (any lane is in this phase)`: one ballot and one scalar branch per
+//     trip) around a flat predicated step;
+//   * the node step has no branch at all: the far child is stored above the stack top unconditionally (it
+//     only counts if sp advances), the entry below the top is fetched at the top of the step together with
+//     the node record (so a pop costs no extra LDS round trip), and near / far / pop are selects;
+//   * the ROOT accel's ray stays in registers, and entering an accel whose inverse transform is exactly the
+//     identity (every mesh: BVHAccel::from_mesh uses transform::ID, bvh.rs:147) keeps the ray as it is when
+//     all six components are finite and not -0 -- ((1*x + 0*y) + 0*z) + 0*w is then x, bit for bit -- and
+//     the matching return keeps it too; other returns recompute the parent's ray from the root's, through
+//     the same sequence of transforms (bit-identical, as before).
+// ------------------------------------------------------------------------------------------
+enum : uint32_t { ST_NODE = 0u, ST_LEAF = 1u, ST_LEVEL_DONE = 2u, ST_DONE = 3u };
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// finite and not -0: not one of sNaN, qNaN, -inf, -0, +inf (v_cmp_class_f64)
+__device__ __forceinline__ bool f64_plain(double x) { return !__builtin_amdgcn_class(x, 0x001 | 0x002 | 0x004 | 0x020 | 0x200); }
+__device__ __forceinline__ bool ray_plain(const Ray &r) {
+    return f64_plain(r.o.x) && f64_plain(r.o.y) && f64_plain(r.o.z) && f64_plain(r.d.x) && f64_plain(r.d.y) && f64_plain(r.d.z);
+}
+__device__ __forceinline__ uint32_t neg_mask(const Ray &r) {
+    return (r.dinv.x < 0.0 ? 1u : 0u) | (r.dinv.y < 0.0 ? 2u : 0u) | (r.dinv.z < 0.0 ? 4u : 0u);
+}
+constexpr uint32_t FRAME_SAME_RAY = 0x80000000u; // level frame, third word: the level was entered without changing the ray
+
+struct Lvl { // the accel level a lane is walking
+    uint32_t accel, node_base, prim_base, soup_delta, flags;
+};
+template <bool LDSS>
+__device__ __forceinline__ void lvl_set(const DParams &P, Lvl &L, uint32_t accel) {
+    const DAccel *A = P.accels + accel;
+    L.accel = accel;
+    L.node_base = LDSS ? A->lnode_base : A->node_base;
+    L.prim_base = LDSS ? A->lprim_base : A->prim_base;
+    L.soup_delta = LDSS ? A->prim_base - A->lprim_base : 0u;
+    L.flags = A->flags;
+}
+// One fat mesh leaf [li, le) of the second formulation: the reference's leaf loop (bvh.rs:483-488) over
+// triangle records streamed one slot ahead; returns true when an any-hit ray is done.
+template <int KZ, bool LDSS>
+__device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, const V3 o, const TriSetup tri, uint32_t li, const uint32_t le,
+                                           const uint32_t soup_delta, const uint32_t accel, const bool anyhit, Best &best) {
+    const uint32_t last = le - 1u;
+    LeafRec cur = load_rec(P, li + soup_delta);
+    for (; li < le; ++li) {
+        LeafRec r = cur;
+        cur = load_rec(P, (li < last ? li + 1u : last) + soup_delta); // prefetch the next slot (clamped: always a valid slot)
+        V3 p0{rec_f32(r.a.x), rec_f32(r.a.y), rec_f32(r.a.z)}, p1{rec_f32(r.a.w), rec_f32(r.b.x), rec_f32(r.b.y)},
+            p2{rec_f32(r.b.z), rec_f32(r.b.w), rec_f32(r.c.x)};
+        TriHit h;
+        if (!triangle_t_pre<KZ>(p0, p1, p2, o, tri.sx, tri.sy, tri.sz, h)) continue;
+        if (h.t >= best.t) continue;
+        best.t = h.t; best.ref = load_primref<LDSS>(P, scn, li); best.accel = accel;
+        if (anyhit && h.t < 1.0) return true; // point.rs:49
+    }
+    return false;
+}
+
+template <bool LDSS>
+__device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
+                                             Best &best, const uint4 *scn) {
+    best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
+    uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
+    Lvl L;
+    lvl_set<LDSS>(P, L, 0u);
+    // ---- the root accel's local ray (bvh.rs:462), kept for the returns
+    Ray root = wray;
+    if (!((L.flags & AF_IDENTITY) && ray_plain(wray))) root = ray_to_local(P.accels->minv, wray);
+    Ray ray = root;
+    double dd = dot(ray.d, ray.d);      // a of every sphere's quadratic at this level
+    uint32_t negmask = neg_mask(ray);   // dir_is_neg (bvh.rs:463)
+    uint32_t sp = 0, base = 0, cur = 0, li = 0, le = 0;
+    uint32_t state = ST_NODE;
+    for (;;) {
+        // ---- phase A: interior nodes (bvh.rs:471-505), until no lane of the wave is at a node
+        while (wave_any(state == ST_NODE)) {
+            if (state == ST_NODE) {
+                const NodeRec nd = load_node<LDSS>(P, scn, L.node_base + cur);
+                const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
+                const bool hit = slab_intersects(nd.bmin, nd.bmax, ray);
+                const uint32_t link = nd.link, meta = nd.meta;
+                const bool leaf = (meta & NODE_LEAF) != 0u;
+                const uint32_t count = meta & 0xFFFFu;
+                const bool neg = ((negmask >> (meta & 3u)) & 1u) != 0u; // dir_is_neg[axis] (bvh.rs:496)
+                const uint32_t near_node = neg ? link : cur + 1u, far_node = neg ? cur + 1u : link;
+                const bool interior_hit = hit && !leaf, leaf_hit = hit && leaf && count != 0u;
+                const bool pop = !(interior_hit || leaf_hit), can_pop = sp != base;
+                stk[sp * stride] = far_node; // counts only if sp advances (bvh.rs:493-504)
+                cur = interior_hit ? near_node : popped;
+                sp = sp + (interior_hit ? 1u : 0u) - (pop && can_pop ? 1u : 0u);
+                li = L.prim_base + link; le = li + count; // (read in ST_LEAF only)
+                state = leaf_hit ? ST_LEAF : (pop && !can_pop) ? ST_LEVEL_DONE : ST_NODE;
+            }
+        }
+        // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
+        const bool mesh = (L.flags & AF_MESH) != 0u;
+        if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
+            const TriSetup tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
+            bool done;
+            if (tri.kz == 0) done = mesh_leaf2<0, LDSS>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best);
+            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best);
+            else done = mesh_leaf2<2, LDSS>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best);
+            if (done) state = ST_DONE;
+            else if (sp != base) { --sp; cur = stk[sp * stride]; state = ST_NODE; }
+            else state = ST_LEVEL_DONE;
+        }
+        while (wave_any(state == ST_LEAF)) {
+            if (state == ST_LEAF) {
+                const uint32_t slot = li;
+                const uint32_t ref = load_primref<LDSS>(P, scn, slot);
+                LeafRec g;
+                if (LDSS) { const uint4 *q = scn + (P.lds_soup_off + slot * 3u); g = LeafRec{q[0], q[1], q[2]}; }
+                else g = load_rec(P, slot);
+                const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
+                li = slot + 1u;
+                const uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
+                bool accepted = false;
+                double t = 0.0;
+                if (kind == PK_SPHERE) { // Sphere::intersect_t + quad_roots (sphere.rs:30-69, core/math.rs) == sphere_t_a
+                    const V3 cen{rec_f64(g.a.x, g.a.y), rec_f64(g.a.z, g.a.w), rec_f64(g.b.x, g.b.y)};
+                    const double rad = rec_f64(g.b.z, g.b.w);
+                    const V3 l = ray.o - cen;
+                    const double b = 2.0 * dot(ray.d, l);
+                    const double c = dot(l, l) - rad * rad;
+                    bool has = false;
+                    if (dd == 0.0) {
+                        if (b != 0.0) { t = -c / b; has = true; }
+                    } else {
+                        const double disc = b * b - 4.0 * dd * c;
+                        if (!(disc < 0.0)) {
+                            const double q = -(b + signum(b) * sqrt(disc)) / 2.0;
+                            const double r0 = q / dd;
+                            const double r1 = (q == 0.0) ? r0 : c / q;
+                            const double t0 = fmin_(r0, r1), t1 = fmax_(r0, r1);
+                            t = t0 < 0.0 ? t1 : t0;
+                            has = true;
+                        }
+                    }
+                    accepted = has && !(t < 0.0) && !(t >= best.t);
+                } else if (kind == PK_CUBOID) {
+                    double mn[3] = {rec_f64(g.a.x, g.a.y), rec_f64(g.a.z, g.a.w), rec_f64(g.b.x, g.b.y)};
+                    double mx[3] = {rec_f64(g.b.z, g.b.w), rec_f64(g.c.x, g.c.y), rec_f64(g.c.z, g.c.w)};
+                    V3 d0, d1;
+                    if (cuboid_hit<false>(mn, mx, ray, t, d0, d1)) accepted = !(t >= best.t);
+                } else if (kind == PK_ACCEL) {
+                    // nested BVHAccel (Group / Mesh): park this level, re-express the ray (bvh.rs:462)
+                    const uint32_t aflags = P.accels[idx].flags;
+                    const bool same = (aflags & AF_IDENTITY) != 0u && ray_plain(ray);
+                    stk[sp * stride] = li; stk[(sp + 1u) * stride] = le; stk[(sp + 2u) * stride] = base | (same ? FRAME_SAME_RAY : 0u);
+                    sp += 3u; base = sp;
+                    if (!same) {
+                        ray = ray_to_local(P.accels[idx].minv, ray);
+                        dd = dot(ray.d, ray.d);
+                        negmask = neg_mask(ray);
+                    }
+                    lvl_set<LDSS>(P, L, idx);
+                    cur = 0u;
+                    state = ST_NODE; // node 0 is tested when visited (bvh.rs:472-473)
+                } else { // a triangle outside a mesh accel cannot be built by the scene API; kept for completeness
+                    const uint32_t *vi = P.tri_v + 3ull * idx;
+                    TriHit h;
+                    if (triangle_t(load_f3(P.vpos, vi[0]), load_f3(P.vpos, vi[1]), load_f3(P.vpos, vi[2]), ray, h)) { t = h.t; accepted = !(t >= best.t); }
+                }
+                if (accepted) {
+                    best.t = t; best.ref = ref; best.accel = L.accel;
+                    if (anyhit && t < 1.0) state = ST_DONE; // occluded: point.rs:49 only asks isect.t < 1.0
+                }
+                if (state == ST_LEAF && li >= le) { // leaf exhausted: next pending node of this level, or the level is done
+                    if (sp != base) { --sp; cur = popped; state = ST_NODE; }
+                    else state = ST_LEVEL_DONE;
+                }
+            }
+        }
+        // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
+        if (state == ST_LEVEL_DONE) {
+            if (L.accel == 0u) state = ST_DONE;
+            else {
+                const uint32_t w2 = stk[(sp - 1u) * stride];
+                le = stk[(sp - 2u) * stride]; li = stk[(sp - 3u) * stride];
+                sp -= 3u; base = w2 & ~FRAME_SAME_RAY;
+                const uint32_t parent = (uint32_t)P.accels[L.accel].parent;
+                lvl_set<LDSS>(P, L, parent);
+                if (!(w2 & FRAME_SAME_RAY)) { // the parent's ray again: from the root's, through the same transforms
+                    ray = root;
+                    const DAccel *A = P.accels + parent;
+                    for (uint32_t i = 1; i < A->nchain; ++i) {
+                        const DAccel *C = P.accels + A->chain[i];
+                        if (!((C->flags & AF_IDENTITY) && ray_plain(ray))) ray = ray_to_local(C->minv, ray);
+                    }
+                    dd = dot(ray.d, ray.d);
+                    negmask = neg_mask(ray);
+                }
+                if (li < le) state = ST_LEAF;
+                else if (sp != base) { --sp; cur = stk[sp * stride]; state = ST_NODE; }
+                else state = ST_LEVEL_DONE; // handled by the next trip
+            }
+        }
+        if (!wave_any(state != ST_DONE)) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Packet traversal (streaming pipeline, reference tree): ONE walk per wavefront.
 //
 // The 64 rays of an 8x8 tile (primary) or of its hit points towards one light (shadow) visit
@@ -1247,6 +1455,34 @@ __device__ __forceinline__ V3 frame_get3(const DParams &P, uint32_t depth, int f
     return V3{frame_at(P, depth, field, g), frame_at(P, depth, field + 1, g), frame_at(P, depth, field + 2, g)};
 }
 
+// Which pixel a work item (tile, lane) renders and where its result goes (lib.rs:110-162 addresses pixels by
+// offset = y * w + x; the three modes are three ways of enumerating offsets).
+struct Pixel {
+    uint32_t x, y;
+    unsigned long long pix; // index into out_rgba (x4 bytes) / out_radiance (x3 doubles)
+    bool active;
+};
+__device__ __forceinline__ Pixel pixel_of(const DParams &P, uint32_t tile, uint32_t lane) {
+    Pixel px;
+    if (P.mode == 0) {
+        uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+        px.x = P.x0 + tx * 8u + (lane & 7u);
+        const uint32_t vy = P.y0 + ty * 8u + (lane >> 3); // row of the output buffer's addressing (== y unless rows are interleaved)
+        px.active = px.x < P.x1 && vy < P.y1;
+        px.y = P.ilv_n > 1u ? ((vy / P.ilv_b) * P.ilv_n + P.ilv_r) * P.ilv_b + vy % P.ilv_b : vy;
+        px.pix = (unsigned long long)(vy - P.out_row0) * P.out_pitch + (px.x - P.out_x0);
+    } else {
+        unsigned long long i = (unsigned long long)tile * 64ull + lane;
+        px.active = i < P.sub_count;
+        // mode 1: the strided subset {k + i*n} (lib.rs:152); mode 2: an explicit list of pixel offsets
+        unsigned long long off = P.mode == 1 ? P.sub_k + i * P.sub_n : (px.active ? P.pixel_list[i] : 0ull);
+        px.x = (uint32_t)(off % P.w);
+        px.y = (uint32_t)(off / P.w);
+        px.pix = P.out_compact ? i : off;
+    }
+    return px;
+}
+
 extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
 
 // Shading frame of a hit from the ray that found it (resolve_hit + SurfaceInteraction::from,
@@ -1326,22 +1562,9 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
         tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
         if (tile >= P.ntiles) break; // every wave reaches this exit
 
-        uint32_t x, y, vy; // vy = row of the output buffer's addressing (== y unless rows are interleaved)
-        bool active;
-        if (P.mode == 0) {
-            uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-            x = P.x0 + tx * 8u + (lane & 7u);
-            vy = P.y0 + ty * 8u + (lane >> 3);
-            active = x < P.x1 && vy < P.y1;
-            y = P.ilv_n > 1u ? ((vy / P.ilv_b) * P.ilv_n + P.ilv_r) * P.ilv_b + vy % P.ilv_b : vy;
-        } else {
-            unsigned long long i = (unsigned long long)tile * 64ull + lane;
-            active = i < P.sub_count;
-            unsigned long long off = P.sub_k + i * P.sub_n;
-            x = (uint32_t)(off % P.w);
-            y = (uint32_t)(off / P.w);
-            vy = y;
-        }
+        const Pixel px = pixel_of(P, tile, lane);
+        const uint32_t x = px.x, y = px.y;
+        const bool active = px.active;
         if (!active) continue; // lanes past the edge idle for this tile
 
         // ---- Camera::sample (camera.rs:113-146)
@@ -1527,7 +1750,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
         color = color * weight; // integrate.rs:19
 
         // ---- Img::set (img.rs:46-67)
-        unsigned long long pix = (unsigned long long)(vy - P.out_row0) * P.w + x;
+        const unsigned long long pix = px.pix;
         if (P.out_rgba) {
             uint32_t rgba = to_byte(color.x) | (to_byte(color.y) << 8) | (to_byte(color.z) << 16) | (255u << 24);
             reinterpret_cast<uint32_t *>(P.out_rgba)[pix] = rgba;
@@ -1562,28 +1785,6 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
 // Every f64 is produced by the same expressions as in the megakernel; only their placement in
 // kernels differs.  Up to 32 lights; scenes with more use the megakernel.
 // ------------------------------------------------------------------------------------------
-struct Pixel {
-    uint32_t x, y, vy;
-    bool active;
-};
-__device__ __forceinline__ Pixel pixel_of(const DParams &P, uint32_t tile, uint32_t lane) {
-    Pixel px;
-    if (P.mode == 0) {
-        uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-        px.x = P.x0 + tx * 8u + (lane & 7u);
-        px.vy = P.y0 + ty * 8u + (lane >> 3);
-        px.active = px.x < P.x1 && px.vy < P.y1;
-        px.y = P.ilv_n > 1u ? ((px.vy / P.ilv_b) * P.ilv_n + P.ilv_r) * P.ilv_b + px.vy % P.ilv_b : px.vy;
-    } else {
-        unsigned long long i = (unsigned long long)tile * 64ull + lane;
-        px.active = i < P.sub_count;
-        unsigned long long off = P.sub_k + i * P.sub_n;
-        px.x = (uint32_t)(off % P.w);
-        px.y = (uint32_t)(off / P.w);
-        px.vy = px.y;
-    }
-    return px;
-}
 // Camera::sample for sample `sidx` of pixel (x, y) (camera.rs:113-146)
 __device__ __forceinline__ Ray camera_ray(const DParams &P, uint32_t x, uint32_t y, uint32_t sidx) {
     double img_plane_height = P.image_plane_height;
@@ -1664,6 +1865,10 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             Ray ray = camera_ray(P, px.x, px.y, P.sample_index);
             Best b;
             bool tie = false;
+#ifndef LG_OLD_TRAVERSE
+            if (!FAST) traverse_ref<LDSS>(P, ray, false, stack, stride, b, scn);
+            else
+#endif
             traverse<false, FAST, LDSS>(P, ray, false, stack, stride, b, cnt, tie, scn);
             if (FAST && tie) traverse<false, false>(P, ray, false, stack, stride, b, cnt, tie);
             P.hit_ref[widx] = b.ref; // (t and the accel instance are consumed by park_frame right here)
@@ -1683,6 +1888,10 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
                 Ray sray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
                 Best b;
                 bool tie = false;
+#ifndef LG_OLD_TRAVERSE
+                if (!FAST) traverse_ref<LDSS>(P, sray, true, stack, stride, b, scn);
+                else
+#endif
                 traverse<false, FAST, LDSS>(P, sray, true, stack, stride, b, cnt, tie, scn);
                 if (FAST && tie && !(b.t < 1.0)) traverse<false, false>(P, sray, true, stack, stride, b, cnt, tie);
                 if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
@@ -1810,7 +2019,7 @@ __global__ void __launch_bounds__(LG_BLOCK, 3) stream_shade_kernel(const DParams
     }
     const double weight = 1. / (double)nsamples;
     color = color * weight;
-    unsigned long long pix = (unsigned long long)(px.vy - P.out_row0) * P.w + px.x;
+    const unsigned long long pix = px.pix;
     if (P.out_rgba) {
         uint32_t rgba = to_byte(color.x) | (to_byte(color.y) << 8) | (to_byte(color.z) << 16) | (255u << 24);
         reinterpret_cast<uint32_t *>(P.out_rgba)[pix] = rgba;

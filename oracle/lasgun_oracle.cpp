@@ -1609,6 +1609,33 @@ int orc_capture_subset_mt(size_t k, size_t n, const void *accel, void *film, siz
     for (auto &t : th) t.join();
     return 0;
 }
+// Any list of pixel offsets (y * w + x) of a w x h film, results compact and in list order (samples and crops of
+// films too large to render whole on the CPU): rgba_out[4*i..] and / or rgb_out[3*i..] for offsets[i].
+// The per-pixel body is capture_subset_impl's (lib.rs:110-162).
+int orc_capture_pixels(const void *accel, uint32_t w, uint32_t h, const uint64_t *offsets, size_t count, uint8_t *rgba_out, double *rgb_out, size_t nthreads) {
+    const Accel *acc = (const Accel *)accel;
+    const Img img = mk_img(w, h);
+    const size_t area = (size_t)w * h;
+    for (size_t i = 0; i < count; ++i) if (offsets[i] >= area) { tl_error = "pixel offset outside the film"; return 1; }
+    if (nthreads == 0) nthreads = 1;
+    auto work = [=](size_t t) {
+        std::vector<Ray> samples(acc->scene->camera.num_samples());
+        double weight = 1. / (double)samples.size();
+        for (size_t i = t; i < count; i += nthreads) {
+            size_t offset = (size_t)offsets[i];
+            uint32_t x = (uint32_t)(offset % w), y = (uint32_t)(offset / w);
+            acc->scene->camera.sample(x, y, img, samples.data());
+            V3 color = integrate(*acc, samples.data(), samples.size(), weight);
+            if (rgba_out) { uint8_t *p = rgba_out + 4 * i; p[0] = to_byte(color.x); p[1] = to_byte(color.y); p[2] = to_byte(color.z); p[3] = 255; }
+            if (rgb_out) { double *r = rgb_out + 3 * i; r[0] = color.x; r[1] = color.y; r[2] = color.z; }
+        }
+        flush_stats();
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+    for (auto &t : th) t.join();
+    return 0;
+}
 void orc_stats_reset(void) { std::lock_guard<std::mutex> g(*g_stats_mutex); g_stats_total = Stats(); tl_stats = Stats(); }
 void orc_stats_read(orc_stats *o) {
     flush_stats();

@@ -10,6 +10,8 @@ Each fixture holds, for one scene of lasgun_amd/scenes.py rendered at a small si
   rgba      (h, w, 4) uint8   -- oracle, libm trig (what the Rust binary would call)
   radiance  (h, w, 3) float64 -- oracle, PORTABLE trig (bit-comparable with the GPU)
   stats     deterministic work counters of that render (closest-hit shadow rays, as in the reference)
+CROPS (golden_cases.py) are 64x64 crops of the full-size films of BASELINE.json's configs[3] and configs[4]
+(4096x4096 100k-triangle mesh, 8192x8192 mixed), evaluated pixel by pixel with orc_capture_pixels.
 Usage: python tests/golden/make_golden.py
 """
 import json
@@ -22,7 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 
-from golden_cases import CASES  # noqa: E402
+from golden_cases import CASES, CROPS  # noqa: E402
 from oracle_lib import oracle  # noqa: E402
 
 
@@ -46,6 +48,18 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=rgba, radiance=rad,
                             stats=np.frombuffer(json.dumps(stats).encode(), dtype=np.uint8))
         print(name, rgba.shape, stats)
+    # crops of the full-size config films: rgba (libm trig), radiance (portable trig), no stats (a crop's counters
+    # are not a quantity of the reference)
+    for name, (builder, w, h, x0, y0, cw, ch) in CROPS.items():
+        acc = o.Accel(builder(o))
+        o.set_trig_mode(0)
+        rgba, _ = o.capture_rect(acc, w, h, x0, y0, x0 + cw, y0 + ch, radiance=False)
+        o.set_trig_mode(1)
+        rgba2, rad = o.capture_rect(acc, w, h, x0, y0, x0 + cw, y0 + ch)
+        o.set_trig_mode(0)
+        assert np.array_equal(rgba, rgba2), "RGBA8 depends on the trig implementation for " + name
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=rgba, radiance=rad, rect=np.array([w, h, x0, y0, cw, ch]))
+        print(name, rgba.shape, "std %.1f" % rgba[..., :3].std())
 
 
 if __name__ == "__main__":

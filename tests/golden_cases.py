@@ -12,3 +12,14 @@ CASES = {
     "mesh_metal_flat": (lambda api: S.mesh_scene(api, 24, 24, "metal", smoothing=False), 48, 40),
     "mesh_default": (lambda api: S.mesh_scene(api, 16, 16, "default"), 40, 48),
 }
+
+# 64x64 crops of the FULL-SIZE films of BASELINE.json's configs[3] (100k-triangle mesh, glass / metal, mirror sphere:
+# secondary rays) and configs[4] (8192x8192 mixed mesh + spheres): name -> (builder, film w, film h, x0, y0, crop w, crop h).
+# The crops sit on the torus' silhouette / its refractions and on sphere clusters in front of the mesh.
+CROPS = {
+    "config4_glass_crop_a": (lambda api: S.mesh_scene(api, 224, 224, "glass"), 4096, 4096, 1080, 1500, 64, 64),
+    "config4_glass_crop_b": (lambda api: S.mesh_scene(api, 224, 224, "glass"), 4096, 4096, 1800, 1900, 64, 64),
+    "config4_metal_crop": (lambda api: S.mesh_scene(api, 224, 224, "metal"), 4096, 4096, 1080, 1500, 64, 64),
+    "config5_mixed_crop_a": (lambda api: S.mixed_scene(api), 8192, 8192, 4000, 3000, 64, 64),
+    "config5_mixed_crop_b": (lambda api: S.mixed_scene(api), 8192, 8192, 3000, 4500, 64, 64),
+}

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_cases import CASES
+from golden_cases import CASES, CROPS
 from oracle_lib import oracle
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -36,6 +36,30 @@ def test_oracle_matches_golden(name):
         o.set_trig_mode(0)
     assert np.array_equal(got.view(np.uint64), rad.view(np.uint64))
     assert np.array_equal(film2.pixels(), rgba)  # RGBA8 does not depend on the trig implementation
+
+
+@pytest.mark.parametrize("name", list(CROPS))
+def test_oracle_matches_full_size_crop_golden(name):
+    """64x64 crops of the 4096x4096 mesh films (configs[3]) and the 8192x8192 mixed film (configs[4])."""
+    o = oracle()
+    builder, w, h, x0, y0, cw, ch = CROPS[name]
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert list(z["rect"]) == [w, h, x0, y0, cw, ch]
+    acc = o.Accel(builder(o))
+    rgba, _ = o.capture_rect(acc, w, h, x0, y0, x0 + cw, y0 + ch, radiance=False, nthreads=4)
+    assert np.array_equal(rgba, z["rgba"])
+    o.set_trig_mode(1)
+    try:
+        rgba_p, rad = o.capture_rect(acc, w, h, x0, y0, x0 + cw, y0 + ch, nthreads=4)
+    finally:
+        o.set_trig_mode(0)
+    assert np.array_equal(rgba_p, z["rgba"])
+    assert np.array_equal(rad.view(np.uint64), z["radiance"].view(np.uint64))
+    # the pixel-list entry point and the reference-shaped strided subset address the same pixels
+    film = o.Film(w, h)
+    k = y0 * w + x0
+    o.capture_subset(k, w * h, acc, film)  # exactly one pixel: offset k
+    assert np.array_equal(film.pixels()[y0, x0], z["rgba"][0, 0])
 
 
 def test_trig_modes_agree_within_fp32_ulp():
