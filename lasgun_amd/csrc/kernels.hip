@@ -320,11 +320,13 @@ template <bool LDSS>
 __device__ __forceinline__ NodeRec load_node(const DParams &P, const uint4 *scn, uint32_t idx) {
     NodeRec n;
     if (LDSS) {
-        const uint4 *q = scn + (P.lds_node_off + idx * LDS_NODE_STRIDE); // compile-time stride: shift + add, no quarter-rate multiply
-        uint4 a = q[0], b = q[1], c = q[2];
-        uint2 d = *reinterpret_cast<const uint2 *>(q + 3);
-        n.bmin[0] = u2d(a.x, a.y); n.bmin[1] = u2d(a.z, a.w); n.bmin[2] = u2d(b.x, b.y);
-        n.bmax[0] = u2d(b.z, b.w); n.bmax[1] = u2d(c.x, c.y); n.bmax[2] = u2d(c.z, c.w);
+        static_assert(LDS_NODE_STRIDE == 5u, "idx * 5 below is written as a shift and an add");
+        const uint4 *q4 = scn + (P.lds_node_off + ((idx << 2) + idx)); // no quarter-rate 32-bit multiply
+        const double2 *q = reinterpret_cast<const double2 *>(q4);
+        const double2 a = q[0], b = q[1], c = q[2]; // three ds_read_b128
+        const uint2 d = *reinterpret_cast<const uint2 *>(q4 + 3);
+        n.bmin[0] = a.x; n.bmin[1] = a.y; n.bmin[2] = b.x;
+        n.bmax[0] = b.y; n.bmax[1] = c.x; n.bmax[2] = c.y;
         n.link = d.x; n.meta = d.y;
     } else {
         // one 64-byte record = four 16-byte loads from a single line, all issued before the slab test
@@ -338,7 +340,7 @@ __device__ __forceinline__ NodeRec load_node(const DParams &P, const uint4 *scn,
 template <bool LDSS>
 __device__ __forceinline__ void load_node_link(const DParams &P, const uint4 *scn, uint32_t idx, uint32_t &link, uint32_t &meta) {
     if (LDSS) {
-        uint2 d = *reinterpret_cast<const uint2 *>(scn + (P.lds_node_off + idx * LDS_NODE_STRIDE + 3u));
+        uint2 d = *reinterpret_cast<const uint2 *>(scn + (P.lds_node_off + ((idx << 2) + idx) + 3u));
         link = d.x; meta = d.y;
     } else {
         const DNode *nd = P.nodes + idx;
@@ -750,7 +752,7 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
 // nested per-lane loops with breaks; hipcc turns every one of those into lane masks kept in SGPR pairs
 // and merged with s_and / s_andn2 / s_or triplets: 87 scalar and 86 vector instructions per node or
 // primitive step, of which 26 are the slab test.  Here
-//   * a lane's phase is ONE integer (ST_NODE / ST_LEAF / ST_LEVEL_DONE / ST_DONE);
+//   * a lane's phase is ONE integer (ST_NODE / ST_LEAF / ST_ENTER / ST_LEVEL_DONE / ST_DONE);
 //   * every loop is WAVE-UNIFORM (`while (any lane is in this phase)`: one ballot and one scalar branch per
 //     trip) around a flat predicated step;
 //   * the node step has no branch at all: the far child is stored above the stack top unconditionally (it
@@ -762,7 +764,7 @@ __device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool
 //     the matching return keeps it too; other returns recompute the parent's ray from the root's, through
 //     the same sequence of transforms (bit-identical, as before).
 // ------------------------------------------------------------------------------------------
-enum : uint32_t { ST_NODE = 0u, ST_LEAF = 1u, ST_LEVEL_DONE = 2u, ST_DONE = 3u };
+enum : uint32_t { ST_NODE = 0u, ST_LEAF = 1u, ST_LEVEL_DONE = 2u, ST_DONE = 3u, ST_ENTER = 4u };
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // finite and not -0: not one of sNaN, qNaN, -inf, -0, +inf (v_cmp_class_f64)
 __device__ __forceinline__ bool f64_plain(double x) { return !__builtin_amdgcn_class(x, 0x001 | 0x002 | 0x004 | 0x020 | 0x200); }
@@ -820,7 +822,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     Ray ray = root;
     double dd = dot(ray.d, ray.d);      // a of every sphere's quadratic at this level
     uint32_t negmask = neg_mask(ray);   // dir_is_neg (bvh.rs:463)
-    uint32_t sp = 0, base = 0, cur = 0, li = 0, le = 0;
+    uint32_t sp = 0, base = 0, cur = 0, li = 0, le = 0, enter = 0;
     uint32_t state = ST_NODE;
     for (;;) {
         // ---- phase A: interior nodes (bvh.rs:471-505), until no lane of the wave is at a node
@@ -894,19 +896,10 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     V3 d0, d1;
                     if (cuboid_hit<false>(mn, mx, ray, t, d0, d1)) accepted = !(t >= best.t);
                 } else if (kind == PK_ACCEL) {
-                    // nested BVHAccel (Group / Mesh): park this level, re-express the ray (bvh.rs:462)
-                    const uint32_t aflags = P.accels[idx].flags;
-                    const bool same = (aflags & AF_IDENTITY) != 0u && ray_plain(ray);
-                    stk[sp * stride] = li; stk[(sp + 1u) * stride] = le; stk[(sp + 2u) * stride] = base | (same ? FRAME_SAME_RAY : 0u);
-                    sp += 3u; base = sp;
-                    if (!same) {
-                        ray = ray_to_local(P.accels[idx].minv, ray);
-                        dd = dot(ray.d, ray.d);
-                        negmask = neg_mask(ray);
-                    }
-                    lvl_set<LDSS>(P, L, idx);
-                    cur = 0u;
-                    state = ST_NODE; // node 0 is tested when visited (bvh.rs:472-473)
+                    // nested BVHAccel (Group / Mesh): entered below, outside this loop -- the ray and the level are
+                    // loop-invariant here, which keeps them out of the loop's register shuffles
+                    enter = idx;
+                    state = ST_ENTER;
                 } else { // a triangle outside a mesh accel cannot be built by the scene API; kept for completeness
                     const uint32_t *vi = P.tri_v + 3ull * idx;
                     TriHit h;
@@ -921,6 +914,21 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     else state = ST_LEVEL_DONE;
                 }
             }
+        }
+        // ---- a leaf slot that is a nested BVHAccel (Group / Mesh): park this level, re-express the ray (bvh.rs:462)
+        if (state == ST_ENTER) {
+            const uint32_t aflags = P.accels[enter].flags;
+            const bool same = (aflags & AF_IDENTITY) != 0u && ray_plain(ray);
+            stk[sp * stride] = li; stk[(sp + 1u) * stride] = le; stk[(sp + 2u) * stride] = base | (same ? FRAME_SAME_RAY : 0u);
+            sp += 3u; base = sp;
+            if (!same) {
+                ray = ray_to_local(P.accels[enter].minv, ray);
+                dd = dot(ray.d, ray.d);
+                negmask = neg_mask(ray);
+            }
+            lvl_set<LDSS>(P, L, enter);
+            cur = 0u;
+            state = ST_NODE; // node 0 is tested when visited (bvh.rs:472-473)
         }
         // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
         if (state == ST_LEVEL_DONE) {
