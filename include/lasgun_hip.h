@@ -213,6 +213,9 @@ int lg_kat_intersect(int kind, const double *params, const char *obj_text, size_
 int lg_kat_surface_interaction(const double origin[3], const double d[3], double t, const double dpdu[3],
                                const double dpdv[3], double out_ng[3]);
 int lg_math_eval(int op, size_t n, const double *a, const double *b, double *out);
+/* Measured rates of the current device in GB/s: what 0 = HBM copy (16 bytes per lane, 1 GiB, read + written bytes),
+ * 1 = aggregate LDS read rate (ds_read_b128, every CU streaming): the measured denominators of bench.py's roofline. */
+int lg_probe_rate(int what, double *gbps);
 
 #ifdef __cplusplus
 }

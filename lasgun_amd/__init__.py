@@ -46,6 +46,7 @@ _EXTRA = {
     "profile_read_kinds": (_C.c_int, [_C.c_void_p, _C.c_double * 5, _C.c_uint64 * 5]),
     "capture_stats_kind": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_int, _C.POINTER(CStats)]),
     "profile_read": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.c_double), _C.POINTER(_C.c_uint64)]),
+    "probe_rate": (_C.c_int, [_C.c_int, _C.POINTER(_C.c_double)]),
     "accel_info": (_C.c_int, [_C.c_void_p, _C.c_uint64 * 8]),
     "trace_pixel": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_int, _C.POINTER(_C.c_double), _C.c_size_t]),
     "host_build_dump": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.POINTER(_C.c_double)), _C.POINTER(_C.c_size_t),
@@ -201,6 +202,13 @@ class HipApi(Api):
         i = _np.ctypeslib.as_array(pi, shape=(ni.value,)).copy()
         keys = ("nodes", "primrefs", "spheres", "cuboids", "triangles", "accels", "max_stack", "has_specular")
         return f, i, dict(zip(keys, [int(v) for v in info]))
+
+    def probe_rate(self, what):
+        """Measured GB/s of the current device: "hbm_copy" (read + written bytes) or "lds_read"."""
+        v = _C.c_double()
+        if self.call("probe_rate", {"hbm_copy": 0, "lds_read": 1}[what], _C.byref(v)):
+            raise LasgunError(self.last_error())
+        return v.value
 
     def accel_info(self, accel):
         out = (_C.c_uint64 * 8)()

@@ -32,6 +32,8 @@ hipError_t launch_kat(int kind, const double *params, const float *vpos, const u
 hipError_t launch_kat_si(V3 o, V3 d, double t, V3 dpdu, V3 dpdv, double *out, hipStream_t stream);
 hipError_t launch_math(int op, size_t n, const double *a, const double *b, double *out, hipStream_t stream);
 hipError_t launch_trace_pixel(const DParams &P, bool fast, uint32_t stack_depth, uint32_t x, uint32_t y, double *out, hipStream_t stream);
+hipError_t launch_probe_copy(const void *src, void *dst, size_t bytes, hipStream_t stream);
+hipError_t launch_probe_lds(uint32_t blocks, uint32_t iters, uint32_t *sink, hipStream_t stream);
 } // namespace lg
 
 using namespace lg;
@@ -1106,6 +1108,51 @@ int lg_trace_pixel(const lg_accel *a, uint32_t w, uint32_t h, uint32_t x, uint32
         HIP_TRY(hipMemcpyAsync(out, dout.p, need * sizeof(double), hipMemcpyDeviceToHost, a->stream));
         if (P.dbg_log) HIP_TRY(hipMemcpyAsync(out + need, dlog.p, log_n * sizeof(double), hipMemcpyDeviceToHost, a->stream));
         HIP_TRY(hipStreamSynchronize(a->stream));
+    });
+}
+// Measured rates of the current device, GB/s: what 0 = HBM copy (16 B per lane, 1 GiB each way, read + written bytes),
+// 1 = aggregate LDS read rate (ds_read_b128, every CU streaming).  The roofline's measured denominators (bench.py).
+int lg_probe_rate(int what, double *gbps) {
+    return guarded([&] {
+        use_device();
+        if (what != 0 && what != 1) throw Error("what: 0 = HBM copy, 1 = LDS read");
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        double best = 0.0;
+        if (what == 0) {
+            const size_t bytes = 1ull << 30;
+            DevBuf<uint8_t> a, b;
+            a.alloc(bytes); b.alloc(bytes);
+            HIP_TRY(hipMemset(a.p, 1, bytes)); HIP_TRY(hipMemset(b.p, 2, bytes));
+            for (int rep = 0; rep < 5; ++rep) {
+                HIP_TRY(hipEventRecord(e0, nullptr));
+                HIP_TRY(launch_probe_copy(a.p, b.p, bytes, nullptr));
+                HIP_TRY(hipEventRecord(e1, nullptr));
+                HIP_TRY(hipEventSynchronize(e1));
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                if (rep > 0 && ms > 0.f) best = std::max(best, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+            }
+        } else {
+            int cus = 0, dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            DevBuf<uint32_t> sink;
+            sink.alloc((size_t)cus);
+            const uint32_t iters = 4096;
+            for (int rep = 0; rep < 4; ++rep) {
+                HIP_TRY(hipEventRecord(e0, nullptr));
+                HIP_TRY(launch_probe_lds((uint32_t)cus, iters, sink.p, nullptr));
+                HIP_TRY(hipEventRecord(e1, nullptr));
+                HIP_TRY(hipEventSynchronize(e1));
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                const double bytes = (double)cus * 1024.0 * 16.0 * 16.0 * iters;
+                if (rep > 0 && ms > 0.f) best = std::max(best, bytes / (ms * 1e-3) / 1e9);
+            }
+        }
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *gbps = best;
     });
 }
 int lg_math_eval(int op, size_t n, const double *a, const double *b, double *out) {

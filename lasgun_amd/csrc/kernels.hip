@@ -826,7 +826,10 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     uint32_t state = ST_NODE;
     for (;;) {
         // ---- phase A: interior nodes (bvh.rs:471-505), until no lane of the wave is at a node
-        while (wave_any(state == ST_NODE)) {
+        // (loops are written with their wave-uniform condition in a variable tested at the bottom: hipcc then keeps the
+        // loop-carried state in place instead of copying it in and out of the loop on every trip)
+        bool more_nodes = wave_any(state == ST_NODE);
+        while (more_nodes) {
             if (state == ST_NODE) {
                 const NodeRec nd = load_node<LDSS>(P, scn, L.node_base + cur);
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
@@ -844,6 +847,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 li = L.prim_base + link; le = li + count; // (read in ST_LEAF only)
                 state = leaf_hit ? ST_LEAF : (pop && !can_pop) ? ST_LEVEL_DONE : ST_NODE;
             }
+            more_nodes = wave_any(state == ST_NODE);
         }
         // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
         const bool mesh = (L.flags & AF_MESH) != 0u;
@@ -857,12 +861,13 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
             else if (sp != base) { --sp; cur = stk[sp * stride]; state = ST_NODE; }
             else state = ST_LEVEL_DONE;
         }
-        while (wave_any(state == ST_LEAF)) {
+        bool more_prims = wave_any(state == ST_LEAF);
+        while (more_prims) {
             if (state == ST_LEAF) {
                 const uint32_t slot = li;
                 const uint32_t ref = load_primref<LDSS>(P, scn, slot);
                 LeafRec g;
-                if (LDSS) { const uint4 *q = scn + (P.lds_soup_off + slot * 3u); g = LeafRec{q[0], q[1], q[2]}; }
+                if (LDSS) { const uint4 *q = scn + (P.lds_soup_off + __umul24(slot, 3u)); g = LeafRec{q[0], q[1], q[2]}; }
                 else g = load_rec(P, slot);
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
                 li = slot + 1u;
@@ -914,6 +919,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     else state = ST_LEVEL_DONE;
                 }
             }
+            more_prims = wave_any(state == ST_LEAF);
         }
         // ---- a leaf slot that is a nested BVHAccel (Group / Mesh): park this level, re-express the ray (bvh.rs:462)
         if (state == ST_ENTER) {
@@ -2131,6 +2137,38 @@ __global__ void math_kernel(int op, size_t n, const double *a, const double *b, 
     default: r = 0.0; break;
     }
     out[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// rate probes (lg_probe_rate): the two memory denominators of the roofline bookkeeping, measured on the box
+// ------------------------------------------------------------------------------------------
+// 16 bytes per lane, grid-stride: the float4 copy the HBM figure of MI355X_MICROARCH.md is quoted on
+__global__ void __launch_bounds__(256) probe_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// every lane streams conflict-free 16-byte reads from a 64 KB LDS window (ds_read_b128, the instruction the
+// LDS-resident scene is walked with); `sink` is written only if the xor of everything read is a magic value
+__global__ void __launch_bounds__(1024) probe_lds_kernel(uint32_t iters, uint32_t *sink) {
+    uint4 *lds = reinterpret_cast<uint4 *>(lds_stack);
+    for (uint32_t i = threadIdx.x; i < 4096u; i += 1024u) lds[i] = uint4{i, i + 1u, i + 2u, i + 3u};
+    __syncthreads();
+    uint4 acc{0u, 0u, 0u, 0u};
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; ++j) {
+            const uint4 v = lds[(threadIdx.x + ((it + j) & 3u) * 1024u) & 4095u];
+            acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[blockIdx.x] = acc.x;
+}
+hipError_t launch_probe_copy(const void *src, void *dst, size_t bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(probe_copy_kernel, dim3(256 * 8), dim3(256), 0, stream, (const uint4 *)src, (uint4 *)dst, bytes / 16);
+    return hipGetLastError();
+}
+hipError_t launch_probe_lds(uint32_t blocks, uint32_t iters, uint32_t *sink, hipStream_t stream) {
+    hipLaunchKernelGGL(probe_lds_kernel, dim3(blocks), dim3(1024), 65536, stream, iters, sink);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
