@@ -178,7 +178,7 @@ struct lg_accel {
     uint32_t stream_blocks = 1, stream_blocks_fast = 1;
     // LDS-resident scene (reference tree only): the tables in their LDS layout, when they fit beside the stacks
     DevBuf<uint32_t> lds_image;
-    uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_prim_off = 0, lds_soup_off = 0;
+    uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_prim_off = 0, lds_soup_off = 0, lds_accel_off = 0;
     uint32_t ldss_blocks = 0;         // one 1024-lane workgroup per CU; 0 = variant unavailable for this scene
     uint32_t packet_blocks = 1;       // grid of the 256-lane packet kernels
     uint32_t cus = 1;                 // compute units of the accel's device
@@ -281,7 +281,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         uint32_t depth = a.fast ? a.stack_depth_fast : a.stack_depth;
         if (!a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS
             P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
-            P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off;
+            P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
             blocks = a.ldss_blocks;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -295,8 +295,11 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
             HIP_TRY(launch());
             if (a.profiling) { HIP_TRY(hipEventRecord(k1, stream)); a.kind_events[kind].emplace_back(k0, k1); }
         };
-#ifdef LG_PKT_STATS
+#if defined(LG_PKT_STATS) || defined(LG_STAMPS)
         P.stats = a.stats.p;
+#endif
+#ifdef LG_STAMPS
+        P.stamp_counts = reinterpret_cast<unsigned long long *>(a.stats.p + 1);
 #endif
         const bool packet = a.packet && !a.fast; // one tree walk per wavefront, then a fix-up pass over the lanes that met a tie
         uint32_t pblocks = blocks, fblocks = 1;
@@ -305,7 +308,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
             P.tie_flag = c.st_tie_flag.p; P.tie_tiles = c.st_tie_tiles.p;
             if (a.lds_scene && a.packet_lds) { // the image fits in LDS: one 1024-lane workgroup per CU
                 P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
-                P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off;
+                P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
                 pblocks = a.cus;
             } else {
                 pblocks = (P.ntiles + 3u) / 4u;
@@ -341,7 +344,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     uint32_t maxb = a.max_blocks > a.max_blocks_fast ? a.max_blocks : a.max_blocks_fast;
     if (!stats && !a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS: one 1024-lane workgroup per CU
         P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
-        P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off;
+        P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
         blocks = a.ldss_blocks;
     }
     if (maxb < a.ldss_blocks * 4u) maxb = a.ldss_blocks * 4u; // per-lane slots below: 1024 lanes per LDS-scene workgroup
@@ -577,7 +580,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->sphere_ref_leaf.upload(f.sphere_ref_leaf); a->cuboid_ref_leaf.upload(f.cuboid_ref_leaf);
         a->tri_ref_leaf.upload(f.tri_ref_leaf); a->accel_ref_leaf.upload(f.accel_ref_leaf); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
         a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
-        a->stats.alloc(1);
+        a->stats.alloc(2); // (the second record: iteration counters of the diagnostic build)
         a->device_bytes = f.nodes.size() * (sizeof(DNode) + sizeof(DNode2)) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
                           f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 + f.leaf_soup.size() * sizeof(DLeafRec) +
                           f.accels.size() * sizeof(DAccel) + f.materials.size() * sizeof(DMaterial);
@@ -664,14 +667,21 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
             const size_t stack_bytes = (size_t)a->stack_depth * 1024 * 4; // per-lane stacks of the private walks
             const size_t wave_stacks = (size_t)a->stack_depth * 16 * 16;  // per-wave stacks of the packet walk
             const size_t prim16 = ((size_t)np + 3) / 4;
-            // image: [nodes, LDS_NODE_STRIDE units each][primrefs][leaf records, 3 units per slot]
-            const size_t n16 = (size_t)nn * LDS_NODE_STRIDE + prim16 + (size_t)np_soup * 3;
+            // image: [nodes, LDS_NODE_STRIDE units each][primrefs][leaf records, 3 units per slot][accel records]
+            const size_t accel16 = fm.accels.size() * LDS_ACCEL_UNITS;
+            const size_t n16 = (size_t)nn * LDS_NODE_STRIDE + prim16 + (size_t)np_soup * 3 + accel16;
             if (wave_stacks + n16 * 16 <= LDS_MAX) {
                 std::vector<uint32_t> img(n16 * 4, 0u);
                 a->lds_node_off = 0;
                 for (auto &r : nruns)
-                    for (uint32_t i = 0, e = extent(nb, r.first, fm.nodes.size()); i < e; ++i)
-                        std::memcpy(&img[((size_t)(r.second + i) * LDS_NODE_STRIDE) * 4], &fm.nodes[r.first + i], 56);
+                    for (uint32_t i = 0, e = extent(nb, r.first, fm.nodes.size()); i < e; ++i) {
+                        uint32_t *rec = &img[((size_t)(r.second + i) * LDS_NODE_STRIDE) * 4];
+                        std::memcpy(rec, &fm.nodes[r.first + i], 56);
+                        // interior records also carry their second child's BYTE offset within the tree (meta = axis | offset << 2):
+                        // the second formulation of the reference walk addresses nodes by byte offset (kernels.hip, Lvl)
+                        const DNode &nd = fm.nodes[r.first + i];
+                        if (!(nd.meta & NODE_LEAF)) rec[13] = (nd.meta & 3u) | ((nd.link * LDS_NODE_STRIDE * 16u) << 2);
+                    }
                 a->lds_prim_off = nn * LDS_NODE_STRIDE;
                 a->lds_soup_off = a->lds_prim_off + (uint32_t)prim16;
                 for (auto &r : pruns)
@@ -680,6 +690,16 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                         if (r.second + i < np_soup)
                             std::memcpy(&img[((size_t)a->lds_soup_off + (size_t)(r.second + i) * 3) * 4], &fm.leaf_soup[r.first + i], 48);
                     }
+                a->lds_accel_off = a->lds_soup_off + np_soup * 3u;
+                for (size_t i = 0; i < fm.accels.size(); ++i) {
+                    const DAccel &A = fm.accels[i];
+                    uint32_t *rec = &img[((size_t)a->lds_accel_off + i * LDS_ACCEL_UNITS) * 4];
+                    std::memcpy(rec, &A.minv, 96);
+                    rec[24] = a->lds_node_off * 16u + A.lnode_base * LDS_NODE_STRIDE * 16u;
+                    rec[25] = A.lprim_base; rec[26] = A.prim_base - A.lprim_base; rec[27] = A.flags;
+                    rec[28] = (uint32_t)A.parent; rec[29] = A.nchain;
+                    for (int k = 0; k < MAX_CHAIN; ++k) rec[32 + k] = A.chain[k];
+                }
                 a->lds_image.upload(img);
                 a->lds_image_n16 = (uint32_t)n16;
                 HIP_TRY(stream_trace_ldss_prepare(LDS_MAX));
@@ -1169,13 +1189,13 @@ int lg_math_eval(int op, size_t n, const double *a, const double *b, double *out
 
 } // extern "C"
 
-#ifdef LG_PKT_STATS
+#if defined(LG_PKT_STATS) || defined(LG_STAMPS)
 extern "C" int lg_debug_stats(const lg_accel *a, int clear, unsigned long long *out9) { // analysis builds only
     return guarded([&] {
         use_device(a->device);
         HIP_TRY(hipDeviceSynchronize());
-        if (clear) HIP_TRY(hipMemset(a->stats.p, 0, sizeof(DStats)));
-        else HIP_TRY(hipMemcpy(out9, a->stats.p, sizeof(DStats), hipMemcpyDeviceToHost));
+        if (clear) HIP_TRY(hipMemset(a->stats.p, 0, 2 * sizeof(DStats)));
+        else HIP_TRY(hipMemcpy(out9, a->stats.p, 2 * sizeof(DStats), hipMemcpyDeviceToHost));
     });
 }
 #endif

@@ -33,6 +33,10 @@ constexpr uint32_t NODE_LEAF = 0x80000000u;
 // LDS-resident scene image: node stride in 16-byte units.  80-byte nodes (and the 48-byte leaf records) make 16
 // consecutive records start in 16 different bank groups; a compile-time constant so that indexing is a shift and an add.
 constexpr uint32_t LDS_NODE_STRIDE = 5u;
+// LDS image, per accel (10 units = 160 bytes): [0..5] minv (12 doubles), [6] {byte offset of its tree in the image, compact prim
+// base, leaf_soup slot delta, flags}, [7] {parent, nchain, -, -}, [8..9] chain[8].  Entering and leaving nested accels is
+// a chain of DEPENDENT fetches of these fields; from LDS each link costs ~64 cycles instead of an L2 round trip.
+constexpr uint32_t LDS_ACCEL_UNITS = 10u;
 
 struct alignas(64) DNode {
     double bmin[3];
@@ -185,6 +189,8 @@ struct DParams {
     uint32_t lds_node_off;                  // DNode without its pad, LDS_NODE_STRIDE units per node
     uint32_t lds_prim_off;                  // primref[] as dwords from here
     uint32_t lds_soup_off;                  // one 3-unit (48-byte) leaf record per primref slot
+    uint32_t lds_accel_off;                 // LDS_ACCEL_UNITS units per accel: what the walk needs of a DAccel (see LDS_ACCEL_UNITS)
+    unsigned long long *stamp_counts; // diagnostic build (-DLG_STAMPS) only
     uint32_t stats_filter;      // counting variant: 0 = all traversals, 1 = closest-hit (primary/secondary) only, 2 = shadow only
 };
 

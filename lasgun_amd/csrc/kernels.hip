@@ -169,7 +169,8 @@ __device__ __forceinline__ TriSetup tri_setup(const Ray &ray) {
     int kx = s.kz + 1; if (kx == 3) kx = 0;
     int ky = kx + 1; if (ky == 3) ky = 0;
     double dx = comp(ray.d, kx), dy = comp(ray.d, ky), dz = comp(ray.d, s.kz);
-    s.sx = -dx / dz; s.sy = -dy / dz; s.sz = 1.0 / dz;
+    s.sx = -dx / dz; s.sy = -dy / dz;
+    s.sz = comp(ray.dinv, s.kz); // 1.0 / dz: the quotient Ray::new already formed (ray.rs:28-33; every Ray here comes from ray_new)
     return s;
 }
 template <int KZ> __device__ __forceinline__ V3 permute_kz(V3 v) { // (kx, ky, kz) = (KZ+1, KZ+2, KZ) mod 3
@@ -779,14 +780,33 @@ constexpr uint32_t FRAME_SAME_RAY = 0x80000000u; // level frame, third word: the
 struct Lvl { // the accel level a lane is walking
     uint32_t accel, node_base, prim_base, soup_delta, flags;
 };
+// Node cursor of the second formulation.  Global tables: the node's index relative to its tree (64-byte DNode records).
+// LDS image: the node's BYTE offset from its tree's first record -- interior records of the image carry their second
+// child's offset ready-made (meta = axis | offset << 2), so a step forms the record's address with one add and never multiplies.
+constexpr uint32_t LDS_NODE_BYTES = LDS_NODE_STRIDE * 16u;
+// What the walk needs of a DAccel: from the LDS image (LDS_ACCEL_UNITS) or from the table in HBM / L2
 template <bool LDSS>
-__device__ __forceinline__ void lvl_set(const DParams &P, Lvl &L, uint32_t accel) {
-    const DAccel *A = P.accels + accel;
+__device__ __forceinline__ void lvl_set(const DParams &P, const uint4 *scn, Lvl &L, uint32_t accel) {
     L.accel = accel;
-    L.node_base = LDSS ? A->lnode_base : A->node_base;
-    L.prim_base = LDSS ? A->lprim_base : A->prim_base;
-    L.soup_delta = LDSS ? A->prim_base - A->lprim_base : 0u;
-    L.flags = A->flags;
+    if (LDSS) {
+        const uint4 info = scn[P.lds_accel_off + accel * LDS_ACCEL_UNITS + 6u];
+        L.node_base = info.x; L.prim_base = info.y; L.soup_delta = info.z; L.flags = info.w;
+    } else {
+        const DAccel *A = P.accels + accel;
+        L.node_base = A->node_base; L.prim_base = A->prim_base; L.soup_delta = 0u; L.flags = A->flags;
+    }
+}
+template <bool LDSS>
+__device__ __forceinline__ Ray accel_local_ray(const DParams &P, const uint4 *scn, uint32_t accel, const Ray &r) { // inverse_transform_ray (bvh.rs:462)
+    if (LDSS) {
+        const double2 *q = reinterpret_cast<const double2 *>(scn + (P.lds_accel_off + accel * LDS_ACCEL_UNITS));
+        const double2 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
+        Affine m;
+        m.c[0][0] = a.x; m.c[0][1] = a.y; m.c[0][2] = b.x; m.c[1][0] = b.y; m.c[1][1] = c.x; m.c[1][2] = c.y;
+        m.c[2][0] = d.x; m.c[2][1] = d.y; m.c[2][2] = e.x; m.c[3][0] = e.y; m.c[3][1] = f.x; m.c[3][2] = f.y;
+        return ray_to_local(m, r);
+    }
+    return ray_to_local(P.accels[accel].minv, r);
 }
 // One fat mesh leaf [li, le) of the second formulation: the reference's leaf loop (bvh.rs:483-488) over
 // triangle records streamed one slot ahead; returns true when an any-hit ray is done.
@@ -809,21 +829,33 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
     return false;
 }
 
+// Diagnostic build (-DLG_STAMPS, never shipped): cycles a wave spends in each phase of the walk, summed into P.stats
+// (nine 64-bit words: setup, A nodes, B mesh leaves, B leaf slots, enter, C returns, trips, -, -).  tools/stamp_phases.py reads them.
+#ifdef LG_STAMPS
+#define LG_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } while (0)
+#else
+#define LG_STAMP(i) do { } while (0)
+#endif
 template <bool LDSS>
 __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
                                              Best &best, const uint4 *scn) {
+#ifdef LG_STAMPS
+    unsigned long long stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_readcyclecounter();
+    unsigned long long stamp_cnt[5] = {0, 0, 0, 0, 0};
+#endif
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
     uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
     Lvl L;
-    lvl_set<LDSS>(P, L, 0u);
+    lvl_set<LDSS>(P, scn, L, 0u);
     // ---- the root accel's local ray (bvh.rs:462), kept for the returns
     Ray root = wray;
-    if (!((L.flags & AF_IDENTITY) && ray_plain(wray))) root = ray_to_local(P.accels->minv, wray);
+    if (!((L.flags & AF_IDENTITY) && ray_plain(wray))) root = accel_local_ray<LDSS>(P, scn, 0u, wray);
     Ray ray = root;
     double dd = dot(ray.d, ray.d);      // a of every sphere's quadratic at this level
     uint32_t negmask = neg_mask(ray);   // dir_is_neg (bvh.rs:463)
     uint32_t sp = 0, base = 0, cur = 0, li = 0, le = 0, enter = 0;
     uint32_t state = ST_NODE;
+    LG_STAMP(0);
     for (;;) {
         // ---- phase A: interior nodes (bvh.rs:471-505), until no lane of the wave is at a node
         // (loops are written with their wave-uniform condition in a variable tested at the bottom: hipcc then keeps the
@@ -831,14 +863,26 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         bool more_nodes = wave_any(state == ST_NODE);
         while (more_nodes) {
             if (state == ST_NODE) {
-                const NodeRec nd = load_node<LDSS>(P, scn, L.node_base + cur);
+                NodeRec nd;
+                if (LDSS) {
+                    const char *rec = reinterpret_cast<const char *>(scn) + (L.node_base + cur);
+                    const double2 *q = reinterpret_cast<const double2 *>(rec);
+                    const double2 a = q[0], b = q[1], c = q[2]; // three ds_read_b128
+                    const uint2 d = *reinterpret_cast<const uint2 *>(rec + 48);
+                    nd.bmin[0] = a.x; nd.bmin[1] = a.y; nd.bmin[2] = b.x; nd.bmax[0] = b.y; nd.bmax[1] = c.x; nd.bmax[2] = c.y;
+                    nd.link = d.x; nd.meta = d.y;
+                } else {
+                    nd = load_node<false>(P, scn, L.node_base + cur);
+                }
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
                 const bool hit = slab_intersects(nd.bmin, nd.bmax, ray);
-                const uint32_t link = nd.link, meta = nd.meta;
+                const uint32_t meta = nd.meta;
                 const bool leaf = (meta & NODE_LEAF) != 0u;
                 const uint32_t count = meta & 0xFFFFu;
                 const bool neg = ((negmask >> (meta & 3u)) & 1u) != 0u; // dir_is_neg[axis] (bvh.rs:496)
-                const uint32_t near_node = neg ? link : cur + 1u, far_node = neg ? cur + 1u : link;
+                const uint32_t first = cur + (LDSS ? LDS_NODE_BYTES : 1u), second = LDSS ? (meta >> 2) : nd.link; // the two children (interior nodes)
+                const uint32_t link = nd.link;
+                const uint32_t near_node = neg ? second : first, far_node = neg ? first : second;
                 const bool interior_hit = hit && !leaf, leaf_hit = hit && leaf && count != 0u;
                 const bool pop = !(interior_hit || leaf_hit), can_pop = sp != base;
                 stk[sp * stride] = far_node; // counts only if sp advances (bvh.rs:493-504)
@@ -848,9 +892,16 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 state = leaf_hit ? ST_LEAF : (pop && !can_pop) ? ST_LEVEL_DONE : ST_NODE;
             }
             more_nodes = wave_any(state == ST_NODE);
+#ifdef LG_STAMPS
+            stamp_cnt[0] += 1;
+#endif
         }
+        LG_STAMP(1);
         // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
         const bool mesh = (L.flags & AF_MESH) != 0u;
+#ifdef LG_STAMPS
+        if (wave_any(state == ST_LEAF && mesh)) stamp_cnt[1] += 1;
+#endif
         if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
             const TriSetup tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
             bool done;
@@ -861,6 +912,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
             else if (sp != base) { --sp; cur = stk[sp * stride]; state = ST_NODE; }
             else state = ST_LEVEL_DONE;
         }
+        LG_STAMP(2);
         bool more_prims = wave_any(state == ST_LEAF);
         while (more_prims) {
             if (state == ST_LEAF) {
@@ -920,48 +972,79 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 }
             }
             more_prims = wave_any(state == ST_LEAF);
+#ifdef LG_STAMPS
+            stamp_cnt[2] += 1;
+#endif
         }
+        LG_STAMP(3);
         // ---- a leaf slot that is a nested BVHAccel (Group / Mesh): park this level, re-express the ray (bvh.rs:462)
+#ifdef LG_STAMPS
+        if (wave_any(state == ST_ENTER)) stamp_cnt[3] += 1;
+        if (wave_any(state == ST_LEVEL_DONE)) stamp_cnt[4] += 1;
+#endif
         if (state == ST_ENTER) {
-            const uint32_t aflags = P.accels[enter].flags;
-            const bool same = (aflags & AF_IDENTITY) != 0u && ray_plain(ray);
+            lvl_set<LDSS>(P, scn, L, enter);
+            const bool same = (L.flags & AF_IDENTITY) != 0u && ray_plain(ray);
             stk[sp * stride] = li; stk[(sp + 1u) * stride] = le; stk[(sp + 2u) * stride] = base | (same ? FRAME_SAME_RAY : 0u);
             sp += 3u; base = sp;
             if (!same) {
-                ray = ray_to_local(P.accels[enter].minv, ray);
+                ray = accel_local_ray<LDSS>(P, scn, enter, ray);
                 dd = dot(ray.d, ray.d);
                 negmask = neg_mask(ray);
             }
-            lvl_set<LDSS>(P, L, enter);
             cur = 0u;
             state = ST_NODE; // node 0 is tested when visited (bvh.rs:472-473)
         }
+        LG_STAMP(4);
         // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
-        if (state == ST_LEVEL_DONE) {
+        while (state == ST_LEVEL_DONE) { // (a lane comes back through every level that is exhausted with it)
             if (L.accel == 0u) state = ST_DONE;
             else {
                 const uint32_t w2 = stk[(sp - 1u) * stride];
                 le = stk[(sp - 2u) * stride]; li = stk[(sp - 3u) * stride];
                 sp -= 3u; base = w2 & ~FRAME_SAME_RAY;
-                const uint32_t parent = (uint32_t)P.accels[L.accel].parent;
-                lvl_set<LDSS>(P, L, parent);
+                uint32_t parent, nchain;
+                const uint32_t *chain;
+                if (LDSS) {
+                    const uint4 *rec = scn + (P.lds_accel_off + L.accel * LDS_ACCEL_UNITS);
+                    parent = rec[7].x;
+                    const uint4 *prec = scn + (P.lds_accel_off + parent * LDS_ACCEL_UNITS);
+                    nchain = prec[7].y; chain = reinterpret_cast<const uint32_t *>(prec + 8);
+                } else {
+                    parent = (uint32_t)P.accels[L.accel].parent;
+                    nchain = P.accels[parent].nchain; chain = P.accels[parent].chain;
+                }
+                lvl_set<LDSS>(P, scn, L, parent);
                 if (!(w2 & FRAME_SAME_RAY)) { // the parent's ray again: from the root's, through the same transforms
                     ray = root;
-                    const DAccel *A = P.accels + parent;
-                    for (uint32_t i = 1; i < A->nchain; ++i) {
-                        const DAccel *C = P.accels + A->chain[i];
-                        if (!((C->flags & AF_IDENTITY) && ray_plain(ray))) ray = ray_to_local(C->minv, ray);
+                    for (uint32_t i = 1; i < nchain; ++i) {
+                        const uint32_t c = chain[i];
+                        const uint32_t cflags = LDSS ? scn[P.lds_accel_off + c * LDS_ACCEL_UNITS + 6u].w : P.accels[c].flags;
+                        if (!((cflags & AF_IDENTITY) && ray_plain(ray))) ray = accel_local_ray<LDSS>(P, scn, c, ray);
                     }
                     dd = dot(ray.d, ray.d);
                     negmask = neg_mask(ray);
                 }
                 if (li < le) state = ST_LEAF;
                 else if (sp != base) { --sp; cur = stk[sp * stride]; state = ST_NODE; }
-                else state = ST_LEVEL_DONE; // handled by the next trip
+                else state = ST_LEVEL_DONE; // the parent level is exhausted as well
             }
         }
+        LG_STAMP(5);
+#ifdef LG_STAMPS
+        stamp_acc[6] += 1;
+#endif
         if (!wave_any(state != ST_DONE)) break;
     }
+#ifdef LG_STAMPS
+    if ((threadIdx.x & 63u) == 0u && P.stats) {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(P.stats);
+        for (int i = 0; i < 7; ++i) atomicAdd(dst + i, stamp_acc[i]);
+        atomicAdd(dst + 7, 1ull);
+        unsigned long long *cnt = P.stamp_counts;
+        if (cnt) for (int i = 0; i < 5; ++i) atomicAdd(cnt + i, stamp_cnt[i]);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Where the reference walk spends its cycles (diagnostic build: make -C lasgun_amd/csrc EXTRA_DEVFLAGS=-DLG_STAMPS
+EXTRA_HOSTFLAGS=-DLG_STAMPS OUT=../liblasgun_hip_stamps.so, then LASGUN_HIP_LIB=lasgun_amd/liblasgun_hip_stamps.so python tools/stamp_phases.py)."""
+import ctypes as C
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import lasgun_amd as la
+G = la.api
+lib = G.lib
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+acc = G.Accel(la.scenes.spheres_scene(G))
+film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
+G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0); G.synchronize(acc)
+out = (C.c_ulonglong * 18)()
+lib.lg_debug_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+lib.lg_debug_stats(acc.h, 1, out)
+G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0); G.synchronize(acc)
+lib.lg_debug_stats(acc.h, 0, out)
+names = ["setup", "A nodes", "B mesh leaves", "B leaf slots", "enter", "C returns", "trips", "walks"]
+tot = sum(out[i] for i in range(6))
+for i, n in enumerate(names):
+    print("%-14s %14d  %5.1f %%" % (n, out[i], 100.0 * out[i] / tot if i < 6 else 0.0))
+print("cycles per walk %.0f, trips per walk %.1f" % (tot / out[7], out[6] / out[7]))
+cn = ["node-loop trips", "mesh-leaf blocks", "leaf-slot trips", "enter blocks", "return blocks"]
+for i, n in enumerate(cn):
+    print("%-18s %12d  %7.1f per walk" % (n, out[9 + i], out[9 + i] / out[7]))
