@@ -164,6 +164,8 @@ def main():
     t0 = time.perf_counter()
     acc = G.Accel(scene)  # host HLBVH build + flatten + upload (outside the timed region, reported below)
     accel_build_s = time.perf_counter() - t0
+    if os.environ.get("LASGUN_WAVEFRONT"):  # A/B: 0 = the earlier three-kernel pipeline over dense pixels
+        G.set_wavefront(acc, os.environ["LASGUN_WAVEFRONT"] == "1")
     if os.environ.get("LASGUN_PACKET"):  # A/B: one tree walk per wavefront
         G.set_packet(acc, os.environ["LASGUN_PACKET"] == "1")
     # LASGUN_NO_LDS_SCENE=1 (A/B): the traversal kernels read the scene tables through L1/L2 instead of LDS
@@ -319,8 +321,9 @@ def main():
             dom_ms = per_kernel[dom]
             dst = dict(share_stats(2 if "shadow" in dom else 1))
             dst["primary_rays"] = 0  # the RGBA write belongs to the shade kernel, not to a traversal kernel
-            tail = ", true, false>" if lds_scene else ", false, false>"  # <FAST, SHADOW, scene tables resident in LDS, FIXUP>
-            kernel_name = "lg::" + dom.replace("<primary>", "<false, false" + tail).replace("<shadow>", "<false, true" + tail)
+            # wavefront pipeline: lg::wf_trace_kernel<FAST, SHADOW, scene tables resident in LDS>, lg::wf_shade_kernel
+            kernel_name = ("lg::wf_trace_kernel<false, %s, %s>" % ("true" if "shadow" in dom else "false", "true" if lds_scene else "false")
+                           if dom.startswith("trace<") else "lg::wf_%s_kernel" % dom)
         else:  # megakernel
             dom_ms, dst, kernel_name = frame_ms, st, "lg::trace_kernel<false, false, %s>" % ("true" if lds_scene else "false")
         dom_bytes, dom_flops = algorithmic_bytes(dst), algorithmic_flops(dst)

@@ -166,6 +166,13 @@ int lg_accel_set_mode(const lg_accel *, int mode);
  * single persistent megakernel.  2 = use the pipeline wherever it is possible (tests). */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
 
+/* Which pipeline "streaming" means.  1 (default): the WAVEFRONT pipeline -- li() level by level: per recursion level a
+ * closest-hit pass (hits compacted into a queue, misses finished on the spot), an any-hit shadow pass and a shade pass
+ * that appends the specular children to the next level's ray queue, then the levels are combined bottom-up in the
+ * reference's (output + reflected) + refracted order.  It serves every scene, glass / mirror included.  0: the earlier
+ * three-kernel pipeline over dense pixels (scenes without glass / mirror only; specular scenes then run in the megakernel). */
+int lg_accel_set_wavefront(const lg_accel *, int enabled);
+
 /* LDS-resident scene (reference traversal; streaming pipeline and megakernel): when the scene's node,
  * primref, sphere and cuboid tables fit beside 1024 per-lane stacks in one CU's 160 KB of LDS, the
  * kernels that traverse run as one 1024-lane workgroup per CU that copies those tables into LDS once

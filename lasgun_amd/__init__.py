@@ -36,6 +36,7 @@ _EXTRA = {
     "accel_set_mode": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_streaming": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_lds_scene": (_C.c_int, [_C.c_void_p, _C.c_int]),
+    "accel_set_wavefront": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_packet": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
     "capture_radiance": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
@@ -72,6 +73,11 @@ class HipApi(Api):
     def set_streaming(self, accel, enabled):
         """True (default) = three-kernel streaming pipeline where the scene allows it; False = megakernel only."""
         self.call("accel_set_streaming", accel.h, int(enabled) if enabled in (0, 1, 2) else (1 if enabled else 0))
+
+    def set_wavefront(self, accel, enabled):
+        """True (default): "streaming" is the level-by-level wavefront pipeline (any scene); False: the earlier three-kernel
+        pipeline (scenes without glass / mirror; others fall back to the megakernel)."""
+        self.call("accel_set_wavefront", accel.h, 1 if enabled else 0)
 
     def set_packet(self, accel, enabled):
         """One tree walk per wavefront (packet traversal) in the streaming traversal kernels."""
@@ -180,7 +186,7 @@ class HipApi(Api):
         ms = (_C.c_double * 5)(); n = (_C.c_uint64 * 5)()
         if self.call("profile_read_kinds", accel.h, ms, n):
             raise LasgunError(self.last_error())
-        names = ("stream_trace_kernel<primary>", "(unused)", "stream_trace_kernel<shadow>", "stream_shade_kernel", "trace_kernel")
+        names = ("trace<closest>", "combine", "trace<shadow>", "shade", "trace_kernel")
         return {names[i]: (ms[i], int(n[i])) for i in range(5)}
 
     def profile_enable(self, accel, enabled=True):

@@ -24,6 +24,10 @@ hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, bool fi
 hipError_t launch_stream_packet(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream);
 hipError_t stream_packet_occupancy(uint32_t stack_depth, int *blocks_per_cu);
 hipError_t launch_stream_shade(const DParams &P, hipStream_t stream);
+hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
+hipError_t launch_wf_shade(const DParams &P, uint32_t blocks, hipStream_t stream);
+hipError_t launch_wf_combine(const DParams &P, uint32_t blocks, hipStream_t stream);
+hipError_t wf_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
 hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
 hipError_t trace_set_lds_limit(size_t bytes);
 hipError_t stream_trace_ldss_prepare(size_t bytes);
@@ -166,6 +170,8 @@ struct lg_accel {
         DevBuf<double> frames, stash;                          // megakernel: Whitted frame stack, parked shading frame
         DevBuf<double> st_frame, st_accum;                     // streaming pipeline state (sized by the largest launch so far)
         DevBuf<uint32_t> st_hit_ref, st_vis, st_tie_flag, st_tie_tiles;
+        DevBuf<uint8_t> wf_mem;                                // wavefront pipeline: every per-level array of a chunk, carved from one allocation
+        DevBuf<uint32_t> wf_counters;                          // its queue counts and per-launch tile counters
     };
     mutable std::vector<std::unique_ptr<LaunchCtx>> ctxs;
     mutable unsigned long long ctx_clock = 0;
@@ -176,6 +182,9 @@ struct lg_accel {
     bool streaming_pays = false;
     unsigned long long streaming_min_items = 1ull << 20;
     uint32_t stream_blocks = 1, stream_blocks_fast = 1;
+    uint32_t wf_blocks = 1, wf_blocks_fast = 1;   // grids of the wavefront pipeline's 256-lane traversal kernels
+    mutable bool wavefront = true;               // lg_accel_set_wavefront: level-by-level pipeline instead of the three-kernel one
+    mutable size_t wf_budget = 0;                 // bytes one launch context may hold for it (0 = from the free memory at first use)
     // LDS-resident scene (reference tree only): the tables in their LDS layout, when they fit beside the stacks
     DevBuf<uint32_t> lds_image;
     uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_prim_off = 0, lds_soup_off = 0, lds_accel_off = 0;
@@ -255,11 +264,140 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     return P;
 }
 
+// The wavefront pipeline (kernels.hip): per chunk of the film and per supersample, levels 0 .. L-1 top-down (closest,
+// shadow, shade), then the combine passes bottom-up.  Queue capacities are worst case (level d holds at most 2^d rays per
+// pixel of the chunk), so the chunk is sized to the memory budget of the launch context: nothing can overflow.
+constexpr size_t WF_FULL_MIN_HOST = 48; // == WF_FULL_MIN of kernels.hip
+static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c, hipStream_t stream) {
+    const uint32_t levels = (a.flat.has_specular && P0.recursion > 0) ? P0.recursion + 1u : 1u;
+    const uint32_t nsamples = P0.ss_root * P0.ss_root;
+    // bytes per pixel of a chunk
+    auto level_bytes = [&](uint32_t d) -> size_t {
+        size_t b = 0;
+        if (d >= 1) b += 6 * 8;                       // ray queue
+        if (levels > 1) b += 3 * 8;                   // output / li
+        if (d + 1 < levels) b += 8 * 8 + 2 * 4;       // children's weights and indices
+        return b;
+    };
+    size_t per_pixel = (nsamples > 1 ? 3 * 8 : 0);
+    for (uint32_t d = 0; d < levels; ++d) per_pixel += level_bytes(d) << d;
+    per_pixel += ((size_t)(4 + STASH_DOUBLES * 8 + 4) << (levels - 1)) * 7 / 4; // hit queue, frame, visibility of the widest level: dense part + appended part
+    if (a.wf_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        size_t budget = free_b / 3;
+        const char *env = std::getenv("LASGUN_WF_BUDGET_MB");
+        if (env && std::atoll(env) > 0) budget = (size_t)std::atoll(env) << 20;
+        else if (budget > (32ull << 30)) budget = 32ull << 30;
+        a.wf_budget = budget < (64ull << 20) ? (64ull << 20) : budget;
+    }
+    unsigned long long chunk_tiles = a.wf_budget / (per_pixel * 64);
+    const unsigned long long cap_limit = (0xFFFFFFF0ull >> (levels - 1)) / 64ull; // ray indices are 32-bit
+    if (chunk_tiles > cap_limit) chunk_tiles = cap_limit;
+    if (chunk_tiles < 1) chunk_tiles = 1;
+    if (chunk_tiles > P0.ntiles) chunk_tiles = P0.ntiles;
+    const unsigned long long n0 = chunk_tiles * 64ull;
+    const size_t need = (size_t)n0 * per_pixel + 4096 * (3 * levels + 4);
+    if (c.wf_mem.n < need) { HIP_TRY(hipDeviceSynchronize()); c.wf_mem.alloc(need); }
+    const uint32_t nlaunch = 4 * levels;
+    const uint32_t CL = 64; // the queue counts (3 per level) in the first 256 bytes, then every tile counter on a line of its own
+    if (c.wf_counters.n < CL * (1 + nlaunch)) { HIP_TRY(hipDeviceSynchronize()); c.wf_counters.alloc(CL * (1 + nlaunch)); }
+    // carve (256-byte aligned)
+    uint8_t *cur = c.wf_mem.p;
+    auto take = [&](size_t bytes) { uint8_t *p = cur; cur += (bytes + 255) & ~(size_t)255; return p; };
+    std::vector<double *> q(levels, nullptr), out(levels, nullptr), spec(levels, nullptr);
+    std::vector<uint32_t *> child(levels, nullptr);
+    for (uint32_t d = 0; d < levels; ++d) {
+        const size_t cap = (size_t)n0 << d;
+        if (d >= 1) q[d] = (double *)take(cap * 6 * 8);
+        if (levels > 1) out[d] = (double *)take(cap * 3 * 8);
+        if (d + 1 < levels) { spec[d] = (double *)take(cap * 8 * 8); child[d] = (uint32_t *)take(cap * 2 * 4); }
+    }
+    const size_t hit_cap = (size_t)n0 << (levels - 1);
+    const size_t hit_len = hit_cap + hit_cap / 64 * (WF_FULL_MIN_HOST - 1); // appended part: fewer than WF_FULL_MIN hits per block of 64 rays
+    uint32_t *hq = (uint32_t *)take(hit_len * 4);
+    double *frame = (double *)take(hit_len * STASH_DOUBLES * 8);
+    uint32_t *vis = (uint32_t *)take(hit_len * 4);
+    double *accum = nsamples > 1 ? (double *)take((size_t)n0 * 3 * 8) : nullptr;
+
+    const bool ldss = !a.fast && a.lds_scene && a.ldss_blocks;
+    const uint32_t depth = a.fast ? a.stack_depth_fast : a.stack_depth;
+    const uint32_t trace_cap = ldss ? a.ldss_blocks : (a.fast ? a.wf_blocks_fast : a.wf_blocks);
+    const uint32_t flat_cap = a.cus * 16u;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (a.profiling) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
+    auto timed = [&](int kind, auto &&launch) { // HIP events around ONE kernel on its launch stream
+        hipEvent_t k0 = nullptr, k1 = nullptr;
+        if (a.profiling) { HIP_TRY(hipEventCreate(&k0)); HIP_TRY(hipEventCreate(&k1)); HIP_TRY(hipEventRecord(k0, stream)); }
+        HIP_TRY(launch());
+        if (a.profiling) { HIP_TRY(hipEventRecord(k1, stream)); a.kind_events[kind].emplace_back(k0, k1); }
+    };
+    if (std::getenv("LASGUN_DEBUG"))
+        std::fprintf(stderr, "[lasgun] wavefront: levels %u, %llu tiles in chunks of %llu (%.1f MiB per context), trace grid %u x %u, stack %u, max_blocks %u\n", levels,
+                     (unsigned long long)P0.ntiles, chunk_tiles, need / 1048576.0, trace_cap, ldss ? 1024u : 256u, depth, a.max_blocks);
+    for (unsigned long long t0 = 0; t0 < P0.ntiles; t0 += chunk_tiles) {
+        DParams P = P0;
+        P.tile0 = (uint32_t)t0;
+        P.ntiles = (uint32_t)std::min<unsigned long long>(chunk_tiles, P0.ntiles - t0);
+        P.n_items = n0; // stride of the sample accumulator
+        P.accum = accum;
+        P.wf_levels = levels;
+        P.wf_counts = c.wf_counters.p;
+        P.wf_hit_cap = hit_cap; P.wf_hit_stride = hit_len; P.wf_hq = hq; P.frame = frame; P.vis = vis;
+        if (ldss) {
+            P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
+            P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
+        }
+        const uint32_t tiles_needed = (P.ntiles + 3u) / 4u;
+        const uint32_t trace_blocks0 = ldss ? trace_cap : std::min(trace_cap, tiles_needed);
+        const uint32_t flat_blocks0 = (uint32_t)(((unsigned long long)P.ntiles * 64ull + 255ull) / 256ull); // level 0: one thread per pixel
+        // level-0 shade: one wave per dense tile and per tile the appended hits can fill (< WF_FULL_MIN of every 64 rays)
+        const uint32_t shade_blocks0 = (uint32_t)(((unsigned long long)P.ntiles + ((unsigned long long)P.ntiles * (WF_FULL_MIN_HOST - 1) + 63ull) / 64ull + 3ull) / 4ull);
+        for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
+            P.sample_index = sidx;
+            HIP_TRY(hipMemsetAsync(c.wf_counters.p, 0, CL * (1 + nlaunch) * sizeof(uint32_t), stream));
+            uint32_t launch_no = 0;
+            auto level_params = [&](uint32_t d) {
+                P.wf_level = d;
+                P.wf_cap = (unsigned long long)n0 << d; P.wf_cap_next = (unsigned long long)n0 << (d + 1);
+                P.wf_q = q[d]; P.wf_out = out[d]; P.wf_spec = spec[d]; P.wf_child = child[d];
+                P.wf_q_next = d + 1 < levels ? q[d + 1] : nullptr;
+                P.wf_out_next = d + 1 < levels ? out[d + 1] : nullptr;
+                P.tile_counter = c.wf_counters.p + CL * (1 + launch_no++);
+            };
+            for (uint32_t d = 0; d < levels; ++d) {
+                // (deeper levels: the number of rays is only known on the device; grids are sized for a full level 0, which
+                // every deeper level may exceed only in waves, never in work per wave)
+                const uint32_t tb = d == 0 ? trace_blocks0 : trace_cap, fb = d == 0 ? shade_blocks0 : flat_cap;
+                level_params(d);
+                timed(0, [&] { return launch_wf_trace(P, a.fast, false, tb, depth, stream); });
+                if (P.nlights > 0) {
+                    level_params(d);
+                    timed(2, [&] { return launch_wf_trace(P, a.fast, true, tb, depth, stream); });
+                }
+                level_params(d);
+                timed(3, [&] { return launch_wf_shade(P, fb, stream); });
+            }
+            for (uint32_t d = levels - 1; d-- > 0;) {
+                level_params(d);
+                timed(1, [&] { return launch_wf_combine(P, d == 0 ? flat_blocks0 : flat_cap, stream); });
+            }
+        }
+    }
+    if (a.profiling) { HIP_TRY(hipEventRecord(e1, stream)); a.events.emplace_back(e0, e1); }
+}
+
 // Enqueue one render on `stream`.  Caller holds a.mtx.
 static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t stream) {
     if (P.ntiles == 0) return;
     lg_accel::LaunchCtx &c = ctx_for(a, stream);
     P.tile_counter = c.tile_counter.p;
+    // ---- wavefront pipeline: li() level by level (any scene with <= 32 lights; not the counting variant, not the packet walk)
+    if (a.streaming && a.wavefront && !stats && P.nlights <= 32 && P.recursion < 20 && !(a.packet && !a.fast) &&
+        (a.streaming_forced || (a.streaming_pays && (unsigned long long)P.ntiles * 64ull >= a.streaming_min_items))) {
+        enqueue_wavefront(a, P, c, stream);
+        return;
+    }
     // ---- streaming pipeline: no glass / mirror (no recursion), <= 32 lights, not the counting variant
     // and enough work to amortise 4 launches per supersample (below ~1 Mpixel the megakernel wins: measured)
     if (a.streaming && !stats && !a.flat.has_specular && P.nlights <= 32 &&
@@ -630,6 +768,11 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         HIP_TRY(stream_trace_occupancy(a->stack_depth_fast, true, &spf));
         a->stream_blocks = (uint32_t)((sp < 1 ? 1 : sp) * cus);
         a->stream_blocks_fast = (uint32_t)((spf < 1 ? 1 : spf) * cus);
+        int wb = 0, wbf = 0;
+        HIP_TRY(wf_trace_occupancy(a->stack_depth, false, &wb));
+        HIP_TRY(wf_trace_occupancy(a->stack_depth_fast, true, &wbf));
+        a->wf_blocks = (uint32_t)((wb < 1 ? 1 : wb) * cus);
+        a->wf_blocks_fast = (uint32_t)((wbf < 1 ? 1 : wbf) * cus);
         int pk = 0;
         HIP_TRY(stream_packet_occupancy(a->stack_depth, &pk));
         a->packet_blocks = (uint32_t)((pk < 1 ? 1 : pk) * cus);
@@ -716,8 +859,14 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         {
             size_t big_mesh = 0;
             for (const auto &m : a->scene->meshes) if (m && m->tri.size() / 3 > big_mesh) big_mesh = m->tri.size() / 3;
-            a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512;
-            a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 20);
+            // Scenes with glass / mirror (tools/bench_configs.py --org=...): level by level they win where the levels are
+            // cheap to launch and balanced (Cornell glass 512^2: 0.82 against 0.90 ms); with a big mesh the deeper levels are few, long,
+            // incoherent walks through 254-triangle leaves whose slowest wave sets each launch's length (100k-triangle glass torus:
+            // 226 against 135 ms), so those stay in the megakernel, where other tiles fill the gaps.
+            const bool specular_pays = f.has_specular && big_mesh < 4096;
+            a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512 || specular_pays;
+            if (f.has_specular && big_mesh >= 4096) a->streaming_pays = false;
+            a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : specular_pays ? (1ull << 18) : (1ull << 20);
         }
 }
 
@@ -998,6 +1147,11 @@ int lg_accel_set_packet(const lg_accel *a, int enabled) {
     a->packet = enabled != 0;
     return 0;
 }
+int lg_accel_set_wavefront(const lg_accel *a, int enabled) {
+    std::lock_guard<std::mutex> g(a->mtx);
+    a->wavefront = enabled != 0;
+    return 0;
+}
 int lg_accel_set_streaming(const lg_accel *a, int enabled) {
     std::lock_guard<std::mutex> g(a->mtx);
     a->streaming = enabled != 0;
@@ -1045,6 +1199,7 @@ int lg_profile_read_kinds(const lg_accel *a, double ms[5], uint64_t launches[5])
                 HIP_TRY(hipEventSynchronize(e.second));
                 float t = 0.f;
                 HIP_TRY(hipEventElapsedTime(&t, e.first, e.second));
+                if (std::getenv("LASGUN_DEBUG")) std::fprintf(stderr, "[lasgun] kind %d launch: %.3f ms\n", k, t);
                 total += t;
                 (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
             }

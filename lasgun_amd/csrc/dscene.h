@@ -28,6 +28,7 @@ namespace lg {
 enum PrimKind : uint32_t { PK_SPHERE = 0, PK_CUBOID = 1, PK_TRIANGLE = 2, PK_ACCEL = 3 };
 constexpr uint32_t PRIM_INDEX_MASK = 0x3FFFFFFFu;
 constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
+constexpr uint32_t WF_NONE = 0xFFFFFFFFu, WF_MISS = 0xFFFFFFFEu; // wavefront pipeline: no such child / the ray hit nothing
 constexpr int MAX_CHAIN = 8;      // scene-graph nesting levels (root = 1)
 constexpr uint32_t NODE_LEAF = 0x80000000u;
 // LDS-resident scene image: node stride in 16-byte units.  80-byte nodes (and the 48-byte leaf records) make 16
@@ -178,6 +179,27 @@ struct DParams {
     uint32_t *vis;              // [n_items] bit l set <=> light l is visible from the hit
     double *accum;              // [3][n_items] running sum over the pixel's samples (integrate.rs:17-18)
     uint32_t sample_index;      // which supersample this pass renders
+    // ---- wavefront pipeline: li() level by level.  Level d holds the rays of recursion depth d
+    // (level 0: the chunk's pixels, dense; deeper: a compacted queue fed by the level above).  Per level: closest-hit
+    // pass (misses are finished on the spot, hits are COMPACTED into a hit queue and get their shading frame), any-hit
+    // shadow pass over the hit queue, shade pass (radiance of the hit, specular children appended to the next level),
+    // then bottom-up: value = (output + spec_r * value[child_r]) + spec_t * value[child_t] * a / pdf (integrate.rs:79,103,129).
+    uint32_t wf_level;          // level of this launch
+    uint32_t wf_levels;         // number of levels (recursion + 1, or 1 for scenes without glass / mirror)
+    uint32_t tile0;             // first tile of the chunk (level 0: pixel tile = tile0 + work tile)
+    uint32_t pad_wf;
+    uint32_t *wf_counts;        // device counters: [d] rays of level d (d >= 1), [wf_levels + d] appended hits of level d
+    unsigned long long wf_cap;      // capacity (rays) of this level's arrays
+    unsigned long long wf_cap_next; // ... of the next level's
+    unsigned long long wf_hit_cap;  // dense part of the hit queue / frame / vis arrays (= capacity of the widest level); appended hits sit behind it
+    unsigned long long wf_hit_stride; // their allocated length (SoA stride of the frame)
+    double *wf_q;               // [6][wf_cap] origin, direction of this level's rays (levels >= 1)
+    double *wf_out;             // [3][wf_cap] output of the hit / background of the miss; the combine pass turns it into li()
+    double *wf_spec;            // [8][wf_cap] spectrum of the reflected child (3), of the refracted child (3), |wi.n|, pdf
+    uint32_t *wf_child;         // [2][wf_cap] index of the reflected / refracted child in the next level (WF_NONE, WF_MISS)
+    double *wf_q_next;          // [6][wf_cap_next]
+    double *wf_out_next;        // [3][wf_cap_next] (the combine pass reads the children's values)
+    uint32_t *wf_hq;            // [wf_hit_cap] ray index of hit h
     // packet organisation: lanes whose packet walk met an exact tie in t (or a NaN t) are re-traced privately
     uint32_t *tie_flag;         // [n_items] bit l: light l (shadow pass) / bit 0 (primary pass)
     uint32_t *tie_tiles;        // [ntiles] tiles with at least one flagged lane

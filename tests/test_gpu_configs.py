@@ -32,8 +32,10 @@ FULL = {
     "config4_metal": (lambda api: S.mesh_scene(api, 224, 224, "metal"), 4096, 1031, 77),
     "config5_mixed": (lambda api: S.mixed_scene(api), 8192, 4099, 1234),
 }
-# (streaming, fast): 0 = megakernel, 2 = streaming pipeline wherever it exists for the scene
-ORGANISATIONS = [("megakernel", 0, False), ("pipeline", 2, False), ("megakernel-fast", 0, True), ("pipeline-fast", 2, True)]
+# (label, streaming, wavefront, fast).  streaming 0 = megakernel; 2 = streamed wherever the organisation exists for the scene:
+# the wavefront pipeline takes every scene (glass / mirror: level by level), the three-kernel one only scenes without them
+ORGANISATIONS = [("megakernel", 0, True, False), ("wavefront", 2, True, False), ("pipeline3", 2, False, False),
+                 ("megakernel-fast", 0, True, True), ("wavefront-fast", 2, True, True)]
 
 
 @pytest.mark.parametrize("name", list(FULL))
@@ -55,11 +57,14 @@ def test_full_size_config_vs_oracle_sample(name):
     assert np.array_equal(want_rgba, want_rgba_p)
     acc = G.Accel(builder(G))
     film = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
     first = None
-    for label, streaming, fast in ORGANISATIONS:
+    for label, streaming, wavefront, fast in ORGANISATIONS:
         G.set_streaming(acc, streaming)
+        G.set_wavefront(acc, wavefront)
         G.set_mode(acc, fast)
         film.zero_()
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
         G.capture_rows_device(acc, w, h, 0, h, film.data_ptr(), row0=0)
         G.synchronize(acc)
         flat = film.view(-1, 4)
@@ -75,6 +80,7 @@ def test_full_size_config_vs_oracle_sample(name):
         else:
             assert torch.equal(film, first), (name, label)  # whole film, organisation against organisation
     G.set_streaming(acc, 1)
+    G.set_wavefront(acc, True)
     G.set_mode(acc, False)
     # ray accounting on two 32-row bands: through the torus (config 4 glass: its refractions) and through the mirror sphere
     a, b = G.capture_stats(acc, w, h, h // 2, h // 2 + 32), G.capture_stats(acc, w, h, (h * 11) // 16, (h * 11) // 16 + 32)
@@ -91,8 +97,9 @@ def test_full_size_config_crop_goldens(name):
     builder, w, h, x0, y0, cw, ch = CROPS[name]
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     acc = G.Accel(builder(G))
-    for label, streaming, fast in ORGANISATIONS:
+    for label, streaming, wavefront, fast in ORGANISATIONS:
         G.set_streaming(acc, streaming)
+        G.set_wavefront(acc, wavefront)
         G.set_mode(acc, fast)
         rgba, rad = G.capture_rect(acc, w, h, x0, y0, x0 + cw, y0 + ch)
         assert np.array_equal(rgba, z["rgba"]), (name, label)

@@ -141,6 +141,8 @@ MID = {
     "ragged_67x13": (lambda api: S.cornell_scene(api, "glass"), 67, 13),
     "ragged_5x131": (lambda api: S.spheres_scene(api, 64, seed=11), 5, 131),
     "one_pixel": (lambda api: S.simple_scene(api, 1), 1, 1),
+    # sparse hits: one small sphere in front of the background (most 8x8 tiles have no hit or a few: the compacted part of the hit queue)
+    "readme_sparse_200x120": (S.readme_scene, 200, 120),
 }
 
 
@@ -194,7 +196,9 @@ def test_fast_mode_full_size_films_are_identical():
     for builder, size in cases:
         acc = G.Accel(builder(G))
         a = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
         b = torch.zeros_like(a)
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
         G.capture_rows_device(acc, size, size, 0, size, a.data_ptr(), row0=0)
         G.synchronize(acc)
         G.set_mode(acc, True)
@@ -203,15 +207,68 @@ def test_fast_mode_full_size_films_are_identical():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name", list(MID))
+def test_wavefront_pipeline_matches_oracle(name):
+    """li() level by level (hits compacted into queues, specular children queued per recursion level, levels combined
+    bottom-up in the (output + reflected) + refracted order of integrate.rs:79) against the oracle: bytes and radiance
+    bits, whole film and a strided subset, reference and fast traversal -- on every scene of the suite, recursion 0 .. 4,
+    supersampling, ragged and one-pixel films included."""
+    builder, w, h = MID[name]
+    o = oracle()
+    oacc = o.Accel(builder(o))
+    ofilm = o.Film(w, h)
+    o.capture_subset_mt(0, 1, oacc, ofilm, 8)
+    o.set_trig_mode(1)
+    try:
+        orad = o.capture_radiance(oacc, w, h, nthreads=8)
+    finally:
+        o.set_trig_mode(0)
+    acc = G.Accel(builder(G))
+    G.set_streaming(acc, 2)  # streamed whatever the size of the launch
+    G.set_wavefront(acc, True)
+    for fast in (False, True):
+        G.set_mode(acc, fast)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        assert np.array_equal(film.pixels(), ofilm.pixels()), fast
+        assert np.array_equal(bits(G.capture_radiance(acc, w, h)), bits(orad)), fast
+        sub = G.Film.new_with_output(w, h, np.full((h, w, 4), 7, np.uint8))
+        G.capture_subset(1, 3, acc, sub)
+        idx = np.arange(1, w * h, 3)
+        got, want = sub.pixels().reshape(-1, 4), ofilm.pixels().reshape(-1, 4)
+        assert np.array_equal(got[idx], want[idx])
+        mask = np.ones(w * h, bool); mask[idx] = False
+        assert np.all(got[mask] == 7)
+
+
+def test_wavefront_pipeline_in_small_chunks():
+    """A memory budget that cuts the film into many chunks (every chunk sized so that its worst-case queues fit): same film."""
+    w, h = 200, 152
+    o = oracle()
+    for builder in (lambda api: S.cornell_scene(api, "glass"), lambda api: S.kitchen_sink_scene(api, "perspective", recursion=4, supersampling=1)):
+        ofilm = o.Film(w, h)
+        o.capture_subset_mt(0, 1, o.Accel(builder(o)), ofilm, 8)
+        os.environ["LASGUN_WF_BUDGET_MB"] = "1"  # read when an accel first uses the pipeline: 64 MiB is the floor
+        try:
+            acc = G.Accel(builder(G))
+            G.set_streaming(acc, 2)
+            film = G.Film(w, h)
+            G.capture_subset(0, 1, acc, film)
+        finally:
+            del os.environ["LASGUN_WF_BUDGET_MB"]
+        assert np.array_equal(film.pixels(), ofilm.pixels())
+
+
 @pytest.mark.parametrize("name", ["spheres_512", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "instanced_mesh_176", "ragged_5x131", "one_pixel"])
 def test_streaming_pipeline_and_megakernel_agree(name):
-    """The two kernel organisations (and both traversal modes under each) give the same bytes and bits."""
+    """The kernel organisations (and both traversal modes under each) give the same bytes and bits."""
     builder, w, h = MID[name]
     acc = G.Accel(builder(G))
     outs = []
-    for streaming in (2, 0):  # 2 = streaming pipeline forced even for small films, 0 = megakernel
+    for streaming, wavefront in ((2, True), (2, False), (0, True)):  # 2 = streamed even for small films (wavefront / three-kernel), 0 = megakernel
         for fast in (False, True):
             G.set_streaming(acc, streaming)
+            G.set_wavefront(acc, wavefront)
             G.set_mode(acc, fast)
             film = G.Film(w, h)
             G.capture_subset(0, 1, acc, film)
@@ -363,6 +420,7 @@ def test_random_scene_parity(seed):
     finally:
         o.set_trig_mode(0)
     acc = G.Accel(S.random_scene(G, seed))
+    # megakernel, wavefront pipeline, both in either traversal mode; three-kernel pipeline with the packet walk (no glass / mirror only)
     for streaming, fast, packet in ((0, False, False), (0, True, False), (2, False, False), (2, True, False), (2, False, True)):
         G.set_streaming(acc, streaming)
         G.set_mode(acc, fast)
@@ -416,6 +474,7 @@ def test_row_tiles_on_device_assemble_to_the_full_film():
     w, h = 200, 123
     acc = G.Accel(S.spheres_scene(G, 200, seed=3))
     full = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
     G.capture_rows_device(acc, w, h, 0, h, full.data_ptr(), row0=0)
     G.synchronize(acc)
     from lasgun_amd.distributed import row_tile
@@ -423,6 +482,7 @@ def test_row_tiles_on_device_assemble_to_the_full_film():
     for r in range(3):
         y0, y1 = row_tile(r, 3, h)
         t = torch.zeros((y1 - y0, w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
         G.capture_rows_device(acc, w, h, y0, y1, t.data_ptr())
         G.synchronize(acc)
         parts.append(t)
@@ -451,10 +511,12 @@ def test_interleaved_blocks_on_device_match_the_full_film():
     w, h, b, n = 120, 96, 8, 3
     acc = G.Accel(S.cornell_scene(G, "glass"))
     full = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
     G.capture_rows_device(acc, w, h, 0, h, full.data_ptr(), row0=0)
     G.synchronize(acc)
     for r in range(n):
         t = torch.zeros((h // n, w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
         G.capture_interleaved_device(acc, w, h, b, n, r, t.data_ptr())
         G.synchronize(acc)
         assert torch.equal(t, full[interleaved_rows(r, n, h, b)])
@@ -477,10 +539,12 @@ def test_headline_4096_properties():
     scene = S.spheres_scene(G)
     acc = G.Accel(scene)
     full = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
     G.capture_rows_device(acc, w, h, 0, h, full.data_ptr(), row0=0)
     G.synchronize(acc)
     # (1) idempotence / determinism: a second render is byte-identical
     again = torch.zeros_like(full)
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
     G.capture_rows_device(acc, w, h, 0, h, again.data_ptr(), row0=0)
     G.synchronize(acc)
     assert torch.equal(full, again)
@@ -489,6 +553,7 @@ def test_headline_4096_properties():
     for r in range(8):
         y0, y1 = row_tile(r, 8, h)
         t = torch.zeros((y1 - y0, w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
         G.capture_rows_device(acc, w, h, y0, y1, t.data_ptr())
         G.synchronize(acc)
         assert torch.equal(t, full[y0:y1])
@@ -520,10 +585,12 @@ def test_headline_4096_full_frame_vs_oracle():
     ref = ofilm.pixels()
     acc = G.Accel(S.spheres_scene(G))
     film = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
     for streaming, lds, fast, packet in ((1, True, False, False), (1, False, False, False), (0, True, False, False), (1, True, True, False),
                                          (1, True, False, True), (1, False, False, True)):
         G.set_streaming(acc, streaming); G.set_lds_scene(acc, lds); G.set_mode(acc, fast); G.set_packet(acc, packet)
         film.zero_()
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
         G.capture_rows_device(acc, w, h, 0, h, film.data_ptr(), row0=0)
         G.synchronize(acc)
         diff = int((film.cpu().numpy() != ref).sum())
@@ -609,7 +676,7 @@ def test_library_first_then_torch_share_one_hip_runtime():
             "import lasgun_amd as la\n"
             "G = la.api; f = G.Film(64, 64); G.capture(la.scenes.readme_scene(G), f)\n"
             "import torch\n"
-            "t = torch.zeros((64, 64, 4), dtype=torch.uint8, device='cuda')\n"
+            "t = torch.zeros((64, 64, 4), dtype=torch.uint8, device='cuda'); torch.cuda.synchronize()\n"
             "acc = G.Accel(la.scenes.readme_scene(G)); G.capture_rows_device(acc, 64, 64, 0, 64, t.data_ptr(), row0=0); G.synchronize(acc)\n"
             "assert (t.cpu().numpy() == f.pixels()).all(); print('shared runtime ok')\n") % root
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)

@@ -26,7 +26,9 @@ CONFIGS = [
 
 def main():
     fast = "--fast" in sys.argv
-    only = [a for a in sys.argv[1:] if a != "--fast"]
+    org = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--org=")]  # default | megakernel | wavefront | pipeline3
+    org = org[0] if org else "default"
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
     G.set_device(0)
     for name, build, size in CONFIGS:
         if only and not any(o in name for o in only):
@@ -36,6 +38,12 @@ def main():
         acc = G.Accel(scene)
         build_s = time.perf_counter() - t0
         G.set_mode(acc, fast)
+        if org == "megakernel":
+            G.set_streaming(acc, 0)
+        elif org == "wavefront":
+            G.set_streaming(acc, 2)
+        elif org == "pipeline3":
+            G.set_streaming(acc, 2); G.set_wavefront(acc, False)
         film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
         stream = torch.cuda.current_stream().cuda_stream
         G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)
@@ -46,9 +54,15 @@ def main():
             G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
+        G.profile_enable(acc, True)
+        G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)
+        torch.cuda.synchronize()
+        kinds = {k: round(v[0], 3) for k, v in G.profile_read_kinds(acc).items() if v[1]}
+        G.profile_read(acc)
+        G.profile_enable(acc, False)
         st = G.capture_stats(acc, size, size)
         rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
-        print(json.dumps({"config": name, "mode": "fast" if fast else "parity", "ms": round(ms, 3), "Mrays_s": round(rays / ms / 1e3, 1), "rays": rays,
+        print(json.dumps({"config": name, "mode": "fast" if fast else "parity", "org": org, "ms": round(ms, 3), "kernels_ms": kinds, "Mrays_s": round(rays / ms / 1e3, 1), "rays": rays,
                           "accel_build_s": round(build_s, 3), "info": G.accel_info(acc), "stats": st}), flush=True)
 
 
