@@ -116,6 +116,30 @@ int lg_device_count(void);
  * concurrently on that device).  lg_accel handles stay bound to the device they were created on. */
 int lg_set_devices(const int *device_ids, int count);
 
+/* Accel::from on a given device (lg_accel_from uses the device of lg_set_device). */
+lg_accel *lg_accel_from_on(const lg_scene *, int device);
+
+/* ONE film on several GPUs of this process, gathered over xGMI -- the node-level counterpart of the reference's fan-out
+ * over threads (lib.rs:55-104).  lg_multi_create builds the scene's accel on every device of the list (device_ids[0] is
+ * the ROOT) and, when the list names more than one distinct device, one RCCL communicator per device (ncclCommInitAll;
+ * RCCL is dlopen'ed at that moment, never for single-device use).  A capture renders rank r's share on its device --
+ * the `block_rows`-row blocks {r, r+n, ...} when the height is a multiple of block_rows * n (64 balances the load to a few
+ * per cent), contiguous row tiles otherwise or when block_rows is 0 -- and then moves every share with ONE grouped RCCL
+ * exchange (ncclSend on the owners, ncclRecv on the root, inside one ncclGroupStart / ncclGroupEnd) straight to its place
+ * in the film in the ROOT's device memory; the root's own contiguous tile is rendered in place.  A device may repeat in the
+ * list (its shares are then copied device-locally): that is how a 1-GPU box rehearses the split; with the environment
+ * variable LASGUN_MULTI_FORCE_RCCL=1 such shares travel through RCCL as well (send / recv to self).
+ * lg_multi_capture_device: dev_rgba is width*height*4 bytes on the root device; synchronous.  lg_multi_capture: the
+ * same into a host film (+ one D2H copy).  The scene must outlive the lg_multi. */
+typedef struct lg_multi lg_multi;
+lg_multi *lg_multi_create(const lg_scene *, const int *device_ids, int count, uint32_t block_rows);
+void lg_multi_free(lg_multi *);
+int lg_multi_capture_device(lg_multi *, uint32_t width, uint32_t height, void *dev_rgba_on_root);
+int lg_multi_capture(lg_multi *, lg_film *);
+int lg_multi_rank_count(const lg_multi *);
+lg_accel *lg_multi_accel(const lg_multi *, int rank);   /* rank's accel (to select traversal mode / organisation per rank) */
+int lg_multi_uses_rccl(const lg_multi *);                /* 1 when a communicator was created */
+
 /* Render image rows [y0, y1) of a width x height film straight into DEVICE memory, no host copy:
  * dev_rgba[0] is pixel (0, row0) of the image.  `hip_stream` is the hipStream_t to enqueue on,
  * used as given (NULL = HIP's default stream, as everywhere in HIP; lg_accel_stream() = the

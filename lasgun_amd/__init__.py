@@ -48,6 +48,14 @@ _EXTRA = {
     "capture_stats_kind": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_int, _C.POINTER(CStats)]),
     "profile_read": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.c_double), _C.POINTER(_C.c_uint64)]),
     "probe_rate": (_C.c_int, [_C.c_int, _C.POINTER(_C.c_double)]),
+    "accel_from_on": (_C.c_void_p, [_C.c_void_p, _C.c_int]),
+    "multi_create": (_C.c_void_p, [_C.c_void_p, _C.POINTER(_C.c_int), _C.c_int, _C.c_uint32]),
+    "multi_free": (None, [_C.c_void_p]),
+    "multi_capture_device": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
+    "multi_capture": (_C.c_int, [_C.c_void_p, _C.c_void_p]),
+    "multi_rank_count": (_C.c_int, [_C.c_void_p]),
+    "multi_accel": (_C.c_void_p, [_C.c_void_p, _C.c_int]),
+    "multi_uses_rccl": (_C.c_int, [_C.c_void_p]),
     "accel_info": (_C.c_int, [_C.c_void_p, _C.c_uint64 * 8]),
     "trace_pixel": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_int, _C.POINTER(_C.c_double), _C.c_size_t]),
     "host_build_dump": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.POINTER(_C.c_double)), _C.POINTER(_C.c_size_t),
@@ -208,6 +216,55 @@ class HipApi(Api):
         i = _np.ctypeslib.as_array(pi, shape=(ni.value,)).copy()
         keys = ("nodes", "primrefs", "spheres", "cuboids", "triangles", "accels", "max_stack", "has_specular")
         return f, i, dict(zip(keys, [int(v) for v in info]))
+
+    def Multi(self, scene, devices, block_rows=64):
+        """One film on several GPUs of this process, gathered on devices[0] over xGMI with one grouped RCCL exchange
+        (lg_multi_*): `.capture_device(w, h, dev_ptr)`, `.capture(film)`, `.accel(rank)`, `.uses_rccl`."""
+        api = self
+
+        class _Multi:
+            def __init__(self):
+                ids = list(devices)
+                arr = (_C.c_int * max(len(ids), 1))(*ids)
+                self.scene = scene  # borrowed by the C side: keep it alive
+                self.h = api.call("multi_create", scene.h, arr, len(ids), int(block_rows))
+                if not self.h:
+                    raise LasgunError(api.last_error())
+
+            @property
+            def uses_rccl(self):
+                return bool(api.call("multi_uses_rccl", self.h))
+
+            @property
+            def ranks(self):
+                return int(api.call("multi_rank_count", self.h))
+
+            def accel(self, rank):
+                class _Borrowed:  # the multi owns it
+                    pass
+                a = _Borrowed()
+                a.h = api.call("multi_accel", self.h, int(rank))
+                return a
+
+            def capture_device(self, w, h, dev_ptr):
+                if api.call("multi_capture_device", self.h, int(w), int(h), _C.c_void_p(int(dev_ptr))):
+                    raise LasgunError(api.last_error())
+
+            def capture(self, film):
+                if api.call("multi_capture", self.h, film.h):
+                    raise LasgunError(api.last_error())
+
+            def close(self):
+                if self.h:
+                    api.call("multi_free", self.h)
+                    self.h = None
+
+            def __del__(self):
+                try:
+                    self.close()
+                except Exception:  # noqa: BLE001
+                    pass
+        return _Multi()
 
     def probe_rate(self, what):
         """Measured GB/s of the current device: "hbm_copy" (read + written bytes) or "lds_read"."""

@@ -552,6 +552,7 @@ template <class F> static int guarded(F f) {
 extern "C" {
 
 const char *lg_last_error(void) { return tl_error.c_str(); }
+void lg_set_last_error(const char *msg) { tl_error = msg ? msg : ""; } // (multi.cpp reports through the same thread-local message)
 
 static lg_material pack(const Material &m) { lg_material r; r.kind = m.kind; std::memcpy(r.p, m.p, sizeof r.p); return r; }
 static Material unpack(const lg_material *m) { Material r; r.kind = m->kind; std::memcpy(r.p, m->p, sizeof r.p); return r; }
@@ -890,6 +891,7 @@ static lg_accel *accel_from_on(const lg_scene *s, int device) {
     return a;
 }
 lg_accel *lg_accel_from(const lg_scene *s) { return accel_from_on(s, g_device); }
+lg_accel *lg_accel_from_on(const lg_scene *s, int device) { return accel_from_on(s, device); }
 void lg_accel_free(lg_accel *a) {
     if (!a) return;
     // its buffers go back to the pool and may be handed out again at once: nothing on any stream may still use them
@@ -1074,6 +1076,20 @@ int lg_capture(const lg_scene *s, lg_film *film) { // lib.rs:55-104: the BVH is 
     }
     const uint32_t n = (uint32_t)devs.size();
     const uint32_t block_rows = film->h % (64u * n) == 0 ? 64u : 0u;
+    {   // more than one DISTINCT device: the shares are gathered on the first device over xGMI (one grouped RCCL exchange,
+        // multi.cpp) and the film leaves the node with one D2H copy -- the north-star's gather, behind the reference's capture()
+        bool distinct = false;
+        for (uint32_t r = 1; r < n; ++r) distinct = distinct || devs[r] != devs[0];
+        if (distinct && !std::getenv("LASGUN_CAPTURE_NO_RCCL")) {
+            lg_multi *m = lg_multi_create(s, devs.data(), (int)n, block_rows);
+            if (!m) return 1;
+            int rc = lg_multi_capture(m, film);
+            std::string e = rc ? tl_error : std::string();
+            lg_multi_free(m);
+            if (rc) tl_error = e;
+            return rc;
+        }
+    }
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);
     std::vector<std::thread> workers;

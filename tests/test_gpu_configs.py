@@ -157,3 +157,53 @@ def test_capture_subset_from_concurrent_threads():
                 t.join()
             assert not errs, errs
             assert np.array_equal(buf, want.pixels())
+
+
+@pytest.mark.parametrize("devices, w, h, block_rows", [([0, 0], 256, 256, 64), ([0, 0, 0], 203, 160, 64), ([0, 0, 0, 0], 128, 512, 64),
+                                                       ([0, 0], 128, 256, 0), ([0], 64, 64, 64)])
+def test_multi_device_capture_gathers_the_film_on_the_root(devices, w, h, block_rows):
+    """lg_multi_*: every rank renders its share (64-row blocks dealt round-robin, or contiguous row tiles) on its device, the
+    shares are gathered in the ROOT's device memory.  A 1-GPU box names its device several times (device-local copies); the
+    same film must come out as from a single-device capture -- device film and host film."""
+    import torch
+    scene = S.kitchen_sink_scene(G)
+    one = G.Film(w, h)
+    G.capture(scene, one)
+    m = G.Multi(scene, devices, block_rows)
+    assert m.ranks == len(devices) and not m.uses_rccl  # one distinct device: RCCL is not even loaded
+    dev = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):  # tiles are reused
+        m.capture_device(w, h, dev.data_ptr())
+        assert np.array_equal(dev.cpu().numpy(), one.pixels())
+    host = G.Film.new_with_output(w, h, np.full((h, w, 4), 9, np.uint8))
+    m.capture(host)
+    assert np.array_equal(host.pixels(), one.pixels())
+    G.set_mode(m.accel(len(devices) - 1), True)  # per-rank settings through the rank's accel: fast mode on the last rank
+    m.capture(host)
+    assert np.array_equal(host.pixels(), one.pixels())
+    m.close()
+
+
+def test_multi_device_capture_through_rccl_on_one_gpu():
+    """The RCCL leg on a 1-GPU box: LASGUN_MULTI_FORCE_RCCL=1 sends the shares of a repeated device through
+    ncclSend / ncclRecv to self inside ONE ncclGroupStart / ncclGroupEnd (communicator from ncclCommInitAll, dlopen'ed
+    librccl).  In a child process with a time limit: a collective that does not complete must not hang the suite."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os; sys.path.insert(0, %r)\n"
+            "os.environ['LASGUN_MULTI_FORCE_RCCL'] = '1'\n"
+            "import numpy as np, torch, lasgun_amd as la\n"
+            "G = la.api; S = la.scenes\n"
+            "scene = S.cornell_scene(G, 'glass'); w, h = 160, 256\n"
+            "one = G.Film(w, h); G.capture(scene, one)\n"
+            "for devices, b in (([0, 0], 64), ([0, 0, 0, 0], 64), ([0, 0], 0)):\n"
+            "    m = G.Multi(scene, devices, b); assert m.uses_rccl\n"
+            "    dev = torch.full((h, w, 4), 9, dtype=torch.uint8, device='cuda'); torch.cuda.synchronize()\n"
+            "    m.capture_device(w, h, dev.data_ptr()); m.capture_device(w, h, dev.data_ptr())\n"
+            "    assert np.array_equal(dev.cpu().numpy(), one.pixels()), devices\n"
+            "    m.close()\n"
+            "print('rccl gather ok')\n") % root
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0 and "rccl gather ok" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
