@@ -107,6 +107,10 @@ typedef struct lg_stats { /* deterministic work counters of one render (stats ke
 
 int lg_set_device(int device);      /* HIP device new accels are created on (default 0) */
 int lg_device_count(void);
+/* Device allocations of 1 MiB and more are recycled through a small per-process pool (at most 4 GiB parked per device;
+ * flushed automatically when an allocation runs out of memory).  lg_trim_pool gives the parked blocks of `device`
+ * (-1: of every device) back to the driver and returns the number of bytes freed. */
+uint64_t lg_trim_pool(int device);
 /* Devices a host-film lg_capture / lg_render is split over, one host thread per device -- the counterpart
  * of the reference's split over `scene.threads` CPU threads (lib.rs:58-104): count == 0 selects every visible
  * device; a non-zero `scene.threads` caps how many of them are used.  Each device renders the 64-row blocks

@@ -25,6 +25,7 @@ if not _os.path.exists(LIB_PATH):
 _EXTRA = {
     "set_device": (_C.c_int, [_C.c_int]),
     "device_count": (_C.c_int, []),
+    "trim_pool": (_C.c_uint64, [_C.c_int]),
     "set_devices": (_C.c_int, [_C.POINTER(_C.c_int), _C.c_int]),
     "capture_rows_device": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32,
                                        _C.c_void_p, _C.c_void_p]),
@@ -128,6 +129,10 @@ class HipApi(Api):
         arr = (_C.c_int * max(len(ids), 1))(*ids)
         if self.call("set_devices", arr, len(ids)):
             raise LasgunError(self.last_error())
+
+    def trim_pool(self, device=-1):
+        """Give the device buffers parked in the library's pool back to the driver; returns the bytes freed."""
+        return int(self.call("trim_pool", int(device)))
 
     def device_count(self):
         return int(self.call("device_count"))

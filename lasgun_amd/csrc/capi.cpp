@@ -78,7 +78,8 @@ struct DevPool {
     std::vector<Block> parked;
     size_t parked_bytes[64] = {0};
     static constexpr size_t MIN_BYTES = 1u << 20, CAP = 4ull << 30;
-    void *take(int device, size_t bytes) {
+    // a parked block of at least `bytes` (and at most 1.25x that); *capacity receives its real size
+    void *take(int device, size_t bytes, size_t *capacity) {
         std::lock_guard<std::mutex> g(mtx);
         size_t best = parked.size();
         for (size_t i = 0; i < parked.size(); ++i)
@@ -86,6 +87,7 @@ struct DevPool {
                 (best == parked.size() || parked[i].bytes < parked[best].bytes)) best = i;
         if (best == parked.size()) return nullptr;
         void *p = parked[best].p;
+        *capacity = parked[best].bytes;
         parked_bytes[device & 63] -= parked[best].bytes;
         parked.erase(parked.begin() + (long)best);
         return p;
@@ -97,8 +99,31 @@ struct DevPool {
         parked_bytes[device & 63] += bytes;
         return true;
     }
+    // give the parked blocks of `device` (or of every device: -1) back to the driver; returns the bytes freed.
+    // The caller has made sure nothing on the device still uses them (blocks are parked only after a synchronise).
+    size_t trim(int device) {
+        std::vector<Block> drop;
+        {
+            std::lock_guard<std::mutex> g(mtx);
+            for (size_t i = 0; i < parked.size();)
+                if (device < 0 || parked[i].device == device) {
+                    drop.push_back(parked[i]);
+                    parked_bytes[parked[i].device & 63] -= parked[i].bytes;
+                    parked.erase(parked.begin() + (long)i);
+                } else ++i;
+        }
+        size_t freed = 0;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (const Block &b : drop) {
+            if (hipSetDevice(b.device) == hipSuccess && hipFree(b.p) == hipSuccess) freed += b.bytes;
+        }
+        (void)hipSetDevice(cur);
+        return freed;
+    }
 };
-DevPool g_pool;
+// never destroyed: buffers released at interpreter exit, after static destructors have begun, still find it
+DevPool &g_pool = *new DevPool();
 } // namespace
 
 template <class T> struct DevBuf {
@@ -106,12 +131,24 @@ template <class T> struct DevBuf {
     size_t n = 0;
     size_t bytes_ = 0; // capacity in bytes (what the pool is told)
     int device_ = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    friend void swap(DevBuf &a, DevBuf &b) { std::swap(a.p, b.p); std::swap(a.n, b.n); std::swap(a.bytes_, b.bytes_); std::swap(a.device_, b.device_); }
     void obtain(size_t bytes) {
         release();
         HIP_TRY(hipGetDevice(&device_));
         bytes_ = bytes;
-        void *q = bytes >= DevPool::MIN_BYTES ? g_pool.take(device_, bytes) : nullptr;
-        if (!q) HIP_TRY(hipMalloc(&q, bytes));
+        void *q = bytes >= DevPool::MIN_BYTES ? g_pool.take(device_, bytes, &bytes_) : nullptr; // bytes_: the block's real capacity
+        if (!q) {
+            hipError_t e = hipMalloc(&q, bytes);
+            if (e == hipErrorOutOfMemory) { // the pool may be sitting on the memory: hand it back and try once more
+                (void)hipGetLastError();
+                g_pool.trim(device_);
+                e = hipMalloc(&q, bytes);
+            }
+            if (e != hipSuccess) throw Error(std::string("hipMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+        }
         p = (T *)q;
     }
     void upload(const std::vector<T> &v) {
@@ -700,6 +737,7 @@ int lg_set_devices(const int *ids, int count) {
         g_devices = v;
     });
 }
+uint64_t lg_trim_pool(int device) { return (uint64_t)g_pool.trim(device); }
 int lg_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -871,12 +909,42 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         }
 }
 
-// First request for the fast mode: build its trees now and upload the tables again.  Caller holds a->mtx.
-static void ensure_fast_trees(const lg_accel *a) {
-    if (a->flat.has_fast) return;
+// First request for the fast mode: its trees are built and every table is uploaded into a SECOND accel; only when all of
+// that has succeeded are the tables swapped in (a failure -- a HIP error, out of memory -- leaves the accel as it was).
+// The reference trees must come out as they did at lg_accel_from: a scene modified since is an error, not a silent
+// change of the parity tables.  Caller holds a->mtx.
+static void swap_tables(lg_accel &x, lg_accel &y) {
+    using std::swap;
+    swap(x.flat, y.flat);
+    swap(x.nodes, y.nodes); swap(x.nodes2, y.nodes2); swap(x.primref, y.primref); swap(x.spheres, y.spheres); swap(x.sphere_mat, y.sphere_mat);
+    swap(x.cuboids, y.cuboids); swap(x.cuboid_mat, y.cuboid_mat); swap(x.tri_v, y.tri_v); swap(x.tri_n, y.tri_n); swap(x.tri_t, y.tri_t);
+    swap(x.vpos, y.vpos); swap(x.vnorm, y.vnorm); swap(x.vtex, y.vtex); swap(x.leaf_soup, y.leaf_soup);
+    swap(x.sphere_ref_leaf, y.sphere_ref_leaf); swap(x.cuboid_ref_leaf, y.cuboid_ref_leaf); swap(x.tri_ref_leaf, y.tri_ref_leaf); swap(x.accel_ref_leaf, y.accel_ref_leaf);
+    swap(x.accels, y.accels); swap(x.materials, y.materials); swap(x.lights, y.lights);
+    swap(x.lds_image, y.lds_image);
+    swap(x.lds_image_n16, y.lds_image_n16); swap(x.lds_node_off, y.lds_node_off); swap(x.lds_prim_off, y.lds_prim_off);
+    swap(x.lds_soup_off, y.lds_soup_off); swap(x.lds_accel_off, y.lds_accel_off);
+    swap(x.ldss_blocks, y.ldss_blocks); swap(x.packet_blocks, y.packet_blocks); swap(x.packet_lds, y.packet_lds); swap(x.cus, y.cus);
+    swap(x.stack_depth, y.stack_depth); swap(x.stack_depth_fast, y.stack_depth_fast); swap(x.max_blocks, y.max_blocks); swap(x.max_blocks_fast, y.max_blocks_fast);
+    swap(x.stream_blocks, y.stream_blocks); swap(x.stream_blocks_fast, y.stream_blocks_fast); swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast);
+    swap(x.device_bytes, y.device_bytes); swap(x.fast_available, y.fast_available); swap(x.fast_refusal, y.fast_refusal);
+    swap(x.streaming_pays, y.streaming_pays); swap(x.streaming_min_items, y.streaming_min_items);
+}
+static void ensure_fast_trees(const lg_accel *ca) {
+    if (ca->flat.has_fast) return;
+    lg_accel *a = const_cast<lg_accel *>(ca);
     use_device(a->device);
+    std::unique_ptr<lg_accel> next(new lg_accel());
+    next->scene = a->scene;
+    next->device = a->device;
+    build_and_upload(next.get(), true); // throws: `a` is untouched
+    if (next->flat.dump_f != a->flat.dump_f || next->flat.dump_i != a->flat.dump_i)
+        throw Error("the scene was modified after lg_accel_from: the accel's reference trees no longer match it (build a new accel)");
     HIP_TRY(hipDeviceSynchronize()); // nothing may still be reading the tables that are about to be replaced
-    build_and_upload(const_cast<lg_accel *>(a), true);
+    swap_tables(*a, *next);
+    std::swap(a->flat.dump_f, next->flat.dump_f); // same contents; keeps the storage lg_accel_dump's callers point into
+    std::swap(a->flat.dump_i, next->flat.dump_i);
+    // `next` (the old tables) is released here; its stream was never created for launches
 }
 
 static lg_accel *accel_from_on(const lg_scene *s, int device) {

@@ -363,11 +363,7 @@ def test_fast_mode_adversarial_scenes():
     """Scenes built against fast mode's margins (wall-sized spheres, lights a hair from a surface, needle boxes, twin
     spheres); seeds 75 and 375 differed by one pixel each before the fast walk's winner was put to the reference tree's
     own box tests (a shadow ray leaving a giant sphere 3e-11 above its box)."""
-    import importlib.util
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "tools", "fast_adversarial.py")).read().split("a, b = int(sys.argv[1])")[0]
-    ns = {"__file__": os.path.join(root, "tools", "fast_adversarial.py")}
-    exec(compile(src, "fast_adversarial", "exec"), ns)
+    ns = {"scene": lambda seed: S.adversarial_scene(G, seed), "scene2": lambda seed: S.adversarial_mesh_scene(G, seed)}
     w, h = 128, 96
     for seed in (75, 375, 1, 2, 3, 4, 5, 6):
         acc = G.Accel(ns["scene"](seed))
@@ -624,16 +620,9 @@ def test_adversarial_scenes_match_the_oracle(gen):
     """tools/fast_adversarial.py's generators (giant spheres, needle boxes, degenerate meshes, nested anisotropic groups,
     non-unit rotation axes, distant / orthographic cameras) through the reference traversal, every kernel organisation,
     against the CPU oracle: the reference's behaviour on ill-conditioned input is reproduced too."""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "tools", "fast_adversarial.py")).read().split("a, b = int(sys.argv[1])")[0]
     o = oracle()
-
-    def make(api):
-        ns = {"__file__": os.path.join(root, "tools", "fast_adversarial.py")}
-        exec(compile(src, "fast_adversarial", "exec"), ns)
-        ns["G"] = api; ns["M"] = api.Material
-        return ns
-    ns_g, ns_o = make(G), make(o)
+    build = S.adversarial_scene if gen == "scene" else S.adversarial_mesh_scene
+    ns_g, ns_o = {gen: lambda seed: build(G, seed)}, {gen: lambda seed: build(o, seed)}
     w, h = 96, 72
     for seed in (75, 375, 381, 589, 591, 11, 12, 13, 14, 15):
         oacc = o.Accel(ns_o[gen](seed))

@@ -1,5 +1,7 @@
 # LDS / SQ counter passes on the bench for the traversal kernels (each --pmc set is its own run; no trace flags with --pmc)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?}"
 run() { name=$1; shift; LASGUN_PACKET=${LASGUN_PACKET:-0} rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmcl_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmcl_$name.log 2>&1; }
 run a SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU
 run b SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA
