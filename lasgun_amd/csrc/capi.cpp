@@ -381,6 +381,10 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
         P.wf_levels = levels;
         P.wf_counts = c.wf_counters.p;
         P.wf_hit_cap = hit_cap; P.wf_hit_stride = hit_len; P.wf_hq = hq; P.frame = frame; P.vis = vis;
+#ifdef LG_STAMPS
+        P.stats = a.stats.p;
+        P.stamp_counts = reinterpret_cast<unsigned long long *>(a.stats.p + 1);
+#endif
         if (ldss) {
             P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
             P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
@@ -898,14 +902,13 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         {
             size_t big_mesh = 0;
             for (const auto &m : a->scene->meshes) if (m && m->tri.size() / 3 > big_mesh) big_mesh = m->tri.size() / 3;
-            // Scenes with glass / mirror (tools/bench_configs.py --org=...): level by level they win where the levels are
-            // cheap to launch and balanced (Cornell glass 512^2: 0.82 against 0.90 ms); with a big mesh the deeper levels are few, long,
-            // incoherent walks through 254-triangle leaves whose slowest wave sets each launch's length (100k-triangle glass torus:
-            // 226 against 135 ms), so those stay in the megakernel, where other tiles fill the gaps.
-            const bool specular_pays = f.has_specular && big_mesh < 4096;
-            a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512 || specular_pays;
-            if (f.has_specular && big_mesh >= 4096) a->streaming_pays = false;
-            a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : specular_pays ? (1ull << 18) : (1ull << 20);
+            // Scenes with glass / mirror run level by level in the wavefront pipeline under the same criterion (tools/bench_configs.py
+            // --org=...): where node and sphere tests dominate.  Small specular scenes are a wash (Cornell glass
+            // 512^2: 0.81 ms level by level, 0.80 ms in the megakernel since both walk with traverse_ref), and with a big mesh the deeper
+            // levels are few, long, incoherent walks through 254-triangle leaves whose slowest wave sets each launch's length
+            // (100k-triangle glass torus: 226 against 136 ms): those stay in the megakernel, where other tiles fill the gaps.
+            a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512 && !(f.has_specular && big_mesh >= 4096);
+            a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 20);
         }
 }
 

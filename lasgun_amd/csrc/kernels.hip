@@ -841,7 +841,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                                              Best &best, const uint4 *scn) {
 #ifdef LG_STAMPS
     unsigned long long stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_readcyclecounter();
-    unsigned long long stamp_cnt[5] = {0, 0, 0, 0, 0};
+    unsigned long long stamp_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
     uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
@@ -937,6 +937,14 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                         if (b != 0.0) { t = -c / b; has = true; }
                     } else {
                         const double disc = b * b - 4.0 * dd * c;
+#ifdef LG_STAMPS
+                        {
+                            const unsigned long long need_m = __builtin_amdgcn_ballot_w64(!(disc < 0.0));
+                            const unsigned long long ahead_m = __builtin_amdgcn_ballot_w64(!(disc < 0.0) && !(b > 0.0 && c > 0.0));
+                            if (need_m) { stamp_cnt[5] += 1; stamp_cnt[6] += (unsigned long long)__builtin_popcountll(need_m); }
+                            if (ahead_m) stamp_cnt[7] += 1;
+                        }
+#endif
                         if (!(disc < 0.0)) {
                             const double q = -(b + signum(b) * sqrt(disc)) / 2.0;
                             const double r0 = q / dd;
@@ -1042,7 +1050,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         for (int i = 0; i < 7; ++i) atomicAdd(dst + i, stamp_acc[i]);
         atomicAdd(dst + 7, 1ull);
         unsigned long long *cnt = P.stamp_counts;
-        if (cnt) for (int i = 0; i < 5; ++i) atomicAdd(cnt + i, stamp_cnt[i]);
+        if (cnt) for (int i = 0; i < 8; ++i) atomicAdd(cnt + i, stamp_cnt[i]);
     }
 #endif
 }
@@ -1703,6 +1711,10 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
                 {
                     bool tie = false;
                     Counters before = cnt;
+#ifndef LG_OLD_TRAVERSE
+                    if (!STATS && !FAST) traverse_ref<LDSS>(P, tray, shadow_job, stack, stride, b, scn);
+                    else
+#endif
                     traverse<STATS, FAST, LDSS>(P, tray, shadow_job, stack, stride, b, cnt, tie, scn);
                     // fast mode: exact ties in t are decided by the reference's visit order -> re-trace this ray with it.
                     // (an occluded any-hit ray needs no re-trace: the answer "some t < 1 exists" is order-independent)

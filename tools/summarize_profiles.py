@@ -7,9 +7,9 @@ import os
 import statistics
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final2"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-tag = sys.argv[3] if len(sys.argv) > 3 else "r01_final"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
 
 
 def newest(pattern):
@@ -17,7 +17,11 @@ def newest(pattern):
     return files[-1] if files else None
 
 
-out = {"kernels": {}, "kernel_stats": []}
+import hashlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = {"kernels": {}, "kernel_stats": [],
+       # the source these passes were collected on: bench.py reports `traffic` from this file only while kernels.hip still has this hash
+       "kernels_hip_sha16": hashlib.sha256(open(os.path.join(ROOT, "lasgun_amd", "csrc", "kernels.hip"), "rb").read()).hexdigest()[:16]}
 ks = newest("prof/**/*kernel_stats.csv")
 if ks:
     rows = list(csv.DictReader(open(ks)))
