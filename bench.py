@@ -322,8 +322,10 @@ def main():
             dst = dict(share_stats(2 if "shadow" in dom else 1))
             dst["primary_rays"] = 0  # the RGBA write belongs to the shade kernel, not to a traversal kernel
             # wavefront pipeline: lg::wf_trace_kernel<FAST, SHADOW, scene tables resident in LDS>, lg::wf_shade_kernel
-            kernel_name = ("lg::wf_trace_kernel<false, %s, %s>" % ("true" if "shadow" in dom else "false", "true" if lds_scene else "false")
-                           if dom.startswith("trace<") else "lg::wf_%s_kernel" % dom)
+            # wavefront pipeline: lg::wf_trace_kernel<FAST, SHADOW, scene tables resident in LDS, level-0 closest pass>, lg::wf_shade_kernel<KIND, L0>
+            shadow = "shadow" in dom
+            kernel_name = ("lg::wf_trace_kernel<false, %s, %s, %s>" % ("true" if shadow else "false", "true" if lds_scene else "false", "false" if shadow else "true")
+                           if dom.startswith("trace<") else "lg::wf_shade_kernel<0, true>")
         else:  # megakernel
             dom_ms, dst, kernel_name = frame_ms, st, "lg::trace_kernel<false, false, %s>" % ("true" if lds_scene else "false")
         dom_bytes, dom_flops = algorithmic_bytes(dst), algorithmic_flops(dst)

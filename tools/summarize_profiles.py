@@ -33,6 +33,13 @@ if ks:
                 w.writerow(r)
                 out["kernel_stats"].append({"name": r["Name"].replace("void ", "").replace("(lg::DParams)", ""), "calls": int(r["Calls"]),
                                             "avg_ms": float(r["AverageNs"]) / 1e6})
+ko = newest("prof_overlap/**/*kernel_stats.csv")
+if ko:
+    rows = [r for r in csv.DictReader(open(ko)) if "lg::" in r["Name"]]
+    with open(os.path.join(dst, tag + "_kernel_stats_overlapped_frames.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(rows)
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
