@@ -916,7 +916,8 @@ void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     fl.aggregate(*scene.root, -1, b, need, fneed);
     out.max_stack = need;
     out.max_stack_fast = fneed;
-    out.leaf_soup.resize(out.primref.size(), DLeafRec{});
+    if (out.primref.size() > 80000000u) throw Error("too many primitive slots for the 32-bit record offsets of the triangle stream");
+    out.leaf_soup.resize(out.primref.size() + 2, DLeafRec{}); // two spare records: the mesh leaf loop keeps the next slot in flight
     out.sphere_ref_leaf.resize(out.spheres.size(), NO_HIT);
     out.cuboid_ref_leaf.resize(out.cuboids.size(), NO_HIT);
     out.tri_ref_leaf.resize(out.tri_v.size() / 3, NO_HIT);

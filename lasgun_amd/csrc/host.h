@@ -115,7 +115,7 @@ struct FlatScene {
     std::vector<int32_t> cuboid_mat;
     std::vector<uint32_t> tri_v, tri_n, tri_t;
     std::vector<float> vpos, vnorm, vtex;
-    std::vector<DLeafRec> leaf_soup; // one per primref slot
+    std::vector<DLeafRec> leaf_soup; // one per primref slot (+2 spare)
     // fast mode's candidate check: a hit found through the fast tree counts only if the REFERENCE tree would have tested
     // that primitive for this ray, i.e. if every box on its root-to-leaf path in the reference tree passes the slab test
     std::vector<uint32_t> sphere_ref_leaf, cuboid_ref_leaf, tri_ref_leaf; // per primitive: the leaf of ITS accel's reference tree holding it

@@ -808,29 +808,72 @@ __device__ __forceinline__ Ray accel_local_ray(const DParams &P, const uint4 *sc
     }
     return ray_to_local(P.accels[accel].minv, r);
 }
-// One fat mesh leaf [li, le) of the second formulation: the reference's leaf loop (bvh.rs:483-488) over
-// triangle records streamed one slot ahead; returns true when an any-hit ray is done.
+// One fat mesh leaf [li, le) of the second formulation: the reference's leaf loop (bvh.rs:483-488) over the leaf-ordered
+// 48-byte f32 position records, two triangles per trip in ping-pong (while one record is tested the next is in flight and
+// neither is ever copied), one address add per triangle; returns true when an any-hit ray is done.
+// (Records pre-widened to f64 -- 80 bytes, nine conversions fewer per triangle -- were measured again this round: 138 -> 170 ms
+// on config 4.  Lanes of incoherent rays read different triangles and the loop then waits on the vector L1, not on the VALU.)
+// The sign test of the edge functions (triangle.rs:224-230) is written with v_cmp_class: "negative" = -normal, -subnormal,
+// -inf and "positive" likewise -- exactly `e < 0.0` / `e > 0.0` (zeros and NaNs are neither) -- which keeps hipcc from
+// turning the six comparisons into a min / max chain with canonicalising moves.
+__device__ __forceinline__ bool f64_neg(double x) { return __builtin_amdgcn_class(x, 0x004 | 0x008 | 0x010); }
+__device__ __forceinline__ bool f64_pos(double x) { return __builtin_amdgcn_class(x, 0x080 | 0x100 | 0x200); }
+__device__ __forceinline__ LeafRec load_rec_at(const char *base, uint32_t off) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(base + off);
+    return LeafRec{q[0], q[1], q[2]};
+}
+template <int KZ>
+__device__ __forceinline__ bool tri_rec_t(const LeafRec &r, V3 o, double sx, double sy, double sz, TriHit &h) {
+    const V3 p0{rec_f32(r.a.x), rec_f32(r.a.y), rec_f32(r.a.z)}, p1{rec_f32(r.a.w), rec_f32(r.b.x), rec_f32(r.b.y)},
+        p2{rec_f32(r.b.z), rec_f32(r.b.w), rec_f32(r.c.x)};
+    V3 p0t = permute_kz<KZ>(p0 - o), p1t = permute_kz<KZ>(p1 - o), p2t = permute_kz<KZ>(p2 - o);
+    p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
+    p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
+    p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+    double e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    double e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    double e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if ((f64_neg(e0) || f64_neg(e1) || f64_neg(e2)) && (f64_pos(e0) || f64_pos(e1) || f64_pos(e2))) return false;
+    double det = e0 + e1 + e2;
+    if (det == 0.0) return false;
+    p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+    double tscaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if ((det < 0.0 && tscaled >= 0.0) || (det > 0.0 && tscaled <= 0.0)) return false;
+    double invdet = 1.0 / det;
+    h.b0 = e0 * invdet; h.b1 = e1 * invdet; h.b2 = e2 * invdet;
+    h.t = tscaled * invdet;
+    return true;
+}
 template <int KZ, bool LDSS>
 __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, const V3 o, const TriSetup tri, uint32_t li, const uint32_t le,
                                            const uint32_t soup_delta, const uint32_t accel, const bool anyhit, Best &best) {
-    const uint32_t last = le - 1u;
-    LeafRec cur = load_rec(P, li + soup_delta);
-    for (; li < le; ++li) {
-        LeafRec r = cur;
-        cur = load_rec(P, (li < last ? li + 1u : last) + soup_delta); // prefetch the next slot (clamped: always a valid slot)
-        V3 p0{rec_f32(r.a.x), rec_f32(r.a.y), rec_f32(r.a.z)}, p1{rec_f32(r.a.w), rec_f32(r.b.x), rec_f32(r.b.y)},
-            p2{rec_f32(r.b.z), rec_f32(r.b.w), rec_f32(r.c.x)};
-        TriHit h;
-        if (!triangle_t_pre<KZ>(p0, p1, p2, o, tri.sx, tri.sy, tri.sz, h)) continue;
-        if (h.t >= best.t) continue;
-        best.t = h.t; best.ref = load_primref<LDSS>(P, scn, li); best.accel = accel;
-        if (anyhit && h.t < 1.0) return true; // point.rs:49
+    const char *base = reinterpret_cast<const char *>(P.leaf_soup);
+    constexpr uint32_t REC = (uint32_t)sizeof(DLeafRec);
+    uint32_t off = (li + soup_delta) * REC; // (the array holds < 2^32 / 48 slots: checked by the host)
+#define LG_TRI(R, SLOT)                                                                                                  \
+    do {                                                                                                                 \
+        TriHit h_;                                                                                                       \
+        if (tri_rec_t<KZ>(R, o, tri.sx, tri.sy, tri.sz, h_) && !(h_.t >= best.t)) {                                      \
+            best.t = h_.t; best.ref = load_primref<LDSS>(P, scn, (SLOT)); best.accel = accel;                            \
+            if (anyhit && h_.t < 1.0) return true; /* point.rs:49 */                                                     \
+        }                                                                                                                \
+    } while (0)
+    LeafRec ra = load_rec_at(base, off);
+    for (; li + 1u < le; li += 2u) {
+        const LeafRec rb = load_rec_at(base, off + REC);
+        LG_TRI(ra, li);
+        off += 2u * REC;
+        ra = load_rec_at(base, off); // (two spare records behind the last slot: always readable)
+        LG_TRI(rb, li + 1u);
     }
+    if (li < le) LG_TRI(ra, li);
+#undef LG_TRI
     return false;
 }
 
 // Diagnostic build (-DLG_STAMPS, never shipped): cycles a wave spends in each phase of the walk, summed into P.stats
-// (nine 64-bit words: setup, A nodes, B mesh leaves, B leaf slots, enter, C returns, trips, -, -).  tools/stamp_phases.py reads them.
+// (nine 64-bit words: setup, A nodes, B mesh leaves, B leaf slots, enter, C returns, trips, -, -), and wave-level trip
+// counts into P.stamp_counts.  tools/stamp_phases.py reads them.
 #ifdef LG_STAMPS
 #define LG_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } while (0)
 #else
