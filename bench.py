@@ -316,7 +316,7 @@ def main():
         value = rays * args.steps / elapsed / 1e6
         frame_ms = kernel_ms / max(launches, 1)
         per_kernel = {k: v[0] / v[1] for k, v in kinds.items() if v[1] > 0}
-        if len(per_kernel) > 1 or "trace_kernel" not in per_kernel:  # streaming pipeline: primary trace (+ frame), shadow trace, shade
+        if per_kernel and (len(per_kernel) > 1 or "trace_kernel" not in per_kernel):  # pipeline: closest trace (+ frame), shadow trace, shade
             dom = max(per_kernel, key=per_kernel.get)
             dom_ms = per_kernel[dom]
             dst = dict(share_stats(2 if "shadow" in dom else 1))
@@ -326,8 +326,9 @@ def main():
             shadow = "shadow" in dom
             kernel_name = ("lg::wf_trace_kernel<false, %s, %s, %s>" % ("true" if shadow else "false", "true" if lds_scene else "false", "false" if shadow else "true")
                            if dom.startswith("trace<") else "lg::wf_shade_kernel<0, true>")
-        else:  # megakernel
+        else:  # megakernel (a share too small for the pipeline, e.g. a small --size over many ranks)
             dom_ms, dst, kernel_name = frame_ms, st, "lg::trace_kernel<false, false, %s>" % ("true" if lds_scene else "false")
+            per_kernel = {"trace_kernel": frame_ms}
         dom_bytes, dom_flops = algorithmic_bytes(dst), algorithmic_flops(dst)
         secs = dom_ms * 1e-3
         traffic, traffic_src = profiled_traffic(kernel_name, world, args.size)
