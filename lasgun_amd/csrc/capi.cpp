@@ -863,10 +863,6 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                     for (uint32_t i = 0, e = extent(nb, r.first, fm.nodes.size()); i < e; ++i) {
                         uint32_t *rec = &img[((size_t)(r.second + i) * LDS_NODE_STRIDE) * 4];
                         std::memcpy(rec, &fm.nodes[r.first + i], 56);
-                        // interior records also carry their second child's BYTE offset within the tree (meta = axis | offset << 2):
-                        // the second formulation of the reference walk addresses nodes by byte offset (kernels.hip, Lvl)
-                        const DNode &nd = fm.nodes[r.first + i];
-                        if (!(nd.meta & NODE_LEAF)) rec[13] = (nd.meta & 3u) | ((nd.link * LDS_NODE_STRIDE * 16u) << 2);
                     }
                 a->lds_prim_off = nn * LDS_NODE_STRIDE;
                 a->lds_soup_off = a->lds_prim_off + (uint32_t)prim16;
@@ -876,6 +872,17 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                         if (r.second + i < np_soup)
                             std::memcpy(&img[((size_t)a->lds_soup_off + (size_t)(r.second + i) * 3) * 4], &fm.leaf_soup[r.first + i], 48);
                     }
+                // walk words of every record (words 16..19; kernels.hip, traverse_ref): the second formulation of the reference walk
+                // addresses nodes by their byte offset in the image and takes a leaf's slot range ready-made
+                for (const DAccel &A : fm.accels) {
+                    const uint32_t tree0 = a->lds_node_off * 16u + A.lnode_base * LDS_NODE_STRIDE * 16u;
+                    for (uint32_t i = 0, e = extent(nb, A.node_base, fm.nodes.size()); i < e; ++i) {
+                        uint32_t *rec = &img[((size_t)(A.lnode_base + i) * LDS_NODE_STRIDE) * 4];
+                        const DNode &nd = fm.nodes[A.node_base + i];
+                        if (nd.meta & NODE_LEAF) { rec[16] = A.lprim_base + nd.link; rec[17] = NODE_LEAF; rec[18] = rec[16] + (nd.meta & 0xFFFFu); }
+                        else { rec[16] = tree0 + nd.link * LDS_NODE_STRIDE * 16u; rec[17] = 1u << (nd.meta & 3u); rec[18] = 0u; }
+                    }
+                }
                 a->lds_accel_off = a->lds_soup_off + np_soup * 3u;
                 for (size_t i = 0; i < fm.accels.size(); ++i) {
                     const DAccel &A = fm.accels[i];

@@ -600,7 +600,11 @@ struct Flattener {
             DNode d{};
             d.bmin[0] = n.b.min.x; d.bmin[1] = n.b.min.y; d.bmin[2] = n.b.min.z;
             d.bmax[0] = n.b.max.x; d.bmax[1] = n.b.max.y; d.bmax[2] = n.b.max.z;
-            if (n.leaf) { d.link = n.a; d.meta = NODE_LEAF | (n.c & 0xFFFFu); }
+            if (n.leaf) {
+                // the reference tells leaves from interior nodes by n_primitives > 0 (bvh.rs:475); the walk relies on that too
+                if ((n.c & 0xFFFFu) == 0u) throw Error("BVH build: leaf without primitives");
+                d.link = n.a; d.meta = NODE_LEAF | (n.c & 0xFFFFu);
+            }
             else { d.link = n.c; d.meta = n.a & 3u; }
             out.nodes.push_back(d);
         }

@@ -69,6 +69,22 @@ __device__ __forceinline__ bool slab_intersects(const double bmin[3], const doub
     return tnear <= tfar && tfar > 0.0;
 }
 
+// The same test without the two clamps.  fmax / fmin ignore a NaN operand, so the chains above yield the largest / smallest
+// non-NaN term, with -inf / +inf standing in when every term is NaN (0 * inf on all three axes).  fmin(t1, t2) is NaN exactly
+// when fmax(t1, t2) is, so tnear is NaN exactly when tfar is; the clamped test then reads -inf <= +inf && +inf > 0 = true, and
+// the negated comparisons below read !(NaN > NaN) && !(NaN <= 0) = true as well; on numbers they are the same comparisons.
+__device__ __forceinline__ bool slab_intersects_nc(const double bmin[3], const double bmax[3], const Ray &r) {
+    double t1 = (bmin[0] - r.o.x) * r.dinv.x, t2 = (bmax[0] - r.o.x) * r.dinv.x;
+    double tnear = fmin_(t1, t2), tfar = fmax_(t1, t2);
+    t1 = (bmin[1] - r.o.y) * r.dinv.y; t2 = (bmax[1] - r.o.y) * r.dinv.y;
+    tnear = fmax_(tnear, fmin_(t1, t2));
+    tfar = fmin_(tfar, fmax_(t1, t2));
+    t1 = (bmin[2] - r.o.z) * r.dinv.z; t2 = (bmax[2] - r.o.z) * r.dinv.z;
+    tnear = fmax_(tnear, fmin_(t1, t2));
+    tfar = fmin_(tfar, fmax_(t1, t2));
+    return !(tnear > tfar) && !(tfar <= 0.0);
+}
+
 // the same test, also handing back its tnear (used by the fast mode's front-to-back pruning)
 __device__ __forceinline__ bool slab_intersects_t(const double bmin[3], const double bmax[3], const Ray &r, double &tnear_out, double &tfar_out) {
     double t1 = (bmin[0] - r.o.x) * r.dinv.x, t2 = (bmax[0] - r.o.x) * r.dinv.x;
@@ -780,10 +796,13 @@ constexpr uint32_t FRAME_SAME_RAY = 0x80000000u; // level frame, third word: the
 struct Lvl { // the accel level a lane is walking
     uint32_t accel, node_base, prim_base, soup_delta, flags;
 };
-// Node cursor of the second formulation.  Global tables: the node's index relative to its tree (64-byte DNode records).
-// LDS image: the node's BYTE offset from its tree's first record -- interior records of the image carry their second
-// child's offset ready-made (meta = axis | offset << 2), so a step forms the record's address with one add and never multiplies.
+// Node cursor of the second formulation.  Global tables: the node's index in P.nodes (64-byte DNode records).
+// LDS image: the node's BYTE offset in the image -- every record of the image carries "walk words" made by the host
+// (capi.cpp, the image builder): an interior node its second child's cursor and 1 << axis, a leaf its first slot, NODE_LEAF
+// and its last slot + 1 -- so a step forms the record's address with one add, never multiplies or shifts, and takes a
+// leaf's slot range as it is.
 constexpr uint32_t LDS_NODE_BYTES = LDS_NODE_STRIDE * 16u;
+constexpr uint32_t LDS_NODE_WALK_OFF = 64u; // words 16..19 of the 80-byte record
 // What the walk needs of a DAccel: from the LDS image (LDS_ACCEL_UNITS) or from the table in HBM / L2
 template <bool LDSS>
 __device__ __forceinline__ void lvl_set(const DParams &P, const uint4 *scn, Lvl &L, uint32_t accel) {
@@ -896,7 +915,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     Ray ray = root;
     double dd = dot(ray.d, ray.d);      // a of every sphere's quadratic at this level
     uint32_t negmask = neg_mask(ray);   // dir_is_neg (bvh.rs:463)
-    uint32_t sp = 0, base = 0, cur = 0, li = 0, le = 0, enter = 0;
+    uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0;
     uint32_t state = ST_NODE;
     LG_STAMP(0);
     for (;;) {
@@ -906,32 +925,36 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         bool more_nodes = wave_any(state == ST_NODE);
         while (more_nodes) {
             if (state == ST_NODE) {
-                NodeRec nd;
+                // the record's walk words: interior -> (second child's cursor, 1 << split axis, -), leaf -> (first slot, NODE_LEAF, last slot + 1)
+                double bmin[3], bmax[3];
+                uint32_t w_link, w_meta, w_end;
                 if (LDSS) {
-                    const char *rec = reinterpret_cast<const char *>(scn) + (L.node_base + cur);
+                    const char *rec = reinterpret_cast<const char *>(scn) + cur;
                     const double2 *q = reinterpret_cast<const double2 *>(rec);
-                    const double2 a = q[0], b = q[1], c = q[2]; // three ds_read_b128
-                    const uint2 d = *reinterpret_cast<const uint2 *>(rec + 48);
-                    nd.bmin[0] = a.x; nd.bmin[1] = a.y; nd.bmin[2] = b.x; nd.bmax[0] = b.y; nd.bmax[1] = c.x; nd.bmax[2] = c.y;
-                    nd.link = d.x; nd.meta = d.y;
+                    const double2 a = q[0], b = q[1], c = q[2]; // four ds_read_b128
+                    const uint4 d = *reinterpret_cast<const uint4 *>(rec + LDS_NODE_WALK_OFF);
+                    bmin[0] = a.x; bmin[1] = a.y; bmin[2] = b.x; bmax[0] = b.y; bmax[1] = c.x; bmax[2] = c.y;
+                    w_link = d.x; w_meta = d.y; w_end = d.z;
                 } else {
-                    nd = load_node<false>(P, scn, L.node_base + cur);
+                    const NodeRec nd = load_node<false>(P, scn, cur);
+                    bmin[0] = nd.bmin[0]; bmin[1] = nd.bmin[1]; bmin[2] = nd.bmin[2]; bmax[0] = nd.bmax[0]; bmax[1] = nd.bmax[1]; bmax[2] = nd.bmax[2];
+                    const bool lf = (nd.meta & NODE_LEAF) != 0u;
+                    w_link = (lf ? L.prim_base : L.node_base) + nd.link;
+                    w_meta = lf ? NODE_LEAF : 1u << (nd.meta & 3u);
+                    w_end = w_link + (nd.meta & 0xFFFFu);
                 }
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
-                const bool hit = slab_intersects(nd.bmin, nd.bmax, ray);
-                const uint32_t meta = nd.meta;
-                const bool leaf = (meta & NODE_LEAF) != 0u;
-                const uint32_t count = meta & 0xFFFFu;
-                const bool neg = ((negmask >> (meta & 3u)) & 1u) != 0u; // dir_is_neg[axis] (bvh.rs:496)
-                const uint32_t first = cur + (LDSS ? LDS_NODE_BYTES : 1u), second = LDSS ? (meta >> 2) : nd.link; // the two children (interior nodes)
-                const uint32_t link = nd.link;
+                const bool hit = slab_intersects_nc(bmin, bmax, ray);
+                const bool leaf = (int32_t)w_meta < 0;            // n_primitives > 0 (bvh.rs:475): the builder emits no empty leaf
+                const bool neg = (negmask & w_meta) != 0u;        // dir_is_neg[axis] (bvh.rs:496)
+                const uint32_t first = cur + (LDSS ? LDS_NODE_BYTES : 1u), second = w_link; // the two children (interior nodes)
                 const uint32_t near_node = neg ? second : first, far_node = neg ? first : second;
-                const bool interior_hit = hit && !leaf, leaf_hit = hit && leaf && count != 0u;
-                const bool pop = !(interior_hit || leaf_hit), can_pop = sp != base;
+                const bool interior_hit = hit && !leaf, leaf_hit = hit && leaf;
+                const bool pop = !hit, can_pop = sp != base;
                 stk[sp * stride] = far_node; // counts only if sp advances (bvh.rs:493-504)
                 cur = interior_hit ? near_node : popped;
                 sp = sp + (interior_hit ? 1u : 0u) - (pop && can_pop ? 1u : 0u);
-                li = L.prim_base + link; le = li + count; // (read in ST_LEAF only)
+                li = w_link; le = w_end; // (read in ST_LEAF only)
                 state = leaf_hit ? ST_LEAF : (pop && !can_pop) ? ST_LEVEL_DONE : ST_NODE;
             }
             more_nodes = wave_any(state == ST_NODE);
@@ -1043,7 +1066,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 dd = dot(ray.d, ray.d);
                 negmask = neg_mask(ray);
             }
-            cur = 0u;
+            cur = L.node_base;
             state = ST_NODE; // node 0 is tested when visited (bvh.rs:472-473)
         }
         LG_STAMP(4);
