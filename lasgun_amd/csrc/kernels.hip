@@ -85,6 +85,19 @@ __device__ __forceinline__ bool slab_intersects_nc(const double bmin[3], const d
     return !(tnear > tfar) && !(tfar <= 0.0);
 }
 
+__device__ __forceinline__ bool slab_intersects_nc_t(const double bmin[3], const double bmax[3], const Ray &r, double &tnear_out, double &tfar_out) {
+    double t1 = (bmin[0] - r.o.x) * r.dinv.x, t2 = (bmax[0] - r.o.x) * r.dinv.x;
+    double tnear = fmin_(t1, t2), tfar = fmax_(t1, t2);
+    t1 = (bmin[1] - r.o.y) * r.dinv.y; t2 = (bmax[1] - r.o.y) * r.dinv.y;
+    tnear = fmax_(tnear, fmin_(t1, t2));
+    tfar = fmin_(tfar, fmax_(t1, t2));
+    t1 = (bmin[2] - r.o.z) * r.dinv.z; t2 = (bmax[2] - r.o.z) * r.dinv.z;
+    tnear = fmax_(tnear, fmin_(t1, t2));
+    tfar = fmin_(tfar, fmax_(t1, t2));
+    tnear_out = tnear; tfar_out = tfar;
+    return !(tnear > tfar) && !(tfar <= 0.0);
+}
+
 // the same test, also handing back its tnear (used by the fast mode's front-to-back pruning)
 __device__ __forceinline__ bool slab_intersects_t(const double bmin[3], const double bmax[3], const Ray &r, double &tnear_out, double &tfar_out) {
     double t1 = (bmin[0] - r.o.x) * r.dinv.x, t2 = (bmax[0] - r.o.x) * r.dinv.x;
@@ -804,7 +817,7 @@ struct Lvl { // the accel level a lane is walking
 constexpr uint32_t LDS_NODE_BYTES = LDS_NODE_STRIDE * 16u;
 constexpr uint32_t LDS_NODE_WALK_OFF = 64u; // words 16..19 of the 80-byte record
 // What the walk needs of a DAccel: from the LDS image (LDS_ACCEL_UNITS) or from the table in HBM / L2
-template <bool LDSS>
+template <bool LDSS, bool FAST = false>
 __device__ __forceinline__ void lvl_set(const DParams &P, const uint4 *scn, Lvl &L, uint32_t accel) {
     L.accel = accel;
     if (LDSS) {
@@ -812,7 +825,7 @@ __device__ __forceinline__ void lvl_set(const DParams &P, const uint4 *scn, Lvl 
         L.node_base = info.x; L.prim_base = info.y; L.soup_delta = info.z; L.flags = info.w;
     } else {
         const DAccel *A = P.accels + accel;
-        L.node_base = A->node_base; L.prim_base = A->prim_base; L.soup_delta = 0u; L.flags = A->flags;
+        L.node_base = FAST ? A->fnode_base : A->node_base; L.prim_base = FAST ? A->fprim_base : A->prim_base; L.soup_delta = 0u; L.flags = A->flags;
     }
 }
 template <bool LDSS>
@@ -863,18 +876,21 @@ __device__ __forceinline__ bool tri_rec_t(const LeafRec &r, V3 o, double sx, dou
     h.t = tscaled * invdet;
     return true;
 }
-template <int KZ, bool LDSS>
+template <int KZ, bool LDSS, bool FAST = false>
 __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, const V3 o, const TriSetup tri, uint32_t li, const uint32_t le,
-                                           const uint32_t soup_delta, const uint32_t accel, const bool anyhit, Best &best) {
+                                           const uint32_t soup_delta, const uint32_t accel, const bool anyhit, Best &best, bool &tie) {
     const char *base = reinterpret_cast<const char *>(P.leaf_soup);
     constexpr uint32_t REC = (uint32_t)sizeof(DLeafRec);
     uint32_t off = (li + soup_delta) * REC; // (the array holds < 2^32 / 48 slots: checked by the host)
 #define LG_TRI(R, SLOT)                                                                                                  \
     do {                                                                                                                 \
         TriHit h_;                                                                                                       \
-        if (tri_rec_t<KZ>(R, o, tri.sx, tri.sy, tri.sz, h_) && !(h_.t >= best.t)) {                                      \
-            best.t = h_.t; best.ref = load_primref<LDSS>(P, scn, (SLOT)); best.accel = accel;                            \
-            if (anyhit && h_.t < 1.0) return true; /* point.rs:49 */                                                     \
+        if (tri_rec_t<KZ>(R, o, tri.sx, tri.sy, tri.sz, h_)) {                                                           \
+            if (FAST && ((h_.t == best.t && best.ref != NO_HIT) || h_.t != h_.t)) tie = true; /* visit order decides */  \
+            if (!(h_.t >= best.t)) {                                                                                     \
+                best.t = h_.t; best.ref = load_primref<LDSS>(P, scn, (SLOT)); best.accel = accel;                        \
+                if (anyhit && h_.t < 1.0) return true; /* point.rs:49 */                                                 \
+            }                                                                                                            \
         }                                                                                                                \
     } while (0)
     LeafRec ra = load_rec_at(base, off);
@@ -898,9 +914,15 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 #else
 #define LG_STAMP(i) do { } while (0)
 #endif
-template <bool LDSS>
+// FAST (lg_accel_set_mode(1), opt-in, NOT the reference's traversal): the same walk over the binned-SAH trees with <= 4 primitives
+// per leaf, near child first by dir_is_neg[axis] as before, and a node is skipped when its slab tnear lies beyond the best hit so
+// far (closest) or beyond the light (any-hit) -- margins as in prune_limit().  Exact ties in t (and NaN t), where the reference's
+// visit order decides, raise `tie`; the caller (walk() below) then puts the winner to the reference tree's own box tests
+// (ref_candidate) and re-traces with the reference walk when either fails.
+template <bool LDSS, bool FAST = false>
 __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
-                                             Best &best, const uint4 *scn) {
+                                             Best &best, const uint4 *scn, bool &tie) {
+    static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
 #ifdef LG_STAMPS
     unsigned long long stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_readcyclecounter();
     unsigned long long stamp_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -908,7 +930,10 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
     uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
     Lvl L;
-    lvl_set<LDSS>(P, scn, L, 0u);
+    lvl_set<LDSS, FAST>(P, scn, L, 0u);
+    double limit = prune_limit(INFINITY, anyhit); // FAST: nodes whose tnear lies beyond this are skipped
+    TriSetup tri;                                  // FAST: per mesh level (its leaves hold <= 4 triangles: per leaf the three divides would dominate)
+    tri.kz = 0; tri.sx = 0.0; tri.sy = 0.0; tri.sz = 0.0;
     // ---- the root accel's local ray (bvh.rs:462), kept for the returns
     Ray root = wray;
     if (!((L.flags & AF_IDENTITY) && ray_plain(wray))) root = accel_local_ray<LDSS>(P, scn, 0u, wray);
@@ -944,12 +969,19 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     w_end = w_link + (nd.meta & 0xFFFFu);
                 }
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
-                const bool hit = slab_intersects_nc(bmin, bmax, ray);
+                bool hit;
+                if (FAST) {
+                    // a primitive's computed t can undershoot its box's tnear by the error of its own formula: for a sphere
+                    // the quadratic's cancellation, ~sqrt(eps) of the distance to its centre, which lies inside the box
+                    double tn, tf;
+                    hit = slab_intersects_nc_t(bmin, bmax, ray, tn, tf);
+                    hit = hit && !(tn - 4e-8 * fabs(tf) > limit);
+                } else hit = slab_intersects_nc(bmin, bmax, ray);
                 const bool leaf = (int32_t)w_meta < 0;            // n_primitives > 0 (bvh.rs:475): the builder emits no empty leaf
                 const bool neg = (negmask & w_meta) != 0u;        // dir_is_neg[axis] (bvh.rs:496)
                 const uint32_t first = cur + (LDSS ? LDS_NODE_BYTES : 1u), second = w_link; // the two children (interior nodes)
                 const uint32_t near_node = neg ? second : first, far_node = neg ? first : second;
-                const bool interior_hit = hit && !leaf, leaf_hit = hit && leaf;
+                const bool leaf_hit = hit && leaf, interior_hit = hit != leaf_hit;
                 const bool pop = !hit, can_pop = sp != base;
                 stk[sp * stride] = far_node; // counts only if sp advances (bvh.rs:493-504)
                 cur = interior_hit ? near_node : popped;
@@ -969,11 +1001,12 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         if (wave_any(state == ST_LEAF && mesh)) stamp_cnt[1] += 1;
 #endif
         if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
-            const TriSetup tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
+            if (!FAST) tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
             bool done;
-            if (tri.kz == 0) done = mesh_leaf2<0, LDSS>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best);
-            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best);
-            else done = mesh_leaf2<2, LDSS>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best);
+            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
+            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
+            else done = mesh_leaf2<2, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
+            if (FAST) limit = prune_limit(best.t, anyhit);
             if (done) state = ST_DONE;
             else if (sp != base) { --sp; cur = stk[sp * stride]; state = ST_NODE; }
             else state = ST_LEVEL_DONE;
@@ -1036,8 +1069,10 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     TriHit h;
                     if (triangle_t(load_f3(P.vpos, vi[0]), load_f3(P.vpos, vi[1]), load_f3(P.vpos, vi[2]), ray, h)) { t = h.t; accepted = !(t >= best.t); }
                 }
+                if (FAST && kind != PK_ACCEL && ((!accepted && t == best.t && best.ref != NO_HIT) || t != t)) tie = true; // visit order decides
                 if (accepted) {
                     best.t = t; best.ref = ref; best.accel = L.accel;
+                    if (FAST) limit = prune_limit(t, anyhit);
                     if (anyhit && t < 1.0) state = ST_DONE; // occluded: point.rs:49 only asks isect.t < 1.0
                 }
                 if (state == ST_LEAF && li >= le) { // leaf exhausted: next pending node of this level, or the level is done
@@ -1057,7 +1092,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         if (wave_any(state == ST_LEVEL_DONE)) stamp_cnt[4] += 1;
 #endif
         if (state == ST_ENTER) {
-            lvl_set<LDSS>(P, scn, L, enter);
+            lvl_set<LDSS, FAST>(P, scn, L, enter);
             const bool same = (L.flags & AF_IDENTITY) != 0u && ray_plain(ray);
             stk[sp * stride] = li; stk[(sp + 1u) * stride] = le; stk[(sp + 2u) * stride] = base | (same ? FRAME_SAME_RAY : 0u);
             sp += 3u; base = sp;
@@ -1066,6 +1101,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 dd = dot(ray.d, ray.d);
                 negmask = neg_mask(ray);
             }
+            if (FAST && (L.flags & AF_MESH)) tri = tri_setup(ray);
             cur = L.node_base;
             state = ST_NODE; // node 0 is tested when visited (bvh.rs:472-473)
         }
@@ -1088,7 +1124,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     parent = (uint32_t)P.accels[L.accel].parent;
                     nchain = P.accels[parent].nchain; chain = P.accels[parent].chain;
                 }
-                lvl_set<LDSS>(P, scn, L, parent);
+                lvl_set<LDSS, FAST>(P, scn, L, parent);
                 if (!(w2 & FRAME_SAME_RAY)) { // the parent's ray again: from the root's, through the same transforms
                     ray = root;
                     for (uint32_t i = 1; i < nchain; ++i) {
@@ -1119,6 +1155,28 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         if (cnt) for (int i = 0; i < 8; ++i) atomicAdd(cnt + i, stamp_cnt[i]);
     }
 #endif
+}
+
+// One ray through the scene in the accel's mode.  Reference mode: the reference walk.  Fast mode: the fast walk, then
+//   * closest hit: the winner counts if no exact tie (or NaN) was met and the reference tree would have tested it (ref_candidate);
+//   * any-hit: an occluder counts if the reference tree would have tested it (the reference then finds it or one before it);
+//     "not occluded" stands unless a tie / NaN makes the reference's own answer depend on its visit order;
+// otherwise the ray is traced again with the reference walk over the tables in HBM / L2.
+template <bool LDSS, bool FAST>
+__device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const bool anyhit, uint32_t *stack, const uint32_t stride, Best &best,
+                                     const uint4 *scn) {
+    bool tie = false;
+    traverse_ref<LDSS, FAST>(P, ray, anyhit, stack, stride, best, scn, tie);
+    if (!FAST) return;
+    bool redo;
+    if (anyhit && !(best.t < 1.0)) redo = tie;
+    else {
+        redo = anyhit ? false : tie;
+#ifndef LG_NO_REFCHECK
+        if (!redo && best.ref != NO_HIT) redo = !ref_candidate(P, ray, best);
+#endif
+    }
+    if (redo) traverse_ref<false, false>(P, ray, anyhit, stack, stride, best, nullptr, tie);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1778,13 +1836,15 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
                     bool tie = false;
                     Counters before = cnt;
 #ifndef LG_OLD_TRAVERSE
-                    if (!STATS && !FAST) traverse_ref<LDSS>(P, tray, shadow_job, stack, stride, b, scn);
+                    if (!STATS) walk<LDSS, FAST>(P, tray, shadow_job, stack, stride, b, scn);
                     else
 #endif
+                    {
                     traverse<STATS, FAST, LDSS>(P, tray, shadow_job, stack, stride, b, cnt, tie, scn);
                     // fast mode: exact ties in t are decided by the reference's visit order -> re-trace this ray with it.
                     // (an occluded any-hit ray needs no re-trace: the answer "some t < 1 exists" is order-independent)
                     if (FAST && tie && !(shadow_job && b.t < 1.0)) traverse<STATS, false>(P, tray, shadow_job, stack, stride, b, cnt, tie);
+                    }
                     if (STATS && P.stats_filter != 0u && (P.stats_filter == 2u) != shadow_job) { // not the kind being counted
                         cnt.nodes = before.nodes; cnt.spheres = before.spheres; cnt.cuboids = before.cuboids;
                         cnt.triangles = before.triangles; cnt.entries = before.entries;
@@ -2015,7 +2075,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
         __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling tiles
         scn = dst;
     }
-    Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)cnt;
     for (;;) {
         uint32_t tile = 0;
         if (FIXUP) {
@@ -2041,11 +2101,12 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             Best b;
             bool tie = false;
 #ifndef LG_OLD_TRAVERSE
-            if (!FAST) traverse_ref<LDSS>(P, ray, false, stack, stride, b, scn);
-            else
-#endif
+            walk<LDSS, FAST>(P, ray, false, stack, stride, b, scn);
+#else
             traverse<false, FAST, LDSS>(P, ray, false, stack, stride, b, cnt, tie, scn);
             if (FAST && tie) traverse<false, false>(P, ray, false, stack, stride, b, cnt, tie);
+#endif
+            (void)tie;
             P.hit_ref[widx] = b.ref; // (t and the accel instance are consumed by park_frame right here)
             park_frame(P, widx, ray, b);
         } else {
@@ -2064,11 +2125,12 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
                 Best b;
                 bool tie = false;
 #ifndef LG_OLD_TRAVERSE
-                if (!FAST) traverse_ref<LDSS>(P, sray, true, stack, stride, b, scn);
-                else
-#endif
+                walk<LDSS, FAST>(P, sray, true, stack, stride, b, scn);
+#else
                 traverse<false, FAST, LDSS>(P, sray, true, stack, stride, b, cnt, tie, scn);
                 if (FAST && tie && !(b.t < 1.0)) traverse<false, false>(P, sray, true, stack, stride, b, cnt, tie);
+#endif
+                (void)tie;
                 if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
                 else if (FIXUP) vis &= ~(1u << l);
             }
@@ -2331,7 +2393,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
         __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling tiles
         scn = dst;
     }
-    Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)cnt;
     for (;;) {
         uint32_t tile = 0;
         if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
@@ -2354,11 +2416,8 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             b.ref = NO_HIT; b.t = INFINITY; b.accel = 0u;
             if (active) {
                 bool tie = false;
-                if (!FAST) traverse_ref<LDSS>(P, ray, false, stack, stride, b, scn);
-                else {
-                    traverse<false, FAST, LDSS>(P, ray, false, stack, stride, b, cnt, tie, scn);
-                    if (tie) traverse<false, false>(P, ray, false, stack, stride, b, cnt, tie);
-                }
+                walk<LDSS, FAST>(P, ray, false, stack, stride, b, scn);
+                (void)tie;
             }
             const bool hit = active && b.ref != NO_HIT;
             // ---- this wave's slots in the level's hit queue
@@ -2409,11 +2468,8 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
                 Ray sray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
                 Best b;
                 bool tie = false;
-                if (!FAST) traverse_ref<LDSS>(P, sray, true, stack, stride, b, scn);
-                else {
-                    traverse<false, FAST, LDSS>(P, sray, true, stack, stride, b, cnt, tie, scn);
-                    if (tie && !(b.t < 1.0)) traverse<false, false>(P, sray, true, stack, stride, b, cnt, tie);
-                }
+                walk<LDSS, FAST>(P, sray, true, stack, stride, b, scn);
+                (void)tie;
                 if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
             }
             P.vis[h] = vis;
