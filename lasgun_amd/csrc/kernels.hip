@@ -908,7 +908,7 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 
 // Diagnostic build (-DLG_STAMPS, never shipped): cycles a wave spends in each phase of the walk, summed into P.stats
 // (nine 64-bit words: setup, A nodes, B mesh leaves, B leaf slots, enter, C returns, trips, -, -), and wave-level trip
-// counts into P.stamp_counts.  tools/stamp_phases.py reads them.
+// counts and lane sums (lanes stepping / lanes already done, per node trip and per leaf-slot trip) into P.stamp_counts.  tools/stamp_phases.py reads them.
 #ifdef LG_STAMPS
 #define LG_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } while (0)
 #else
@@ -925,7 +925,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
 #ifdef LG_STAMPS
     unsigned long long stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_readcyclecounter();
-    unsigned long long stamp_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
     uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
@@ -949,6 +949,9 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         // loop-carried state in place instead of copying it in and out of the loop on every trip)
         bool more_nodes = wave_any(state == ST_NODE);
         while (more_nodes) {
+#ifdef LG_STAMPS
+            stamp_cnt[5] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_NODE));
+#endif
             if (state == ST_NODE) {
                 // the record's walk words: interior -> (second child's cursor, 1 << split axis, -), leaf -> (first slot, NODE_LEAF, last slot + 1)
                 double bmin[3], bmax[3];
@@ -989,10 +992,11 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 li = w_link; le = w_end; // (read in ST_LEAF only)
                 state = leaf_hit ? ST_LEAF : (pop && !can_pop) ? ST_LEVEL_DONE : ST_NODE;
             }
-            more_nodes = wave_any(state == ST_NODE);
 #ifdef LG_STAMPS
-            stamp_cnt[0] += 1;
+            stamp_cnt[0] += 1; // (lanes that took this step: those whose state was ST_NODE when it began -- counted after it as "not idle")
+            stamp_cnt[6] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_DONE));
 #endif
+            more_nodes = wave_any(state == ST_NODE);
         }
         LG_STAMP(1);
         // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
@@ -1014,6 +1018,10 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         LG_STAMP(2);
         bool more_prims = wave_any(state == ST_LEAF);
         while (more_prims) {
+#ifdef LG_STAMPS
+            stamp_cnt[7] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_LEAF));
+            stamp_cnt[8] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_DONE));
+#endif
             if (state == ST_LEAF) {
                 const uint32_t slot = li;
                 const uint32_t ref = load_primref<LDSS>(P, scn, slot);
@@ -1036,14 +1044,6 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                         if (b != 0.0) { t = -c / b; has = true; }
                     } else {
                         const double disc = b * b - 4.0 * dd * c;
-#ifdef LG_STAMPS
-                        {
-                            const unsigned long long need_m = __builtin_amdgcn_ballot_w64(!(disc < 0.0));
-                            const unsigned long long ahead_m = __builtin_amdgcn_ballot_w64(!(disc < 0.0) && !(b > 0.0 && c > 0.0));
-                            if (need_m) { stamp_cnt[5] += 1; stamp_cnt[6] += (unsigned long long)__builtin_popcountll(need_m); }
-                            if (ahead_m) stamp_cnt[7] += 1;
-                        }
-#endif
                         if (!(disc < 0.0)) {
                             const double q = -(b + signum(b) * sqrt(disc)) / 2.0;
                             const double r0 = q / dd;
@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         for (int i = 0; i < 7; ++i) atomicAdd(dst + i, stamp_acc[i]);
         atomicAdd(dst + 7, 1ull);
         unsigned long long *cnt = P.stamp_counts;
-        if (cnt) for (int i = 0; i < 8; ++i) atomicAdd(cnt + i, stamp_cnt[i]);
+        if (cnt) for (int i = 0; i < 9; ++i) atomicAdd(cnt + i, stamp_cnt[i]);
     }
 #endif
 }

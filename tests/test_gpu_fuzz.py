@@ -1,0 +1,88 @@
+"""Parity fuzz campaign: seeded random / adversarial scenes through every kernel organisation and both traversal
+modes against the CPU oracle (RGBA8 byte-identical, f64 radiance bit-identical).
+
+The default run is a handful of seeds beyond the ones tests/test_gpu_parity.py pins; a long campaign is
+    LASGUN_FUZZ_SEEDS=1000:1400 LASGUN_FUZZ_LOG=gpurun_out/fuzz.json python -m pytest tests/test_gpu_fuzz.py -q -m gpu
+(profiles/r02_fuzz.json is the log of this round's campaign)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lasgun_amd as la
+from oracle_lib import oracle
+
+pytestmark = pytest.mark.gpu
+G = la.api
+S = la.scenes
+
+
+def same_f64(a, b):
+    """Bit-identical, except that a NaN matches any NaN: which NaN an invalid operation yields (sign, payload) is the
+    platform's choice (x86's default NaN has the sign bit set, gfx950's does not), in Rust as in C++; the film maps it to 0."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return bool(np.all((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))))
+
+
+def seed_range():
+    spec = os.environ.get("LASGUN_FUZZ_SEEDS", "100:106")
+    lo, hi = spec.split(":")
+    return range(int(lo), int(hi))
+
+
+GENERATORS = {
+    "random": (S.random_scene, (56, 40)),
+    "adversarial": (S.adversarial_scene, (64, 48)),
+    "adversarial_mesh": (S.adversarial_mesh_scene, (64, 48)),
+}
+# (streaming, fast, packet): megakernel and wavefront pipeline in either traversal mode, three-kernel pipeline with the packet walk
+ORGANISATIONS = ((0, False, False), (0, True, False), (2, False, False), (2, True, False), (2, False, True))
+
+
+@pytest.mark.parametrize("gen", sorted(GENERATORS))
+def test_fuzz_campaign(gen):
+    build, (w, h) = GENERATORS[gen]
+    o = oracle()
+    done = {"generator": gen, "film": [w, h], "seeds": [seed_range().start, seed_range().stop], "scenes": 0, "renders": 0,
+            "refused_by_both": 0, "fast_refused": 0, "nan_pixels": 0, "mismatches": []}
+    for seed in seed_range():
+        try:
+            oacc = o.Accel(build(o, seed))
+        except la.LasgunError:
+            with pytest.raises(la.LasgunError):
+                G.Accel(build(G, seed))  # what the reference cannot build, neither side builds
+            done["refused_by_both"] += 1
+            continue
+        ofilm = o.Film(w, h)
+        o.capture_subset_mt(0, 1, oacc, ofilm, 8)
+        o.set_trig_mode(1)
+        try:
+            orad = o.capture_radiance(oacc, w, h, nthreads=8)
+        finally:
+            o.set_trig_mode(0)
+        acc = G.Accel(build(G, seed))
+        done["scenes"] += 1
+        done["nan_pixels"] += int(np.isnan(np.asarray(orad)).any(axis=-1).sum())
+        for streaming, fast, packet in ORGANISATIONS:
+            G.set_streaming(acc, streaming)
+            try:
+                G.set_mode(acc, fast)
+            except la.LasgunError as e:  # a transform whose matrix and inverse disagree: fast mode is refused, not wrong
+                assert fast and "inverse" in str(e), (seed, str(e))
+                done["fast_refused"] += 1
+                continue
+            G.set_packet(acc, packet)
+            film = G.Film(w, h)
+            G.capture_subset(0, 1, acc, film)
+            rad = G.capture_radiance(acc, w, h)
+            done["renders"] += 1
+            if not (np.array_equal(film.pixels(), ofilm.pixels()) and same_f64(rad, orad)):
+                done["mismatches"].append([seed, streaming, fast, packet])
+        if done["scenes"] % 25 == 0:
+            print("fuzz %s: %d scenes, %d renders, %d mismatches" % (gen, done["scenes"], done["renders"], len(done["mismatches"])), flush=True)
+    log = os.environ.get("LASGUN_FUZZ_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(json.dumps(done) + "\n")
+    assert not done["mismatches"], done

@@ -22,6 +22,8 @@ tot = sum(out[i] for i in range(6))
 for i, n in enumerate(names):
     print("%-14s %14d  %5.1f %%" % (n, out[i], 100.0 * out[i] / tot if i < 6 else 0.0))
 print("cycles per walk %.0f, trips per walk %.1f" % (tot / out[7], out[6] / out[7]))
-cn = ["node-loop trips", "mesh-leaf blocks", "leaf-slot trips", "enter blocks", "return blocks", "sphere trips with a root computation", "lanes computing roots", "sphere trips with a root that is not (b > 0 and c > 0)"]
+cn = ["node-loop trips", "mesh-leaf blocks", "leaf-slot trips", "enter blocks", "return blocks", "lanes stepping, summed over node trips", "lanes already done, summed over node trips",
+      "lanes stepping, summed over leaf-slot trips", "lanes already done, summed over leaf-slot trips"]
 for i, n in enumerate(cn):
-    print("%-40s %12d  %7.1f per walk" % (n, out[9 + i], out[9 + i] / out[7]))
+    print("%-48s %12d  %7.1f per walk" % (n, out[9 + i], out[9 + i] / out[7]))
+print("node trips: %.1f lanes stepping, %.1f done;  leaf-slot trips: %.1f lanes stepping, %.1f done" % (out[14] / out[9], out[15] / out[9], out[16] / out[11], out[17] / out[11]))
