@@ -72,53 +72,69 @@ def interleaved_rows(rank, world, height, block_rows):
 class InterleavedGather:
     """One RCCL gather per frame of compact interleaved tiles, multi-buffered so that the gather of
     frame k overlaps the renders of the following frames (`tile()` hands out the buffer to render into after
-    making the CURRENT stream wait for the gather that last read it; `submit()` orders the gather
-    after whatever the current stream has enqueued).  Callers that alternate two render streams
-    (bench.py) call both inside `with torch.cuda.stream(s)`."""
+    making the CURRENT stream wait for whatever last used it; `submit()` orders the gather after whatever the
+    current stream has enqueued).  On rank 0 EVERY frame ends in its final layout: the gathered blocks are put in
+    row order (one 4*w*h-byte device copy, on the stream the frame was rendered on) before the frame counts as
+    done -- the film is not complete while its blocks are still rank-major.  Callers that alternate two render
+    streams (bench.py) call both inside `with torch.cuda.stream(s)`."""
 
     def __init__(self, width, height, rank, world, block_rows, device, group=None, always_gather=False, buffers=3):
         assert interleave_ok(world, height, block_rows)
         self.w, self.h, self.rank, self.world, self.b, self.group = width, height, rank, world, block_rows, group
         self.collective = world > 1 or always_gather  # always_gather: run the collective even at world size 1 (rehearsal)
         self.rows = height // world
-        # three tile buffers: the gather of frame k may take until frame k+3's render wants its buffer back
+        # three buffer sets: the gather of frame k may take until frame k+3's render wants its buffers back
         self.nbuf = max(2, int(buffers))
         self.tiles = [torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(self.nbuf)]
-        self.pending = [None] * self.nbuf
+        self.pending = [None] * self.nbuf   # gather still reading tiles[i] (ranks other than 0)
+        self.placed = [None] * self.nbuf    # rank 0, CUDA: event after frame i's blocks were put in row order
         self.k = 0
         self.recv = None
         self.out = None
-        if rank == 0:
-            self.recv = torch.empty((world, self.rows, width, 4), dtype=torch.uint8, device=device)
-            self.out = torch.empty((height, width, 4), dtype=torch.uint8, device=device)
+        self.cuda = torch.device(device).type == "cuda"
+        if rank == 0 and self.collective:
+            self.recv = [torch.empty((world, self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(self.nbuf)]
+            self.out = [torch.empty((height, width, 4), dtype=torch.uint8, device=device) for _ in range(self.nbuf)]
 
     def tile(self):
         i = self.k % self.nbuf
         if self.pending[i] is not None:
             self.pending[i].wait()  # stream-level wait: the buffer is free again
             self.pending[i] = None
+        if self.placed[i] is not None:
+            self.placed[i].wait()   # (the frame that used this set may have been rendered on the other stream)
+            self.placed[i] = None
         return self.tiles[i]
 
     def submit(self):
-        """Start the gather of the tile handed out by the last tile() call."""
+        """Gather the tile handed out by the last tile() call; on rank 0 also put the frame in row order."""
         i = self.k % self.nbuf
         self.k += 1
         if not self.collective:
             return
-        glist = [self.recv[r] for r in range(self.world)] if self.rank == 0 else None
-        self.pending[i] = dist.gather(self.tiles[i], gather_list=glist, dst=0, group=self.group, async_op=True)
+        glist = [self.recv[i][r] for r in range(self.world)] if self.rank == 0 else None
+        work = dist.gather(self.tiles[i], gather_list=glist, dst=0, group=self.group, async_op=True)
+        if self.rank != 0:
+            self.pending[i] = work
+            return
+        work.wait()  # (stream-level with RCCL: the current stream continues after the gather; the other stream renders meanwhile)
+        g = self.h // (self.b * self.world)
+        self.out[i].view(g, self.world, self.b, self.w, 4).copy_(
+            self.recv[i].view(self.world, g, self.b, self.w, 4).permute(1, 0, 2, 3, 4))
+        if self.cuda:
+            self.placed[i] = torch.cuda.Event()
+            self.placed[i].record()
 
     def finish(self):
-        """Wait for outstanding gathers; on rank 0 return the assembled (height, width, 4) film."""
+        """Wait for outstanding gathers; on rank 0 return the last frame's (height, width, 4) film."""
         for i in range(self.nbuf):
             if self.pending[i] is not None:
                 self.pending[i].wait()
                 self.pending[i] = None
+            if self.placed[i] is not None:
+                self.placed[i].wait()
+                self.placed[i] = None
         if self.rank != 0:
             return None
-        if not self.collective:
-            return self.tiles[(self.k - 1) % self.nbuf]
-        g = self.h // (self.b * self.world)
-        self.out.view(g, self.world, self.b, self.w, 4).copy_(
-            self.recv.view(self.world, g, self.b, self.w, 4).permute(1, 0, 2, 3, 4))
-        return self.out
+        last = (self.k - 1) % self.nbuf
+        return self.out[last] if self.collective else self.tiles[last]

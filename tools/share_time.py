@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""What one rank's share of the headline frame costs at N = 1, 2, 4, 8 (one GPU, no gather): the fixed per-frame costs
+that bound strong scaling.  usage: python tools/share_time.py [size]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import lasgun_amd as la  # noqa: E402
+
+G = la.api
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+G.set_device(0)
+acc = G.Accel(la.scenes.spheres_scene(G))
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+for world in (1, 2, 4, 8):
+    tiles = [torch.zeros((size // world, size, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    out = {"world": world}
+    for overlap in (False, True):
+        def frame(k):
+            s = streams[k % 2] if overlap else streams[0]
+            G.capture_interleaved_device(acc, size, size, 64, world, 0, tiles[k % 2].data_ptr(), stream=s.cuda_stream)
+        for k in range(4):
+            frame(k)
+        torch.cuda.synchronize()
+        n = 20
+        t0 = time.perf_counter()
+        for k in range(n):
+            frame(k)
+        torch.cuda.synchronize()
+        out["overlapped_ms" if overlap else "sequential_ms"] = round((time.perf_counter() - t0) / n * 1e3, 3)
+    out["ideal_ms"] = None
+    print(json.dumps(out), flush=True)
