@@ -21,6 +21,7 @@ timeout -k 10 300 python3 tools/bench_configs.py > "$O/configs_parity.jsonl" 2>/
 timeout -k 10 300 python3 tools/bench_configs.py --fast > "$O/configs_fast.jsonl" 2>/dev/null
 timeout -k 10 300 python3 tools/bench_configs.py --org=megakernel > "$O/configs_megakernel.jsonl" 2>/dev/null
 timeout -k 10 300 python3 tools/bench_configs.py --org=wavefront > "$O/configs_wavefront.jsonl" 2>/dev/null
+timeout -k 10 300 python3 tools/bench_configs.py --org=pipeline3 "1a" "1b" "2P" "3 sph" > "$O/configs_pipeline3.jsonl" 2>/dev/null
 timeout -k 10 200 python3 tools/bench_multi.py --devices 0,0 --steps 5 > "$O/multi_2x_same_device.json" 2>/dev/null
 LASGUN_MULTI_FORCE_RCCL=1 timeout -k 10 200 python3 tools/bench_multi.py --devices 0,0 --steps 5 > "$O/multi_2x_same_device_rccl.json" 2>/dev/null
 tail -c 400 "$O/bench.json"
