@@ -1,0 +1,518 @@
+"""A third, independent witness for the shading half of the path -- TEST INFRASTRUCTURE, like oracle/.
+
+Plain-Python (IEEE f64 `float`, `math`) restatement of the reference's Whitted integrator for scenes made of spheres
+placed directly under an untransformed root: camera, sphere intersection and differentials, SurfaceInteraction, the five
+materials and every BxDF they use, point lights with shadow rays, specular recursion, background.  It was written from the
+Rust sources cited below, not from oracle/lasgun_oracle.cpp, shares no code with it, and finds the closest hit by brute
+force over the spheres (no BVH: scenes must not contain exact ties in t, where the reference's visit order decides).
+
+It pins nothing (only the reference's own 17 known-answer tests do), but a transcription slip in the oracle's camera /
+shading / recursion code would have to be made twice, in two languages, to go unseen.  tests/test_pyref_witness.py compares
+it with the oracle (libm trigonometry on both sides: Rust and CPython both call glibc).
+
+cgmath 0.17 operation order as in SURVEY.md Appendix A1 (dot = (x*x + y*y) + z*z, normalize = v * (1 / |v|), ...).
+"""
+import math
+
+PI = math.pi
+FRAC_1_PI = 0.318309886183790671537767526745028724  # std::f64::consts::FRAC_1_PI
+INF = float("inf")
+
+
+# ---- cgmath-shaped vector helpers -------------------------------------------------------------
+def add(a, b): return (a[0] + b[0], a[1] + b[1], a[2] + b[2])
+def sub(a, b): return (a[0] - b[0], a[1] - b[1], a[2] - b[2])
+def mul(a, s): return (a[0] * s, a[1] * s, a[2] * s)          # v * s
+def smul(s, a): return (s * a[0], s * a[1], s * a[2])          # s * v
+def div(a, s): return (a[0] / s, a[1] / s, a[2] / s)
+def neg(a): return (-a[0], -a[1], -a[2])
+def mulv(a, b): return (a[0] * b[0], a[1] * b[1], a[2] * b[2])  # mul_element_wise
+def divv(a, b): return (a[0] / b[0], a[1] / b[1], a[2] / b[2])
+def dot(a, b): return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+def cross(a, b): return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+def magnitude(a): return math.sqrt(dot(a, a))
+def normalize(a): return mul(a, 1.0 / magnitude(a))
+def fmin(a, b): return b if (a != a) else (a if (b != b) else min(a, b))  # f64::min (NaN-ignoring)
+def fmax(a, b): return b if (a != a) else (a if (b != b) else max(a, b))
+ZERO = (0.0, 0.0, 0.0)
+
+
+def signum(x):  # f64::signum: +0 -> 1, -0 -> -1, NaN -> NaN
+    if x != x:
+        return x
+    return math.copysign(1.0, x)
+
+
+# ---- scene description (duck-typed like lasgun_amd.api / the oracle's api, spheres only) -------
+class Material:
+    def __init__(self, kind, *p):
+        self.kind, self.p = kind, p
+
+    @staticmethod
+    def matte(kd, sigma): return Material("matte", tuple(map(float, kd)), fmin(fmax(float(sigma), 0.0), 90.0))  # matte.rs:15
+    @staticmethod
+    def plastic(kd, ks, rough): return Material("plastic", tuple(map(float, kd)), tuple(map(float, ks)), float(rough))
+    @staticmethod
+    def metal(eta, k, ur, vr): return Material("metal", tuple(map(float, eta)), tuple(map(float, k)), float(ur), float(vr))
+    @staticmethod
+    def glass(kr, kt, eta): return Material("glass", tuple(map(float, kr)), tuple(map(float, kt)), float(eta))
+    @staticmethod
+    def mirror(kr): return Material("mirror", tuple(map(float, kr)))
+
+
+class Camera:  # camera.rs:59-102
+    def __init__(self, perspective, param):
+        self.perspective, self.param = perspective, float(param)
+        self.origin, self.view, self.up, self.aux = ZERO, (0.0, 0.0, 1.0), (0.0, 1.0, 0.0), (1.0, 0.0, 0.0)
+        self.root, self.distance = 1, 1.0
+        self.image_plane_height = self._iph(1.0)
+        self.pixel_separation = 0.0 if perspective else 1.0
+
+    def _iph(self, focal):  # camera.rs:158-164
+        return focal * math.tan(self.param * PI / 360.0) * 2.0 if self.perspective else self.param
+
+    def look_at(self, origin, look, up):  # camera.rs:85-94
+        origin, look, up = tuple(map(float, origin)), tuple(map(float, look)), tuple(map(float, up))
+        view = sub(look, origin)
+        aux = cross(view, up)
+        self.origin = origin
+        self.up = normalize(cross(aux, view))
+        self.aux = normalize(aux)
+        self.view = view
+        self.image_plane_height = self._iph(magnitude(view))
+        return self
+
+    def set_supersampling(self, base):  # camera.rs:189-193
+        self.root = int(base) + 1
+        self.distance = 1.0 / float(self.root)
+        return self
+
+    def sample(self, x, y, w, h):  # camera.rs:113-146, Film's cached 1/w, 1/h, w/h (film.rs:40-42)
+        winv, hinv, aspect = 1.0 / float(w), 1.0 / float(h), float(w) / float(h)
+        iph = self.image_plane_height
+        ipw = iph * aspect
+        pixel_size = iph * hinv
+        sep = self.distance * pixel_size
+        sx = (float(x) * winv - 0.5) * ipw
+        sy = (0.5 - float(y + 1) * hinv) * iph
+        origin = add(add(self.origin, mul(self.up, sy * self.pixel_separation)), mul(self.aux, sx * self.pixel_separation))
+        d = add(add(self.view, smul(sy, self.up)), smul(sx, self.aux))
+        updiff, auxdiff = mul(self.up, sep), mul(self.aux, sep)
+        halfdiff = add(mul(updiff, 0.5), mul(auxdiff, 0.5))
+        rays = []
+        for i in range(self.root):
+            for j in range(self.root):
+                rays.append((origin, add(add(add(d, smul(float(j), updiff)), smul(float(i), auxdiff)), halfdiff)))
+        return rays
+
+
+class Aggregate:
+    def __init__(self):
+        self.spheres = []
+
+    @staticmethod
+    def new(): return Aggregate()
+
+    def add_sphere(self, c, r, mat):
+        self.spheres.append((tuple(map(float, c)), float(r), mat))
+        return self
+
+
+class Scene:  # scene.rs:49-62 defaults
+    def __init__(self):
+        self.root = Aggregate()
+        self.camera = Camera(True, 45.0)
+        self.bg_inner = self.bg_outer = ZERO
+        self.bg_scale = 1.0
+        self.ambient = ZERO
+        self.recursion = 3
+        self.lights = []
+
+    @staticmethod
+    def new(): return Scene()
+
+    def set_perspective_camera(self, fov):
+        self.camera = Camera(True, fov)
+        return self.camera
+
+    def set_orthographic_camera(self, height):
+        self.camera = Camera(False, height)
+        return self.camera
+
+    def set_solid_background(self, c): self.bg_inner = self.bg_outer = tuple(map(float, c)); self.bg_scale = 1.0
+    def set_radial_background(self, a, b, s): self.bg_inner, self.bg_outer, self.bg_scale = tuple(map(float, a)), tuple(map(float, b)), float(s)
+    def set_ambient_light(self, c): self.ambient = tuple(map(float, c))
+    def set_max_recursion_depth(self, d): self.recursion = int(d)
+    def add_point_light(self, pos, intensity, falloff): self.lights.append((tuple(map(float, pos)), tuple(map(float, intensity)), tuple(map(float, falloff))))
+    def set_root(self, agg): self.root = agg
+
+
+class Api:
+    Scene, Aggregate, Material = Scene, Aggregate, Material
+
+
+# ---- sphere (shape/sphere.rs:30-123, core/math.rs:7-30) ----------------------------------------
+def quad_roots(a, b, c):
+    if a == 0.0:
+        if b == 0.0:
+            return None
+        return (-c / b,)
+    d = b * b - 4.0 * a * c
+    if d < 0.0:
+        return None
+    q = -(b + signum(b) * math.sqrt(d)) / 2.0
+    q_over_a = q / a
+    return (q_over_a, q_over_a if q == 0.0 else c / q)
+
+
+def sphere_t(o, d, cen, rad):
+    l = sub(o, cen)
+    a = dot(d, d)
+    b = 2.0 * dot(d, l)
+    c = dot(l, l) - rad * rad
+    roots = quad_roots(a, b, c)
+    if roots is None:
+        return -INF, False
+    if len(roots) == 1:
+        return roots[0], False
+    t0, t1 = fmin(roots[0], roots[1]), fmax(roots[0], roots[1])
+    return (t1, True) if t0 < 0.0 else (t0, False)
+
+
+def sphere_isect(o, d, cen, rad, t, inside):
+    p = sub(add(o, mul(d, t)), cen)
+    if p[0] == 0.0 and p[1] == 0.0:
+        p = (1e-5 * rad, p[1], p[2])
+    phi = math.atan2(p[1], p[0])
+    if phi < 0.0:
+        phi += 2.0 * PI
+    theta = math.acos(fmin(fmax(p[2] / rad, -1.0), 1.0))
+    dpdu = (-2.0 * PI * p[1], 2.0 * PI * p[0], 0.0)
+    dpdv = smul(PI, (p[2] * math.cos(phi), p[2] * math.sin(phi), -rad * math.sin(theta)))
+    return (dpdu, dpdv) if inside else (dpdv, dpdu)
+
+
+def closest(scene, o, d):
+    """(t, dpdu, dpdv, material) of the closest sphere, or None.  Brute force in insertion order with the reference's
+    acceptance rule (sphere.rs:82-86: reject t < 0 and t >= isect.t)."""
+    best = None
+    best_t = INF
+    for cen, rad, mat in scene.root.spheres:
+        t, inside = sphere_t(o, d, cen, rad)
+        if t < 0.0 or t >= best_t:
+            continue
+        best_t = t
+        best = (cen, rad, mat, inside)
+    if best is None:
+        return None
+    cen, rad, mat, inside = best
+    dpdu, dpdv = sphere_isect(o, d, cen, rad, best_t, inside)
+    return best_t, dpdu, dpdv, mat
+
+
+# ---- BxDF utilities (core/bxdf/mod.rs:237-288) --------------------------------------------------
+def cos2_theta(w): return w[2] * w[2]
+def sin2_theta(w): return fmax(1.0 - cos2_theta(w), 0.0)
+def sin_theta(w): return math.sqrt(sin2_theta(w))
+def tan_theta(w): return _div(sin_theta(w), w[2])
+def tan2_theta(w): return _div(sin2_theta(w), cos2_theta(w))
+
+
+def _div(a, b):  # IEEE division (Python raises on a zero divisor)
+    if b == 0.0:
+        if a != a or a == 0.0:
+            return float("nan")
+        return math.copysign(INF, a) * math.copysign(1.0, b)
+    return a / b
+
+
+def cos_phi(w):
+    s = sin_theta(w)
+    return 1.0 if s == 0.0 else fmin(fmax(w[0] / s, -1.0), 1.0)
+
+
+def sin_phi(w):
+    s = sin_theta(w)
+    return 0.0 if s == 0.0 else fmin(fmax(w[1] / s, -1.0), 1.0)
+
+
+def reflect(wo, n):  # -1.0 * wo + 2.0 * wo.dot(n) * n
+    return add(smul(-1.0, wo), smul(2.0 * dot(wo, n), n))
+
+
+def refract(wi, n, eta):
+    cos_i = dot(n, wi)
+    sin2_i = fmax(1.0 - cos_i * cos_i, 0.0)
+    sin2_t = eta * eta * sin2_i
+    if sin2_t >= 1.0:
+        return None
+    cos_t = math.sqrt(1.0 - sin2_t)
+    return add(smul(eta * -1.0, wi), smul(eta * cos_i - cos_t, n))
+
+
+# ---- Fresnel (core/bxdf/fresnel.rs:37-91) --------------------------------------------------------
+def fr_dielectric(cos_i, eta_i, eta_t):
+    cos_i = fmin(fmax(cos_i, -1.0), 1.0)
+    if not cos_i > 0.0:
+        eta_i, eta_t = eta_t, eta_i
+        cos_i = abs(cos_i)
+    sin_i = math.sqrt(fmax(1.0 - cos_i * cos_i, 0.0))
+    sin_t = eta_i / eta_t * sin_i
+    if sin_t >= 1.0:
+        return 1.0
+    cos_t = math.sqrt(fmax(1.0 - sin_t * sin_t, 0.0))
+    r_parl = _div((eta_t * cos_i) - (eta_i * cos_t), (eta_t * cos_i) + (eta_i * cos_t))
+    r_perp = _div((eta_i * cos_i) - (eta_t * cos_t), (eta_i * cos_i) + (eta_t * cos_t))
+    return (r_parl * r_parl + r_perp * r_perp) * 0.5
+
+
+def fr_conductor(cos_i, eta_i, eta_t, k):
+    cos_i = fmin(fmax(cos_i, -1.0), 1.0)
+    out = []
+    for c in range(3):
+        eta = eta_t[c] / eta_i[c]
+        etak = k[c] / eta_i[c]
+        cos2 = cos_i * cos_i
+        sin2 = 1.0 - cos2
+        eta2, etak2 = eta * eta, etak * etak
+        t0 = eta2 - etak2 - sin2
+        a2plusb2 = math.sqrt(t0 * t0 + 4.0 * (eta2 * etak2))
+        t1 = a2plusb2 + cos2
+        a = math.sqrt(0.5 * (a2plusb2 + t0))
+        t2 = 2.0 * cos_i * a
+        rs = _div(t1 - t2, t1 + t2)
+        t3 = cos2 * a2plusb2 + sin2 * sin2
+        t4 = t2 * sin2
+        rp = _div(rs * (t3 - t4), t3 + t4)
+        out.append(0.5 * (rp + rs))
+    return tuple(out)
+
+
+def substance_eval(sub_, cos_i):
+    if sub_[0] == "dielectric":
+        v = fr_dielectric(cos_i, sub_[1], sub_[2])
+        return (v, v, v)
+    if sub_[0] == "conductor":
+        return fr_conductor(cos_i, sub_[1], sub_[2], sub_[3])
+    return (1.0, 1.0, 1.0)
+
+
+# ---- BxDFs: ("lambert", r) ("oren", r, a, b) ("micro", r, substance, ax, ay) ("srefl", r, substance) ("strans", t, ea, eb)
+REFLECTION, TRANSMISSION, SPECULAR = 1, 2, 16
+BXDF_TYPE = {"lambert": 1 | 4, "oren": 1 | 4, "micro": 1 | 8, "srefl": 1 | 16, "strans": 2 | 16}
+
+
+def oren_new(r, sigma):  # diffuse.rs:29-35
+    sigma = sigma * (PI / 180.0)  # Rad::from(Deg(sigma))
+    s2 = sigma * sigma
+    a = 1.0 - (s2 / 2.0 * (s2 + 0.33))
+    b = 0.45 * s2 / (s2 + 0.09)
+    return ("oren", r, a, b)
+
+
+def tr_d(ax, ay, wh):  # microfacet.rs:31-40
+    t2 = tan2_theta(wh)
+    if math.isinf(t2):
+        return 0.0
+    cos4 = cos2_theta(wh) * cos2_theta(wh)
+    e = ((cos_phi(wh) * cos_phi(wh)) / (ax * ax) + (sin_phi(wh) * sin_phi(wh)) / (ay * ay)) * t2
+    return 1.0 / (PI * ax * ay * cos4 * (1.0 + e) * (1.0 + e))
+
+
+def tr_lambda(ax, ay, w):  # microfacet.rs:55-66
+    att = abs(tan_theta(w))
+    if math.isinf(att):
+        return 0.0
+    alpha = math.sqrt((cos_phi(w) * cos_phi(w)) * ax * ax + (sin_phi(w) * sin_phi(w)) * ay * ay)
+    a2t2 = (alpha * att) * (alpha * att)
+    return (math.sqrt(1.0 + a2t2) - 1.0) / 2.0
+
+
+def bxdf_f(b, wo, wi):  # bxdf/mod.rs:152-162
+    k = b[0]
+    if k == "lambert":
+        return mul(b[1], FRAC_1_PI)
+    if k == "oren":  # diffuse.rs:37-56
+        _, r, a, bb = b
+        si, so = sin_theta(wi), sin_theta(wo)
+        if si > 1e-4 and so > 1e-4:
+            d_cos = cos_phi(wi) * cos_phi(wo) + sin_phi(wi) * sin_phi(wo)
+            max_cos = fmax(d_cos, 0.0)
+        else:
+            max_cos = 0.0
+        if abs(wi[2]) > abs(wo[2]):
+            sin_alpha, tan_beta = so, si / abs(wi[2])
+        else:
+            sin_alpha, tan_beta = si, _div(so, abs(wo[2]))
+        return mul(mul(r, FRAC_1_PI), a + bb * max_cos * sin_alpha * tan_beta)
+    if k == "micro":  # microfacet.rs:101-115
+        _, r, sub_, ax, ay = b
+        cos_o, cos_i = abs(wo[2]), abs(wi[2])
+        wh = add(wi, wo)
+        if cos_i == 0.0 or cos_o == 0.0:
+            return ZERO
+        if wh[0] == 0.0 and wh[1] == 0.0 and wh[2] == 0.0:
+            return ZERO
+        wh = normalize(wh)
+        spectrum = substance_eval(sub_, dot(wi, wh))
+        g = 1.0 / (1.0 + tr_lambda(ax, ay, wo) + tr_lambda(ax, ay, wi))
+        return div(mulv(mul(mul(r, tr_d(ax, ay, wh)), g), spectrum), 4.0 * cos_i * cos_o)
+    return ZERO  # specular BxDFs scatter only through sample_f
+
+
+def bxdf_sample_f(b, wo):  # specular.rs:17-24, 43-63 (the only BxDFs the integrator samples)
+    if b[0] == "srefl":
+        wi = (-wo[0], -wo[1], wo[2])
+        spectrum = div(mulv(substance_eval(b[2], wi[2]), b[1]), abs(wi[2]))
+        return spectrum, wi, 1.0
+    _, t, eta_a, eta_b = b
+    entering = wo[2] > 0.0
+    eta_i, eta_t = (eta_a, eta_b) if entering else (eta_b, eta_a)
+    wi = refract(wo, (0.0, 0.0, 1.0), eta_i / eta_t)
+    if wi is None:
+        return ZERO, ZERO, 0.0
+    fr = substance_eval(("dielectric", eta_a, eta_b), wi[2])
+    spectrum = div(mulv(t, sub((1.0, 1.0, 1.0), fr)), abs(wi[2]))
+    return spectrum, wi, 1.0
+
+
+def scattering(mat):  # material/*.rs
+    k, p = mat.kind, mat.p
+    if k == "matte":
+        return [("lambert", p[0])] if p[1] == 0.0 else [oren_new(p[0], p[1])]
+    if k == "plastic":
+        out = []
+        if p[0] != ZERO:
+            out.append(("lambert", p[0]))
+        if p[1] != ZERO:
+            out.append(("micro", p[1], ("dielectric", 1.0, 1.5), p[2], p[2]))
+        return out
+    if k == "metal":
+        white = (1.0, 1.0, 1.0)
+        return [("micro", white, ("conductor", white, p[0], p[1]), p[2], p[3])]
+    if k == "mirror":
+        return [("srefl", p[0], ("noop",))]
+    out = []  # glass with roughness 0 (material/mod.rs:39-40)
+    if p[0] != ZERO:
+        out.append(("srefl", p[0], ("dielectric", 1.0, p[2])))
+    if p[1] != ZERO:
+        out.append(("strans", p[1], 1.0, p[2]))
+    return out
+
+
+class BSDF:  # interaction/bsdf.rs
+    def __init__(self, ng, ns, ss, bxdfs):
+        self.ng, self.ns, self.ss, self.ts, self.bxdfs = ng, ns, ss, cross(ns, ss), bxdfs
+
+    def to_local(self, v): return (dot(v, self.ss), dot(v, self.ts), dot(v, self.ns))
+
+    def to_world(self, v):
+        s, t, n = self.ss, self.ts, self.ns
+        return (s[0] * v[0] + t[0] * v[1] + n[0] * v[2], s[1] * v[0] + t[1] * v[1] + n[1] * v[2], s[2] * v[0] + t[2] * v[1] + n[2] * v[2])
+
+    def f(self, wo, wi):  # bsdf.rs:73-92
+        reflect_ = dot(wi, self.ng) * dot(wo, self.ng) > 0.0
+        wo_l, wi_l = self.to_local(wo), self.to_local(wi)
+        if wo_l[2] == 0.0:
+            return ZERO
+        f = ZERO
+        for b in self.bxdfs:
+            t = BXDF_TYPE[b[0]]
+            if (reflect_ and (t & REFLECTION)) or (not reflect_ and (t & TRANSMISSION)):
+                f = add(f, bxdf_f(b, wo_l, wi_l))
+        return f
+
+    def sample_f(self, wo, flags):  # bsdf.rs:94-145 with the integrator's fixed sample (0.5, 0.5)
+        match = [b for b in self.bxdfs if (BXDF_TYPE[b[0]] & flags) == BXDF_TYPE[b[0]]]
+        if not match:
+            return ZERO, ZERO, 0.0
+        comp = min(int(math.floor(0.5 * float(len(match)))), len(match) - 1)
+        b = match[comp]
+        wo_l = self.to_local(wo)
+        if wo_l[2] == 0.0:
+            return ZERO, ZERO, 0.0
+        spectrum, wi_l, pdf = bxdf_sample_f(b, wo_l)
+        if pdf == 0.0:
+            return spectrum, wi_l, pdf
+        wi = self.to_world(wi_l)
+        spectrum = tuple(fmin(fmax(c, 0.0), 1.0) for c in spectrum)  # (every sampled BxDF is specular)
+        return spectrum, wi, pdf / float(len(match))
+
+
+# ---- integrator (integrate/integrate.rs:23-132, interaction/surface.rs:158-183, light/point.rs:42-54) ----
+def background(scene, d):  # material/background.rs:25-34
+    a = abs(dot((0.0, 0.0, 1.0), d))
+    t = fmin(math.sqrt(1.0 - a * a) / scene.bg_scale, 1.0)  # powf(2.) is x * x (LLVM folds it)
+    return tuple(scene.bg_inner[i] * (1.0 - t) + scene.bg_outer[i] * t for i in range(3))
+
+
+def li(scene, o, d, depth):
+    hit = closest(scene, o, d)
+    if hit is None:
+        return background(scene, normalize(d))
+    t, dpdu, dpdv, mat = hit
+    wo = neg(normalize(d))
+    ng = normalize(cross(dpdu, dpdv))
+    if dot(ng, wo) < 0.0:
+        ng = neg(ng)
+    ns = normalize(cross(dpdu, dpdv))  # surface shading = geometry for spheres; NOT face-forwarded (surface.rs:163)
+    err = 2.220446049250313e-16 * 2.0 ** 16
+    p0 = add(o, mul(d, t))
+    p_err = mul(ng, err)
+    ss = normalize(dpdu)
+    bsdf = BSDF(ng, ns, ss, scattering(mat))
+    n = ns
+    p = add(p0, p_err)
+    output = ZERO
+    for lpos, lint, fall in scene.lights:
+        sd = sub(lpos, p)
+        occ = closest(scene, p, sd)  # full closest hit, occluded iff t < 1 (point.rs:47-49)
+        if occ is not None and occ[0] < 1.0:
+            continue
+        wi = sub(lpos, p)
+        dist = magnitude(wi)
+        f_att = fall[0] + fall[1] * dist + fall[2] * dist * dist
+        if f_att == 0.0:
+            continue
+        wi = normalize(wi)
+        wi_dot_n = dot(wi, n)
+        f = bsdf.f(wo, wi)
+        output = add(output, div(mul(mulv(smul(PI, lint), f), wi_dot_n), f_att))
+    output = add(output, mulv(scene.ambient, bsdf.f(wo, n)))
+    refracted = reflected = ZERO
+    if depth < scene.recursion:
+        # specular_transmit (integrate.rs:108-132)
+        spectrum, wi, pdf = bsdf.sample_f(wo, TRANSMISSION | SPECULAR)
+        if not (pdf <= 0.0 or spectrum == ZERO or abs(dot(wi, ns)) == 0.0):
+            sub_li = li(scene, sub(p0, p_err), wi, depth + 1)
+            refracted = div(mul(mulv(spectrum, sub_li), abs(dot(wi, ns))), pdf)
+        # specular_reflect (integrate.rs:82-106)
+        spectrum, wi, pdf = bsdf.sample_f(wo, REFLECTION | SPECULAR)
+        if not (pdf <= 0.0 or spectrum == ZERO or dot(wi, ns) <= 0.0):
+            wr = reflect(wo, ns)
+            reflected = mulv(spectrum, li(scene, add(p0, p_err), wr, depth + 1))
+    return add(add(output, reflected), refracted)
+
+
+def to_byte(c):  # img.rs:65-67
+    v = fmin(fmax(c, 0.0), 1.0) * 255.0
+    return int(math.floor(v + 0.5)) if v == v else 0  # round half away from zero (v >= 0); NaN as u8 = 0
+
+
+def render(scene, w, h):
+    """(radiance [h][w] of 3-tuples, rgba bytes [h][w] of 4-tuples) -- lib.rs:110-162, integrate.rs:16-20"""
+    rad, rgba = [], []
+    for y in range(h):
+        rrow, brow = [], []
+        for x in range(w):
+            rays = scene.camera.sample(x, y, w, h)
+            weight = 1.0 / float(len(rays))
+            c = ZERO
+            for o, d in rays:
+                c = add(c, li(scene, o, d, 0))
+            c = mul(c, weight)
+            rrow.append(c)
+            brow.append((to_byte(c[0]), to_byte(c[1]), to_byte(c[2]), 255))
+        rad.append(rrow)
+        rgba.append(brow)
+    return rad, rgba
