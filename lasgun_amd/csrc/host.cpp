@@ -67,25 +67,30 @@ Transform transform_scale(double x, double y, double z) { // transform.rs:101-10
 static inline double to_rad(double deg) { return deg * (PI / 180.0); } // cgmath Rad::from(Deg)
 static Transform from_rotation(const Mat4 &m) { return Transform{m, mat_transpose(m)}; } // transform.rs:125-147
 Transform transform_rotate_x(double deg) {
-    double th = to_rad(deg), s = std::sin(th), c = std::cos(th);
+    double th = to_rad(deg), s, c;
+    ::sincos(th, &s, &c); // Rad::sin_cos: glibc's sincos(), not sin() and cos() -- they differ in the last bit for some angles; g++ -O2 merged the pair anyway
     Mat4 m = mat_identity();
     m.m[1][1] = c; m.m[1][2] = s; m.m[2][1] = -s; m.m[2][2] = c;
     return from_rotation(m);
 }
 Transform transform_rotate_y(double deg) {
-    double th = to_rad(deg), s = std::sin(th), c = std::cos(th);
+    double th = to_rad(deg), s, c;
+    ::sincos(th, &s, &c); // Rad::sin_cos: glibc's sincos(), not sin() and cos() -- they differ in the last bit for some angles; g++ -O2 merged the pair anyway
     Mat4 m = mat_identity();
     m.m[0][0] = c; m.m[0][2] = -s; m.m[2][0] = s; m.m[2][2] = c;
     return from_rotation(m);
 }
 Transform transform_rotate_z(double deg) {
-    double th = to_rad(deg), s = std::sin(th), c = std::cos(th);
+    double th = to_rad(deg), s, c;
+    ::sincos(th, &s, &c); // Rad::sin_cos: glibc's sincos(), not sin() and cos() -- they differ in the last bit for some angles; g++ -O2 merged the pair anyway
     Mat4 m = mat_identity();
     m.m[0][0] = c; m.m[0][1] = s; m.m[1][0] = -s; m.m[1][1] = c;
     return from_rotation(m);
 }
 Transform transform_rotate(double deg, const double ax[3]) { // cgmath Matrix4::from_axis_angle
-    double th = to_rad(deg), s = std::sin(th), c = std::cos(th), k = 1.0 - c;
+    double th = to_rad(deg), s, c;
+    ::sincos(th, &s, &c);
+    const double k = 1.0 - c;
     double x = ax[0], y = ax[1], z = ax[2];
     Mat4 m = mat_identity();
     m.m[0][0] = k * x * x + c;     m.m[0][1] = k * x * y + s * z; m.m[0][2] = k * x * z - s * y;

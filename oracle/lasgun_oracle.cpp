@@ -51,6 +51,13 @@ static inline double t_atan2(double y, double x) { return g_trig_mode.load(std::
 static inline double t_acos(double x) { return g_trig_mode.load(std::memory_order_relaxed) ? orc_acos(x) : std::acos(x); }
 static inline double t_sin(double x) { return g_trig_mode.load(std::memory_order_relaxed) ? orc_sin(x) : std::sin(x); }
 static inline double t_cos(double x) { return g_trig_mode.load(std::memory_order_relaxed) ? orc_cos(x) : std::cos(x); }
+// sin and cos of ONE argument in one expression: a native build of the reference calls glibc's sincos() there (LLVM turns an
+// fsin / fcos pair on the same operand into the sincos libcall on *-linux-gnu, as GCC does for the rotation matrices
+// below), and sincos(x) is not always bit-identical to (sin(x), cos(x)) -- 71.69565646291534 degrees is an example
+static inline void t_sincos(double x, double &s, double &c) {
+    if (g_trig_mode.load(std::memory_order_relaxed)) { s = orc_sin(x); c = orc_cos(x); }
+    else ::sincos(x, &s, &c);
+}
 
 // ---- Rust float semantics -----------------------------
 static inline double fmin_(double a, double b) { return std::fmin(a, b); } // f64::min: NaN-ignoring
@@ -151,19 +158,23 @@ static inline M4 m4_from_scale(double x, double y, double z) {
 }
 static inline double deg_to_rad(double deg) { return deg * (PI / 180.0); } // Rad::from(Deg)
 static inline M4 m4_from_angle_x(double deg) {
-    double t = deg_to_rad(deg), s = std::sin(t), c = std::cos(t);
+    double t = deg_to_rad(deg), s, c;
+    ::sincos(t, &s, &c); // Rad::sin_cos (cgmath): one glibc sincos() call in a native build, which is what g++ -O2 made of a sin / cos pair anyway
     return M4{{{1, 0, 0, 0}, {0, c, s, 0}, {0, -s, c, 0}, {0, 0, 0, 1}}};
 }
 static inline M4 m4_from_angle_y(double deg) {
-    double t = deg_to_rad(deg), s = std::sin(t), c = std::cos(t);
+    double t = deg_to_rad(deg), s, c;
+    ::sincos(t, &s, &c); // Rad::sin_cos (cgmath): one glibc sincos() call in a native build, which is what g++ -O2 made of a sin / cos pair anyway
     return M4{{{c, 0, -s, 0}, {0, 1, 0, 0}, {s, 0, c, 0}, {0, 0, 0, 1}}};
 }
 static inline M4 m4_from_angle_z(double deg) {
-    double t = deg_to_rad(deg), s = std::sin(t), c = std::cos(t);
+    double t = deg_to_rad(deg), s, c;
+    ::sincos(t, &s, &c); // Rad::sin_cos (cgmath): one glibc sincos() call in a native build, which is what g++ -O2 made of a sin / cos pair anyway
     return M4{{{c, s, 0, 0}, {-s, c, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}};
 }
 static inline M4 m4_from_axis_angle(V3 a, double deg) {
-    double t = deg_to_rad(deg), s = std::sin(t), c = std::cos(t);
+    double t = deg_to_rad(deg), s, c;
+    ::sincos(t, &s, &c); // Rad::sin_cos (cgmath): one glibc sincos() call in a native build, which is what g++ -O2 made of a sin / cos pair anyway
     double k = 1.0 - c;
     return M4{{{k * a.x * a.x + c, k * a.x * a.y + s * a.z, k * a.x * a.z - s * a.y, 0.0},
                {k * a.x * a.y - s * a.z, k * a.y * a.y + c, k * a.y * a.z + s * a.x, 0.0},
@@ -493,7 +504,9 @@ struct Sphere : Primitive {
         if (phi < 0.0) phi += 2.0 * PI;
         double theta = t_acos(fmin_(fmax_(p.z / radius, -1.0), 1.0));
         V3 dpdu{-2.0 * PI * p.y, 2.0 * PI * p.x, 0.0};
-        V3 dpdv = PI * V3{p.z * t_cos(phi), p.z * t_sin(phi), -radius * t_sin(theta)};
+        double sin_phi, cos_phi;
+        t_sincos(phi, sin_phi, cos_phi); // phi.cos(), phi.sin() (sphere.rs:107-108)
+        V3 dpdv = PI * V3{p.z * cos_phi, p.z * sin_phi, -radius * t_sin(theta)};
         if (inside) isect = isect_new(t, 0.0, 0.0, dpdu, dpdv);
         else isect = isect_new(t, 0.0, 0.0, dpdv, dpdu);
         return this;

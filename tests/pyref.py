@@ -1,10 +1,12 @@
 """A third, independent witness for the shading half of the path -- TEST INFRASTRUCTURE, like oracle/.
 
 Plain-Python (IEEE f64 `float`, `math`) restatement of the reference's Whitted integrator for scenes made of spheres
-placed directly under an untransformed root: camera, sphere intersection and differentials, SurfaceInteraction, the five
-materials and every BxDF they use, point lights with shadow rays, specular recursion, background.  It was written from the
+and boxes in nested, transformed groups: camera, sphere and cuboid intersection with their differentials, Transform3 and
+the aggregates' transform concatenation, backface swapping, SurfaceInteraction, the five materials and every BxDF they use,
+point lights with shadow rays, specular recursion, background.  It was written from the
 Rust sources cited below, not from oracle/lasgun_oracle.cpp, shares no code with it, and finds the closest hit by brute
-force over the spheres (no BVH: scenes must not contain exact ties in t, where the reference's visit order decides).
+force over every primitive of every group (no BVH: scenes must not contain exact ties in t, where the reference's visit
+order decides, nor rays grazing a primitive's bounding box to the last bit).
 
 It pins nothing (only the reference's own 17 known-answer tests do), but a transcription slip in the oracle's camera /
 shading / recursion code would have to be made twice, in two languages, to go unseen.  tests/test_pyref_witness.py compares
@@ -12,9 +14,24 @@ it with the oracle (libm trigonometry on both sides: Rust and CPython both call 
 
 cgmath 0.17 operation order as in SURVEY.md Appendix A1 (dot = (x*x + y*y) + z*z, normalize = v * (1 / |v|), ...).
 """
+import ctypes
+import ctypes.util
 import math
 
 PI = math.pi
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+_libm.sincos.restype = None
+
+
+def sincos(x):
+    """(sin x, cos x) from glibc's sincos(): what a native build of the reference calls where it takes both of one argument
+    (cgmath's Rad::sin_cos in the rotation matrices, `phi.cos()` / `phi.sin()` in sphere.rs:107-108) -- LLVM merges an
+    fsin / fcos pair on one operand into the sincos libcall on *-linux-gnu.  It is not always bit-identical to
+    (math.sin(x), math.cos(x)): this witness found that on its 36th random scene (rotate_x(71.69565646291534))."""
+    s, c = ctypes.c_double(), ctypes.c_double()
+    _libm.sincos(x, ctypes.byref(s), ctypes.byref(c))
+    return s.value, c.value
 FRAC_1_PI = 0.318309886183790671537767526745028724  # std::f64::consts::FRAC_1_PI
 INF = float("inf")
 
@@ -106,16 +123,106 @@ class Camera:  # camera.rs:59-102
         return rays
 
 
-class Aggregate:
+# ---- Transform3 (space/transform.rs; cgmath 0.17 Matrix4, column-major m[col][row]) ----------------
+def mat_identity():
+    return [[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]]
+
+
+def mat_mul_vec4(m, v):  # ((c0*x + c1*y) + c2*z) + c3*w
+    return tuple(((m[0][r] * v[0] + m[1][r] * v[1]) + m[2][r] * v[2]) + m[3][r] * v[3] for r in range(4))
+
+
+def mat_mul(a, b):  # a * b: column j of the product = a * (column j of b)
+    return [list(mat_mul_vec4(a, b[j])) for j in range(4)]
+
+
+def mat_transpose(m):
+    return [[m[r][c] for r in range(4)] for c in range(4)]
+
+
+def transform_vector(m, v):
+    return mat_mul_vec4(m, (v[0], v[1], v[2], 0.0))[:3]
+
+
+def transform_point(m, p):
+    h = mat_mul_vec4(m, (p[0], p[1], p[2], 1.0))
+    return mul(h[:3], 1.0 / h[3])
+
+
+def transform_normal(minv, n):  # transform.rs:202-209
+    return tuple(minv[i][0] * n[0] + minv[i][1] * n[1] + minv[i][2] * n[2] for i in range(3))
+
+
+class Transform:
     def __init__(self):
-        self.spheres = []
+        self.m, self.minv = mat_identity(), mat_identity()
+
+    def concat_self(self, m, minv):  # transform.rs:191-197: m <- other.m * m, minv <- minv * other.minv
+        self.m, self.minv = mat_mul(m, self.m), mat_mul(self.minv, minv)
+
+
+def _rot(theta_deg, axis):  # Matrix4::from_angle_{x,y,z}; Rad = Deg * (pi / 180)
+    r = theta_deg * (PI / 180.0)
+    s, c = sincos(r)
+    m = mat_identity()
+    if axis == 0:
+        m[1], m[2] = [0.0, c, s, 0.0], [0.0, -s, c, 0.0]
+    elif axis == 1:
+        m[0], m[2] = [c, 0.0, -s, 0.0], [s, 0.0, c, 0.0]
+    else:
+        m[0], m[1] = [c, s, 0.0, 0.0], [-s, c, 0.0, 0.0]
+    return m
+
+
+class Aggregate:  # scene/node.rs:25-115
+    def __init__(self):
+        self.contents = []  # ("sphere", c, r, mat) / ("cuboid", min, max, mat) / ("group", Aggregate)
+        self.transform = Transform()
+        self.swap = False
 
     @staticmethod
     def new(): return Aggregate()
 
     def add_sphere(self, c, r, mat):
-        self.spheres.append((tuple(map(float, c)), float(r), mat))
+        self.contents.append(("sphere", tuple(map(float, c)), float(r), mat))
         return self
+
+    def add_cube(self, origin, dim, mat):  # cuboid.rs:23-29: max = origin + Vector::from_value(dim)
+        o = tuple(map(float, origin))
+        self.contents.append(("cuboid", o, (o[0] + float(dim), o[1] + float(dim), o[2] + float(dim)), mat))
+        return self
+
+    def add_box(self, mn, mx, mat):
+        self.contents.append(("cuboid", tuple(map(float, mn)), tuple(map(float, mx)), mat))
+        return self
+
+    def add_group(self, agg):
+        self.contents.append(("group", agg))
+        return self
+
+    def swap_backface(self):
+        self.swap = not self.swap
+        return self
+
+    def translate(self, d):
+        d = tuple(map(float, d))
+        m, minv = mat_identity(), mat_identity()
+        m[3] = [d[0], d[1], d[2], 1.0]
+        minv[3] = [-d[0], -d[1], -d[2], 1.0]
+        self.transform.concat_self(m, minv)
+        return self
+
+    def scale(self, x, y, z):
+        x, y, z = float(x), float(y), float(z)
+        m, minv = mat_identity(), mat_identity()
+        m[0][0], m[1][1], m[2][2] = x, y, z
+        minv[0][0], minv[1][1], minv[2][2] = 1.0 / x, 1.0 / y, 1.0 / z
+        self.transform.concat_self(m, minv)
+        return self
+
+    def rotate_x(self, t): m = _rot(float(t), 0); self.transform.concat_self(m, mat_transpose(m)); return self
+    def rotate_y(self, t): m = _rot(float(t), 1); self.transform.concat_self(m, mat_transpose(m)); return self
+    def rotate_z(self, t): m = _rot(float(t), 2); self.transform.concat_self(m, mat_transpose(m)); return self
 
 
 class Scene:  # scene.rs:49-62 defaults
@@ -188,26 +295,87 @@ def sphere_isect(o, d, cen, rad, t, inside):
         phi += 2.0 * PI
     theta = math.acos(fmin(fmax(p[2] / rad, -1.0), 1.0))
     dpdu = (-2.0 * PI * p[1], 2.0 * PI * p[0], 0.0)
-    dpdv = smul(PI, (p[2] * math.cos(phi), p[2] * math.sin(phi), -rad * math.sin(theta)))
+    sin_phi, cos_phi = sincos(phi)
+    dpdv = smul(PI, (p[2] * cos_phi, p[2] * sin_phi, -rad * math.sin(theta)))
     return (dpdu, dpdv) if inside else (dpdv, dpdu)
 
 
-def closest(scene, o, d):
-    """(t, dpdu, dpdv, material) of the closest sphere, or None.  Brute force in insertion order with the reference's
-    acceptance rule (sphere.rs:82-86: reject t < 0 and t >= isect.t)."""
-    best = None
-    best_t = INF
-    for cen, rad, mat in scene.root.spheres:
-        t, inside = sphere_t(o, d, cen, rad)
-        if t < 0.0 or t >= best_t:
-            continue
-        best_t = t
-        best = (cen, rad, mat, inside)
-    if best is None:
+CUBE_DIFFERENTIALS = (((0.0, 1.0, 0.0), (0.0, 0.0, 1.0)), ((0.0, 0.0, 1.0), (1.0, 0.0, 0.0)), ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0)))  # cuboid.rs:126-130
+
+
+def cuboid_isect(o, d, dinv, mn, mx, best_t):  # Bounds::intersect, cuboid.rs:55-102 -> (t, dp0, dp1, n) or None
+    tnear, tfar = -INF, INF
+    near = far = CUBE_DIFFERENTIALS[0]
+    for i in range(3):
+        dp = CUBE_DIFFERENTIALS[i]
+        t1 = (mn[i] - o[i]) * dinv[i]
+        t2 = (mx[i] - o[i]) * dinv[i]
+        if t1 < t2:
+            tmin, tmax, dp0, dp1 = t1, t2, dp[1], dp[0]
+        else:
+            tmin, tmax, dp0, dp1 = t2, t1, dp[0], dp[1]
+        if tmin > tnear:
+            near = (dp0, dp1)
+        if tmax < tfar:
+            far = (dp1, dp0)
+        tnear = fmax(tnear, tmin)
+        tfar = fmin(tfar, tmax)
+    if tnear > tfar or tfar <= 0.0:
         return None
-    cen, rad, mat, inside = best
-    dpdu, dpdv = sphere_isect(o, d, cen, rad, best_t, inside)
-    return best_t, dpdu, dpdv, mat
+    t, dp = (tfar, far) if tnear <= 0.0 else (tnear, near)
+    if t >= best_t:
+        return None
+    n = cross(dp[0], dp[1])
+    if dot(n, neg(d)) < 0.0:
+        n = neg(n)
+    return t, dp[0], dp[1], n
+
+
+def intersect(agg, o, d, best_t):
+    """BVHAccel::intersect of one aggregate without the BVH (bvh.rs:461-522): every primitive in insertion order, nested
+    groups recursively with the running best t.  Returns None or an isect dict in the PARENT's space."""
+    tr = agg.transform
+    o_l, d_l = transform_point(tr.minv, o), transform_vector(tr.minv, d)
+    dinv = (_div(1.0, d_l[0]), _div(1.0, d_l[1]), _div(1.0, d_l[2]))
+    hit = None
+    for node in agg.contents:
+        if node[0] == "sphere":
+            _, cen, rad, mat = node
+            t, inside = sphere_t(o_l, d_l, cen, rad)
+            if t < 0.0 or t >= best_t:
+                continue
+            dpdu, dpdv = sphere_isect(o_l, d_l, cen, rad, t, inside)
+            hit = {"t": t, "g": (dpdu, dpdv), "s": (dpdu, dpdv), "n": None, "mat": mat}
+        elif node[0] == "cuboid":
+            _, mn, mx, mat = node
+            r = cuboid_isect(o_l, d_l, dinv, mn, mx, best_t)
+            if r is None:
+                continue
+            t, dp0, dp1, n = r
+            hit = {"t": t, "g": (dp0, dp1), "s": (dp0, dp1), "n": n, "mat": mat}
+        else:
+            r = intersect(node[1], o_l, d_l, best_t)
+            if r is None:
+                continue
+            hit = r
+        best_t = hit["t"]
+    if hit is None:
+        return None
+    # transform_ray_intersection (transform.rs:243-264), then swap_backface (surface.rs:87-99)
+    g = (transform_vector(tr.m, hit["g"][0]), transform_vector(tr.m, hit["g"][1]))
+    if hit["g"] != hit["s"]:
+        sfc = (transform_vector(tr.m, hit["s"][0]), transform_vector(tr.m, hit["s"][1]))
+    else:
+        sfc = g
+    n = None if hit["n"] is None else transform_normal(tr.minv, hit["n"])
+    if agg.swap:
+        g, sfc = (g[1], g[0]), (sfc[1], sfc[0])
+        n = None if n is None else neg(n)
+    return {"t": hit["t"], "g": g, "s": sfc, "n": n, "mat": hit["mat"]}
+
+
+def closest(scene, o, d):
+    return intersect(scene.root, o, d, INF)
 
 
 # ---- BxDF utilities (core/bxdf/mod.rs:237-288) --------------------------------------------------
@@ -450,12 +618,14 @@ def li(scene, o, d, depth):
     hit = closest(scene, o, d)
     if hit is None:
         return background(scene, normalize(d))
-    t, dpdu, dpdv, mat = hit
+    t, mat = hit["t"], hit["mat"]
     wo = neg(normalize(d))
-    ng = normalize(cross(dpdu, dpdv))
+    ng = normalize(cross(hit["g"][0], hit["g"][1]))  # isect.ng() face-forwarded to wo (surface.rs:161-162)
     if dot(ng, wo) < 0.0:
         ng = neg(ng)
-    ns = normalize(cross(dpdu, dpdv))  # surface shading = geometry for spheres; NOT face-forwarded (surface.rs:163)
+    # isect.ns(): the authoritative normal if the shape set one, else from the surface shading; NOT face-forwarded (surface.rs:163)
+    ns = normalize(hit["n"]) if hit["n"] is not None else normalize(cross(hit["s"][0], hit["s"][1]))
+    dpdu = hit["s"][0]
     err = 2.220446049250313e-16 * 2.0 ** 16
     p0 = add(o, mul(d, t))
     p_err = mul(ng, err)
@@ -467,7 +637,7 @@ def li(scene, o, d, depth):
     for lpos, lint, fall in scene.lights:
         sd = sub(lpos, p)
         occ = closest(scene, p, sd)  # full closest hit, occluded iff t < 1 (point.rs:47-49)
-        if occ is not None and occ[0] < 1.0:
+        if occ is not None and occ["t"] < 1.0:
             continue
         wi = sub(lpos, p)
         dist = magnitude(wi)
