@@ -1,7 +1,8 @@
 """A third, independent witness for the shading half of the path -- TEST INFRASTRUCTURE, like oracle/.
 
 Plain-Python (IEEE f64 `float`, `math`) restatement of the reference's Whitted integrator for scenes made of spheres
-and boxes in nested, transformed groups: camera, sphere and cuboid intersection with their differentials, Transform3 and
+boxes and OBJ triangle meshes in nested, transformed groups: camera, sphere / cuboid / triangle intersection with their
+differentials and shading normals, Transform3 and
 the aggregates' transform concatenation, backface swapping, SurfaceInteraction, the five materials and every BxDF they use,
 point lights with shadow rays, specular recursion, background.  It was written from the
 Rust sources cited below, not from oracle/lasgun_oracle.cpp, shares no code with it, and finds the closest hit by brute
@@ -41,14 +42,14 @@ def add(a, b): return (a[0] + b[0], a[1] + b[1], a[2] + b[2])
 def sub(a, b): return (a[0] - b[0], a[1] - b[1], a[2] - b[2])
 def mul(a, s): return (a[0] * s, a[1] * s, a[2] * s)          # v * s
 def smul(s, a): return (s * a[0], s * a[1], s * a[2])          # s * v
-def div(a, s): return (a[0] / s, a[1] / s, a[2] / s)
+def div(a, s): return (_div(a[0], s), _div(a[1], s), _div(a[2], s))
 def neg(a): return (-a[0], -a[1], -a[2])
 def mulv(a, b): return (a[0] * b[0], a[1] * b[1], a[2] * b[2])  # mul_element_wise
 def divv(a, b): return (a[0] / b[0], a[1] / b[1], a[2] / b[2])
 def dot(a, b): return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
 def cross(a, b): return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
 def magnitude(a): return math.sqrt(dot(a, a))
-def normalize(a): return mul(a, 1.0 / magnitude(a))
+def normalize(a): return mul(a, _div(1.0, magnitude(a)))  # a zero vector becomes NaNs, as in cgmath
 def fmin(a, b): return b if (a != a) else (a if (b != b) else min(a, b))  # f64::min (NaN-ignoring)
 def fmax(a, b): return b if (a != a) else (a if (b != b) else max(a, b))
 ZERO = (0.0, 0.0, 0.0)
@@ -200,6 +201,14 @@ class Aggregate:  # scene/node.rs:25-115
         self.contents.append(("group", agg))
         return self
 
+    def add_obj(self, mesh):  # node.rs:69-76: a mesh with the default material
+        self.contents.append(("mesh", mesh, None))
+        return self
+
+    def add_obj_of(self, mesh, mat):
+        self.contents.append(("mesh", mesh, mat))
+        return self
+
     def swap_backface(self):
         self.swap = not self.swap
         return self
@@ -234,6 +243,7 @@ class Scene:  # scene.rs:49-62 defaults
         self.ambient = ZERO
         self.recursion = 3
         self.lights = []
+        self.smoothing = True
 
     @staticmethod
     def new(): return Scene()
@@ -252,10 +262,146 @@ class Scene:  # scene.rs:49-62 defaults
     def set_max_recursion_depth(self, d): self.recursion = int(d)
     def add_point_light(self, pos, intensity, falloff): self.lights.append((tuple(map(float, pos)), tuple(map(float, intensity)), tuple(map(float, falloff))))
     def set_root(self, agg): self.root = agg
+    def set_mesh_smoothing(self, on): self.smoothing = bool(on)
+
+    def parse_obj(self, text):  # scene.rs:109-123: normals are dropped at add time when smoothing is off
+        obj = ObjData(text)
+        if not self.smoothing:
+            obj.normal = []
+        return obj
 
 
 class Api:
     Scene, Aggregate, Material = Scene, Aggregate, Material
+
+
+# ---- OBJ meshes and triangles (shape/triangle.rs:39-307, scene.rs:109-123; obj 0.10's data model) -----------
+def parse_f32(text):
+    """The f32 nearest to the decimal `text` (ties to even), as an f64 -- str::parse::<f32>() followed by `.into()`.
+    (float(text) rounded to f32 would round twice.)"""
+    import fractions
+    import struct
+    exact = fractions.Fraction(text)
+    guess = struct.unpack("f", struct.pack("f", float(text)))[0]
+    bits = struct.unpack("I", struct.pack("f", guess))[0]
+    best = None
+    for b in (bits - 1, bits, bits + 1):
+        if b < 0:
+            continue
+        c = struct.unpack("f", struct.pack("I", b & 0xFFFFFFFF))[0]
+        if c != c or c in (INF, -INF):
+            continue
+        err = abs(fractions.Fraction(c) - exact)
+        key = (err, b & 1)
+        if best is None or key < best[0]:
+            best = (key, c)
+    return best[1]
+
+
+class ObjData:
+    """position / texture / normal arrays (f32 widened) and the polygons in file order, each a list of (v, vt, vn) index
+    tuples (0-based, None where absent).  Only what triangle.rs reads: the first three tuples of a polygon."""
+
+    def __init__(self, text):
+        self.position, self.texture, self.normal, self.polys = [], [], [], []
+        for line in text.splitlines():
+            f = line.split("#", 1)[0].split()
+            if not f:
+                continue
+            if f[0] == "v":
+                self.position.append(tuple(parse_f32(x) for x in f[1:4]))
+            elif f[0] == "vt":
+                self.texture.append(tuple(parse_f32(x) for x in f[1:3]))
+            elif f[0] == "vn":
+                self.normal.append(tuple(parse_f32(x) for x in f[1:4]))
+            elif f[0] == "f":
+                poly = []
+                for tok in f[1:]:
+                    parts = tok.split("/")
+                    idx = []
+                    for k, arr in enumerate((self.position, self.texture, self.normal)):
+                        if k < len(parts) and parts[k] != "":
+                            i = int(parts[k])
+                            idx.append(i - 1 if i > 0 else len(arr) + i)
+                        else:
+                            idx.append(None)
+                    poly.append(tuple(idx))
+                self.polys.append(poly)
+
+
+def max_dimension(v):  # space/mod.rs:33-36
+    if v[0] > v[1]:
+        return 0 if v[0] > v[2] else 2
+    return 1 if v[1] > v[2] else 2
+
+
+def coordinate_system(v1):  # space/mod.rs:39-47
+    if abs(v1[0]) > abs(v1[1]):
+        v2 = div((-v1[2], 0.0, v1[0]), math.sqrt(v1[0] * v1[0] + v1[2] * v1[2]))
+    else:
+        v2 = div((0.0, v1[2], -v1[1]), math.sqrt(v1[1] * v1[1] + v1[2] * v1[2]))
+    return v2, cross(v1, v2)
+
+
+def triangle_isect(obj, poly, o, d, best_t):  # Triangle::intersect, triangle.rs:161-304 -> isect fields or None
+    p0, p1, p2 = obj.position[poly[0][0]], obj.position[poly[1][0]], obj.position[poly[2][0]]
+    p0t, p1t, p2t = sub(p0, o), sub(p1, o), sub(p2, o)
+    kz = max_dimension((abs(d[0]), abs(d[1]), abs(d[2])))
+    kx = (kz + 1) % 3
+    ky = (kx + 1) % 3
+    dd = (d[kx], d[ky], d[kz])
+    p0t, p1t, p2t = [p0t[kx], p0t[ky], p0t[kz]], [p1t[kx], p1t[ky], p1t[kz]], [p2t[kx], p2t[ky], p2t[kz]]
+    sx, sy, sz = _div(-dd[0], dd[2]), _div(-dd[1], dd[2]), _div(1.0, dd[2])
+    for q in (p0t, p1t, p2t):
+        q[0] += sx * q[2]
+        q[1] += sy * q[2]
+    e0 = p1t[0] * p2t[1] - p1t[1] * p2t[0]
+    e1 = p2t[0] * p0t[1] - p2t[1] * p0t[0]
+    e2 = p0t[0] * p1t[1] - p0t[1] * p1t[0]
+    if (e0 < 0.0 or e1 < 0.0 or e2 < 0.0) and (e0 > 0.0 or e1 > 0.0 or e2 > 0.0):
+        return None
+    det = e0 + e1 + e2
+    if det == 0.0:
+        return None
+    p0t[2] *= sz
+    p1t[2] *= sz
+    p2t[2] *= sz
+    tscaled = e0 * p0t[2] + e1 * p1t[2] + e2 * p2t[2]
+    if (det < 0.0 and tscaled >= 0.0) or (det > 0.0 and tscaled <= 0.0):
+        return None
+    invdet = 1.0 / det
+    b0, b1, b2 = e0 * invdet, e1 * invdet, e2 * invdet
+    t = tscaled * invdet
+    if t >= best_t:
+        return None
+    if obj.texture:
+        uv = [obj.texture[poly[i][1]] for i in range(3)]
+    else:
+        uv = [(0.0, 0.0), (1.0, 0.0), (1.0, 1.0)]
+    duv02 = (uv[0][0] - uv[2][0], uv[0][1] - uv[2][1])
+    duv12 = (uv[1][0] - uv[2][0], uv[1][1] - uv[2][1])
+    dp02, dp12 = sub(p0, p2), sub(p1, p2)
+    determinant = (duv02[0] * duv12[1]) - (duv02[1] * duv12[0])
+    if determinant == 0.0:
+        dpdu, dpdv = coordinate_system(cross(sub(p2, p1), sub(p1, p0)))
+    else:
+        inv = 1.0 / determinant
+        dpdu = mul(sub(smul(duv12[1], dp02), smul(duv02[1], dp12)), inv)
+        dpdv = mul(sub(smul(-duv12[0], dp02), smul(duv02[0], dp12)), inv)
+    if obj.normal:
+        n0, n1, n2 = obj.normal[poly[0][2]], obj.normal[poly[1][2]], obj.normal[poly[2][2]]
+        ns = add(add(smul(b0, n0), smul(b1, n1)), smul(b2, n2))
+        ss = dpdu
+        ts = cross(ns, ss)
+        if dot(ts, ts) > 0.0:
+            ss, ts = cross(ts, ns), ts
+        else:
+            ss, ts = coordinate_system(ns)
+        return t, (dpdu, dpdv), (ss, ts), ns
+    n = cross(dp02, dp12)
+    if dot(n, neg(d)) < 0.0:
+        n = neg(n)
+    return t, (dpdu, dpdv), (dpdu, dpdv), n
 
 
 # ---- sphere (shape/sphere.rs:30-123, core/math.rs:7-30) ----------------------------------------
@@ -353,6 +499,11 @@ def intersect(agg, o, d, best_t):
                 continue
             t, dp0, dp1, n = r
             hit = {"t": t, "g": (dp0, dp1), "s": (dp0, dp1), "n": n, "mat": mat}
+        elif node[0] == "mesh":
+            r = intersect_mesh(node[1], node[2], o_l, d_l, best_t)
+            if r is None:
+                continue
+            hit = r
         else:
             r = intersect(node[1], o_l, d_l, best_t)
             if r is None:
@@ -372,6 +523,29 @@ def intersect(agg, o, d, best_t):
         g, sfc = (g[1], g[0]), (sfc[1], sfc[0])
         n = None if n is None else neg(n)
     return {"t": hit["t"], "g": g, "s": sfc, "n": n, "mat": hit["mat"]}
+
+
+DEFAULT_MATERIAL = Material.matte([0.5, 0.5, 0.5], 0.0)  # material/mod.rs:15-17
+
+
+def intersect_mesh(obj, mat, o, d, best_t):
+    """BVHAccel::from_mesh (bvh.rs:141-147): an accel of its own with the identity transform, the mesh's material (or the
+    default) as the accel's default material; triangles in file order."""
+    ident = mat_identity()
+    o_l, d_l = transform_point(ident, o), transform_vector(ident, d)
+    hit = None
+    for poly in obj.polys:
+        r = triangle_isect(obj, poly, o_l, d_l, best_t)
+        if r is None:
+            continue
+        hit = r
+        best_t = r[0]
+    if hit is None:
+        return None
+    t, g, sfc, n = hit
+    g2 = (transform_vector(ident, g[0]), transform_vector(ident, g[1]))
+    s2 = (transform_vector(ident, sfc[0]), transform_vector(ident, sfc[1])) if g != sfc else g2
+    return {"t": t, "g": g2, "s": s2, "n": transform_normal(ident, n), "mat": mat if mat is not None else DEFAULT_MATERIAL}
 
 
 def closest(scene, o, d):
