@@ -10,9 +10,10 @@ N ranks : one process per GPU (torch.distributed.run); the SAME film is cut into
           (rank r renders blocks r, r+N, ... into a compact tile) and ONE RCCL gather per frame brings the tiles
           to rank 0 -> total work is fixed -> "strong" scaling.
 
-ONE policy at every N (N = 1 included): consecutive frames alternate between two HIP streams, each with its
-own launch context in the library, so the primary pass of frame k+1 fills the tails of frame k's shadow and
-shade passes (and, for N > 1, the gather of frame k overlaps the render of frame k+1).  `value` is that
+ONE policy at every N (N = 1 included): consecutive frames rotate over FRAMES_IN_FLIGHT HIP streams, each with
+its own launch context in the library, so the kernels of the following frames fill the tails of a frame's
+closest, shadow and shade passes and the gaps between its launches (and, for N > 1, the gather of frame k
+overlaps the renders of the frames behind it).  `value` is that
 pipelined throughput over exactly K steps; `latency_ms` is one frame (render + gather) issued alone with a
 full synchronisation around it, at the same N -- so the numbers at N = 1, 2, 4, 8 are like for like.
 
@@ -37,6 +38,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of streams
+# that share a queue run one after the other.  The frames in flight (FRAMES_IN_FLIGHT below) need a queue each beside the
+# default stream, the accel's own stream and RCCL's: with 4 queues the four frame streams pair up and 4 frames in flight are
+# worth no more than 2 (7.57 ms per frame); with 8 they overlap (7.23 ms).  Read by the runtime at initialisation, so it is
+# set before torch is imported; an explicit setting in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -54,6 +61,9 @@ BYTES_NODE, BYTES_SPHERE, BYTES_CUBOID, BYTES_TRI, BYTES_ACCEL_ENTRY, BYTES_HIT,
 FLOPS_NODE, FLOPS_SPHERE, FLOPS_CUBOID, FLOPS_TRI, FLOPS_ACCEL_ENTRY = 26, 26, 26, 36, 78
 VALU_F64_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 BLOCK_ROWS = 64
+# frames in flight (the library keeps up to four launch contexts per accel); measured on one GPU with a hardware queue per
+# stream, ms per frame at N = 1 / one rank's share at N = 8: 1 stream 7.80 / 1.17, 2 streams 7.56 / 1.07, 4 streams 7.22 / 0.96
+FRAMES_IN_FLIGHT = int(os.environ.get("LASGUN_BENCH_FRAMES", "4"))  # (the variable: A/B only)
 
 
 def algorithmic_bytes(st):
@@ -174,13 +184,14 @@ def main():
     y0, y1 = row_tile(rank, world, h)
     cur_stream = torch.cuda.current_stream()
     if balanced:
-        ig = InterleavedGather(w, h, rank, world, BLOCK_ROWS, "cuda" if args.backend == "nccl" else "cpu", always_gather=args.force_dist)
+        ig = InterleavedGather(w, h, rank, world, BLOCK_ROWS, "cuda" if args.backend == "nccl" else "cpu", always_gather=args.force_dist,
+                               buffers=FRAMES_IN_FLIGHT + 1)
         cuda_tile = torch.zeros((h // world, w, 4), dtype=torch.uint8, device="cuda") if args.backend != "nccl" else None
-        frame_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        frame_streams = [torch.cuda.Stream() for _ in range(FRAMES_IN_FLIGHT)]
         overlap = [not args.sequential]
 
         def step():
-            s = frame_streams[ig.k % 2] if overlap[0] else cur_stream
+            s = frame_streams[ig.k % FRAMES_IN_FLIGHT] if overlap[0] else cur_stream
             with torch.cuda.stream(s):
                 t = ig.tile()  # makes `s` wait for the gather that last read this buffer
                 if t.is_cuda:
@@ -210,6 +221,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if balanced:  # set-up, not a step: every stream's launch context allocates its queues on first use
+        for _ in range(FRAMES_IN_FLIGHT):
+            step()
+        finish()
+        fence()
     for _ in range(args.warmup):
         step()
     finish()
@@ -346,7 +362,7 @@ def main():
                        "rays_per_frame": rays, "primary": total["primary_rays"], "shadow": total["shadow_rays"],
                        "parallelism": ("64-row blocks dealt round-robin over %d rank(s)%s; consecutive frames %s"
                                        % (world, " + 1 RCCL gather per frame" if multi else "",
-                                          "overlap on two streams" if overlap[0] else "one after the other")) if balanced
+                                          "overlap, %d in flight" % FRAMES_IN_FLIGHT if overlap[0] else "one after the other")) if balanced
                        else ("contiguous row tiles x%d + 1 gather, frames one after the other" % world),
                        "accel_build_s": accel_build_s, "host_film_capture_ms": e2e_ms,
                        "work_per_frame": {k: total[k] for k in ("nodes_tested", "spheres_tested", "cuboids_tested", "triangles_tested", "accel_entries", "hits")}},

@@ -8,7 +8,7 @@ O=gpurun_out/final2; rm -rf "$O"; mkdir -p "$O"
 timeout -k 10 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"
 # per-kernel durations: frames one after the other (the form bench.py's roofline.kernel_ms_avg is measured in) ...
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -- python3 bench.py --steps 5 --warmup 1 --no-extras --sequential > "$O/prof.log" 2>&1; echo "stats rc=$?"
-# ... and the default command (consecutive frames overlap on two streams: kernels of two frames share the chip, durations stretch)
+# ... and the default command (consecutive frames overlap, four in flight: kernels of several frames share the chip, durations stretch)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_overlap" -- python3 bench.py --steps 5 --warmup 1 --no-extras > "$O/prof_overlap.log" 2>&1; echo "stats(overlap) rc=$?"
 run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d "$O/pmc_$name" -- python3 bench.py --steps 2 --warmup 1 --no-extras > "$O/pmc_$name.log" 2>&1; echo "pmc $name rc=$?"; }
 run fetch FETCH_SIZE
