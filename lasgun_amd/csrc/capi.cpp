@@ -255,13 +255,14 @@ struct lg_accel {
     }
 };
 
-// The launch context of `stream` (at most four are kept; the least recently used one is recycled after a
+constexpr size_t MAX_LAUNCH_CTXS = 8;
+// The launch context of `stream` (at most MAX_LAUNCH_CTXS are kept; the least recently used one is recycled after a
 // device-wide synchronise).  Caller holds a.mtx and has made the accel's device current.
 static lg_accel::LaunchCtx &ctx_for(const lg_accel &a, hipStream_t stream) {
     for (auto &c : a.ctxs)
         if (c->key == stream) { c->last_use = ++a.ctx_clock; return *c; }
     lg_accel::LaunchCtx *c = nullptr;
-    if (a.ctxs.size() < 4) {
+    if (a.ctxs.size() < MAX_LAUNCH_CTXS) {
         a.ctxs.emplace_back(new lg_accel::LaunchCtx());
         c = a.ctxs.back().get();
         c->tile_counter.alloc(4);
