@@ -1,0 +1,31 @@
+#!/bin/bash
+# Host side (scene description, OBJ reader, HLBVH builder, flattening, C ABI) under AddressSanitizer + UBSan on the CPU:
+# builds lasgun_amd/csrc/{host,capi,multi}.cpp with -fsanitize=address,undefined, links them with the device object, and
+# runs tests/test_host.py plus the flattening of 450 random / adversarial scenes and the full-size configs through it.
+# (GPU sanitizers are not available on the pool; the kernels are covered by the parity suite and the fuzz campaign.)
+set -eu
+root=$(cd "$(dirname "$0")/.." && pwd)
+b=/tmp/lg_asan; mkdir -p "$b"
+src=$root/lasgun_amd/csrc
+[ -f "$src/kernels.o" ] || make -C "$src" >/dev/null
+for f in host capi multi; do
+  g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$src/$f.cpp" -o "$b/$f.o" &
+done; wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$b/liblasgun_hip_asan.so" "$b/host.o" "$b/capi.o" "$b/multi.o" "$src/kernels.o" -ldl -fsanitize=address,undefined 2>&1 | grep -v hip-link || true
+export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
+export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LASGUN_HIP_LIB="$b/liblasgun_hip_asan.so"
+cd "$root"
+python3 -m pytest tests/test_host.py -x -q
+python3 - <<'PY'
+import lasgun_amd as la
+G, S, n = la.api, la.scenes, 0
+for seed in range(150):
+    for gen in (S.random_scene, S.adversarial_scene, S.adversarial_mesh_scene):
+        try:
+            G.host_build_dump(gen(G, seed)); n += 1
+        except la.LasgunError:
+            pass
+for b in (lambda: S.mesh_scene(G), lambda: S.mixed_scene(G), lambda: S.spheres_scene(G), lambda: S.kitchen_sink_scene(G), lambda: S.instanced_scene(G)):
+    G.host_build_dump(b()); n += 1
+print("flattened", n, "scenes under ASan + UBSan: no report")
+PY
