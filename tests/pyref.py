@@ -229,6 +229,17 @@ class Aggregate:  # scene/node.rs:25-115
         self.transform.concat_self(m, minv)
         return self
 
+    def rotate(self, t, axis):  # Matrix4::from_axis_angle (cgmath 0.17), inverse = transpose (transform.rs:144-148)
+        x, y, z = map(float, axis)
+        s, c = sincos(float(t) * (PI / 180.0))
+        k = 1.0 - c
+        m = mat_identity()
+        m[0] = [k * x * x + c, k * x * y + s * z, k * x * z - s * y, 0.0]
+        m[1] = [k * x * y - s * z, k * y * y + c, k * y * z + s * x, 0.0]
+        m[2] = [k * x * z + s * y, k * y * z - s * x, k * z * z + c, 0.0]
+        self.transform.concat_self(m, mat_transpose(m))
+        return self
+
     def rotate_x(self, t): m = _rot(float(t), 0); self.transform.concat_self(m, mat_transpose(m)); return self
     def rotate_y(self, t): m = _rot(float(t), 1); self.transform.concat_self(m, mat_transpose(m)); return self
     def rotate_z(self, t): m = _rot(float(t), 2); self.transform.concat_self(m, mat_transpose(m)); return self
@@ -549,6 +560,8 @@ def intersect_mesh(obj, mat, o, d, best_t):
 
 
 def closest(scene, o, d):
+    if getattr(scene, "_closest", None) is not None:  # tests/pyref_bvh.py: through the reference's BVH instead of by brute force
+        return scene._closest(scene, o, d)
     return intersect(scene.root, o, d, INF)
 
 
