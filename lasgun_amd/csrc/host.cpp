@@ -823,6 +823,7 @@ struct Flattener {
                 pb[i] = b_new(c - V3{r, r, r}, c + V3{r, r, r});
                 ref[i] = (PK_SPHERE << 30) | (uint32_t)(out.spheres.size() - 1);
                 std::memcpy(rec[i].w, &out.spheres.back(), sizeof(DSphere));
+                { const double r2 = r * r; std::memcpy(rec[i].w + 8, &r2, sizeof r2); } // rad*rad of Sphere::intersect_t (sphere.rs:52), the same IEEE product
                 break;
             }
             case SceneNode::CUBE:   // cuboid.rs:24-30

@@ -939,6 +939,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     if (!((L.flags & AF_IDENTITY) && ray_plain(wray))) root = accel_local_ray<LDSS>(P, scn, 0u, wray);
     Ray ray = root;
     double dd = dot(ray.d, ray.d);      // a of every sphere's quadratic at this level
+    double four_a = 4.0 * dd;           // 4.0 * a of its discriminant b*b - 4.0*a*c (core/math.rs:16: (4.0 * a) * c)
     uint32_t negmask = neg_mask(ray);   // dir_is_neg (bvh.rs:463)
     uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0;
     uint32_t state = ST_NODE;
@@ -1035,15 +1036,14 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 double t = 0.0;
                 if (kind == PK_SPHERE) { // Sphere::intersect_t + quad_roots (sphere.rs:30-69, core/math.rs) == sphere_t_a
                     const V3 cen{rec_f64(g.a.x, g.a.y), rec_f64(g.a.z, g.a.w), rec_f64(g.b.x, g.b.y)};
-                    const double rad = rec_f64(g.b.z, g.b.w);
                     const V3 l = ray.o - cen;
                     const double b = 2.0 * dot(ray.d, l);
-                    const double c = dot(l, l) - rad * rad;
+                    const double c = dot(l, l) - rec_f64(g.c.x, g.c.y); // rad * rad, formed by the host
                     bool has = false;
                     if (dd == 0.0) {
                         if (b != 0.0) { t = -c / b; has = true; }
                     } else {
-                        const double disc = b * b - 4.0 * dd * c;
+                        const double disc = b * b - four_a * c;
                         if (!(disc < 0.0)) {
                             const double q = -(b + signum(b) * sqrt(disc)) / 2.0;
                             const double r0 = q / dd;
@@ -1099,6 +1099,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
             if (!same) {
                 ray = accel_local_ray<LDSS>(P, scn, enter, ray);
                 dd = dot(ray.d, ray.d);
+                four_a = 4.0 * dd;
                 negmask = neg_mask(ray);
             }
             if (FAST && (L.flags & AF_MESH)) tri = tri_setup(ray);
@@ -1133,6 +1134,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                         if (!((cflags & AF_IDENTITY) && ray_plain(ray))) ray = accel_local_ray<LDSS>(P, scn, c, ray);
                     }
                     dd = dot(ray.d, ray.d);
+                    four_a = 4.0 * dd;
                     negmask = neg_mask(ray);
                 }
                 if (li < le) state = ST_LEAF;
