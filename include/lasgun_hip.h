@@ -201,6 +201,16 @@ int lg_accel_set_streaming(const lg_accel *, int enabled);
  * three-kernel pipeline over dense pixels (scenes without glass / mirror only; specular scenes then run in the megakernel). */
 int lg_accel_set_wavefront(const lg_accel *, int enabled);
 
+/* Wavefront pipeline, launches of 2 Mpixel and more: cut the launch into `bands` row bands (2..8) rendered on internal streams,
+ * each with launch state of its own, so one band's closest pass fills the tails of another band's shadow and shade passes
+ * and the sparse deeper levels of a recursive scene run beside other bands' level 0; the caller's stream forks into them
+ * and joins them, results are unchanged.  0 = the default (LASGUN_WF_SPLIT, else 1 = off).  Worth it for a caller that
+ * renders one frame at a time (headline frame 7.79 -> 7.50 ms with 4 bands); a caller that keeps several frames in
+ * flight on streams of its own already has that overlap and loses with it (7.20 -> 7.46 ms).  The internal streams overlap
+ * only if the HIP runtime gives them hardware queues of their own (GPU_MAX_HW_QUEUES, default 4, counts every stream of
+ * the process).  No counterpart in the reference. */
+int lg_accel_set_wf_split(const lg_accel *, int bands);
+
 /* LDS-resident scene (reference traversal; streaming pipeline and megakernel): when the scene's node,
  * primref, sphere and cuboid tables fit beside 1024 per-lane stacks in one CU's 160 KB of LDS, the
  * kernels that traverse run as one 1024-lane workgroup per CU that copies those tables into LDS once

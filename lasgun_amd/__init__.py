@@ -38,6 +38,7 @@ _EXTRA = {
     "accel_set_streaming": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_lds_scene": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_wavefront": (_C.c_int, [_C.c_void_p, _C.c_int]),
+    "accel_set_wf_split": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_packet": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
     "capture_radiance": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
@@ -82,6 +83,10 @@ class HipApi(Api):
     def set_streaming(self, accel, enabled):
         """True (default) = three-kernel streaming pipeline where the scene allows it; False = megakernel only."""
         self.call("accel_set_streaming", accel.h, int(enabled) if enabled in (0, 1, 2) else (1 if enabled else 0))
+
+    def set_wf_split(self, accel, bands):
+        """Bands of a big wavefront launch on internal streams (0 = default; include/lasgun_hip.h, lg_accel_set_wf_split)."""
+        self.call("accel_set_wf_split", accel.h, int(bands))
 
     def set_wavefront(self, accel, enabled):
         """True (default): "streaming" is the level-by-level wavefront pipeline (any scene); False: the earlier three-kernel

@@ -207,3 +207,26 @@ def test_multi_device_capture_through_rccl_on_one_gpu():
             "print('rccl gather ok')\n") % root
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert p.returncode == 0 and "rccl gather ok" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+def test_wavefront_bands_on_internal_streams_leave_the_film_unchanged():
+    """lg_accel_set_wf_split: a 2048^2 launch cut into 1 / 2 / 4 / 8 bands rendered on internal streams (fork from and join
+    into the caller's stream), glass scene included: byte-identical films, and identical to the megakernel's."""
+    import torch
+    w = h = 2048
+    for build in (lambda: S.spheres_scene(G), lambda: S.cornell_scene(G, "glass")):
+        acc = G.Accel(build())
+        G.set_streaming(acc, 0)
+        ref = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        G.capture_rows_device(acc, w, h, 0, h, ref.data_ptr(), row0=0)
+        G.synchronize(acc)
+        G.set_streaming(acc, 2)
+        for bands in (1, 2, 4, 8, 0):
+            G.set_wf_split(acc, bands)
+            film = torch.full((h, w, 4), 7, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            s = torch.cuda.Stream()
+            G.capture_rows_device(acc, w, h, 0, h, film.data_ptr(), row0=0, stream=s.cuda_stream)
+            s.synchronize()
+            assert torch.equal(film, ref), bands
