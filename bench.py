@@ -145,6 +145,12 @@ def main():
                     help="world size 1 with a process group and a real gather: RCCL rehearsal on a 1-GPU box")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON record: whatever libraries print there (RCCL's version banner at communicator
+    # creation, gloo's connection notes) is sent to stderr by pointing file descriptor 1 at it until the record is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -386,7 +392,8 @@ def main():
             out["fast_mode"] = fast_info
         if world == 1 and not args.no_cpu_baseline and not args.force_dist and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(w, h)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()
