@@ -43,6 +43,8 @@ ORGANISATIONS = ((0, False, False), (0, True, False), (2, False, False), (2, Tru
 @pytest.mark.parametrize("gen", sorted(GENERATORS))
 def test_fuzz_campaign(gen):
     build, (w, h) = GENERATORS[gen]
+    if os.environ.get("LASGUN_FUZZ_FILM"):  # e.g. 97x61: film shapes that do not divide into 8x8 tiles
+        w, h = (int(v) for v in os.environ["LASGUN_FUZZ_FILM"].split("x"))
     o = oracle()
     done = {"generator": gen, "film": [w, h], "seeds": [seed_range().start, seed_range().stop], "scenes": 0, "renders": 0,
             "refused_by_both": 0, "fast_refused": 0, "nan_pixels": 0, "mismatches": []}
