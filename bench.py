@@ -41,9 +41,10 @@ sys.path.insert(0, ROOT)
 # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of streams
 # that share a queue run one after the other.  The frames in flight (FRAMES_IN_FLIGHT below) need a queue each beside the
 # default stream, the accel's own stream and RCCL's: with 4 queues the four frame streams pair up and 4 frames in flight are
-# worth no more than 2 (7.57 ms per frame); with 8 they overlap (7.23 ms).  Read by the runtime at initialisation, so it is
-# set before torch is imported; an explicit setting in the environment wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# worth no more than 2 (7.57 ms per frame); with 8 they overlap (7.23 ms), and with RCCL's streams beside them 12 or more
+# are needed (1/8-size frames with a gather each: 1.30 ms per frame with 8 queues, 1.18 with 12, 1.20 with 16).  Read by
+# the runtime at initialisation, so it is set before torch is imported; an explicit setting in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
