@@ -244,7 +244,8 @@ struct lg_accel {
     mutable std::mutex mtx;
     hipStream_t stream = nullptr;
     uint32_t stack_depth = 1;      // reference traversal
-    uint32_t stack_depth_fast = 1; // fast traversal (two words per pending child)
+    uint32_t stack_depth_fast = 1; // fast traversal, first formulation (two words per pending child): the counting and debug kernels
+    uint32_t stack_depth_fast1 = 1; // fast traversal, second formulation (one word per pending child; also deep enough for its reference re-trace)
     uint32_t max_blocks = 1;
     uint32_t max_blocks_fast = 1;
     uint64_t device_bytes = 0;
@@ -405,7 +406,7 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
     }
 
     const bool ldss = !a.fast && a.lds_scene && a.ldss_blocks;
-    const uint32_t depth = a.fast ? a.stack_depth_fast : a.stack_depth;
+    const uint32_t depth = a.fast ? a.stack_depth_fast1 : a.stack_depth;
     const uint32_t trace_cap = ldss ? a.ldss_blocks : (a.fast ? a.wf_blocks_fast : a.wf_blocks);
     const uint32_t flat_cap = a.cus * 16u;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -516,7 +517,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         uint32_t cap = a.fast ? a.stream_blocks_fast : a.stream_blocks;
         uint32_t blocks = (P.ntiles + 3u) / 4u;
         if (blocks > cap) blocks = cap;
-        uint32_t depth = a.fast ? a.stack_depth_fast : a.stack_depth;
+        uint32_t depth = a.fast ? a.stack_depth_fast1 : a.stack_depth;
         if (!a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS
             P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
             P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
@@ -617,7 +618,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    HIP_TRY(launch_trace(P, stats, a.fast, blocks, a.fast ? a.stack_depth_fast : a.stack_depth, stream));
+    HIP_TRY(launch_trace(P, stats, a.fast, blocks, a.fast ? (stats ? a.stack_depth_fast : a.stack_depth_fast1) : a.stack_depth, stream));
     if (a.profiling) {
         HIP_TRY(hipEventRecord(e1, stream));
         a.events.emplace_back(e0, e1);
@@ -829,6 +830,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         a->stack_depth = f.max_stack + 2;
         // the fast kernel falls back to the reference traversal on exact ties, so its stack must hold either
         a->stack_depth_fast = (f.max_stack > f.max_stack_fast ? f.max_stack : f.max_stack_fast) + 2;
+        a->stack_depth_fast1 = (f.max_stack > f.max_stack_fast1 ? f.max_stack : f.max_stack_fast1) + 2;
         const size_t LDS_MAX = 160 * 1024;
         if ((size_t)a->stack_depth * 256 * 4 > LDS_MAX)
             throw Error("BVH too deep for the LDS traversal stack (" + std::to_string(a->stack_depth) + " entries per lane; the reference panics beyond 64 per level, bvh.rs:497)");
@@ -852,13 +854,13 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                 a->fast_refusal = "fast mode unavailable: an aggregate's transform and inverse do not match (rotate() about a non-unit axis?)";
             }
         }
-        if (!a->fast_available) a->stack_depth_fast = a->stack_depth;
+        if (!a->fast_available) a->stack_depth_fast = a->stack_depth_fast1 = a->stack_depth;
         size_t lds = (size_t)a->stack_depth_fast * 256 * 4;
         if (lds > 64 * 1024) HIP_TRY(trace_set_lds_limit(lds));
         int per_cu = 0, cus = 0;
         HIP_TRY(trace_occupancy(a->stack_depth, false, &per_cu));
         int per_cu_fast = 0;
-        HIP_TRY(trace_occupancy(a->stack_depth_fast, true, &per_cu_fast));
+        HIP_TRY(trace_occupancy(a->stack_depth_fast1, true, &per_cu_fast));
         if (per_cu_fast < 1) per_cu_fast = 1;
         a->max_blocks_fast = (uint32_t)per_cu_fast;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device));
@@ -867,12 +869,12 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         a->max_blocks_fast *= (uint32_t)cus;
         int sp = 0, spf = 0;
         HIP_TRY(stream_trace_occupancy(a->stack_depth, false, &sp));
-        HIP_TRY(stream_trace_occupancy(a->stack_depth_fast, true, &spf));
+        HIP_TRY(stream_trace_occupancy(a->stack_depth_fast1, true, &spf));
         a->stream_blocks = (uint32_t)((sp < 1 ? 1 : sp) * cus);
         a->stream_blocks_fast = (uint32_t)((spf < 1 ? 1 : spf) * cus);
         int wb = 0, wbf = 0;
         HIP_TRY(wf_trace_occupancy(a->stack_depth, false, &wb));
-        HIP_TRY(wf_trace_occupancy(a->stack_depth_fast, true, &wbf));
+        HIP_TRY(wf_trace_occupancy(a->stack_depth_fast1, true, &wbf));
         a->wf_blocks = (uint32_t)((wb < 1 ? 1 : wb) * cus);
         a->wf_blocks_fast = (uint32_t)((wbf < 1 ? 1 : wbf) * cus);
         int pk = 0;
@@ -994,7 +996,7 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.lds_image_n16, y.lds_image_n16); swap(x.lds_node_off, y.lds_node_off); swap(x.lds_prim_off, y.lds_prim_off);
     swap(x.lds_soup_off, y.lds_soup_off); swap(x.lds_accel_off, y.lds_accel_off);
     swap(x.ldss_blocks, y.ldss_blocks); swap(x.packet_blocks, y.packet_blocks); swap(x.packet_lds, y.packet_lds); swap(x.cus, y.cus);
-    swap(x.stack_depth, y.stack_depth); swap(x.stack_depth_fast, y.stack_depth_fast); swap(x.max_blocks, y.max_blocks); swap(x.max_blocks_fast, y.max_blocks_fast);
+    swap(x.stack_depth, y.stack_depth); swap(x.stack_depth_fast, y.stack_depth_fast); swap(x.stack_depth_fast1, y.stack_depth_fast1); swap(x.max_blocks, y.max_blocks); swap(x.max_blocks_fast, y.max_blocks_fast);
     swap(x.stream_blocks, y.stream_blocks); swap(x.stream_blocks_fast, y.stream_blocks_fast); swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast);
     swap(x.device_bytes, y.device_bytes); swap(x.fast_available, y.fast_available); swap(x.fast_refusal, y.fast_refusal);
     swap(x.streaming_pays, y.streaming_pays); swap(x.streaming_min_items, y.streaming_min_items);

@@ -547,7 +547,7 @@ struct MeshTables { // per scene mesh, shared by all its instances
     bool built = false;
     uint32_t node_base = 0, prim_base = 0, nnodes = 0, norder = 0;
     uint32_t max_stack = 0;
-    uint32_t fnode_base = 0, fprim_base = 0, fmax_stack = 0;
+    uint32_t fnode_base = 0, fprim_base = 0, fmax_stack = 0, fmax_stack1 = 0;
     Bounds root_bounds{};
     uint32_t tri_base = 0;
     bool has_n = false, has_uv = false;
@@ -744,7 +744,8 @@ struct Flattener {
                     std::memcpy(&rec.w[3 * k], &obj.position[3 * (size_t)obj.tri[3 * (size_t)o + k].v], 12);
                 out.leaf_soup.push_back(rec);
             }
-            mt.fmax_stack = 2 * stack_need(fb.nodes, refs, [](uint32_t) { return 0u; });
+            mt.fmax_stack1 = stack_need(fb.nodes, refs, [](uint32_t) { return 0u; }); // the second formulation: one word per pending child
+            mt.fmax_stack = 2 * mt.fmax_stack1;
         }
         mt.built = true;
         return mt;
@@ -772,7 +773,7 @@ struct Flattener {
     }
 
     // returns accel id; sets bound = BVHAccel::bound() (bvh.rs:457-459) and need = stack entries
-    uint32_t mesh_instance(uint32_t mesh, bool has_mat, const Material &mat, int32_t parent, Bounds &bound, uint32_t &need, uint32_t &fneed) {
+    uint32_t mesh_instance(uint32_t mesh, bool has_mat, const Material &mat, int32_t parent, Bounds &bound, uint32_t &need, uint32_t &fneed, uint32_t &fneed1) {
         uint32_t id = (uint32_t)out.accels.size();
         out.accels.emplace_back();
         MeshTables &mt = mesh_tables(mesh);
@@ -789,10 +790,11 @@ struct Flattener {
         bound = b_transform(idt.m, mt.root_bounds);
         need = mt.max_stack;
         fneed = mt.fmax_stack;
+        fneed1 = mt.fmax_stack1;
         return id;
     }
 
-    uint32_t aggregate(const Aggregate &agg, int32_t parent, Bounds &bound, uint32_t &need, uint32_t &fneed) { // bvh.rs:150-162
+    uint32_t aggregate(const Aggregate &agg, int32_t parent, Bounds &bound, uint32_t &need, uint32_t &fneed, uint32_t &fneed1) { // bvh.rs:150-162
         uint32_t id = (uint32_t)out.accels.size();
         out.accels.emplace_back();
         {
@@ -810,7 +812,7 @@ struct Flattener {
         std::vector<double> child_f; std::vector<int64_t> child_i;
         std::swap(child_f, out.dump_f); std::swap(child_i, out.dump_i); // children dump into fresh vectors
         std::vector<Bounds> pb(n);
-        std::vector<uint32_t> ref(n), extra(n, 0), fextra(n, 0);
+        std::vector<uint32_t> ref(n), extra(n, 0), fextra(n, 0), fextra1(n, 0);
         std::vector<DLeafRec> rec(n, DLeafRec{});
         for (size_t i = 0; i < n; ++i) {
             const SceneNode &nd = agg.contents[i];
@@ -840,16 +842,18 @@ struct Flattener {
                 break;
             }
             case SceneNode::MESH: {
-                uint32_t cn = 0, fcn = 0;
-                uint32_t cid = mesh_instance(nd.obj, nd.has_mat, nd.mat, (int32_t)id, pb[i], cn, fcn);
+                uint32_t cn = 0, fcn = 0, fcn1 = 0;
+                uint32_t cid = mesh_instance(nd.obj, nd.has_mat, nd.mat, (int32_t)id, pb[i], cn, fcn, fcn1);
+                fextra1[i] = 3 + fcn1;
                 ref[i] = (PK_ACCEL << 30) | cid;
                 extra[i] = 3 + cn;
                 fextra[i] = 3 + fcn;
                 break;
             }
             case SceneNode::GROUP: {
-                uint32_t cn = 0, fcn = 0;
-                uint32_t cid = aggregate(*nd.group, (int32_t)id, pb[i], cn, fcn);
+                uint32_t cn = 0, fcn = 0, fcn1 = 0;
+                uint32_t cid = aggregate(*nd.group, (int32_t)id, pb[i], cn, fcn, fcn1);
+                fextra1[i] = 3 + fcn1;
                 ref[i] = (PK_ACCEL << 30) | cid;
                 extra[i] = 3 + cn;
                 fextra[i] = 3 + fcn;
@@ -883,7 +887,7 @@ struct Flattener {
         out.accels[id].prim_base = prim_base;
         need = stack_need(bvh.nodes, extra_in_order, [](uint32_t e) { return e; });
         bound = b_transform(agg.transform.m, bvh.nodes[0].b);
-        fneed = 0;
+        fneed = 0; fneed1 = 0;
         if (with_fast) { // fast tree over the same primitives (child accels included as primitives)
             const std::vector<Bounds> pbf = inflated(pb);
             BuiltBVH fb = FastBuilder(pbf).run();
@@ -903,6 +907,9 @@ struct Flattener {
             std::vector<uint32_t> half(fextra_in_order.size());
             for (size_t i = 0; i < half.size(); ++i) half[i] = (fextra_in_order[i] + 1) / 2;
             fneed = 2 * stack_need(fb.nodes, half, [](uint32_t e) { return e; });
+            std::vector<uint32_t> one(fb.order.size());
+            for (size_t i = 0; i < one.size(); ++i) one[i] = fextra1[fb.order[i]];
+            fneed1 = stack_need(fb.nodes, one, [](uint32_t e) { return e; }); // second formulation: one word per pending child, 3-word level frames
         }
         // stitch the dump: [prefix][this accel][children]
         std::swap(child_f, out.dump_f); std::swap(child_i, out.dump_i); // out.* = prefix again, child_* = children
@@ -922,10 +929,11 @@ void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     fl.meshes.resize(scene.meshes.size());
     out.default_material = fl.add_material(material_default());
     Bounds b;
-    uint32_t need = 0, fneed = 0;
-    fl.aggregate(*scene.root, -1, b, need, fneed);
+    uint32_t need = 0, fneed = 0, fneed1 = 0;
+    fl.aggregate(*scene.root, -1, b, need, fneed, fneed1);
     out.max_stack = need;
     out.max_stack_fast = fneed;
+    out.max_stack_fast1 = fneed1;
     if (out.primref.size() > 80000000u) throw Error("too many primitive slots for the 32-bit record offsets of the triangle stream");
     out.leaf_soup.resize(out.primref.size() + 2, DLeafRec{}); // two spare records: the mesh leaf loop keeps the next slot in flight
     out.sphere_ref_leaf.resize(out.spheres.size(), NO_HIT);

@@ -126,6 +126,7 @@ struct FlatScene {
     int32_t default_material = 0;
     uint32_t max_stack = 0;      // worst-case per-lane traversal stack entries
     uint32_t max_stack_fast = 0; // same for the fast tree (two words per pending child)
+    uint32_t max_stack_fast1 = 0; // the fast tree walked by the second formulation (one word per pending child)
     bool has_specular = false;   // any glass / mirror material present
     bool has_fast = false;       // the fast mode's trees are part of the tables
     // structure dump in the same format as the oracle's orc_accel_dump (build-parity tests)
