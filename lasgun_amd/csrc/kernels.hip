@@ -1159,6 +1159,216 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
 #endif
 }
 
+// Fast mode's walk with CHILD-PAIR records (nodes2): `cur` is an interior node whose own box is known to be hit; one 128-byte
+// record holds both children's boxes and leaf words, so a step tests two boxes per dependent fetch -- the fast walk waits on
+// those fetches, not on the VALU (half the fetches of the one-node-per-step form).  The nearer hit child (by slab tnear) is
+// taken, the other is pushed (one word: node index, bit 31 = it is a leaf); a popped leaf entry fetches its slot range
+// (ST_OPEN).  Everything else -- levels, leaves, pruning margins, tie / NaN flags -- is traverse_ref<false, true>.
+constexpr uint32_t ST_OPEN = 5u;
+constexpr uint32_t STK_LEAF = 0x80000000u;
+// the root node of a level: its own box, once (bvh.rs:472-473 for node 0)
+__device__ __forceinline__ void fast_level_root(const DParams &P, const Lvl &L, const Ray &ray, const double limit, uint32_t &state, uint32_t &cur,
+                                                uint32_t &li, uint32_t &le) {
+    const NodeRec nd = load_node<false>(P, nullptr, L.node_base);
+    double tn, tf;
+    bool hit = slab_intersects_nc_t(nd.bmin, nd.bmax, ray, tn, tf);
+    hit = hit && !(tn - 4e-8 * fabs(tf) > limit);
+    cur = L.node_base;
+    if (!hit) state = ST_LEVEL_DONE;
+    else if (nd.meta & NODE_LEAF) { li = L.prim_base + nd.link; le = li + (nd.meta & 0xFFFFu); state = ST_LEAF; }
+    else state = ST_NODE;
+}
+__device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
+                                             Best &best, const uint4 *scn, bool &tie) {
+    constexpr bool LDSS = false, FAST = true;
+    best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
+    uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
+    Lvl L;
+    lvl_set<LDSS, FAST>(P, scn, L, 0u);
+    double limit = prune_limit(INFINITY, anyhit); // FAST: nodes whose tnear lies beyond this are skipped
+    TriSetup tri;                                  // FAST: per mesh level (its leaves hold <= 4 triangles: per leaf the three divides would dominate)
+    tri.kz = 0; tri.sx = 0.0; tri.sy = 0.0; tri.sz = 0.0;
+    // ---- the root accel's local ray (bvh.rs:462), kept for the returns
+    Ray root = wray;
+    if (!((L.flags & AF_IDENTITY) && ray_plain(wray))) root = accel_local_ray<LDSS>(P, scn, 0u, wray);
+    Ray ray = root;
+    double dd = dot(ray.d, ray.d);      // a of every sphere's quadratic at this level
+    double four_a = 4.0 * dd;           // 4.0 * a of its discriminant b*b - 4.0*a*c (core/math.rs:16: (4.0 * a) * c)
+    uint32_t negmask = neg_mask(ray); (void)negmask; // (the pair walk orders children by tnear; kept for the level bookkeeping shared with traverse_ref)
+    uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0;
+    uint32_t state = ST_NODE;
+    fast_level_root(P, L, ray, limit, state, cur, li, le);
+    for (;;) {
+        // ---- phase A: interior nodes, two children per step, until no lane of the wave is at a node
+        // (loops are written with their wave-uniform condition in a variable tested at the bottom: hipcc then keeps the
+        // loop-carried state in place instead of copying it in and out of the loop on every trip)
+        bool more_nodes = wave_any(state == ST_NODE);
+        while (more_nodes) {
+            if (state == ST_NODE) {
+                const DNode2 *nd = P.nodes2 + cur;
+                const double b0min[3] = {nd->b0min[0], nd->b0min[1], nd->b0min[2]}, b0max[3] = {nd->b0max[0], nd->b0max[1], nd->b0max[2]};
+                const double b1min[3] = {nd->b1min[0], nd->b1min[1], nd->b1min[2]}, b1max[3] = {nd->b1max[0], nd->b1max[1], nd->b1max[2]};
+                const uint32_t link0 = nd->link0, meta0 = nd->meta0, link1 = nd->link1, meta1 = nd->meta1, second = L.node_base + nd->second;
+                const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
+                // a primitive's computed t can undershoot its box's tnear by the error of its own formula: for a sphere
+                // the quadratic's cancellation, ~sqrt(eps) of the distance to its centre, which lies inside the box
+                double tn0, tf0, tn1, tf1;
+                bool hit0 = slab_intersects_nc_t(b0min, b0max, ray, tn0, tf0);
+                bool hit1 = slab_intersects_nc_t(b1min, b1max, ray, tn1, tf1);
+                hit0 = hit0 && !(tn0 - 4e-8 * fabs(tf0) > limit);
+                hit1 = hit1 && !(tn1 - 4e-8 * fabs(tf1) > limit);
+                const bool swap = hit1 && (!hit0 || tn1 < tn0); // the nearer hit child first
+                const bool any = hit0 || hit1, both = hit0 && hit1;
+                const uint32_t first = cur + 1u;
+                const uint32_t near_idx = swap ? second : first, far_idx = swap ? first : second;
+                const uint32_t near_link = swap ? link1 : link0, near_meta = swap ? meta1 : meta0, far_meta = swap ? meta0 : meta1;
+                const bool near_leaf = (near_meta & NODE_LEAF) != 0u;
+                const bool can_pop = sp != base;
+                stk[sp * stride] = far_idx | ((far_meta & NODE_LEAF) ? STK_LEAF : 0u); // counts only if sp advances
+                const uint32_t next = any ? near_idx : (popped & ~STK_LEAF);
+                sp = sp + (both ? 1u : 0u) - (!any && can_pop ? 1u : 0u);
+                li = L.prim_base + near_link; le = li + (near_meta & 0xFFFFu); // (read in ST_LEAF only)
+                cur = next;
+                state = any ? (near_leaf ? ST_LEAF : ST_NODE) : !can_pop ? ST_LEVEL_DONE : (popped & STK_LEAF) ? ST_OPEN : ST_NODE;
+            }
+            more_nodes = wave_any(state == ST_NODE);
+        }
+        // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
+        const bool mesh = (L.flags & AF_MESH) != 0u;
+        if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
+            if (!FAST) tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
+            bool done;
+            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
+            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
+            else done = mesh_leaf2<2, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
+            if (FAST) limit = prune_limit(best.t, anyhit);
+            if (done) state = ST_DONE;
+            else if (sp != base) { --sp; const uint32_t e = stk[sp * stride]; cur = e & ~STK_LEAF; state = (e & STK_LEAF) ? ST_OPEN : ST_NODE; }
+            else state = ST_LEVEL_DONE;
+        }
+        bool more_prims = wave_any(state == ST_LEAF);
+        while (more_prims) {
+            if (state == ST_LEAF) {
+                const uint32_t slot = li;
+                const uint32_t ref = load_primref<LDSS>(P, scn, slot);
+                LeafRec g;
+                if (LDSS) { const uint4 *q = scn + (P.lds_soup_off + __umul24(slot, 3u)); g = LeafRec{q[0], q[1], q[2]}; }
+                else g = load_rec(P, slot);
+                const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
+                li = slot + 1u;
+                const uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
+                bool accepted = false;
+                double t = 0.0;
+                if (kind == PK_SPHERE) { // Sphere::intersect_t + quad_roots (sphere.rs:30-69, core/math.rs) == sphere_t_a
+                    const V3 cen{rec_f64(g.a.x, g.a.y), rec_f64(g.a.z, g.a.w), rec_f64(g.b.x, g.b.y)};
+                    const V3 l = ray.o - cen;
+                    const double b = 2.0 * dot(ray.d, l);
+                    const double c = dot(l, l) - rec_f64(g.c.x, g.c.y); // rad * rad, formed by the host
+                    bool has = false;
+                    if (dd == 0.0) {
+                        if (b != 0.0) { t = -c / b; has = true; }
+                    } else {
+                        const double disc = b * b - four_a * c;
+                        if (!(disc < 0.0)) {
+                            const double q = -(b + signum(b) * sqrt(disc)) / 2.0;
+                            const double r0 = q / dd;
+                            const double r1 = (q == 0.0) ? r0 : c / q;
+                            const double t0 = fmin_(r0, r1), t1 = fmax_(r0, r1);
+                            t = t0 < 0.0 ? t1 : t0;
+                            has = true;
+                        }
+                    }
+                    accepted = has && !(t < 0.0) && !(t >= best.t);
+                } else if (kind == PK_CUBOID) {
+                    double mn[3] = {rec_f64(g.a.x, g.a.y), rec_f64(g.a.z, g.a.w), rec_f64(g.b.x, g.b.y)};
+                    double mx[3] = {rec_f64(g.b.z, g.b.w), rec_f64(g.c.x, g.c.y), rec_f64(g.c.z, g.c.w)};
+                    V3 d0, d1;
+                    if (cuboid_hit<false>(mn, mx, ray, t, d0, d1)) accepted = !(t >= best.t);
+                } else if (kind == PK_ACCEL) {
+                    // nested BVHAccel (Group / Mesh): entered below, outside this loop -- the ray and the level are
+                    // loop-invariant here, which keeps them out of the loop's register shuffles
+                    enter = idx;
+                    state = ST_ENTER;
+                } else { // a triangle outside a mesh accel cannot be built by the scene API; kept for completeness
+                    const uint32_t *vi = P.tri_v + 3ull * idx;
+                    TriHit h;
+                    if (triangle_t(load_f3(P.vpos, vi[0]), load_f3(P.vpos, vi[1]), load_f3(P.vpos, vi[2]), ray, h)) { t = h.t; accepted = !(t >= best.t); }
+                }
+                if (FAST && kind != PK_ACCEL && ((!accepted && t == best.t && best.ref != NO_HIT) || t != t)) tie = true; // visit order decides
+                if (accepted) {
+                    best.t = t; best.ref = ref; best.accel = L.accel;
+                    if (FAST) limit = prune_limit(t, anyhit);
+                    if (anyhit && t < 1.0) state = ST_DONE; // occluded: point.rs:49 only asks isect.t < 1.0
+                }
+                if (state == ST_LEAF && li >= le) { // leaf exhausted: next pending node of this level, or the level is done
+                    if (sp != base) { --sp; cur = popped & ~STK_LEAF; state = (popped & STK_LEAF) ? ST_OPEN : ST_NODE; }
+                    else state = ST_LEVEL_DONE;
+                }
+            }
+            more_prims = wave_any(state == ST_LEAF);
+        }
+        // ---- a leaf slot that is a nested BVHAccel (Group / Mesh): park this level, re-express the ray (bvh.rs:462)
+        if (state == ST_ENTER) {
+            lvl_set<LDSS, FAST>(P, scn, L, enter);
+            const bool same = (L.flags & AF_IDENTITY) != 0u && ray_plain(ray);
+            stk[sp * stride] = li; stk[(sp + 1u) * stride] = le; stk[(sp + 2u) * stride] = base | (same ? FRAME_SAME_RAY : 0u);
+            sp += 3u; base = sp;
+            if (!same) {
+                ray = accel_local_ray<LDSS>(P, scn, enter, ray);
+                dd = dot(ray.d, ray.d);
+                four_a = 4.0 * dd;
+                negmask = neg_mask(ray);
+            }
+            if (FAST && (L.flags & AF_MESH)) tri = tri_setup(ray);
+            fast_level_root(P, L, ray, limit, state, cur, li, le);
+        }
+        // ---- a pending child that is a leaf (pushed with its box already tested): its slot range
+        if (state == ST_OPEN) {
+            uint32_t link, meta;
+            load_node_link<false>(P, scn, cur, link, meta);
+            li = L.prim_base + link; le = li + (meta & 0xFFFFu);
+            state = ST_LEAF;
+        }
+        // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
+        while (state == ST_LEVEL_DONE) { // (a lane comes back through every level that is exhausted with it)
+            if (L.accel == 0u) state = ST_DONE;
+            else {
+                const uint32_t w2 = stk[(sp - 1u) * stride];
+                le = stk[(sp - 2u) * stride]; li = stk[(sp - 3u) * stride];
+                sp -= 3u; base = w2 & ~FRAME_SAME_RAY;
+                uint32_t parent, nchain;
+                const uint32_t *chain;
+                if (LDSS) {
+                    const uint4 *rec = scn + (P.lds_accel_off + L.accel * LDS_ACCEL_UNITS);
+                    parent = rec[7].x;
+                    const uint4 *prec = scn + (P.lds_accel_off + parent * LDS_ACCEL_UNITS);
+                    nchain = prec[7].y; chain = reinterpret_cast<const uint32_t *>(prec + 8);
+                } else {
+                    parent = (uint32_t)P.accels[L.accel].parent;
+                    nchain = P.accels[parent].nchain; chain = P.accels[parent].chain;
+                }
+                lvl_set<LDSS, FAST>(P, scn, L, parent);
+                if (!(w2 & FRAME_SAME_RAY)) { // the parent's ray again: from the root's, through the same transforms
+                    ray = root;
+                    for (uint32_t i = 1; i < nchain; ++i) {
+                        const uint32_t c = chain[i];
+                        const uint32_t cflags = LDSS ? scn[P.lds_accel_off + c * LDS_ACCEL_UNITS + 6u].w : P.accels[c].flags;
+                        if (!((cflags & AF_IDENTITY) && ray_plain(ray))) ray = accel_local_ray<LDSS>(P, scn, c, ray);
+                    }
+                    dd = dot(ray.d, ray.d);
+                    four_a = 4.0 * dd;
+                    negmask = neg_mask(ray);
+                }
+                if (li < le) state = ST_LEAF;
+                else if (sp != base) { --sp; const uint32_t e = stk[sp * stride]; cur = e & ~STK_LEAF; state = (e & STK_LEAF) ? ST_OPEN : ST_NODE; }
+                else state = ST_LEVEL_DONE; // the parent level is exhausted as well
+            }
+        }
+        if (!wave_any(state != ST_DONE)) break;
+    }
+}
+
+
 // One ray through the scene in the accel's mode.  Reference mode: the reference walk.  Fast mode: the fast walk, then
 //   * closest hit: the winner counts if no exact tie (or NaN) was met and the reference tree would have tested it (ref_candidate);
 //   * any-hit: an occluder counts if the reference tree would have tested it (the reference then finds it or one before it);
@@ -1168,6 +1378,10 @@ template <bool LDSS, bool FAST>
 __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const bool anyhit, uint32_t *stack, const uint32_t stride, Best &best,
                                      const uint4 *scn) {
     bool tie = false;
+#ifndef LG_FAST_ONE_NODE
+    if (FAST) traverse_fast(P, ray, anyhit, stack, stride, best, scn, tie);
+    else
+#endif
     traverse_ref<LDSS, FAST>(P, ray, anyhit, stack, stride, best, scn, tie);
     if (!FAST) return;
     bool redo;
