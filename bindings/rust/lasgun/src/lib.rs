@@ -246,6 +246,10 @@ impl<'s> Accel<'s> {
 impl<'s> Drop for Accel<'s> {
     fn drop(&mut self) { unsafe { sys::lg_accel_free(self.ptr) } }
 }
+// The reference shares `&Accel` between its capture threads (lib.rs:67-103).  The C side guards every entry point that takes
+// an accel with that accel's own mutex (capi.cpp), so the handle may be used and dropped from any thread.
+unsafe impl<'s> Send for Accel<'s> {}
+unsafe impl<'s> Sync for Accel<'s> {}
 
 /// GPUs a `capture` / `render` is split over (none given: every visible device); see `Scene::set_threads`
 pub fn set_devices(devices: &[i32]) {
@@ -338,13 +342,14 @@ pub mod output {
     /// 8-bit RGBA PNG, filter 0 rows in stored (uncompressed) deflate blocks
     fn write_png(filename: &str, w: u32, h: u32, px: &[Pixel]) -> std::io::Result<()> {
         let mut raw = Vec::with_capacity((w as usize * 4 + 1) * h as usize);
-        for row in px.chunks(w as usize) {
+        for row in px.chunks((w as usize).max(1)) {
             raw.push(0u8);
             for p in row { raw.extend_from_slice(p) }
         }
         let (mut a, mut b) = (1u32, 0u32); // adler32
         for &v in &raw { a = (a + v as u32) % 65521; b = (b + a) % 65521 }
         let mut z = vec![0x78u8, 0x01];
+        if raw.is_empty() { z.extend_from_slice(&[1, 0, 0, 0xFF, 0xFF]) } // a film without pixels: one empty final block
         let mut blocks = raw.chunks(65535).peekable();
         while let Some(block) = blocks.next() {
             z.push(if blocks.peek().is_none() { 1 } else { 0 });
