@@ -185,6 +185,14 @@ int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t
  * reference build, so lg_accel_from does not build them: the first lg_accel_set_mode(accel, 1) does (it
  * synchronises the device and uploads the tables again; the Scene must still be alive, as for any use of the accel). */
 int lg_accel_set_mode(const lg_accel *, int mode);
+/* Pruned form of the reference traversal (mode 0 only): the reference's tree and visit order, but a node is skipped when on
+ * some axis the ray reaches its slab only beyond the best accepted hit (closest hit) or beyond the light (shadow rays) by
+ * more than a margin derived from the rounding of the reference's own intersection formulas: every
+ * primitive below such a node would be rejected by the reference's `t >= isect.t` (sphere.rs:86, cuboid.rs:95,
+ * triangle.rs:251), so every pixel is what the unpruned walk gives.  Nodes over a nested BVHAccel are never skipped; inside a
+ * mesh only the ray's dominant axis counts.  -1 (default): on for scenes that carry a mesh of >= 256 triangles (the
+ * reference's 254-triangle leaves are where it pays), off otherwise; 0 / 1: off / on. */
+int lg_accel_set_prune(const lg_accel *, int enabled);
 
 /* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes without
  * glass / mirror, with <= 32 lights and with at least 512 spheres / boxes (where node and sphere

@@ -35,6 +35,7 @@ _EXTRA = {
                                               _C.c_void_p, _C.c_void_p]),
     "accel_stream": (_C.c_void_p, [_C.c_void_p]),
     "accel_set_mode": (_C.c_int, [_C.c_void_p, _C.c_int]),
+    "accel_set_prune": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_streaming": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_lds_scene": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_wavefront": (_C.c_int, [_C.c_void_p, _C.c_int]),
@@ -78,6 +79,12 @@ class HipApi(Api):
     def set_mode(self, accel, fast):
         """False = the reference traversal (parity path, default); True = the opt-in fast mode."""
         if self.call("accel_set_mode", accel.h, 1 if fast else 0):
+            raise LasgunError(self.last_error())
+
+    def set_prune(self, accel, enabled):
+        """Pruned form of the reference traversal: None / -1 = the accel's default (on for scenes with a mesh of >= 256
+        triangles), False / True = off / on (include/lasgun_hip.h, lg_accel_set_prune)."""
+        if self.call("accel_set_prune", accel.h, -1 if enabled is None or enabled == -1 else (1 if enabled else 0)):
             raise LasgunError(self.last_error())
 
     def set_streaming(self, accel, enabled):

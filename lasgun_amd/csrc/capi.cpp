@@ -44,6 +44,7 @@ using namespace lg;
 
 static thread_local std::string tl_error;
 static int g_device = 0;
+static bool g_device_chosen = false; // lg_set_device was called: single-device captures stay on that device
 static std::vector<int> g_devices; // lg_set_devices: the devices a host-film lg_capture is split over (empty = g_device)
 
 static int fail(const std::string &msg) {
@@ -251,6 +252,8 @@ struct lg_accel {
     uint64_t device_bytes = 0;
     mutable bool profiling = false;
     mutable bool fast = false; // opt-in fast traversal mode (lg_accel_set_mode)
+    mutable int prune = -1;    // lg_accel_set_prune: -1 = prune_default
+    bool prune_default = false; // the scene carries a mesh with fat leaves
     bool fast_available = true;
     std::string fast_refusal = "fast mode unavailable: its tree is too deep for the LDS stack";
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -267,6 +270,7 @@ struct lg_accel {
 };
 
 constexpr size_t MAX_LAUNCH_CTXS = 8;
+constexpr unsigned MAX_WF_BANDS = 4; // bands of a big wavefront launch on internal streams (lg_accel_set_wf_split)
 // The launch context of `stream` (at most MAX_LAUNCH_CTXS are kept; the least recently used one is recycled after a
 // device-wide synchronise).  Caller holds a.mtx and has made the accel's device current.
 static lg_accel::LaunchCtx &ctx_for(const lg_accel &a, hipStream_t stream) {
@@ -301,6 +305,11 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     P.recursion = s.recursion;
     P.default_material = a.flat.default_material;
     P.stack_depth = a.stack_depth;
+    {   // LASGUN_PRUNE=0|1 replaces the scene-dependent DEFAULT (test suites run whole under either); lg_accel_set_prune still wins
+        static const int env_default = [] { const char *e = std::getenv("LASGUN_PRUNE"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();
+        const bool dflt = env_default < 0 ? a.prune_default : env_default != 0;
+        P.prune = !a.fast && (a.prune < 0 ? dflt : a.prune != 0) ? 1u : 0u;
+    }
     P.cam_origin = s.camera.origin; P.cam_view = s.camera.view; P.cam_up = s.camera.up; P.cam_aux = s.camera.aux;
     P.image_plane_height = s.camera.image_plane_height;
     P.pixel_separation = s.camera.pixel_separation;
@@ -334,10 +343,13 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
     if (a.wf_budget == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        size_t budget = free_b / 3;
+        // per launch CONTEXT, and an accel keeps up to MAX_LAUNCH_CTXS of them plus the band contexts (a caller with
+        // four frames in flight uses five): a sixteenth of the free memory, at most 8 GiB each (the headline frame
+        // needs 3.3 GB and stays one chunk; an allocation that fails anyway halves the chunk below)
+        size_t budget = free_b / 16;
         const char *env = std::getenv("LASGUN_WF_BUDGET_MB");
         if (env && std::atoll(env) > 0) budget = (size_t)std::atoll(env) << 20;
-        else if (budget > (32ull << 30)) budget = 32ull << 30;
+        else if (budget > (8ull << 30)) budget = 8ull << 30;
         a.wf_budget = budget < (64ull << 20) ? (64ull << 20) : budget;
     }
     unsigned long long chunk_tiles = a.wf_budget / (per_pixel * 64);
@@ -350,9 +362,11 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
     // when the caller already keeps four frames in flight -- which is why it is not the default.
     static const unsigned split_env = [] { const char *e = std::getenv("LASGUN_WF_SPLIT"); return e && std::atoi(e) > 0 ? (unsigned)std::atoi(e) : 1u; }();
     const unsigned want = a.wf_split ? a.wf_split : split_env;
-    const unsigned split = (unsigned long long)P0.ntiles * 64ull >= (1ull << 21) ? std::min(want, 8u) : 1u;
+    // (at most MAX_WF_BANDS bands: their contexts and the callers' streams share the accel's MAX_LAUNCH_CTXS slots, and a
+    // context that has to be recycled costs a device-wide synchronise)
+    const unsigned split = (unsigned long long)P0.ntiles * 64ull >= (1ull << 21) ? std::min(want, MAX_WF_BANDS) : 1u;
     if (split > 1) chunk_tiles = std::min<unsigned long long>(chunk_tiles, (P0.ntiles + split - 1) / split);
-    const unsigned long long nchunks = (P0.ntiles + chunk_tiles - 1) / chunk_tiles;
+    unsigned long long nchunks = (P0.ntiles + chunk_tiles - 1) / chunk_tiles;
     const unsigned nstreams = split > 1 && nchunks > 1 ? (unsigned)std::min<unsigned long long>(split, nchunks) : 0u; // 0: everything on the caller's stream
     if (nstreams && a.aux_streams.size() < nstreams) {
         while (a.aux_streams.size() < nstreams) {
@@ -363,12 +377,18 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
         }
         if (!a.aux_fork) HIP_TRY(hipEventCreateWithFlags(&a.aux_fork, hipEventDisableTiming));
     }
-    const unsigned long long n0 = chunk_tiles * 64ull;
-    const size_t need = (size_t)n0 * per_pixel + 4096 * (3 * levels + 4);
+    unsigned long long n0 = 0;
+    size_t need = 0, hit_cap = 0, hit_len = 0;
     const uint32_t nlaunch = 4 * levels;
     const uint32_t CL = 64; // the queue counts (3 per level) in the first 256 bytes, then every tile counter on a line of its own
-    const size_t hit_cap = (size_t)n0 << (levels - 1);
-    const size_t hit_len = hit_cap + hit_cap / 64 * (WF_FULL_MIN_HOST - 1); // appended part: fewer than WF_FULL_MIN hits per block of 64 rays
+    auto size_chunk = [&] {
+        n0 = chunk_tiles * 64ull;
+        need = (size_t)n0 * per_pixel + 4096 * (3 * levels + 4);
+        hit_cap = (size_t)n0 << (levels - 1);
+        hit_len = hit_cap + hit_cap / 64 * (WF_FULL_MIN_HOST - 1); // appended part: fewer than WF_FULL_MIN hits per block of 64 rays
+        nchunks = (P0.ntiles + chunk_tiles - 1) / chunk_tiles;
+    };
+    size_chunk();
     struct Carved {
         std::vector<double *> q, out, spec;
         std::vector<uint32_t *> child;
@@ -397,12 +417,23 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
     };
     std::vector<Carved> carved;
     std::vector<hipStream_t> lanes;
+    for (;;) { // memory that is not there (other contexts, other accels, other processes): halve the chunk and carve again
+        try {
+            carved.clear(); lanes.clear();
+            if (nstreams) for (unsigned j = 0; j < nstreams; ++j) { lanes.push_back(a.aux_streams[j]); carved.push_back(carve(ctx_for(a, a.aux_streams[j]))); }
+            else { lanes.push_back(stream); carved.push_back(carve(c)); }
+            break;
+        } catch (const Error &e) {
+            if (std::string(e.what()).find("hipMalloc") == std::string::npos || chunk_tiles <= 1) throw;
+            chunk_tiles = (chunk_tiles + 1) / 2;
+            a.wf_budget = std::max<size_t>(a.wf_budget / 2, 64ull << 20); // (later launches start from what fitted)
+            size_chunk();
+            if (std::getenv("LASGUN_DEBUG")) std::fprintf(stderr, "[lasgun] wavefront: %s -- chunks of %llu tiles instead\n", e.what(), chunk_tiles);
+        }
+    }
     if (nstreams) {
-        for (unsigned j = 0; j < nstreams; ++j) { lanes.push_back(a.aux_streams[j]); carved.push_back(carve(ctx_for(a, a.aux_streams[j]))); }
         HIP_TRY(hipEventRecord(a.aux_fork, stream)); // the bands start after whatever the caller's stream holds (a film clear, the previous frame's copy)
         for (unsigned j = 0; j < nstreams; ++j) HIP_TRY(hipStreamWaitEvent(a.aux_streams[j], a.aux_fork, 0));
-    } else {
-        lanes.push_back(stream); carved.push_back(carve(c));
     }
 
     const bool ldss = !a.fast && a.lds_scene && a.ldss_blocks;
@@ -785,6 +816,7 @@ void lg_film_free(lg_film *f) { delete f; }
 
 int lg_set_device(int device) {
     g_device = device;
+    g_device_chosen = true;
     return guarded([] { use_device(); });
 }
 int lg_set_devices(const int *ids, int count) {
@@ -942,6 +974,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                         const DNode &nd = fm.nodes[A.node_base + i];
                         if (nd.meta & NODE_LEAF) { rec[16] = A.lprim_base + nd.link; rec[17] = NODE_LEAF; rec[18] = rec[16] + (nd.meta & 0xFFFFu); }
                         else { rec[16] = tree0 + nd.link * LDS_NODE_STRIDE * 16u; rec[17] = 1u << (nd.meta & 3u); rec[18] = 0u; }
+                        rec[17] |= nd.meta & NODE_NOPRUNE;
                     }
                 }
                 a->lds_accel_off = a->lds_soup_off + np_soup * 3u;
@@ -953,6 +986,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                     rec[25] = A.lprim_base; rec[26] = A.prim_base - A.lprim_base; rec[27] = A.flags;
                     rec[28] = (uint32_t)A.parent; rec[29] = A.nchain;
                     for (int k = 0; k < MAX_CHAIN; ++k) rec[32 + k] = A.chain[k];
+                    std::memcpy(rec + 40, A.prune, sizeof A.prune);
                 }
                 a->lds_image.upload(img);
                 a->lds_image_n16 = (uint32_t)n16;
@@ -975,6 +1009,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
             // 512^2: 0.81 ms level by level, 0.80 ms in the megakernel since both walk with traverse_ref), and with a big mesh the deeper
             // levels are few, long, incoherent walks through 254-triangle leaves whose slowest wave sets each launch's length
             // (100k-triangle glass torus: 226 against 136 ms): those stay in the megakernel, where other tiles fill the gaps.
+            a->prune_default = big_mesh >= 256; // the reference's mesh leaves hold up to 254 triangles (bvh.rs:187,289): skipping one pays for many node steps
             a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512 && !(f.has_specular && big_mesh >= 4096);
             a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 20);
         }
@@ -1009,7 +1044,10 @@ static void ensure_fast_trees(const lg_accel *ca) {
     next->scene = a->scene;
     next->device = a->device;
     build_and_upload(next.get(), true); // throws: `a` is untouched
-    if (next->flat.dump_f != a->flat.dump_f || next->flat.dump_i != a->flat.dump_i)
+    // (bit patterns, not values: a NaN bound of a degenerate scene equals itself here)
+    if (next->flat.dump_f.size() != a->flat.dump_f.size() ||
+        (!a->flat.dump_f.empty() && std::memcmp(next->flat.dump_f.data(), a->flat.dump_f.data(), a->flat.dump_f.size() * sizeof(a->flat.dump_f[0])) != 0) ||
+        next->flat.dump_i != a->flat.dump_i)
         throw Error("the scene was modified after lg_accel_from: the accel's reference trees no longer match it (build a new accel)");
     HIP_TRY(hipDeviceSynchronize()); // nothing may still be reading the tables that are about to be replaced
     swap_tables(*a, *next);
@@ -1201,10 +1239,16 @@ static int capture_share(const lg_scene *s, lg_film *film, int device, uint32_t 
 }
 
 int lg_capture(const lg_scene *s, lg_film *film) { // lib.rs:55-104: the BVH is (re)built inside every capture
-    // The reference splits the film over `scene.threads` CPU threads (0 = all cores, lib.rs:58-62); here the
-    // film is split over the devices chosen with lg_set_devices (default: the one current device), capped by
-    // `scene.threads` when that is non-zero.  Pixels are independent, so the film is the same for any split.
+    // The reference splits the film over `scene.threads` CPU threads, 0 = all cores (lib.rs:58-62); here the film is
+    // split over devices: the ones named with lg_set_devices, the one named with lg_set_device, or -- a process that
+    // named none -- EVERY visible device, capped by `scene.threads` when that is non-zero.  Pixels are independent,
+    // so the film is the same for any split.
     std::vector<int> devs = g_devices;
+    if (devs.empty() && !g_device_chosen) {
+        int n_vis = 0;
+        if (hipGetDeviceCount(&n_vis) == hipSuccess)
+            for (int d = 0; d < n_vis; ++d) devs.push_back(d);
+    }
     if (s->s.threads != 0 && devs.size() > s->s.threads) devs.resize(s->s.threads);
     if (devs.size() <= 1) {
         lg_accel *a = accel_from_on(s, devs.empty() ? g_device : devs[0]);
@@ -1220,13 +1264,17 @@ int lg_capture(const lg_scene *s, lg_film *film) { // lib.rs:55-104: the BVH is 
         bool distinct = false;
         for (uint32_t r = 1; r < n; ++r) distinct = distinct || devs[r] != devs[0];
         if (distinct && !std::getenv("LASGUN_CAPTURE_NO_RCCL")) {
+            // RCCL missing or failing (no librccl, ncclCommInitAll refused, an exchange error) must not fail a capture
+            // that the RCCL-free path below can serve: say why under LASGUN_DEBUG and go on
             lg_multi *m = lg_multi_create(s, devs.data(), (int)n, block_rows);
-            if (!m) return 1;
-            int rc = lg_multi_capture(m, film);
-            std::string e = rc ? tl_error : std::string();
-            lg_multi_free(m);
-            if (rc) tl_error = e;
-            return rc;
+            int rc = m ? lg_multi_capture(m, film) : 1;
+            if (m) { std::string e = rc ? tl_error : std::string(); lg_multi_free(m); if (rc) tl_error = e; }
+            if (rc == 0) return 0;
+            static bool told = false;
+            if (!told && std::getenv("LASGUN_DEBUG")) {
+                told = true;
+                std::fprintf(stderr, "[lasgun] lg_capture: the RCCL gather is unavailable (%s); using one host thread and one D2H copy per device\n", tl_error.c_str());
+            }
         }
     }
     std::vector<int> rcs(n, 0);
@@ -1308,7 +1356,7 @@ int lg_accel_set_wavefront(const lg_accel *a, int enabled) {
     return 0;
 }
 int lg_accel_set_wf_split(const lg_accel *a, int bands) {
-    if (bands < 0 || bands > 8) return fail("bands must be 0 (default) .. 8");
+    if (bands < 0 || bands > 8) return fail("bands must be 0 (default) .. 8 (more than 4 are rendered as 4)");
     std::lock_guard<std::mutex> g(a->mtx);
     a->wf_split = (unsigned)bands;
     return 0;
@@ -1317,6 +1365,12 @@ int lg_accel_set_streaming(const lg_accel *a, int enabled) {
     std::lock_guard<std::mutex> g(a->mtx);
     a->streaming = enabled != 0;
     a->streaming_forced = enabled == 2; // 2 = use it whatever the scene and the launch size (tests)
+    return 0;
+}
+int lg_accel_set_prune(const lg_accel *a, int enabled) {
+    if (enabled < -1 || enabled > 1) return fail("prune must be -1 (default), 0 or 1");
+    std::lock_guard<std::mutex> g(a->mtx);
+    a->prune = enabled;
     return 0;
 }
 int lg_accel_set_mode(const lg_accel *a, int mode) {

@@ -31,13 +31,26 @@ constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
 constexpr uint32_t WF_NONE = 0xFFFFFFFFu, WF_MISS = 0xFFFFFFFEu; // wavefront pipeline: no such child / the ray hit nothing
 constexpr int MAX_CHAIN = 8;      // scene-graph nesting levels (root = 1)
 constexpr uint32_t NODE_LEAF = 0x80000000u;
+// reference trees: a leaf below this node holds a nested BVHAccel -- the pruned walk never skips such a
+// node, because its bounds on a primitive's t are stated per level, for spheres, boxes and triangles only
+constexpr uint32_t NODE_NOPRUNE = 0x40000000u;
+// Margins of the pruned walk, in units of the level's size S = |o - centre|_1 + (sum of the root box's extents):
+// a primitive's accepted hit point o + t*d lies within  e0 + S*(PRUNE_E1 + e2*S)  of its bounds box (per axis; triangles: on the
+// ray's dominant axis only).  u = 2^-53; the derivations give 114 u W^2 / r for a sphere, 4 u (|b| + |o|) for a
+// box, 12 u S for a triangle; the constants below keep a factor >= 8 above them.
+constexpr double PRUNE_E1 = 0x1p-46;          // per unit of S (boxes: 4u, triangles: 12u)
+constexpr double PRUNE_E0_PER_COORD = 0x1p-46; // e0 = this * (largest |coordinate| of the level's boxes): box rounding u|c -+ r|, 8u|b|
+constexpr double PRUNE_E2_TIMES_RMIN = 0x1p-42; // e2 = this / (smallest sphere radius of the level); 114 u = 2^-46.2
+constexpr double PRUNE_LIMIT_REL = 0x1p-40;    // the limit itself is taken as limit * (1 + this): covers the slab's own 3 roundings
+constexpr double PRUNE_RANGE = 0x1p100;        // magnitudes beyond [1/this, this] (scene or ray): the level is walked unpruned
 // LDS-resident scene image: node stride in 16-byte units.  80-byte nodes (and the 48-byte leaf records) make 16
 // consecutive records start in 16 different bank groups; a compile-time constant so that indexing is a shift and an add.
 constexpr uint32_t LDS_NODE_STRIDE = 5u;
 // LDS image, per accel (10 units = 160 bytes): [0..5] minv (12 doubles), [6] {byte offset of its tree in the image, compact prim
 // base, leaf_soup slot delta, flags}, [7] {parent, nchain, -, -}, [8..9] chain[8].  Entering and leaving nested accels is
 // a chain of DEPENDENT fetches of these fields; from LDS each link costs ~64 cycles instead of an L2 round trip.
-constexpr uint32_t LDS_ACCEL_UNITS = 10u;
+// [10..12] the pruned walk's constants of the level: {centre x, y}, {centre z, size}, {e0, e2} (DAccel::prune).
+constexpr uint32_t LDS_ACCEL_UNITS = 13u;
 
 struct alignas(64) DNode {
     double bmin[3];
@@ -102,6 +115,7 @@ struct alignas(16) DAccel {
     uint32_t lnode_base; // reference tree again, in the compact numbering of the LDS-resident scene image (DParams::lds_image)
     uint32_t lprim_base;
     uint32_t pad[2];
+    double prune[6]; // pruned walk: centre of the root box (3), sum of its extents, e0, e2 (e0 = +inf: this level is never pruned)
 };
 
 struct DStats { // per-launch counters (stats kernel variant only)
@@ -187,7 +201,7 @@ struct DParams {
     uint32_t wf_level;          // level of this launch
     uint32_t wf_levels;         // number of levels (recursion + 1, or 1 for scenes without glass / mirror)
     uint32_t tile0;             // first tile of the chunk (level 0: pixel tile = tile0 + work tile)
-    uint32_t pad_wf;
+    uint32_t prune;             // reference traversal: the pruned walk (lg_accel_set_prune / the accel's default; kernels.hip, traverse_ref<.., PRUNE>)
     uint32_t *wf_counts;        // device counters: [d] rays of level d (d >= 1), [wf_levels + d] appended hits of level d
     unsigned long long wf_cap;      // capacity (rays) of this level's arrays
     unsigned long long wf_cap_next; // ... of the next level's

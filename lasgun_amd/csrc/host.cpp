@@ -549,6 +549,7 @@ struct MeshTables { // per scene mesh, shared by all its instances
     uint32_t max_stack = 0;
     uint32_t fnode_base = 0, fprim_base = 0, fmax_stack = 0, fmax_stack1 = 0;
     Bounds root_bounds{};
+    double cmax = 0.0; // largest |coordinate| of its triangle boxes
     uint32_t tri_base = 0;
     bool has_n = false, has_uv = false;
     BuiltBVH bvh; // kept for the structure dump
@@ -599,7 +600,41 @@ struct Flattener {
         return worst;
     }
 
-    void append_nodes(const BuiltBVH &bvh, uint32_t &node_base) {
+    // Constants of the pruned walk for one BVHAccel level (DAccel::prune), from its root box, the
+    // largest coordinate magnitude of its boxes and its smallest sphere radius (0 = the level holds no sphere).
+    static void prune_constants(const Bounds &root, double cmax, double rmin, bool has_sphere, double out6[6]) {
+        const V3 ext = root.max - root.min;
+        const double size = ext.x + ext.y + ext.z;
+        out6[0] = 0.5 * (root.min.x + root.max.x); out6[1] = 0.5 * (root.min.y + root.max.y); out6[2] = 0.5 * (root.min.z + root.max.z);
+        out6[3] = size;
+        bool ok = std::isfinite(size) && std::isfinite(cmax) && size >= 1.0 / PRUNE_RANGE && cmax <= PRUNE_RANGE &&
+                  std::isfinite(out6[0]) && std::isfinite(out6[1]) && std::isfinite(out6[2]);
+        if (has_sphere) ok = ok && std::isfinite(rmin) && rmin >= 1.0 / PRUNE_RANGE; // (a radius <= 0 or NaN never passes)
+        out6[4] = ok ? PRUNE_E0_PER_COORD * cmax : INFINITY;
+        out6[5] = has_sphere && ok ? PRUNE_E2_TIMES_RMIN / rmin : 0.0;
+    }
+    static double bounds_cmax(const std::vector<Bounds> &pb) {
+        double m = 0.0;
+        for (const Bounds &b : pb)
+            for (int a = 0; a < 3; ++a) {
+                const double lo = std::fabs(comp(b.min, a)), hi = std::fabs(comp(b.max, a));
+                if (!(lo <= m)) m = lo; // (a NaN bound makes the maximum NaN: the level is then never pruned)
+                if (!(hi <= m)) m = hi;
+            }
+        return m;
+    }
+    // per node of a reference tree: does a leaf below it hold a nested accel (NODE_NOPRUNE)?
+    static std::vector<char> nodes_over_accels(const BuiltBVH &bvh, const std::vector<uint32_t> &ref) {
+        std::vector<char> np(bvh.nodes.size(), 0);
+        for (size_t i = bvh.nodes.size(); i-- > 0;) { // children follow their parent in the linear order
+            const LinNode &n = bvh.nodes[i];
+            if (n.leaf) { for (uint32_t k = 0; k < (n.c & 0xFFFFu); ++k) if ((ref[bvh.order[n.a + k]] >> 30) == PK_ACCEL) np[i] = 1; }
+            else np[i] = (char)(np[i + 1] | np[n.c]);
+        }
+        return np;
+    }
+
+    void append_nodes(const BuiltBVH &bvh, uint32_t &node_base, const std::vector<char> *noprune = nullptr) {
         node_base = (uint32_t)out.nodes.size();
         for (const LinNode &n : bvh.nodes) {
             DNode d{};
@@ -611,6 +646,7 @@ struct Flattener {
                 d.link = n.a; d.meta = NODE_LEAF | (n.c & 0xFFFFu);
             }
             else { d.link = n.c; d.meta = n.a & 3u; }
+            if (noprune && (*noprune)[out.nodes.size() - node_base]) d.meta |= NODE_NOPRUNE;
             out.nodes.push_back(d);
         }
         // child-pair records for the interior nodes
@@ -729,6 +765,7 @@ struct Flattener {
         mt.nnodes = (uint32_t)mt.bvh.nodes.size();
         mt.norder = (uint32_t)mt.bvh.order.size();
         mt.root_bounds = mt.bvh.nodes[0].b;
+        mt.cmax = bounds_cmax(pb);
         std::vector<uint32_t> refs(mt.bvh.order.size(), 0);
         mt.max_stack = stack_need(mt.bvh.nodes, refs, [](uint32_t) { return 0u; });
         if (with_fast) { // fast tree over the same triangles
@@ -785,6 +822,7 @@ struct Flattener {
         a.material = has_mat ? add_material(mat) : -1;
         a.flags = AF_MESH | (mt.has_n ? AF_HAS_N : 0u) | (mt.has_uv ? AF_HAS_UV : 0u) | (affine_is_identity(a.minv) ? AF_IDENTITY : 0u);
         set_chain(a, parent, id);
+        prune_constants(mt.root_bounds, mt.cmax, 0.0, false, a.prune);
         out.accels[id] = a;
         dump(mt.bvh, has_mat, false, idt);
         bound = b_transform(idt.m, mt.root_bounds);
@@ -863,8 +901,16 @@ struct Flattener {
         }
         BuiltBVH bvh = Builder(pb, n).run();
         uint32_t node_base;
-        append_nodes(bvh, node_base);
+        const std::vector<char> over_accels = nodes_over_accels(bvh, ref);
+        append_nodes(bvh, node_base, &over_accels);
         record_parents(bvh, node_base);
+        {
+            double rmin = INFINITY;
+            bool has_sphere = false;
+            for (size_t i = 0; i < n; ++i)
+                if (agg.contents[i].kind == SceneNode::SPHERE) { has_sphere = true; const double r = agg.contents[i].b[0]; if (!(r >= rmin)) rmin = r; }
+            prune_constants(bvh.nodes[0].b, bounds_cmax(pb), rmin, has_sphere, out.accels[id].prune);
+        }
         const std::vector<uint32_t> ref_leaf = ref_leaf_of_prims(bvh, n);
         out.accel_ref_leaf.resize(out.accels.size(), NO_HIT);
         out.sphere_ref_leaf.resize(out.spheres.size(), NO_HIT);

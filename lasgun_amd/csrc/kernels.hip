@@ -98,6 +98,23 @@ __device__ __forceinline__ bool slab_intersects_nc_t(const double bmin[3], const
     return !(tnear > tfar) && !(tfar <= 0.0);
 }
 
+// slab_intersects_nc, also handing back the three per-axis ENTRY parameters min(t1, t2) (the pruned walk compares each with its
+// own limit).  fmin ignores a NaN operand and yields NaN only when both are NaN (0 * inf twice: never for a box with min < max).
+__device__ __forceinline__ bool slab_intersects_nc_axes(const double bmin[3], const double bmax[3], const Ray &r, double &tx, double &ty, double &tz) {
+    double t1 = (bmin[0] - r.o.x) * r.dinv.x, t2 = (bmax[0] - r.o.x) * r.dinv.x;
+    tx = fmin_(t1, t2);
+    double tnear = tx, tfar = fmax_(t1, t2);
+    t1 = (bmin[1] - r.o.y) * r.dinv.y; t2 = (bmax[1] - r.o.y) * r.dinv.y;
+    ty = fmin_(t1, t2);
+    tnear = fmax_(tnear, ty);
+    tfar = fmin_(tfar, fmax_(t1, t2));
+    t1 = (bmin[2] - r.o.z) * r.dinv.z; t2 = (bmax[2] - r.o.z) * r.dinv.z;
+    tz = fmin_(t1, t2);
+    tnear = fmax_(tnear, tz);
+    tfar = fmin_(tfar, fmax_(t1, t2));
+    return !(tnear > tfar) && !(tfar <= 0.0);
+}
+
 // the same test, also handing back its tnear (used by the fast mode's front-to-back pruning)
 __device__ __forceinline__ bool slab_intersects_t(const double bmin[3], const double bmax[3], const Ray &r, double &tnear_out, double &tfar_out) {
     double t1 = (bmin[0] - r.o.x) * r.dinv.x, t2 = (bmax[0] - r.o.x) * r.dinv.x;
@@ -919,10 +936,23 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 // far (closest) or beyond the light (any-hit) -- margins as in prune_limit().  Exact ties in t (and NaN t), where the reference's
 // visit order decides, raise `tie`; the caller (walk() below) then puts the winner to the reference tree's own box tests
 // (ref_candidate) and re-traces with the reference walk when either fails.
-template <bool LDSS, bool FAST = false>
+//
+// PRUNE (the reference tree, the reference's visit order; DESIGN.md section 3.5 has the derivations): a node is skipped when,
+// on some axis, the ray enters its slab only at a parameter beyond the limit -- the best accepted t so far (closest hit) or 1
+// (any-hit) -- by more than that axis's margin.  Every primitive below such a node would be rejected by the reference's own
+// `t >= isect.t` (sphere.rs:86, cuboid.rs:95, triangle.rs:251) or could not bring isect.t below 1 (point.rs:49), so the lane's
+// sequence of accepted hits is the reference's.  What makes that a statement about COMPUTED values: an accepted hit point
+// o + t*d lies within eps = e0 + S*(PRUNE_E1 + e2*S) of the primitive's bounds box, S = |o - centre|_1 + size of the level --
+// for a sphere because the computed root satisfies the sphere's equation to 114 u W^2, for a box because t IS one of its plane
+// parameters, for a triangle on the ray's dominant axis kz only (its t is a convex combination of the vertices' plane
+// parameters along kz, computed by the slab test's own expression; the other axes promise nothing for a triangle seen edge-on)
+// -- hence t >= (entry parameter on the axis) - eps * |1/d_axis|.  Nodes over a nested accel are never skipped (NODE_NOPRUNE),
+// levels or rays outside the stated magnitude range are walked unpruned (eps = +inf).
+template <bool LDSS, bool FAST = false, bool PRUNE = false>
 __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
                                              Best &best, const uint4 *scn, bool &tie) {
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
+    static_assert(!(FAST && PRUNE), "the fast mode prunes its own trees by its own rule");
 #ifdef LG_STAMPS
     unsigned long long stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_readcyclecounter();
     unsigned long long stamp_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -943,6 +973,37 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     uint32_t negmask = neg_mask(ray);   // dir_is_neg (bvh.rs:463)
     uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0;
     uint32_t state = ST_NODE;
+    // ---- PRUNE: per-axis limits of the level the lane is in, and the level's margin
+    V3 plim{INFINITY, INFINITY, INFINITY};
+    double peps = INFINITY;
+    auto prune_limits = [&](const double limit) { // limit >= 0 (every accepted t is), or +inf before the first hit
+        const double lb = limit + limit * PRUNE_LIMIT_REL;
+        V3 m{lb + peps * fabs(ray.dinv.x), lb + peps * fabs(ray.dinv.y), lb + peps * fabs(ray.dinv.z)}; // (an axis with d == 0: +inf)
+        if (L.flags & AF_MESH) { // triangles: the dominant axis alone (max_dimension as in tri_setup, triangle.rs:186)
+            const int kz = max_dimension(vabs(ray.d));
+            if (kz != 0) m.x = INFINITY;
+            if (kz != 1) m.y = INFINITY;
+            if (kz != 2) m.z = INFINITY;
+        }
+        plim = m;
+    };
+    auto prune_level = [&]() { // after L and ray have changed
+        double c[6];
+        if (LDSS) {
+            const double2 *q = reinterpret_cast<const double2 *>(scn + (P.lds_accel_off + L.accel * LDS_ACCEL_UNITS + 10u));
+            const double2 a = q[0], b = q[1], e = q[2];
+            c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
+        } else {
+            const double *q = P.accels[L.accel].prune;
+            c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[3]; c[4] = q[4]; c[5] = q[5];
+        }
+        const double S = ((fabs(ray.o.x - c[0]) + fabs(ray.o.y - c[1])) + fabs(ray.o.z - c[2])) + c[3];
+        const double idm = fmin_(fmin_(fabs(ray.dinv.x), fabs(ray.dinv.y)), fabs(ray.dinv.z)); // 1 / max |d|
+        const bool in_range = S <= PRUNE_RANGE && idm >= 1.0 / PRUNE_RANGE && idm <= PRUNE_RANGE; // (NaN: false)
+        peps = in_range ? c[4] + S * (PRUNE_E1 + c[5] * S) : INFINITY;
+        prune_limits(anyhit ? 1.0 : best.t);
+    };
+    if (PRUNE) prune_level();
     LG_STAMP(0);
     for (;;) {
         // ---- phase A: interior nodes (bvh.rs:471-505), until no lane of the wave is at a node
@@ -969,7 +1030,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     bmin[0] = nd.bmin[0]; bmin[1] = nd.bmin[1]; bmin[2] = nd.bmin[2]; bmax[0] = nd.bmax[0]; bmax[1] = nd.bmax[1]; bmax[2] = nd.bmax[2];
                     const bool lf = (nd.meta & NODE_LEAF) != 0u;
                     w_link = (lf ? L.prim_base : L.node_base) + nd.link;
-                    w_meta = lf ? NODE_LEAF : 1u << (nd.meta & 3u);
+                    w_meta = (lf ? NODE_LEAF : 1u << (nd.meta & 3u)) | (nd.meta & NODE_NOPRUNE);
                     w_end = w_link + (nd.meta & 0xFFFFu);
                 }
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
@@ -980,6 +1041,13 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     double tn, tf;
                     hit = slab_intersects_nc_t(bmin, bmax, ray, tn, tf);
                     hit = hit && !(tn - 4e-8 * fabs(tf) > limit);
+                } else if (PRUNE) {
+                    // the reference's test, and the node is skipped as well when on some axis the ray reaches its slab only beyond
+                    // the limit (+ that axis's margin); never a node over a nested accel
+                    double tx, ty, tz;
+                    hit = slab_intersects_nc_axes(bmin, bmax, ray, tx, ty, tz);
+                    const bool beyond = tx > plim.x || ty > plim.y || tz > plim.z; // (a NaN entry parameter compares false)
+                    hit = hit && !(beyond && (w_meta & NODE_NOPRUNE) == 0u);
                 } else hit = slab_intersects_nc(bmin, bmax, ray);
                 const bool leaf = (int32_t)w_meta < 0;            // n_primitives > 0 (bvh.rs:475): the builder emits no empty leaf
                 const bool neg = (negmask & w_meta) != 0u;        // dir_is_neg[axis] (bvh.rs:496)
@@ -1012,6 +1080,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
             else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
             else done = mesh_leaf2<2, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
             if (FAST) limit = prune_limit(best.t, anyhit);
+            if (PRUNE && !anyhit) prune_limits(best.t);
             if (done) state = ST_DONE;
             else if (sp != base) { --sp; cur = stk[sp * stride]; state = ST_NODE; }
             else state = ST_LEVEL_DONE;
@@ -1073,6 +1142,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 if (accepted) {
                     best.t = t; best.ref = ref; best.accel = L.accel;
                     if (FAST) limit = prune_limit(t, anyhit);
+                    if (PRUNE && !anyhit) prune_limits(t);
                     if (anyhit && t < 1.0) state = ST_DONE; // occluded: point.rs:49 only asks isect.t < 1.0
                 }
                 if (state == ST_LEAF && li >= le) { // leaf exhausted: next pending node of this level, or the level is done
@@ -1103,6 +1173,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 negmask = neg_mask(ray);
             }
             if (FAST && (L.flags & AF_MESH)) tri = tri_setup(ray);
+            if (PRUNE) prune_level();
             cur = L.node_base;
             state = ST_NODE; // node 0 is tested when visited (bvh.rs:472-473)
         }
@@ -1137,6 +1208,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     four_a = 4.0 * dd;
                     negmask = neg_mask(ray);
                 }
+                if (PRUNE) prune_level();
                 if (li < le) state = ST_LEAF;
                 else if (sp != base) { --sp; cur = stk[sp * stride]; state = ST_NODE; }
                 else state = ST_LEVEL_DONE; // the parent level is exhausted as well
@@ -1374,7 +1446,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
 //   * any-hit: an occluder counts if the reference tree would have tested it (the reference then finds it or one before it);
 //     "not occluded" stands unless a tie / NaN makes the reference's own answer depend on its visit order;
 // otherwise the ray is traced again with the reference walk over the tables in HBM / L2.
-template <bool LDSS, bool FAST>
+template <bool LDSS, bool FAST, bool PRUNE = false>
 __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const bool anyhit, uint32_t *stack, const uint32_t stride, Best &best,
                                      const uint4 *scn) {
     bool tie = false;
@@ -1382,7 +1454,7 @@ __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const boo
     if (FAST) traverse_fast(P, ray, anyhit, stack, stride, best, scn, tie);
     else
 #endif
-    traverse_ref<LDSS, FAST>(P, ray, anyhit, stack, stride, best, scn, tie);
+    traverse_ref<LDSS, FAST, PRUNE>(P, ray, anyhit, stack, stride, best, scn, tie);
     if (!FAST) return;
     bool redo;
     if (anyhit && !(best.t < 1.0)) redo = tie;
@@ -1982,8 +2054,9 @@ __device__ __forceinline__ void stash_get(const DParams &P, unsigned long long g
 #define LG_LDSS_BLOCK 1024
 // LDSS (reference traversal only): one 1024-lane workgroup per CU with the scene's node / primref / sphere /
 // cuboid tables copied into LDS behind the stacks (see load_node); otherwise 256-lane workgroups and L1/L2.
-template <bool STATS, bool FAST, bool LDSS>
+template <bool STATS, bool FAST, bool LDSS, bool PRUNE = false>
 __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(const DParams P) {
+    static_assert(!(PRUNE && (STATS || FAST)), "the pruned reference walk has no counting or fast form");
     static_assert(!(FAST && LDSS) && !(STATS && LDSS), "LDS-resident scene: plain reference traversal only");
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -2052,7 +2125,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
                     bool tie = false;
                     Counters before = cnt;
 #ifndef LG_OLD_TRAVERSE
-                    if (!STATS) walk<LDSS, FAST>(P, tray, shadow_job, stack, stride, b, scn);
+                    if (!STATS) walk<LDSS, FAST, PRUNE>(P, tray, shadow_job, stack, stride, b, scn);
                     else
 #endif
                     {
@@ -2582,9 +2655,10 @@ __device__ __forceinline__ bool hit_of(const DParams &P, const HitSlots &s, uint
 
 // W1 / W2: persistent traversal kernels of the wavefront pipeline (tile counter, per-lane LDS stack; LDSS as above).
 // L0: the launch is level 0's (rays from the camera, work items = the chunk's pixels in 8x8 tiles).
-template <bool FAST, bool SHADOW, bool LDSS, bool L0>
+template <bool FAST, bool SHADOW, bool LDSS, bool L0, bool PRUNE = false>
 __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) wf_trace_kernel(const DParams P) {
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
+    static_assert(!(FAST && PRUNE), "the fast mode prunes its own trees by its own rule");
     static_assert(!(SHADOW && L0), "the shadow pass has one form for every level");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t level = L0 ? 0u : P.wf_level;
@@ -2632,7 +2706,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             b.ref = NO_HIT; b.t = INFINITY; b.accel = 0u;
             if (active) {
                 bool tie = false;
-                walk<LDSS, FAST>(P, ray, false, stack, stride, b, scn);
+                walk<LDSS, FAST, PRUNE>(P, ray, false, stack, stride, b, scn);
                 (void)tie;
             }
             const bool hit = active && b.ref != NO_HIT;
@@ -2684,7 +2758,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
                 Ray sray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
                 Best b;
                 bool tie = false;
-                walk<LDSS, FAST>(P, sray, true, stack, stride, b, scn);
+                walk<LDSS, FAST, PRUNE>(P, sray, true, stack, stride, b, scn);
                 (void)tie;
                 if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
             }
@@ -2959,12 +3033,18 @@ hipError_t launch_probe_lds(uint32_t blocks, uint32_t iters, uint32_t *sink, hip
 // host-callable launchers (used by capi.cpp)
 // ------------------------------------------------------------------------------------------
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
+    const bool prune = P.prune && !stats && !fast;
     if (P.lds_image && !stats && !fast) { // LDS-resident scene: `blocks` = one 1024-lane workgroup per CU
         size_t lds = (size_t)P.stack_depth * LG_LDSS_BLOCK * sizeof(uint32_t) + (size_t)P.lds_image_n16 * 16u;
-        hipLaunchKernelGGL((trace_kernel<false, false, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
+        if (prune) hipLaunchKernelGGL((trace_kernel<false, false, true, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((trace_kernel<false, false, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
         return hipGetLastError();
     }
     size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
+    if (prune) {
+        hipLaunchKernelGGL((trace_kernel<false, false, false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        return hipGetLastError();
+    }
     if (fast) {
         if (stats) hipLaunchKernelGGL((trace_kernel<true, true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
         else hipLaunchKernelGGL((trace_kernel<false, true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
@@ -3008,7 +3088,11 @@ hipError_t stream_packet_occupancy(uint32_t stack_depth, int *blocks_per_cu) { /
 }
 // raise the dynamic-LDS limit of the LDS-resident-scene variants to `bytes`
 hipError_t stream_trace_ldss_prepare(size_t bytes) {
-    const void *fns[8] = {reinterpret_cast<const void *>(trace_kernel<false, false, true>),
+    const void *fns[12] = {reinterpret_cast<const void *>(trace_kernel<false, false, true>),
+                          reinterpret_cast<const void *>(trace_kernel<false, false, true, true>),
+                          reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, true, true>),
+                          reinterpret_cast<const void *>(wf_trace_kernel<false, true, true, false, true>),
+                          reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, false, true>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, true>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, true, true, false>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, false>),
@@ -3029,10 +3113,16 @@ hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t bl
     const uint32_t depth = fast ? stack_depth : P.stack_depth;
     size_t lds = (size_t)depth * block * sizeof(uint32_t) + (ldss ? (size_t)P.lds_image_n16 * 16u : 0u);
 #define LG_LAUNCH(F, S, L, Z) hipLaunchKernelGGL((wf_trace_kernel<F, S, L, Z>), dim3(blocks), dim3(block), lds, stream, P)
+#define LG_LAUNCH_PRUNED(S, L, Z) hipLaunchKernelGGL((wf_trace_kernel<false, S, L, Z, true>), dim3(blocks), dim3(block), lds, stream, P)
+    if (P.prune && !fast) {
+        if (ldss) { if (shadow) LG_LAUNCH_PRUNED(true, true, false); else if (l0) LG_LAUNCH_PRUNED(false, true, true); else LG_LAUNCH_PRUNED(false, true, false); }
+        else { if (shadow) LG_LAUNCH_PRUNED(true, false, false); else if (l0) LG_LAUNCH_PRUNED(false, false, true); else LG_LAUNCH_PRUNED(false, false, false); }
+    } else
     if (fast) { if (shadow) LG_LAUNCH(true, true, false, false); else if (l0) LG_LAUNCH(true, false, false, true); else LG_LAUNCH(true, false, false, false); }
     else if (ldss) { if (shadow) LG_LAUNCH(false, true, true, false); else if (l0) LG_LAUNCH(false, false, true, true); else LG_LAUNCH(false, false, true, false); }
     else { if (shadow) LG_LAUNCH(false, true, false, false); else if (l0) LG_LAUNCH(false, false, false, true); else LG_LAUNCH(false, false, false, false); }
 #undef LG_LAUNCH
+#undef LG_LAUNCH_PRUNED
     return hipGetLastError();
 }
 hipError_t launch_wf_shade(const DParams &P, uint32_t blocks, hipStream_t stream) {
@@ -3090,7 +3180,9 @@ hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu) 
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, false, false>, LG_BLOCK, lds);
 }
 hipError_t trace_set_lds_limit(size_t bytes) {
-    const void *fns[14] = {reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, true>), reinterpret_cast<const void *>(wf_trace_kernel<false, true, false, false>),
+    const void *fns[18] = {reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, true>), reinterpret_cast<const void *>(wf_trace_kernel<false, true, false, false>),
+                          reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, true, true>), reinterpret_cast<const void *>(wf_trace_kernel<false, true, false, false, true>),
+                          reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, false, true>), reinterpret_cast<const void *>(trace_kernel<false, false, false, true>),
                           reinterpret_cast<const void *>(wf_trace_kernel<true, false, false, true>), reinterpret_cast<const void *>(wf_trace_kernel<true, true, false, false>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, false>), reinterpret_cast<const void *>(wf_trace_kernel<true, false, false, false>),
                           reinterpret_cast<const void *>(trace_kernel<false, false, false>), reinterpret_cast<const void *>(trace_kernel<true, false, false>),

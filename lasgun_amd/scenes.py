@@ -548,3 +548,96 @@ def adversarial_mesh_scene(api, seed):
     for i in range(int(rng.integers(1, 3))):
         sc.add_point_light((rng.normal(size=3) * dist * 0.7).tolist(), rng.uniform(0.3, 0.9, 3).tolist(), [1.0, 0.0, 0.0])
     return sc
+
+
+def _slab_mesh_obj(rng, n_quads, snap):
+    """OBJ text: axis-aligned quads in planes whose offsets are multiples of `snap` (rays of an axis-aligned orthographic
+    camera on the same lattice lie IN those planes: triangles seen exactly edge-on), generic triangles, and long thin ones."""
+    lines, nv = [], 0
+    def quad(p, e1, e2):
+        nonlocal nv
+        for v in (p, p + e1, p + e1 + e2, p + e2):
+            lines.append("v %.9g %.9g %.9g" % tuple(v))
+        lines.append("f %d %d %d" % (nv + 1, nv + 2, nv + 3))
+        lines.append("f %d %d %d" % (nv + 1, nv + 3, nv + 4))
+        nv += 4
+    import numpy as np
+    for i in range(n_quads):
+        kind = int(rng.integers(4))
+        p = np.round(rng.uniform(-1.5, 1.5, 3) / snap) * snap
+        if kind < 3:  # a quad in the plane {axis = const}
+            e1 = np.zeros(3); e2 = np.zeros(3)
+            e1[(kind + 1) % 3] = float(np.round(rng.uniform(0.05, 0.8) / snap) * snap) or snap
+            e2[(kind + 2) % 3] = float(np.round(rng.uniform(0.05, 0.8) / snap) * snap) or snap
+            quad(p, e1, e2)
+        else:         # a generic or a needle quad
+            e1 = rng.uniform(-0.5, 0.5, 3)
+            e2 = rng.uniform(-0.5, 0.5, 3) * (10.0 ** rng.uniform(-6, 0))
+            quad(p, e1, e2)
+    return "\n".join(lines) + "\n"
+
+
+def adversarial_prune_scene(api, seed):
+    """Built against the pruned reference walk (lg_accel_set_prune): meshes of several fat leaves (>= 600 triangles) full of
+    coplanar, axis-aligned faces; cameras whose rays lie exactly in those planes (orthographic, axis-aligned, on the same
+    lattice) or graze them; spheres resting on the planes and touching each other (rays through the poles and the tangent
+    points); boxes sharing faces; tiny spheres seen from far away; lights inside, outside and on surfaces."""
+    import numpy as np
+    G = api; M = api.Material
+    rng = np.random.default_rng(seed + 200000)
+    sc = G.Scene.new()
+    snap = 1.0 / 32.0
+    mode = int(rng.integers(4))
+    if mode == 0:    # orthographic, axis-aligned, film lattice = the mesh's lattice (64 x 48 film, scale 3: pixel pitch 1/16)
+        cam = sc.set_orthographic_camera(3.0)
+        eye = np.round(rng.uniform(-0.5, 0.5, 3) / snap) * snap + [0, 0, 6.0]
+        cam.look_at(eye.tolist(), (eye - [0, 0, 6.0]).tolist(), [0, 1, 0])
+    elif mode == 1:  # perspective from a lattice point: the central row and column of rays have an exactly zero component
+        cam = sc.set_perspective_camera(float(rng.uniform(30, 70)))
+        eye = np.round(rng.uniform(-1, 1, 3) / snap) * snap + [0, 0, 5.0]
+        cam.look_at(eye.tolist(), (eye - [0, 0, 5.0]).tolist(), [0, 1, 0])
+    elif mode == 2:  # far away: large |o - c| / r
+        dist = float(10.0 ** rng.uniform(2, 4))
+        cam = sc.set_perspective_camera(float(np.degrees(2.0 * np.arctan(2.0 / dist)) * rng.uniform(0.6, 1.4)))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        cam.look_at((d * dist).tolist(), rng.uniform(-0.3, 0.3, 3).tolist(), [0, 1, 0])
+    else:            # generic, inside the cloud
+        cam = sc.set_perspective_camera(float(rng.uniform(40, 100)))
+        cam.look_at(rng.uniform(-1.2, 1.2, 3).tolist(), rng.uniform(-1, 1, 3).tolist(), [0, 1, 0])
+    sc.set_ambient_light([0.15, 0.15, 0.15])
+    sc.set_max_recursion_depth(int(rng.integers(0, 3)))
+    mats = [M.matte(rng.uniform(0.2, 1, 3).tolist(), 0.0), M.plastic(rng.uniform(0.2, 1, 3).tolist(), [0.5, 0.5, 0.5], 0.3),
+            M.mirror([0.6, 0.6, 0.6]), M.glass([0.9, 0.9, 0.9], [0.9, 0.9, 0.9], 1.3)]
+    nmat = 4 if rng.random() < 0.4 else 2
+    mesh = sc.parse_obj(_slab_mesh_obj(rng, int(rng.integers(300, 700)), snap))
+    root = sc.root
+    if rng.random() < 0.5:
+        root.add_obj_of(mesh, mats[0])                       # the mesh accel directly in the root (identity all the way)
+    else:
+        g = G.Aggregate.new()
+        if rng.random() < 0.5:
+            g.translate((np.round(rng.uniform(-0.5, 0.5, 3) / snap) * snap).tolist())  # lattice-preserving
+        else:
+            g.rotate_y(float(rng.choice([90.0, 180.0, 37.0]))); g.scale(1.0, float(rng.choice([1.0, 0.5, 2.0])), 1.0)
+        g.add_obj_of(mesh, mats[1])
+        root.add_group(g)
+    # spheres resting on lattice planes, chains of touching spheres, twins
+    for i in range(int(rng.integers(10, 120))):
+        r = float(rng.choice([snap, 2 * snap, 0.1, 10.0 ** rng.uniform(-3, -0.7)]))
+        c = np.round(rng.uniform(-1.5, 1.5, 3) / snap) * snap
+        c[1] += r if rng.random() < 0.5 else 0.0             # its lowest point on a lattice plane
+        root.add_sphere(c.tolist(), r, mats[i % nmat])
+        if rng.random() < 0.3:                               # a neighbour touching it exactly (along an axis)
+            ax = int(rng.integers(3)); c2 = c.copy(); c2[ax] += 2 * r
+            root.add_sphere(c2.tolist(), r, mats[(i + 1) % nmat])
+    for i in range(int(rng.integers(0, 16))):                # boxes on the lattice, sharing faces
+        lo = np.round(rng.uniform(-1.5, 1.0, 3) / snap) * snap
+        d = np.round(rng.uniform(snap, 0.6, 3) / snap) * snap
+        root.add_box(lo.tolist(), (lo + d).tolist(), mats[i % nmat])
+        if rng.random() < 0.5:
+            lo2 = lo.copy(); lo2[0] += d[0]
+            root.add_box(lo2.tolist(), (lo2 + d).tolist(), mats[(i + 1) % nmat])
+    for i in range(int(rng.integers(1, 4))):
+        p = np.round(rng.uniform(-1.8, 1.8, 3) / snap) * snap if rng.random() < 0.5 else rng.uniform(-3, 3, 3)
+        sc.add_point_light(p.tolist(), rng.uniform(0.3, 0.9, 3).tolist(), [1.0, 0.0, 0.0])
+    return sc

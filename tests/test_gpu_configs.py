@@ -34,8 +34,10 @@ FULL = {
 }
 # (label, streaming, wavefront, fast).  streaming 0 = megakernel; 2 = streamed wherever the organisation exists for the scene:
 # the wavefront pipeline takes every scene (glass / mirror: level by level), the three-kernel one only scenes without them
-ORGANISATIONS = [("megakernel", 0, True, False), ("wavefront", 2, True, False), ("pipeline3", 2, False, False),
-                 ("megakernel-fast", 0, True, True), ("wavefront-fast", 2, True, True)]
+# prune: the pruned form of the reference walk (lg_accel_set_prune; these scenes' default) against the plain one
+ORGANISATIONS = [("megakernel", 0, True, False, False), ("wavefront", 2, True, False, False), ("pipeline3", 2, False, False, False),
+                 ("megakernel-pruned", 0, True, False, True), ("wavefront-pruned", 2, True, False, True),
+                 ("megakernel-fast", 0, True, True, False), ("wavefront-fast", 2, True, True, False)]
 
 
 @pytest.mark.parametrize("name", list(FULL))
@@ -59,10 +61,11 @@ def test_full_size_config_vs_oracle_sample(name):
     film = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
     first = None
-    for label, streaming, wavefront, fast in ORGANISATIONS:
+    for label, streaming, wavefront, fast, prune in ORGANISATIONS:
         G.set_streaming(acc, streaming)
         G.set_wavefront(acc, wavefront)
         G.set_mode(acc, fast)
+        G.set_prune(acc, prune)
         film.zero_()
         torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
         G.capture_rows_device(acc, w, h, 0, h, film.data_ptr(), row0=0)
@@ -82,6 +85,7 @@ def test_full_size_config_vs_oracle_sample(name):
     G.set_streaming(acc, 1)
     G.set_wavefront(acc, True)
     G.set_mode(acc, False)
+    G.set_prune(acc, None)
     # ray accounting on two 32-row bands: through the torus (config 4 glass: its refractions) and through the mirror sphere
     a, b = G.capture_stats(acc, w, h, h // 2, h // 2 + 32), G.capture_stats(acc, w, h, (h * 11) // 16, (h * 11) // 16 + 32)
     st = {key: a[key] + b[key] for key in a}
@@ -97,10 +101,11 @@ def test_full_size_config_crop_goldens(name):
     builder, w, h, x0, y0, cw, ch = CROPS[name]
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     acc = G.Accel(builder(G))
-    for label, streaming, wavefront, fast in ORGANISATIONS:
+    for label, streaming, wavefront, fast, prune in ORGANISATIONS:
         G.set_streaming(acc, streaming)
         G.set_wavefront(acc, wavefront)
         G.set_mode(acc, fast)
+        G.set_prune(acc, prune)
         rgba, rad = G.capture_rect(acc, w, h, x0, y0, x0 + cw, y0 + ch)
         assert np.array_equal(rgba, z["rgba"]), (name, label)
         assert np.array_equal(bits(rad), bits(z["radiance"])), (name, label)

@@ -35,9 +35,12 @@ GENERATORS = {
     "random": (S.random_scene, (56, 40)),
     "adversarial": (S.adversarial_scene, (64, 48)),
     "adversarial_mesh": (S.adversarial_mesh_scene, (64, 48)),
+    "adversarial_prune": (S.adversarial_prune_scene, (64, 48)),
 }
-# (streaming, fast, packet): megakernel and wavefront pipeline in either traversal mode, three-kernel pipeline with the packet walk
-ORGANISATIONS = ((0, False, False), (0, True, False), (2, False, False), (2, True, False), (2, False, True))
+# (streaming, fast, packet, prune): megakernel and wavefront pipeline in either traversal mode, three-kernel pipeline with the
+# packet walk, and the pruned form of the reference walk in megakernel and wavefront pipeline
+ORGANISATIONS = ((0, False, False, False), (0, True, False, False), (2, False, False, False), (2, True, False, False), (2, False, True, False),
+                 (0, False, False, True), (2, False, False, True))
 
 
 @pytest.mark.parametrize("gen", sorted(GENERATORS))
@@ -66,8 +69,9 @@ def test_fuzz_campaign(gen):
         acc = G.Accel(build(G, seed))
         done["scenes"] += 1
         done["nan_pixels"] += int(np.isnan(np.asarray(orad)).any(axis=-1).sum())
-        for streaming, fast, packet in ORGANISATIONS:
+        for streaming, fast, packet, prune in ORGANISATIONS:
             G.set_streaming(acc, streaming)
+            G.set_prune(acc, prune)
             try:
                 G.set_mode(acc, fast)
             except la.LasgunError as e:  # a transform whose matrix and inverse disagree: fast mode is refused, not wrong
@@ -80,7 +84,7 @@ def test_fuzz_campaign(gen):
             rad = G.capture_radiance(acc, w, h)
             done["renders"] += 1
             if not (np.array_equal(film.pixels(), ofilm.pixels()) and same_f64(rad, orad)):
-                done["mismatches"].append([seed, streaming, fast, packet])
+                done["mismatches"].append([seed, streaming, fast, packet, prune])
         if done["scenes"] % 25 == 0:
             print("fuzz %s: %d scenes, %d renders, %d mismatches" % (gen, done["scenes"], done["renders"], len(done["mismatches"])), flush=True)
     log = os.environ.get("LASGUN_FUZZ_LOG")
