@@ -20,7 +20,7 @@ namespace lg {
 // kernels.hip
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
 hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
-hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, bool fixup, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
+hipError_t launch_stream_fixup(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream);
 hipError_t launch_stream_packet(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream);
 hipError_t stream_packet_occupancy(uint32_t stack_depth, int *blocks_per_cu);
 hipError_t launch_stream_shade(const DParams &P, hipStream_t stream);
@@ -28,7 +28,6 @@ hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t bl
 hipError_t launch_wf_shade(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t launch_wf_combine(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t wf_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
-hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
 hipError_t trace_set_lds_limit(size_t bytes);
 hipError_t stream_trace_ldss_prepare(size_t bytes);
 hipError_t launch_kat(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d, double *out,
@@ -226,7 +225,6 @@ struct lg_accel {
     // ray's cost (tools/threshold_sweep.py): set from the scene by lg_accel_from
     bool streaming_pays = false;
     unsigned long long streaming_min_items = 1ull << 20;
-    uint32_t stream_blocks = 1, stream_blocks_fast = 1;
     uint32_t wf_blocks = 1, wf_blocks_fast = 1;   // grids of the wavefront pipeline's 256-lane traversal kernels
     mutable bool wavefront = true;               // lg_accel_set_wavefront: level-by-level pipeline instead of the three-kernel one
     mutable size_t wf_budget = 0;                 // bytes one launch context may hold for it (0 = from the free memory at first use)
@@ -245,8 +243,7 @@ struct lg_accel {
     mutable std::mutex mtx;
     hipStream_t stream = nullptr;
     uint32_t stack_depth = 1;      // reference traversal
-    uint32_t stack_depth_fast = 1; // fast traversal, first formulation (two words per pending child): the counting and debug kernels
-    uint32_t stack_depth_fast1 = 1; // fast traversal, second formulation (one word per pending child; also deep enough for its reference re-trace)
+    uint32_t stack_depth_fast1 = 1; // fast traversal (one word per pending child; also deep enough for its reference re-trace)
     uint32_t max_blocks = 1;
     uint32_t max_blocks_fast = 1;
     uint64_t device_bytes = 0;
@@ -525,14 +522,14 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     lg_accel::LaunchCtx &c = ctx_for(a, stream);
     P.tile_counter = c.tile_counter.p;
     // ---- wavefront pipeline: li() level by level (any scene with <= 32 lights; not the counting variant, not the packet walk)
-    if (a.streaming && a.wavefront && !stats && P.nlights <= 32 && P.recursion < 20 && !(a.packet && !a.fast) &&
+    if (a.streaming && !stats && P.nlights <= 32 && P.recursion < 20 && !(a.packet && !a.fast) &&
         (a.streaming_forced || (a.streaming_pays && (unsigned long long)P.ntiles * 64ull >= a.streaming_min_items))) {
         enqueue_wavefront(a, P, c, stream);
         return;
     }
-    // ---- streaming pipeline: no glass / mirror (no recursion), <= 32 lights, not the counting variant
-    // and enough work to amortise 4 launches per supersample (below ~1 Mpixel the megakernel wins: measured)
-    if (a.streaming && !stats && !a.flat.has_specular && P.nlights <= 32 &&
+    // ---- packet organisation (opt-in, lg_accel_set_packet): one tree walk per wavefront + fix-up pass + shade; no glass / mirror
+    // (no recursion), <= 32 lights, not the counting variant
+    if (a.streaming && a.packet && !a.fast && !stats && !a.flat.has_specular && P.nlights <= 32 &&
         (a.streaming_forced || (a.streaming_pays && (unsigned long long)P.ntiles * 64ull >= a.streaming_min_items))) {
         const uint32_t nsamples = P.ss_root * P.ss_root;
         P.n_items = (unsigned long long)P.ntiles * 64ull;
@@ -545,15 +542,6 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         if (nsamples > 1 && c.st_accum.n < 3 * n) { HIP_TRY(hipDeviceSynchronize()); c.st_accum.alloc(3 * n); }
         P.hit_ref = c.st_hit_ref.p; P.vis = c.st_vis.p;
         P.frame = c.st_frame.p; P.accum = c.st_accum.p;
-        uint32_t cap = a.fast ? a.stream_blocks_fast : a.stream_blocks;
-        uint32_t blocks = (P.ntiles + 3u) / 4u;
-        if (blocks > cap) blocks = cap;
-        uint32_t depth = a.fast ? a.stack_depth_fast1 : a.stack_depth;
-        if (!a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS
-            P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
-            P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
-            blocks = a.ldss_blocks;
-        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (a.profiling) {
             HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -571,9 +559,8 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
 #ifdef LG_STAMPS
         P.stamp_counts = reinterpret_cast<unsigned long long *>(a.stats.p + 1);
 #endif
-        const bool packet = a.packet && !a.fast; // one tree walk per wavefront, then a fix-up pass over the lanes that met a tie
-        uint32_t pblocks = blocks, fblocks = 1;
-        if (packet) {
+        uint32_t pblocks = 1, fblocks = 1;
+        {
             if (c.st_tie_flag.n < n || c.st_tie_tiles.n < P.ntiles) { HIP_TRY(hipDeviceSynchronize()); c.st_tie_flag.alloc(n); c.st_tie_tiles.alloc(P.ntiles); }
             P.tie_flag = c.st_tie_flag.p; P.tie_tiles = c.st_tie_tiles.p;
             if (a.lds_scene && a.packet_lds) { // the image fits in LDS: one 1024-lane workgroup per CU
@@ -586,15 +573,11 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
             }
             fblocks = (P.ntiles + 3u) / 4u; if (fblocks > 256u) fblocks = 256u;
         }
-        auto trace = [&](bool shadow) {
-            if (!packet) {
-                HIP_TRY(hipMemsetAsync(c.tile_counter.p, 0, sizeof(uint32_t), stream));
-                return launch_stream_trace(P, a.fast, shadow, false, blocks, depth, stream);
-            }
+        auto trace = [&](bool shadow) { // one tree walk per wavefront, then the lanes that met a tie again, privately
             HIP_TRY(hipMemsetAsync(c.tile_counter.p, 0, 3 * sizeof(uint32_t), stream));
             hipError_t e = launch_stream_packet(P, shadow, pblocks, stream);
             if (e != hipSuccess) return e;
-            return launch_stream_trace(P, false, shadow, true, fblocks, depth, stream);
+            return launch_stream_fixup(P, shadow, fblocks, stream);
         };
         for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
             P.sample_index = sidx;
@@ -649,7 +632,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    HIP_TRY(launch_trace(P, stats, a.fast, blocks, a.fast ? (stats ? a.stack_depth_fast : a.stack_depth_fast1) : a.stack_depth, stream));
+    HIP_TRY(launch_trace(P, stats, a.fast, blocks, a.fast ? a.stack_depth_fast1 : a.stack_depth, stream));
     if (a.profiling) {
         HIP_TRY(hipEventRecord(e1, stream));
         a.events.emplace_back(e0, e1);
@@ -861,12 +844,11 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         // per-lane LDS stack: worst case of this scene graph, +2 guard entries
         a->stack_depth = f.max_stack + 2;
         // the fast kernel falls back to the reference traversal on exact ties, so its stack must hold either
-        a->stack_depth_fast = (f.max_stack > f.max_stack_fast ? f.max_stack : f.max_stack_fast) + 2;
         a->stack_depth_fast1 = (f.max_stack > f.max_stack_fast1 ? f.max_stack : f.max_stack_fast1) + 2;
         const size_t LDS_MAX = 160 * 1024;
         if ((size_t)a->stack_depth * 256 * 4 > LDS_MAX)
             throw Error("BVH too deep for the LDS traversal stack (" + std::to_string(a->stack_depth) + " entries per lane; the reference panics beyond 64 per level, bvh.rs:497)");
-        a->fast_available = (size_t)a->stack_depth_fast * 256 * 4 <= LDS_MAX;
+        a->fast_available = (size_t)a->stack_depth_fast1 * 256 * 4 <= LDS_MAX;
         // The fast tree's tight boxes are only meaningful if every accel's `minv` (which moves the rays) really is the
         // inverse of its `m` (which moved the boxes).  Transform3::rotate(theta, axis) takes the transpose for the inverse
         // without normalising the axis (transform.rs:144-148), so a non-unit axis gives a pair that is not: the reference
@@ -886,8 +868,8 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                 a->fast_refusal = "fast mode unavailable: an aggregate's transform and inverse do not match (rotate() about a non-unit axis?)";
             }
         }
-        if (!a->fast_available) a->stack_depth_fast = a->stack_depth_fast1 = a->stack_depth;
-        size_t lds = (size_t)a->stack_depth_fast * 256 * 4;
+        if (!a->fast_available) a->stack_depth_fast1 = a->stack_depth;
+        size_t lds = (size_t)std::max(a->stack_depth, a->stack_depth_fast1) * 256 * 4;
         if (lds > 64 * 1024) HIP_TRY(trace_set_lds_limit(lds));
         int per_cu = 0, cus = 0;
         HIP_TRY(trace_occupancy(a->stack_depth, false, &per_cu));
@@ -899,11 +881,6 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         if (per_cu < 1) per_cu = 1;
         a->max_blocks = (uint32_t)(per_cu * cus);
         a->max_blocks_fast *= (uint32_t)cus;
-        int sp = 0, spf = 0;
-        HIP_TRY(stream_trace_occupancy(a->stack_depth, false, &sp));
-        HIP_TRY(stream_trace_occupancy(a->stack_depth_fast1, true, &spf));
-        a->stream_blocks = (uint32_t)((sp < 1 ? 1 : sp) * cus);
-        a->stream_blocks_fast = (uint32_t)((spf < 1 ? 1 : spf) * cus);
         int wb = 0, wbf = 0;
         HIP_TRY(wf_trace_occupancy(a->stack_depth, false, &wb));
         HIP_TRY(wf_trace_occupancy(a->stack_depth_fast1, true, &wbf));
@@ -1031,8 +1008,8 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.lds_image_n16, y.lds_image_n16); swap(x.lds_node_off, y.lds_node_off); swap(x.lds_prim_off, y.lds_prim_off);
     swap(x.lds_soup_off, y.lds_soup_off); swap(x.lds_accel_off, y.lds_accel_off);
     swap(x.ldss_blocks, y.ldss_blocks); swap(x.packet_blocks, y.packet_blocks); swap(x.packet_lds, y.packet_lds); swap(x.cus, y.cus);
-    swap(x.stack_depth, y.stack_depth); swap(x.stack_depth_fast, y.stack_depth_fast); swap(x.stack_depth_fast1, y.stack_depth_fast1); swap(x.max_blocks, y.max_blocks); swap(x.max_blocks_fast, y.max_blocks_fast);
-    swap(x.stream_blocks, y.stream_blocks); swap(x.stream_blocks_fast, y.stream_blocks_fast); swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast);
+    swap(x.stack_depth, y.stack_depth); swap(x.stack_depth_fast1, y.stack_depth_fast1); swap(x.max_blocks, y.max_blocks); swap(x.max_blocks_fast, y.max_blocks_fast);
+    swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast);
     swap(x.device_bytes, y.device_bytes); swap(x.fast_available, y.fast_available); swap(x.fast_refusal, y.fast_refusal);
     swap(x.streaming_pays, y.streaming_pays); swap(x.streaming_min_items, y.streaming_min_items);
 }
@@ -1443,7 +1420,7 @@ int lg_host_build_dump(const lg_scene *s, const double **f, size_t *nf, const in
 int lg_accel_info(const lg_accel *a, uint64_t out[8]) {
     const FlatScene &f = a->flat;
     out[0] = f.nodes.size(); out[1] = f.primref.size(); out[2] = f.spheres.size(); out[3] = f.cuboids.size();
-    out[4] = f.tri_v.size() / 3; out[5] = f.accels.size(); out[6] = a->fast ? a->stack_depth_fast : a->stack_depth; out[7] = a->device_bytes;
+    out[4] = f.tri_v.size() / 3; out[5] = f.accels.size(); out[6] = a->fast ? a->stack_depth_fast1 : a->stack_depth; out[7] = a->device_bytes;
     return 0;
 }
 
@@ -1494,7 +1471,7 @@ int lg_trace_pixel(const lg_accel *a, uint32_t w, uint32_t h, uint32_t x, uint32
         HIP_TRY(hipMemset(dout.p, 0, need * sizeof(double)));
         const size_t log_n = 1 + 4 * 4000;
         if (out_len >= need + log_n) { dlog.alloc(log_n); HIP_TRY(hipMemset(dlog.p, 0, log_n * sizeof(double))); P.dbg_log = dlog.p; }
-        HIP_TRY(launch_trace_pixel(P, fast != 0, fast ? a->stack_depth_fast : a->stack_depth, x, y, dout.p, a->stream));
+        HIP_TRY(launch_trace_pixel(P, fast != 0, fast ? a->stack_depth_fast1 : a->stack_depth, x, y, dout.p, a->stream));
         HIP_TRY(hipMemcpyAsync(out, dout.p, need * sizeof(double), hipMemcpyDeviceToHost, a->stream));
         if (P.dbg_log) HIP_TRY(hipMemcpyAsync(out + need, dlog.p, log_n * sizeof(double), hipMemcpyDeviceToHost, a->stream));
         HIP_TRY(hipStreamSynchronize(a->stream));

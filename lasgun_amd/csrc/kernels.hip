@@ -8,16 +8,19 @@
 // compile with -ffp-contract=off.  No MFMA: this is branchy traversal, not a contraction.
 //
 // Kernels:
-//   trace_kernel<STATS, FAST, LDSS>           the whole of li() per lane (scenes with glass / mirror, light scenes,
-//                                             small films, the counting variant)
-//   stream_trace_kernel<FAST, SHADOW, LDSS, FIXUP>  traversal only: primary closest-hit or per-light any-hit;
-//                                             (the primary pass also parks the hit's shading frame);
-//                                             LDSS = scene tables resident in LDS, one 1024-lane workgroup per CU;
-//                                             FIXUP = re-trace the lanes the packet pass flagged
-//   stream_packet_kernel<SHADOW, LDSS>        the same two passes with ONE tree walk per wavefront (opt-in)
-//   stream_shade_kernel                       frame + visibility -> radiance -> RGBA8
+//   trace_kernel<STATS, FAST, LDSS, PRUNE>    the whole of li() per lane (scenes with glass / mirror over big meshes, light
+//                                             scenes, small films; STATS = the counting variant behind lg_capture_stats)
+//   wf_trace_kernel<FAST, SHADOW, LDSS, L0, PRUNE>  wavefront pipeline, traversal only: closest hit of a level's rays (hits
+//                                             compacted, frames parked) or per-light any-hit of its hits;
+//                                             LDSS = scene tables resident in LDS, one 1024-lane workgroup per CU
+//   wf_shade_kernel<KIND, L0>, wf_combine_kernel   radiance of a level's hits, specular children queued; levels combined bottom-up
+//   stream_packet_kernel<SHADOW, LDSS>        opt-in: ONE tree walk per wavefront (ballot / vote), stream_fixup_kernel<SHADOW>
+//                                             re-traces the lanes it flagged, stream_shade_kernel finishes the pixels
 //   trace_pixel_kernel<FAST>                  one pixel by one lane, with an event log of the walk (lg_trace_pixel)
 //   kat_kernel, kat_si_kernel, math_kernel    probes behind the test hooks of the C ABI
+//
+// One traversal per mode: traverse_ref<LDSS, FAST, PRUNE, COUNT> (reference tree; FAST: the fast trees one node per step, an
+// A/B) and traverse_fast<COUNT> (fast trees, child pairs), both behind walk<>; traverse_packet<LDSS> for the packet kernels.
 //
 // What is restated from where (file:line under /root/reference):
 //   pixel loop / quantisation   src/lib.rs:110-162, src/img.rs:56-67
@@ -473,43 +476,6 @@ __device__ __forceinline__ bool ref_candidate(const DParams &P, const Ray &wray,
     return true;
 }
 
-// BVHAccel::intersect over the whole nested scene graph (bvh.rs:461-522), one lane = one ray.
-// `stack` is this lane's LDS stack: entry i lives at stack[i * stride].
-//
-// Control flow is "while-while": all lanes of the wavefront first descend interior nodes until
-// each has reached a leaf (or finished), then all process their leaf primitives together, so
-// the two instruction streams are not interleaved lane by lane.  A lane's own visit sequence
-// (near child first by dir_is_neg[axis], leaf primitives in order[], nested accels entered in
-// place) is exactly the reference's, which is what decides ties between equal t.
-struct Trav {
-    Ray ray;             // ray in the current accel's local space
-    uint32_t accel;      // current accel instance
-    uint32_t node_base, prim_base;
-    uint32_t cur;        // node index relative to node_base
-    uint32_t sp, base;   // stack pointer / first entry of the current accel level
-    uint32_t li, le;     // leaf cursor (absolute primref indices)
-    bool in_leaf, done, level_done;
-    bool tie;            // fast mode: two primitives produced exactly the same t
-    uint32_t negmask;    // bit a set <=> dinv[a] < 0 (dir_is_neg, bvh.rs:463)
-    bool mesh;           // current accel is a triangle mesh (every leaf slot is a triangle)
-    uint32_t soup_delta; // LDS-resident scene: leaf_soup slot (global numbering) = compact slot + this; mesh records stay in HBM/L2
-    double dd;           // dot(ray.d, ray.d) (reference traversal only)
-    TriSetup tri;        // valid while `mesh`
-};
-template <bool FAST, bool LDSS = false>
-__device__ __forceinline__ void trav_set_level(const DParams &P, Trav &T, uint32_t accel, const Ray &local) {
-    const DAccel *A = P.accels + accel;
-    T.accel = accel;
-    T.ray = local;
-    if (!FAST) T.dd = dot(local.d, local.d);
-    T.node_base = LDSS ? A->lnode_base : FAST ? A->fnode_base : A->node_base;
-    T.prim_base = LDSS ? A->lprim_base : FAST ? A->fprim_base : A->prim_base;
-    T.soup_delta = LDSS ? A->prim_base - A->lprim_base : 0u;
-    T.negmask = (local.dinv.x < 0.0 ? 1u : 0u) | (local.dinv.y < 0.0 ? 2u : 0u) | (local.dinv.z < 0.0 ? 4u : 0u);
-    T.mesh = (A->flags & AF_MESH) != 0u;
-    if (T.mesh && FAST) T.tri = tri_setup(local); // reference traversal: per fat leaf instead (fewer live registers, measured faster)
-}
-
 // leaf-ordered 48-byte geometry records: three 16-byte loads per slot
 struct LeafRec {
     uint4 a, b, c;
@@ -521,81 +487,7 @@ __device__ __forceinline__ LeafRec load_rec(const DParams &P, uint32_t slot) {
 __device__ __forceinline__ double rec_f64(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 __device__ __forceinline__ double rec_f32(uint32_t w) { return (double)__uint_as_float(w); } // f32 -> f64 `.into()`
 
-// One fat mesh leaf [li, le): the reference's leaf loop (bvh.rs:483-488) specialised for
-// triangles, streaming the leaf-ordered records one slot ahead of the test.
-template <int KZ, bool STATS, bool FAST, bool LDSS>
-__device__ __forceinline__ void mesh_leaf(const DParams &P, const uint4 *scn, Trav &T, bool anyhit, Best &best, Counters &cnt) {
-    const V3 o = T.ray.o;
-    const double sx = T.tri.sx, sy = T.tri.sy, sz = T.tri.sz;
-    uint32_t li = T.li;
-    const uint32_t le = T.le, last = le - 1u;
-    const uint32_t sd = LDSS ? T.soup_delta : 0u; // triangle records are streamed from HBM / L2 in either form
-    LeafRec cur = load_rec(P, li + sd);
-    for (; li < le; ++li) {
-        LeafRec r = cur;
-        cur = load_rec(P, (li < last ? li + 1u : last) + sd); // prefetch the next slot (clamped: always a valid slot)
-        V3 p0{rec_f32(r.a.x), rec_f32(r.a.y), rec_f32(r.a.z)}, p1{rec_f32(r.a.w), rec_f32(r.b.x), rec_f32(r.b.y)},
-            p2{rec_f32(r.b.z), rec_f32(r.b.w), rec_f32(r.c.x)};
-        if (STATS) cnt.triangles++;
-        TriHit h;
-        if (!triangle_t_pre<KZ>(p0, p1, p2, o, sx, sy, sz, h)) continue;
-        if (FAST && h.t == best.t && best.ref != NO_HIT) T.tie = true; // equal t: the reference's visit order decides
-        if (h.t >= best.t) continue;
-        best.t = h.t; best.ref = load_primref<LDSS>(P, scn, li); best.accel = T.accel;
-        if (STATS) dbg_event(P, 6.0, (double)best.ref, h.t, (double)T.accel);
-        if (anyhit && h.t < 1.0) { T.done = true; break; } // point.rs:49
-    }
-    T.li = le;
-}
-// Stack entries: child node index (relative to node_base), bit 31 set when that child is a leaf.
-constexpr uint32_t STACK_LEAF = 0x80000000u;
-
-__device__ __forceinline__ void trav_open_leaf(Trav &T, uint32_t link, uint32_t meta) {
-    T.li = T.prim_base + link;
-    T.le = T.li + (meta & 0xFFFFu);
-    T.in_leaf = true;
-}
-// leave the current node / leaf: next pending (already box-tested) child of this accel level,
-// or flag the level as exhausted
-template <bool LDSS>
-__device__ __forceinline__ void trav_pop(const DParams &P, const uint4 *scn, Trav &T, uint32_t *stack, uint32_t stride) {
-    T.in_leaf = false;
-    if (T.sp != T.base) {
-        --T.sp;
-        uint32_t e = stack[T.sp * stride];
-        if (e & STACK_LEAF) {
-            uint32_t link, meta;
-            load_node_link<LDSS>(P, scn, T.node_base + (e & ~STACK_LEAF), link, meta);
-            trav_open_leaf(T, link, meta);
-        } else {
-            T.cur = e;
-        }
-    } else {
-        T.level_done = true;
-    }
-}
-// entering an accel: test the root node's own box once (bvh.rs:472-473 for node 0)
-template <bool STATS, bool PAIR>
-__device__ __forceinline__ void trav_enter_root(const DParams &P, Trav &T, Counters &cnt) {
-    if (!PAIR) { T.cur = 0; T.in_leaf = false; return; } // one-node-per-step form: node 0 is tested when visited
-    const DNode *nd = P.nodes + T.node_base;
-    double bmin[3] = {nd->bmin[0], nd->bmin[1], nd->bmin[2]};
-    double bmax[3] = {nd->bmax[0], nd->bmax[1], nd->bmax[2]};
-    uint32_t link = nd->link, meta = nd->meta;
-    if (STATS) cnt.nodes++;
-    T.cur = 0; T.in_leaf = false;
-    if (!slab_intersects(bmin, bmax, T.ray)) { T.level_done = true; return; }
-    if (meta & NODE_LEAF) trav_open_leaf(T, link, meta);
-}
-
-// ---- fast mode (opt-in; NOT the reference's traversal) ----------------------------------------
-// Same nested accels, same primitive tests, same arithmetic, but over the binned-SAH tree with
-// <= 4 primitives per leaf, visiting the child with the smaller slab tnear first and skipping
-// children whose tnear lies beyond the current best hit (closest) or beyond the light (any-hit).
-// Pending children carry their tnear (as a float rounded down) so they can be skipped at pop time.
-// Exact ties in t (where the reference's visit order decides) are detected, and the walk's winner is
-// put to the reference tree's own box tests afterwards (ref_candidate); either sends the ray to the
-// reference traversal.
+// ---- fast mode (opt-in; NOT the reference's traversal): the limit beyond which its walk skips a node's subtree
 __device__ __forceinline__ double prune_limit(double tbest, bool anyhit) {
 #ifdef LG_FAST_NOPRUNE
     return INFINITY;
@@ -603,202 +495,17 @@ __device__ __forceinline__ double prune_limit(double tbest, bool anyhit) {
     double lim = anyhit ? 1.0 : tbest;
     return lim + 1e-5 * (fabs(lim) + 1.0); // +inf stays +inf
 }
-__device__ __forceinline__ uint32_t f32_bits_down(double t) { // a float <= t
-    float f = (float)t;
-    if ((double)f > t) f = __uint_as_float(__float_as_uint(f) + (f > 0.f ? -1 : 1)); // one ulp towards -inf
-    if (f == 0.f && t < 0.0) f = -1e-30f;
-    return __float_as_uint(f);
-}
-__device__ __forceinline__ void trav_pop_fast(const DParams &P, Trav &T, uint32_t *stack, uint32_t stride, double limit) {
-    T.in_leaf = false;
-    for (;;) {
-        if (T.sp == T.base) { T.level_done = true; return; }
-        T.sp -= 2;
-        uint32_t e = stack[T.sp * stride];
-        float tn = __uint_as_float(stack[(T.sp + 1) * stride]);
-        if ((double)tn > limit) continue; // beyond the best hit found meanwhile
-        if (e & STACK_LEAF) {
-            const DNode *nd = P.nodes + (T.node_base + (e & ~STACK_LEAF));
-            trav_open_leaf(T, nd->link, nd->meta);
-        } else {
-            T.cur = e;
-        }
-        return;
-    }
-}
 
-template <bool STATS, bool FAST, bool LDSS = false>
-__device__ __forceinline__ void traverse(const DParams &P, const Ray &wray, bool anyhit, uint32_t *stack, uint32_t stride,
-                                         Best &best, Counters &cnt, bool &tie, const uint4 *scn = nullptr) {
-    static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
-#define LG_POP() do { if (FAST) trav_pop_fast(P, T, stack, stride, prune_limit(best.t, anyhit)); else trav_pop<LDSS>(P, scn, T, stack, stride); } while (0)
-    best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
-    Trav T;
-    // the world ray is not kept: everything below the root is derived from the root accel's local ray
-    const Ray root = ray_to_local(P.accels->minv, wray);
-    const V3 root_o = root.o, root_d = root.d;
-    trav_set_level<FAST, LDSS>(P, T, 0u, root);
-    T.sp = 0; T.base = 0; T.li = 0; T.le = 0; T.done = false; T.level_done = false; T.tie = false;
-    if (STATS) cnt.entries++;
-    trav_enter_root<STATS, FAST>(P, T, cnt);
-    while (!T.done) {
-        // ---- phase A: interior nodes
-        if (FAST) {
-        // T.cur is an interior node whose own box is known to be hit; one 128-byte child-pair
-        // record feeds the slab tests of BOTH children.
-        while (!T.in_leaf && !T.level_done) {
-            const DNode2 *nd = P.nodes2 + (T.node_base + T.cur);
-            double b0min[3] = {nd->b0min[0], nd->b0min[1], nd->b0min[2]}, b0max[3] = {nd->b0max[0], nd->b0max[1], nd->b0max[2]};
-            double b1min[3] = {nd->b1min[0], nd->b1min[1], nd->b1min[2]}, b1max[3] = {nd->b1max[0], nd->b1max[1], nd->b1max[2]};
-            uint32_t link0 = nd->link0, meta0 = nd->meta0, link1 = nd->link1, meta1 = nd->meta1;
-            uint32_t axis = nd->axis, second = nd->second;
-            if (STATS) cnt.nodes += 2;
-            if (FAST) {
-                double tn0, tn1, tf0, tf1;
-                bool hit0 = slab_intersects_t(b0min, b0max, T.ray, tn0, tf0);
-                bool hit1 = slab_intersects_t(b1min, b1max, T.ray, tn1, tf1);
-                // a primitive's computed t can undershoot its box's tnear by the error of its own formula: for a sphere
-                // the quadratic's cancellation, ~sqrt(eps) of the distance to its centre, which lies inside the box
-                tn0 -= 4e-8 * fabs(tf0); tn1 -= 4e-8 * fabs(tf1);
-                double limit = prune_limit(best.t, anyhit);
-                if (STATS) { dbg_event(P, 1.0 + (hit0 ? 0.1 : 0.0) + (hit1 ? 0.01 : 0.0), (double)T.accel * 100000.0 + (double)(T.node_base + T.cur), tn0, tn1); }
-                hit0 = hit0 && !(tn0 > limit);
-                hit1 = hit1 && !(tn1 > limit);
-                bool swap = hit1 && (!hit0 || tn1 < tn0); // nearer child first
-                bool near_hit = swap ? hit1 : hit0, far_hit = swap ? hit0 : hit1;
-                uint32_t near_idx = swap ? second : T.cur + 1, far_idx = swap ? T.cur + 1 : second;
-                uint32_t near_link = swap ? link1 : link0, near_meta = swap ? meta1 : meta0;
-                uint32_t far_meta = swap ? meta0 : meta1;
-                double far_tn = swap ? tn0 : tn1;
-                (void)axis;
-                if (near_hit && far_hit) {
-                    stack[T.sp * stride] = far_idx | ((far_meta & NODE_LEAF) ? STACK_LEAF : 0u);
-                    stack[(T.sp + 1) * stride] = f32_bits_down(far_tn);
-                    T.sp += 2;
-                }
-                if (near_hit) {
-                    if (near_meta & NODE_LEAF) trav_open_leaf(T, near_link, near_meta);
-                    else T.cur = near_idx;
-                } else {
-                    LG_POP();
-                }
-            }
-        }
-        } else {
-        // reference traversal, one node per step (bvh.rs:471-505)
-        while (!T.in_leaf && !T.level_done) {
-            // link/meta are decoded branch-free so the compiler cannot sink their load behind the
-            // hit test (that would put a second memory latency on the critical path)
-            const NodeRec nd = load_node<LDSS>(P, scn, T.node_base + T.cur);
-            const uint32_t link = nd.link, meta = nd.meta;
-            if (STATS) cnt.nodes++;
-            bool hit = slab_intersects(nd.bmin, nd.bmax, T.ray);
-            if (STATS) dbg_event(P, 2.0 + (hit ? 0.1 : 0.0), (double)T.accel * 100000.0 + (double)(T.node_base + T.cur), (double)nd.link, (double)nd.meta);
-            bool leaf = (meta & NODE_LEAF) != 0u;
-            uint32_t count = meta & 0xFFFFu;
-            bool neg = ((T.negmask >> (meta & 3u)) & 1u) != 0u; // dir_is_neg[axis] (bvh.rs:463,496)
-            uint32_t near_node = neg ? link : T.cur + 1;
-            uint32_t far_node = neg ? T.cur + 1 : link;
-            if (hit && !leaf) { // near child first, far child on the stack (bvh.rs:493-504)
-                stack[T.sp * stride] = far_node;
-                ++T.sp;
-                T.cur = near_node;
-            } else if (hit && leaf && count != 0u) {
-                trav_open_leaf(T, link, meta);
-            } else {
-                trav_pop<LDSS>(P, scn, T, stack, stride);
-            }
-        }
-        }
-        if (T.in_leaf && T.li >= T.le) { LG_POP(); continue; } // empty leaf (nprims as u16 == 0)
-        // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
-        if (T.in_leaf && T.mesh) {
-            if (!FAST) T.tri = tri_setup(T.ray); // fat reference leaves amortise the three divides
-            if (T.tri.kz == 0) mesh_leaf<0, STATS, FAST, LDSS>(P, scn, T, anyhit, best, cnt);
-            else if (T.tri.kz == 1) mesh_leaf<1, STATS, FAST, LDSS>(P, scn, T, anyhit, best, cnt);
-            else mesh_leaf<2, STATS, FAST, LDSS>(P, scn, T, anyhit, best, cnt);
-            if (!T.done) LG_POP(); // may open the next (already box-tested) leaf
-            else T.in_leaf = false;
-        } else if (T.in_leaf) {
-            while (T.in_leaf) {
-                const uint32_t ref = load_primref<LDSS>(P, scn, T.li);
-                ++T.li;
-                uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
-                bool accepted = false;
-                double t = 0.0;
-                if (kind == PK_SPHERE) {
-                    if (STATS) cnt.spheres++;
-                    bool inside;
-                    DSphere sp = load_sphere<LDSS>(P, scn, idx, T.li - 1u);
-                    // d.d once per accel level in the reference traversal (39 sphere tests per ray in config 3: +0.7 %);
-                    // the fast traversal tests few spheres and is better off with the two registers (measured)
-                    t = FAST ? sphere_t(T.ray, V3{sp.cx, sp.cy, sp.cz}, sp.r, inside) : sphere_t_a(T.ray, T.dd, V3{sp.cx, sp.cy, sp.cz}, sp.r, inside);
-                    accepted = !(t < 0.0) && !(t >= best.t);
-                } else if (kind == PK_CUBOID) {
-                    if (STATS) cnt.cuboids++;
-                    DCuboid cb = load_cuboid<LDSS>(P, scn, idx, T.li - 1u);
-                    double mn[3] = {cb.mn[0], cb.mn[1], cb.mn[2]}, mx[3] = {cb.mx[0], cb.mx[1], cb.mx[2]};
-                    V3 d0, d1;
-                    if (cuboid_hit<false>(mn, mx, T.ray, t, d0, d1)) accepted = !(t >= best.t);
-                } else if (kind == PK_ACCEL) {
-                    // nested BVHAccel (Group / Mesh): save this level, re-express the ray (bvh.rs:462)
-                    stack[T.sp * stride] = T.li; stack[(T.sp + 1) * stride] = T.le; stack[(T.sp + 2) * stride] = T.base;
-                    T.sp += 3; T.base = T.sp;
-                    trav_set_level<FAST, LDSS>(P, T, idx, ray_to_local(P.accels[idx].minv, T.ray));
-                    if (STATS) cnt.entries++;
-                    if (STATS) dbg_event(P, 4.0, (double)idx, (double)T.sp, (double)T.base);
-                    trav_enter_root<STATS, FAST>(P, T, cnt);
-                    if (STATS) dbg_event(P, 4.5, (double)idx, T.level_done ? 1.0 : 0.0, T.in_leaf ? 1.0 : 0.0);
-                    break;
-                } else { // a triangle outside a mesh accel cannot be built by the scene API; kept for completeness
-                    if (STATS) cnt.triangles++;
-                    const uint32_t *vi = P.tri_v + 3ull * idx;
-                    TriHit h;
-                    if (triangle_t(load_f3(P.vpos, vi[0]), load_f3(P.vpos, vi[1]), load_f3(P.vpos, vi[2]), T.ray, h)) { t = h.t; accepted = !(t >= best.t); }
-                }
-                if (FAST && !accepted && t == best.t && best.ref != NO_HIT && kind != PK_ACCEL) T.tie = true; // equal t: visit order decides
-                if (STATS && kind != PK_ACCEL) dbg_event(P, 3.0 + (accepted ? 0.1 : 0.0), (double)ref, t, (double)T.accel);
-                if (accepted) {
-                    best.t = t; best.ref = ref; best.accel = T.accel;
-                    if (anyhit && t < 1.0) { T.done = true; T.in_leaf = false; break; } // occluded: point.rs:49 only asks isect.t < 1.0
-                }
-                if (T.li >= T.le) { LG_POP(); break; } // a popped leaf restarts phase B (fresh prefetch)
-            }
-        }
-        // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
-        if (T.level_done) {
-            T.level_done = false;
-            if (T.accel == 0) { T.done = true; }
-            else {
-                T.base = stack[(T.sp - 1) * stride]; T.le = stack[(T.sp - 2) * stride]; T.li = stack[(T.sp - 3) * stride];
-                T.sp -= 3;
-                if (STATS) dbg_event(P, 5.0, (double)T.accel, (double)T.li, (double)T.le);
-                uint32_t parent = (uint32_t)P.accels[T.accel].parent;
-                trav_set_level<FAST, LDSS>(P, T, parent, level_ray(P, root_o, root_d, parent));
-                if (T.li < T.le) T.in_leaf = true;
-                else LG_POP();
-            }
-        }
-    }
-    tie = T.tie;
-    // fast walk: a winner the reference tree would not have tested is handled like a tie (re-trace with the reference walk)
-    // (the hit is dropped as well, so that an any-hit caller does not take it for a valid occluder and skip the re-trace)
-#ifndef LG_NO_REFCHECK
-    if (FAST && !tie && best.ref != NO_HIT && !(anyhit && !(best.t < 1.0)) && !ref_candidate(P, wray, best)) {
-        tie = true; best.t = INFINITY; best.ref = NO_HIT;
-    }
-#endif
-#undef LG_POP
-}
 
 // ------------------------------------------------------------------------------------------
-// Reference traversal, second formulation (the plain instantiations: no counters, no fast tree).
+// BVHAccel::intersect over the whole nested scene graph (bvh.rs:461-522), one lane = one ray.
+// `stack` is this lane's LDS stack: entry i lives at stack[i * stride].  A lane's own visit sequence (near child
+// first by dir_is_neg[axis], leaf primitives in order[], nested accels entered in place) is exactly the reference's,
+// which is what decides ties between equal t.
 //
-// Same walk, same visit order, same arithmetic as traverse<false, false> above -- what differs is how
-// the divergence is written down.  There the per-lane state is a handful of bools and the phases are
-// nested per-lane loops with breaks; hipcc turns every one of those into lane masks kept in SGPR pairs
-// and merged with s_and / s_andn2 / s_or triplets: 87 scalar and 86 vector instructions per node or
-// primitive step, of which 26 are the slab test.  Here
+// How the divergence is written down matters (round 1 kept the per-lane state in a handful of bools and nested
+// per-lane loops; hipcc turned each into lane masks in SGPR pairs merged with s_and / s_andn2 / s_or triplets: 87
+// scalar and 86 vector instructions per node or primitive step, of which 26 are the slab test).  Here
 //   * a lane's phase is ONE integer (ST_NODE / ST_LEAF / ST_ENTER / ST_LEVEL_DONE / ST_DONE);
 //   * every loop is WAVE-UNIFORM (`while (any lane is in this phase)`: one ballot and one scalar branch per
 //     trip) around a flat predicated step;
@@ -893,19 +600,21 @@ __device__ __forceinline__ bool tri_rec_t(const LeafRec &r, V3 o, double sx, dou
     h.t = tscaled * invdet;
     return true;
 }
-template <int KZ, bool LDSS, bool FAST = false>
+template <int KZ, bool LDSS, bool FAST = false, bool COUNT = false>
 __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, const V3 o, const TriSetup tri, uint32_t li, const uint32_t le,
-                                           const uint32_t soup_delta, const uint32_t accel, const bool anyhit, Best &best, bool &tie) {
+                                           const uint32_t soup_delta, const uint32_t accel, const bool anyhit, Best &best, bool &tie, Counters &cnt) {
     const char *base = reinterpret_cast<const char *>(P.leaf_soup);
     constexpr uint32_t REC = (uint32_t)sizeof(DLeafRec);
     uint32_t off = (li + soup_delta) * REC; // (the array holds < 2^32 / 48 slots: checked by the host)
 #define LG_TRI(R, SLOT)                                                                                                  \
     do {                                                                                                                 \
         TriHit h_;                                                                                                       \
+        if (COUNT) cnt.triangles++;                                                                                      \
         if (tri_rec_t<KZ>(R, o, tri.sx, tri.sy, tri.sz, h_)) {                                                           \
             if (FAST && ((h_.t == best.t && best.ref != NO_HIT) || h_.t != h_.t)) tie = true; /* visit order decides */  \
             if (!(h_.t >= best.t)) {                                                                                     \
                 best.t = h_.t; best.ref = load_primref<LDSS>(P, scn, (SLOT)); best.accel = accel;                        \
+                if (COUNT) dbg_event(P, 6.0, (double)best.ref, h_.t, (double)accel);                                     \
                 if (anyhit && h_.t < 1.0) return true; /* point.rs:49 */                                                 \
             }                                                                                                            \
         }                                                                                                                \
@@ -948,9 +657,12 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 // parameters along kz, computed by the slab test's own expression; the other axes promise nothing for a triangle seen edge-on)
 // -- hence t >= (entry parameter on the axis) - eps * |1/d_axis|.  Nodes over a nested accel are never skipped (NODE_NOPRUNE),
 // levels or rays outside the stated magnitude range are walked unpruned (eps = +inf).
-template <bool LDSS, bool FAST = false, bool PRUNE = false>
+// COUNT: the counting instantiation (lg_capture_stats, lg_trace_pixel): the same walk, plus the deterministic work
+// counters and, for lg_trace_pixel, an event log -- 2.x node tested (.1 = taken), 3.x primitive tested (.1 = accepted),
+// 4 accel entered, 5 returned to the parent, 6 triangle accepted.
+template <bool LDSS, bool FAST = false, bool PRUNE = false, bool COUNT = false>
 __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
-                                             Best &best, const uint4 *scn, bool &tie) {
+                                             Best &best, const uint4 *scn, bool &tie, Counters &cnt) {
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
     static_assert(!(FAST && PRUNE), "the fast mode prunes its own trees by its own rule");
 #ifdef LG_STAMPS
@@ -958,6 +670,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     unsigned long long stamp_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
+    if (COUNT) cnt.entries++; // the root accel
     uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
     Lvl L;
     lvl_set<LDSS, FAST>(P, scn, L, 0u);
@@ -1049,6 +762,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     const bool beyond = tx > plim.x || ty > plim.y || tz > plim.z; // (a NaN entry parameter compares false)
                     hit = hit && !(beyond && (w_meta & NODE_NOPRUNE) == 0u);
                 } else hit = slab_intersects_nc(bmin, bmax, ray);
+                if (COUNT) { cnt.nodes++; dbg_event(P, 2.0 + (hit ? 0.1 : 0.0), (double)L.accel, (double)cur, (double)w_meta); }
                 const bool leaf = (int32_t)w_meta < 0;            // n_primitives > 0 (bvh.rs:475): the builder emits no empty leaf
                 const bool neg = (negmask & w_meta) != 0u;        // dir_is_neg[axis] (bvh.rs:496)
                 const uint32_t first = cur + (LDSS ? LDS_NODE_BYTES : 1u), second = w_link; // the two children (interior nodes)
@@ -1076,9 +790,9 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
             if (!FAST) tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
             bool done;
-            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
-            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
-            else done = mesh_leaf2<2, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
+            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
+            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
+            else done = mesh_leaf2<2, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
             if (FAST) limit = prune_limit(best.t, anyhit);
             if (PRUNE && !anyhit) prune_limits(best.t);
             if (done) state = ST_DONE;
@@ -1138,6 +852,11 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     TriHit h;
                     if (triangle_t(load_f3(P.vpos, vi[0]), load_f3(P.vpos, vi[1]), load_f3(P.vpos, vi[2]), ray, h)) { t = h.t; accepted = !(t >= best.t); }
                 }
+                if (COUNT) {
+                    if (kind == PK_SPHERE) cnt.spheres++; else if (kind == PK_CUBOID) cnt.cuboids++; else if (kind == PK_ACCEL) cnt.entries++; else cnt.triangles++;
+                    if (kind != PK_ACCEL) dbg_event(P, 3.0 + (accepted ? 0.1 : 0.0), (double)ref, t, (double)L.accel);
+                    else dbg_event(P, 4.0, (double)idx, (double)sp, (double)base);
+                }
                 if (FAST && kind != PK_ACCEL && ((!accepted && t == best.t && best.ref != NO_HIT) || t != t)) tie = true; // visit order decides
                 if (accepted) {
                     best.t = t; best.ref = ref; best.accel = L.accel;
@@ -1185,6 +904,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 const uint32_t w2 = stk[(sp - 1u) * stride];
                 le = stk[(sp - 2u) * stride]; li = stk[(sp - 3u) * stride];
                 sp -= 3u; base = w2 & ~FRAME_SAME_RAY;
+                if (COUNT) dbg_event(P, 5.0, (double)L.accel, (double)li, (double)le);
                 uint32_t parent, nchain;
                 const uint32_t *chain;
                 if (LDSS) {
@@ -1239,8 +959,10 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
 constexpr uint32_t ST_OPEN = 5u;
 constexpr uint32_t STK_LEAF = 0x80000000u;
 // the root node of a level: its own box, once (bvh.rs:472-473 for node 0)
+template <bool COUNT>
 __device__ __forceinline__ void fast_level_root(const DParams &P, const Lvl &L, const Ray &ray, const double limit, uint32_t &state, uint32_t &cur,
-                                                uint32_t &li, uint32_t &le) {
+                                                uint32_t &li, uint32_t &le, Counters &cnt) {
+    if (COUNT) cnt.nodes++;
     const NodeRec nd = load_node<false>(P, nullptr, L.node_base);
     double tn, tf;
     bool hit = slab_intersects_nc_t(nd.bmin, nd.bmax, ray, tn, tf);
@@ -1250,10 +972,12 @@ __device__ __forceinline__ void fast_level_root(const DParams &P, const Lvl &L, 
     else if (nd.meta & NODE_LEAF) { li = L.prim_base + nd.link; le = li + (nd.meta & 0xFFFFu); state = ST_LEAF; }
     else state = ST_NODE;
 }
+template <bool COUNT = false>
 __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
-                                             Best &best, const uint4 *scn, bool &tie) {
+                                             Best &best, const uint4 *scn, bool &tie, Counters &cnt) {
     constexpr bool LDSS = false, FAST = true;
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
+    if (COUNT) cnt.entries++; // the root accel
     uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
     Lvl L;
     lvl_set<LDSS, FAST>(P, scn, L, 0u);
@@ -1269,7 +993,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
     uint32_t negmask = neg_mask(ray); (void)negmask; // (the pair walk orders children by tnear; kept for the level bookkeeping shared with traverse_ref)
     uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0;
     uint32_t state = ST_NODE;
-    fast_level_root(P, L, ray, limit, state, cur, li, le);
+    fast_level_root<COUNT>(P, L, ray, limit, state, cur, li, le, cnt);
     for (;;) {
         // ---- phase A: interior nodes, two children per step, until no lane of the wave is at a node
         // (loops are written with their wave-uniform condition in a variable tested at the bottom: hipcc then keeps the
@@ -1282,6 +1006,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
                 const double b1min[3] = {nd->b1min[0], nd->b1min[1], nd->b1min[2]}, b1max[3] = {nd->b1max[0], nd->b1max[1], nd->b1max[2]};
                 const uint32_t link0 = nd->link0, meta0 = nd->meta0, link1 = nd->link1, meta1 = nd->meta1, second = L.node_base + nd->second;
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
+                if (COUNT) cnt.nodes += 2u; // both children's boxes
                 // a primitive's computed t can undershoot its box's tnear by the error of its own formula: for a sphere
                 // the quadratic's cancellation, ~sqrt(eps) of the distance to its centre, which lies inside the box
                 double tn0, tf0, tn1, tf1;
@@ -1310,9 +1035,9 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
         if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
             if (!FAST) tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
             bool done;
-            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
-            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
-            else done = mesh_leaf2<2, LDSS, FAST>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie);
+            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
+            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
+            else done = mesh_leaf2<2, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
             if (FAST) limit = prune_limit(best.t, anyhit);
             if (done) state = ST_DONE;
             else if (sp != base) { --sp; const uint32_t e = stk[sp * stride]; cur = e & ~STK_LEAF; state = (e & STK_LEAF) ? ST_OPEN : ST_NODE; }
@@ -1366,6 +1091,11 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
                     TriHit h;
                     if (triangle_t(load_f3(P.vpos, vi[0]), load_f3(P.vpos, vi[1]), load_f3(P.vpos, vi[2]), ray, h)) { t = h.t; accepted = !(t >= best.t); }
                 }
+                if (COUNT) {
+                    if (kind == PK_SPHERE) cnt.spheres++; else if (kind == PK_CUBOID) cnt.cuboids++; else if (kind == PK_ACCEL) cnt.entries++; else cnt.triangles++;
+                    if (kind != PK_ACCEL) dbg_event(P, 3.0 + (accepted ? 0.1 : 0.0), (double)ref, t, (double)L.accel);
+                    else dbg_event(P, 4.0, (double)idx, (double)sp, (double)base);
+                }
                 if (FAST && kind != PK_ACCEL && ((!accepted && t == best.t && best.ref != NO_HIT) || t != t)) tie = true; // visit order decides
                 if (accepted) {
                     best.t = t; best.ref = ref; best.accel = L.accel;
@@ -1392,7 +1122,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
                 negmask = neg_mask(ray);
             }
             if (FAST && (L.flags & AF_MESH)) tri = tri_setup(ray);
-            fast_level_root(P, L, ray, limit, state, cur, li, le);
+            fast_level_root<COUNT>(P, L, ray, limit, state, cur, li, le, cnt);
         }
         // ---- a pending child that is a leaf (pushed with its box already tested): its slot range
         if (state == ST_OPEN) {
@@ -1408,6 +1138,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
                 const uint32_t w2 = stk[(sp - 1u) * stride];
                 le = stk[(sp - 2u) * stride]; li = stk[(sp - 3u) * stride];
                 sp -= 3u; base = w2 & ~FRAME_SAME_RAY;
+                if (COUNT) dbg_event(P, 5.0, (double)L.accel, (double)li, (double)le);
                 uint32_t parent, nchain;
                 const uint32_t *chain;
                 if (LDSS) {
@@ -1446,16 +1177,17 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
 //   * any-hit: an occluder counts if the reference tree would have tested it (the reference then finds it or one before it);
 //     "not occluded" stands unless a tie / NaN makes the reference's own answer depend on its visit order;
 // otherwise the ray is traced again with the reference walk over the tables in HBM / L2.
-template <bool LDSS, bool FAST, bool PRUNE = false>
+template <bool LDSS, bool FAST, bool PRUNE = false, bool COUNT = false>
 __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const bool anyhit, uint32_t *stack, const uint32_t stride, Best &best,
-                                     const uint4 *scn) {
+                                     const uint4 *scn, Counters &cnt) {
     bool tie = false;
 #ifndef LG_FAST_ONE_NODE
-    if (FAST) traverse_fast(P, ray, anyhit, stack, stride, best, scn, tie);
+    if (FAST) traverse_fast<COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt);
     else
 #endif
-    traverse_ref<LDSS, FAST, PRUNE>(P, ray, anyhit, stack, stride, best, scn, tie);
+    traverse_ref<LDSS, FAST, PRUNE, COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt);
     if (!FAST) return;
+    if (COUNT) dbg_event(P, 9.0, tie ? 1.0 : 0.0, best.t, (double)best.ref);
     bool redo;
     if (anyhit && !(best.t < 1.0)) redo = tie;
     else {
@@ -1464,7 +1196,7 @@ __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const boo
         if (!redo && best.ref != NO_HIT) redo = !ref_candidate(P, ray, best);
 #endif
     }
-    if (redo) traverse_ref<false, false>(P, ray, anyhit, stack, stride, best, nullptr, tie);
+    if (redo) traverse_ref<false, false, false, COUNT>(P, ray, anyhit, stack, stride, best, nullptr, tie, cnt);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2056,7 +1788,7 @@ __device__ __forceinline__ void stash_get(const DParams &P, unsigned long long g
 // cuboid tables copied into LDS behind the stacks (see load_node); otherwise 256-lane workgroups and L1/L2.
 template <bool STATS, bool FAST, bool LDSS, bool PRUNE = false>
 __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(const DParams P) {
-    static_assert(!(PRUNE && (STATS || FAST)), "the pruned reference walk has no counting or fast form");
+    static_assert(!(PRUNE && FAST), "the fast mode prunes its own trees by its own rule");
     static_assert(!(FAST && LDSS) && !(STATS && LDSS), "LDS-resident scene: plain reference traversal only");
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -2122,18 +1854,8 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
             for (;;) {
                 Best b;
                 {
-                    bool tie = false;
                     Counters before = cnt;
-#ifndef LG_OLD_TRAVERSE
-                    if (!STATS) walk<LDSS, FAST, PRUNE>(P, tray, shadow_job, stack, stride, b, scn);
-                    else
-#endif
-                    {
-                    traverse<STATS, FAST, LDSS>(P, tray, shadow_job, stack, stride, b, cnt, tie, scn);
-                    // fast mode: exact ties in t are decided by the reference's visit order -> re-trace this ray with it.
-                    // (an occluded any-hit ray needs no re-trace: the answer "some t < 1 exists" is order-independent)
-                    if (FAST && tie && !(shadow_job && b.t < 1.0)) traverse<STATS, false>(P, tray, shadow_job, stack, stride, b, cnt, tie);
-                    }
+                    walk<LDSS, FAST, PRUNE, STATS>(P, tray, shadow_job, stack, stride, b, scn, cnt);
                     if (STATS && P.stats_filter != 0u && (P.stats_filter == 2u) != shadow_job) { // not the kind being counted
                         cnt.nodes = before.nodes; cnt.spheres = before.spheres; cnt.cuboids = before.cuboids;
                         cnt.triangles = before.triangles; cnt.entries = before.entries;
@@ -2344,58 +2066,31 @@ __device__ __forceinline__ void park_frame(const DParams &P, unsigned long long 
     f[12 * n] = (double)sh.mat;
 }
 
-// K1 / K2: persistent traversal kernels (tile counter, per-lane LDS stack)
-// LDSS: one 1024-lane workgroup per CU (still 4 waves per SIMD) that first copies the scene's
-// node / primref / sphere / cuboid tables into LDS behind the stacks; its waves then pull tiles
-// independently exactly like the 256-lane form.
-// FIXUP: the second pass of the packet organisation -- only the tiles listed in P.tie_tiles, and in
-// them only the lanes (and lights) flagged in P.tie_flag, are re-traced with the private walk.
-template <bool FAST, bool SHADOW, bool LDSS, bool FIXUP>
-__global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_trace_kernel(const DParams P) {
-    static_assert(!(FAST && FIXUP), "ties of the packet walk are resolved by the reference walk");
+// Fix-up pass of the packet organisation (persistent, tile counter, per-lane LDS stack): only the tiles listed in
+// P.tie_tiles, and in them only the lanes (and lights) flagged in P.tie_flag, are re-traced with the private reference walk.
+// (Round 1's three-kernel pipeline ran its two traversal passes through this kernel's plain forms; the wavefront pipeline
+// replaced it in round 2 and those forms were retired in round 3.)
+template <bool SHADOW>
+__global__ void __launch_bounds__(LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_fixup_kernel(const DParams P) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t *stack = lds_stack + tid;
-    constexpr uint32_t stride = LDSS ? LG_LDSS_BLOCK : LG_BLOCK;
-    const uint4 *scn = nullptr;
-    if (LDSS) {
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_stack + P.stack_depth * stride);
-        const uint4 *src = reinterpret_cast<const uint4 *>(P.lds_image);
-        for (uint32_t i = tid; i < P.lds_image_n16; i += stride) dst[i] = src[i];
-        __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling tiles
-        scn = dst;
-    }
+    constexpr uint32_t stride = LG_BLOCK;
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)cnt;
     for (;;) {
         uint32_t tile = 0;
-        if (FIXUP) {
-            if (lane == 0) tile = atomicAdd(P.tile_counter + 2, 1u);
-            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-            if (tile >= P.tile_counter[1]) break; // number of listed tiles (written by the packet pass); every wave reaches this exit
-            tile = P.tie_tiles[tile];
-        } else {
-            if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
-            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-            if (tile >= P.ntiles) break; // every wave reaches this exit
-        }
+        if (lane == 0) tile = atomicAdd(P.tile_counter + 2, 1u);
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+        if (tile >= P.tile_counter[1]) break; // number of listed tiles (written by the packet pass); every wave reaches this exit
+        tile = P.tie_tiles[tile];
         Pixel px = pixel_of(P, tile, lane);
         if (!px.active) continue;
         const unsigned long long widx = (unsigned long long)tile * 64ull + lane;
-        uint32_t redo = 0xFFFFFFFFu; // FIXUP: bit l = light l (shadow) / bit 0 (primary) must be re-traced
-        if (FIXUP) {
-            redo = P.tie_flag[widx];
-            if (redo == 0u) continue;
-        }
+        const uint32_t redo = P.tie_flag[widx]; // bit l = light l (shadow) / bit 0 (primary) must be re-traced
+        if (redo == 0u) continue;
         if (!SHADOW) {
             Ray ray = camera_ray(P, px.x, px.y, P.sample_index);
             Best b;
-            bool tie = false;
-#ifndef LG_OLD_TRAVERSE
-            walk<LDSS, FAST>(P, ray, false, stack, stride, b, scn);
-#else
-            traverse<false, FAST, LDSS>(P, ray, false, stack, stride, b, cnt, tie, scn);
-            if (FAST && tie) traverse<false, false>(P, ray, false, stack, stride, b, cnt, tie);
-#endif
-            (void)tie;
+            walk<false, false>(P, ray, false, stack, stride, b, nullptr, cnt);
             P.hit_ref[widx] = b.ref; // (t and the accel instance are consumed by park_frame right here)
             park_frame(P, widx, ray, b);
         } else {
@@ -2406,22 +2101,15 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             V3 ng{P.frame[3 * n + widx], P.frame[4 * n + widx], P.frame[5 * n + widx]};
             const double err = 2.220446049250313e-16 * 65536.0;
             V3 hit_p = praw + ng * err;
-            uint32_t vis = FIXUP ? P.vis[widx] : 0u;
+            uint32_t vis = P.vis[widx];
             for (uint32_t l = 0; l < P.nlights; ++l) {
-                if (FIXUP && !((redo >> l) & 1u)) continue;
+                if (!((redo >> l) & 1u)) continue;
                 const DLight L = P.lights[l];
                 Ray sray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
                 Best b;
-                bool tie = false;
-#ifndef LG_OLD_TRAVERSE
-                walk<LDSS, FAST>(P, sray, true, stack, stride, b, scn);
-#else
-                traverse<false, FAST, LDSS>(P, sray, true, stack, stride, b, cnt, tie, scn);
-                if (FAST && tie && !(b.t < 1.0)) traverse<false, false>(P, sray, true, stack, stride, b, cnt, tie);
-#endif
-                (void)tie;
+                walk<false, false>(P, sray, true, stack, stride, b, nullptr, cnt);
                 if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
-                else if (FIXUP) vis &= ~(1u << l);
+                else vis &= ~(1u << l);
             }
             P.vis[widx] = vis;
         }
@@ -2430,7 +2118,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
 
 // K1' / K2': the packet organisation of the same two traversal passes -- one tree walk per wavefront
 // (traverse_packet).  Lanes whose walk met an exact tie (or a NaN t) get their bit set in P.tie_flag and
-// their tile appended to P.tie_tiles; the FIXUP form of stream_trace_kernel re-traces just those.
+// their tile appended to P.tie_tiles; stream_fixup_kernel re-traces just those.
 // LDS: [per-wave stacks][scene image (LDSS)].
 template <bool SHADOW, bool LDSS>
 __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) stream_packet_kernel(const DParams P) {
@@ -2706,7 +2394,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             b.ref = NO_HIT; b.t = INFINITY; b.accel = 0u;
             if (active) {
                 bool tie = false;
-                walk<LDSS, FAST, PRUNE>(P, ray, false, stack, stride, b, scn);
+                walk<LDSS, FAST, PRUNE>(P, ray, false, stack, stride, b, scn, cnt);
                 (void)tie;
             }
             const bool hit = active && b.ref != NO_HIT;
@@ -2758,7 +2446,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
                 Ray sray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
                 Best b;
                 bool tie = false;
-                walk<LDSS, FAST, PRUNE>(P, sray, true, stack, stride, b, scn);
+                walk<LDSS, FAST, PRUNE>(P, sray, true, stack, stride, b, scn, cnt);
                 (void)tie;
                 if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
             }
@@ -2960,20 +2648,19 @@ __global__ void trace_pixel_kernel(const DParams P, uint32_t x, uint32_t y, doub
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const Ray ray = camera_ray(P, x, y, 0u);
     Best b;
-    bool tie = false;
-    traverse<true, FAST>(P, ray, false, stack, 1u, b, cnt, tie);
-    if (P.dbg_log) dbg_event(P, 9.0, tie ? 1.0 : 0.0, b.t, (double)b.ref);
-    if (FAST && tie) traverse<true, false>(P, ray, false, stack, 1u, b, cnt, tie);
+    walk<false, FAST, false, true>(P, ray, false, stack, 1u, b, nullptr, cnt); // (the counting instantiation writes the event log)
+    if (!FAST) dbg_event(P, 9.0, 0.0, b.t, (double)b.ref);
     out[0] = b.t; out[1] = (double)b.ref; out[2] = (double)b.accel; out[3] = (double)P.nlights;
     if (b.ref == NO_HIT) return;
     Shade sh;
     shade_frame(P, ray, b, sh);
+    DParams Q = P;
+    Q.dbg_log = nullptr; // the log is the primary ray's
     for (uint32_t l = 0; l < P.nlights; ++l) {
         const DLight L = P.lights[l];
         const Ray sray = ray_new(sh.p, V3{L.pos[0], L.pos[1], L.pos[2]} - sh.p);
         Best sb;
-        traverse<false, FAST>(P, sray, true, stack, 1u, sb, cnt, tie);
-        if (FAST && tie && !(sb.t < 1.0)) traverse<false, false>(P, sray, true, stack, 1u, sb, cnt, tie);
+        walk<false, FAST, false, true>(Q, sray, true, stack, 1u, sb, nullptr, cnt);
         out[4 + 2 * l] = sb.t; out[5 + 2 * l] = (double)sb.ref;
     }
     out[4 + 2 * P.nlights] = sh.p.x; out[5 + 2 * P.nlights] = sh.p.y; out[6 + 2 * P.nlights] = sh.p.z; // origin of the shadow rays
@@ -3033,7 +2720,7 @@ hipError_t launch_probe_lds(uint32_t blocks, uint32_t iters, uint32_t *sink, hip
 // host-callable launchers (used by capi.cpp)
 // ------------------------------------------------------------------------------------------
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
-    const bool prune = P.prune && !stats && !fast;
+    const bool prune = P.prune && !fast;
     if (P.lds_image && !stats && !fast) { // LDS-resident scene: `blocks` = one 1024-lane workgroup per CU
         size_t lds = (size_t)P.stack_depth * LG_LDSS_BLOCK * sizeof(uint32_t) + (size_t)P.lds_image_n16 * 16u;
         if (prune) hipLaunchKernelGGL((trace_kernel<false, false, true, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
@@ -3042,7 +2729,8 @@ hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks
     }
     size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
     if (prune) {
-        hipLaunchKernelGGL((trace_kernel<false, false, false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        if (stats) hipLaunchKernelGGL((trace_kernel<true, false, false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+        else hipLaunchKernelGGL((trace_kernel<false, false, false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
         return hipGetLastError();
     }
     if (fast) {
@@ -3054,17 +2742,10 @@ hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks
     }
     return hipGetLastError();
 }
-hipError_t launch_stream_trace(const DParams &P, bool fast, bool shadow, bool fixup, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
-    const bool ldss = P.lds_image && !fast && !fixup; // LDS-resident scene: `blocks` = one workgroup per CU (the rare fix-up pass reads L1/L2)
-    const uint32_t block = ldss ? LG_LDSS_BLOCK : LG_BLOCK;
-    const uint32_t depth = fast ? stack_depth : P.stack_depth;
-    size_t lds = (size_t)depth * block * sizeof(uint32_t) + (ldss ? (size_t)P.lds_image_n16 * 16u : 0u);
-#define LG_LAUNCH(F, S, L, X) hipLaunchKernelGGL((stream_trace_kernel<F, S, L, X>), dim3(blocks), dim3(block), lds, stream, P)
-    if (fast) { if (shadow) LG_LAUNCH(true, true, false, false); else LG_LAUNCH(true, false, false, false); }
-    else if (ldss) { if (shadow) LG_LAUNCH(false, true, true, false); else LG_LAUNCH(false, false, true, false); }
-    else if (fixup) { if (shadow) LG_LAUNCH(false, true, false, true); else LG_LAUNCH(false, false, false, true); }
-    else { if (shadow) LG_LAUNCH(false, true, false, false); else LG_LAUNCH(false, false, false, false); }
-#undef LG_LAUNCH
+hipError_t launch_stream_fixup(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream) {
+    size_t lds = (size_t)P.stack_depth * LG_BLOCK * sizeof(uint32_t);
+    if (shadow) hipLaunchKernelGGL((stream_fixup_kernel<true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+    else hipLaunchKernelGGL((stream_fixup_kernel<false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     return hipGetLastError();
 }
 hipError_t launch_stream_packet(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream) {
@@ -3088,7 +2769,7 @@ hipError_t stream_packet_occupancy(uint32_t stack_depth, int *blocks_per_cu) { /
 }
 // raise the dynamic-LDS limit of the LDS-resident-scene variants to `bytes`
 hipError_t stream_trace_ldss_prepare(size_t bytes) {
-    const void *fns[12] = {reinterpret_cast<const void *>(trace_kernel<false, false, true>),
+    const void *fns[10] = {reinterpret_cast<const void *>(trace_kernel<false, false, true>),
                           reinterpret_cast<const void *>(trace_kernel<false, false, true, true>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, true, true>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, true, true, false, true>),
@@ -3096,8 +2777,6 @@ hipError_t stream_trace_ldss_prepare(size_t bytes) {
                           reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, true>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, true, true, false>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, false>),
-                          reinterpret_cast<const void *>(stream_trace_kernel<false, false, true, false>),
-                          reinterpret_cast<const void *>(stream_trace_kernel<false, true, true, false>),
                           reinterpret_cast<const void *>(stream_packet_kernel<false, true>),
                           reinterpret_cast<const void *>(stream_packet_kernel<true, true>)};
     for (const void *f : fns) {
@@ -3158,37 +2837,21 @@ hipError_t launch_stream_shade(const DParams &P, hipStream_t stream) {
     hipLaunchKernelGGL(stream_shade_kernel, dim3(blocks), dim3(LG_BLOCK), 0, stream, P);
     return hipGetLastError();
 }
-hipError_t stream_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu) {
-    size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
-    int a = 0, b = 0;
-    hipError_t e;
-    if (fast) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<true, false, false, false>, LG_BLOCK, lds);
-        if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<true, true, false, false>, LG_BLOCK, lds);
-    } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, stream_trace_kernel<false, false, false, false>, LG_BLOCK, lds);
-        if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, stream_trace_kernel<false, true, false, false>, LG_BLOCK, lds);
-    }
-    *blocks_per_cu = a < b ? a : b;
-    return e;
-}
 hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu) {
     size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
     if (fast) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, true, false>, LG_BLOCK, lds);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, false, false>, LG_BLOCK, lds);
 }
 hipError_t trace_set_lds_limit(size_t bytes) {
-    const void *fns[18] = {reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, true>), reinterpret_cast<const void *>(wf_trace_kernel<false, true, false, false>),
+    const void *fns[17] = {reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, true>), reinterpret_cast<const void *>(wf_trace_kernel<false, true, false, false>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, true, true>), reinterpret_cast<const void *>(wf_trace_kernel<false, true, false, false, true>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, false, true>), reinterpret_cast<const void *>(trace_kernel<false, false, false, true>),
                           reinterpret_cast<const void *>(wf_trace_kernel<true, false, false, true>), reinterpret_cast<const void *>(wf_trace_kernel<true, true, false, false>),
                           reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, false>), reinterpret_cast<const void *>(wf_trace_kernel<true, false, false, false>),
                           reinterpret_cast<const void *>(trace_kernel<false, false, false>), reinterpret_cast<const void *>(trace_kernel<true, false, false>),
                           reinterpret_cast<const void *>(trace_kernel<false, true, false>), reinterpret_cast<const void *>(trace_kernel<true, true, false>),
-                          reinterpret_cast<const void *>(stream_trace_kernel<false, false, false, false>), reinterpret_cast<const void *>(stream_trace_kernel<false, true, false, false>),
-                          reinterpret_cast<const void *>(stream_trace_kernel<true, false, false, false>), reinterpret_cast<const void *>(stream_trace_kernel<true, true, false, false>)};
+                          reinterpret_cast<const void *>(trace_kernel<true, false, false, true>),
+                          reinterpret_cast<const void *>(stream_fixup_kernel<false>), reinterpret_cast<const void *>(stream_fixup_kernel<true>)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;

@@ -50,7 +50,7 @@ def test_fuzz_campaign(gen):
         w, h = (int(v) for v in os.environ["LASGUN_FUZZ_FILM"].split("x"))
     o = oracle()
     done = {"generator": gen, "film": [w, h], "seeds": [seed_range().start, seed_range().stop], "scenes": 0, "renders": 0,
-            "refused_by_both": 0, "fast_refused": 0, "nan_pixels": 0, "mismatches": []}
+            "refused_by_both": 0, "fast_refused": 0, "nan_pixels": 0, "libm_sensitive_pixels": 0, "mismatches": []}
     for seed in seed_range():
         try:
             oacc = o.Accel(build(o, seed))
@@ -59,13 +59,20 @@ def test_fuzz_campaign(gen):
                 G.Accel(build(G, seed))  # what the reference cannot build, neither side builds
             done["refused_by_both"] += 1
             continue
-        ofilm = o.Film(w, h)
-        o.capture_subset_mt(0, 1, oacc, ofilm, 8)
+        # The oracle twice: with the portable trigonometry the GPU uses (the comparison: bytes and radiance bits), and with glibc's
+        # (what the Rust binary calls).  The two differ by an ulp in atan2 / acos now and then, and a knife-edge scene -- a shadow or
+        # mirror ray through the point where two spheres touch -- turns that ulp into another pixel value (the
+        # generator adversarial_prune_scene builds such scenes on purpose): counted, not an error of the device.
+        ofilm_libm = o.Film(w, h)
+        o.capture_subset_mt(0, 1, oacc, ofilm_libm, 8)
         o.set_trig_mode(1)
         try:
+            ofilm = o.Film(w, h)
+            o.capture_subset_mt(0, 1, oacc, ofilm, 8)
             orad = o.capture_radiance(oacc, w, h, nthreads=8)
         finally:
             o.set_trig_mode(0)
+        done["libm_sensitive_pixels"] += int((ofilm_libm.pixels() != ofilm.pixels()).any(axis=-1).sum())
         acc = G.Accel(build(G, seed))
         done["scenes"] += 1
         done["nan_pixels"] += int(np.isnan(np.asarray(orad)).any(axis=-1).sum())
