@@ -24,13 +24,16 @@ Prints ONE JSON line on rank 0.
                 over the kernel's average duration, against 256 CUs x 4 SIMDs x 16 f64 lanes x 2.4 GHz).  The
                 SURVEY 8(d) byte figure is kept beside it (`hbm_algorithmic`: those bytes are served by the LDS-resident
                 scene and never reach HBM) together with the box's measured HBM copy rate and the LDS fraction (`lds`).
-  traffic       HBM bytes per launch of that kernel from rocprofv3 PMC passes of THIS source (profiles/r02_pmc.json
-                records the sha of kernels.hip it was collected on); null when the source has changed since.
+  traffic       HBM bytes per launch of that kernel from rocprofv3 PMC passes of THIS source (profiles/r03_pmc.json
+                records the hash of the device sources it was collected on); null when they have changed since.
   cpu_baseline  the CPU oracle (a port: the Rust reference cannot be built here) timed on a bounded strided sample
                 of the same frame on this box's host cores (rank 0, N = 1 only).
+  bit_exact     the TIMED frame (the last of the K steps, as gathered on rank 0) compared byte for byte with the film the
+                cpu_baseline leg renders on the oracle, on every pixel of that sample (the whole film when the host is fast
+                enough: n = 1); a mismatch makes the run exit non-zero after the line is printed.
+  roofline_mesh the same bookkeeping for configs[3] (100k-triangle mesh, glass + mirror, 4096^2) from two untimed frames.
 """
 import argparse
-import hashlib
 import json
 import os
 import sys
@@ -62,7 +65,7 @@ BYTES_NODE, BYTES_SPHERE, BYTES_CUBOID, BYTES_TRI, BYTES_ACCEL_ENTRY, BYTES_HIT,
 FLOPS_NODE, FLOPS_SPHERE, FLOPS_CUBOID, FLOPS_TRI, FLOPS_ACCEL_ENTRY = 26, 26, 26, 36, 78
 VALU_F64_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 BLOCK_ROWS = 64
-# frames in flight (the library keeps up to four launch contexts per accel); measured on one GPU with a hardware queue per
+# frames in flight (the library keeps up to eight launch contexts per accel); measured on one GPU with a hardware queue per
 # stream, ms per frame at N = 1 / one rank's share at N = 8: 1 stream 7.80 / 1.17, 2 streams 7.56 / 1.07, 4 streams 7.22 / 0.96
 FRAMES_IN_FLIGHT = int(os.environ.get("LASGUN_BENCH_FRAMES", "4"))  # (the variable: A/B only)
 
@@ -88,8 +91,9 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(width, height, target_seconds=15.0):
-    """Time the CPU oracle on a bounded strided sample {k + i*n} of the same frame (all host cores)."""
+def cpu_baseline(width, height, gpu_film=None, target_seconds=15.0):
+    """Time the CPU oracle on a bounded strided sample {k + i*n} of the same frame (all host cores); with `gpu_film`
+    (the timed frame, (h, w, 4) uint8 on the host) also compare every pixel of that sample byte for byte."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import oracle
     from lasgun_amd import scenes
@@ -112,23 +116,63 @@ def cpu_baseline(width, height, target_seconds=15.0):
     want_pixels = min(area, max(65536, int(rate * target_seconds / 2.0)))
     n = max(1, area // want_pixels)
     dt, rays, pixels = run(n)
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
-            "sample": "capture_subset(0, n=%d) of the same %dx%d frame: %d pixels, %d rays in %.2f s on %d threads"
-                      % (n, width, height, pixels, rays, dt, cores)}
+    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
+           "sample": "capture_subset(0, n=%d) of the same %dx%d frame: %d pixels, %d rays in %.2f s on %d threads"
+                     % (n, width, height, pixels, rays, dt, cores)}
+    check = None
+    if gpu_film is not None:
+        want = film.pixels().reshape(-1, 4)[::n]
+        got = gpu_film.reshape(-1, 4)[::n]
+        bad = int((want != got).sum())
+        check = {"bit_exact": bad == 0, "mismatched_bytes": bad, "checked_pixels": int(want.shape[0]),
+                 "checked": "the timed frame against the oracle film of the cpu_baseline leg, pixels {0, n, 2n, ...}, n = %d" % n}
+    return out, check
 
 
 def profiled_traffic(kernel_name, world, size):
-    """HBM bytes per launch of `kernel_name` from the committed PMC passes, only if they were collected on this source."""
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes, only if they were collected on these sources."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-        sha = hashlib.sha256(open(os.path.join(ROOT, "lasgun_amd", "csrc", "kernels.hip"), "rb").read()).hexdigest()[:16]
+        import lasgun_amd
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+        sha = lasgun_amd.device_source_sha16()
         t = pmc["kernels"].get(kernel_name)
-        if t and pmc.get("kernels_hip_sha16") == sha and world == 1 and size == 4096:
+        if t and pmc.get("device_source_sha16") == sha and world == 1 and size == 4096:
             # FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): doubled; both in KB
-            return (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0, "profiles/r02_pmc.json @ kernels.hip " + sha
+            return (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0, "profiles/r03_pmc.json @ device sources " + sha
     except (OSError, KeyError, ValueError):
         pass
     return None, None
+
+
+def mesh_roofline(G, la, stream):
+    """configs[3] (generated 100k-triangle torus of glass + mirror sphere, recursion 3, 4096^2) on this GPU, two untimed
+    frames after a warm-up: the triangle-test side of the path (the reference's 254-triangle leaves), in the traversal mode
+    the accel picks by default for such a scene (the pruned reference walk).  Counters from the counting instantiation of
+    the same walk."""
+    size = 4096
+    acc = G.Accel(la.scenes.mesh_scene(G, 224, 224, "glass"))
+    film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 2 * 1e3
+    st = G.capture_stats(acc, size, size, 0, size)
+    rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
+    flops = algorithmic_flops(st)
+    tops = flops / (ms * 1e-3) / 1e12
+    del film
+    torch.cuda.empty_cache()
+    return {"workload": "configs[3]: 4096x4096, 100,352-triangle torus (glass) in a transformed group + mirror sphere in the Cornell shell, recursion 3",
+            "ms_per_frame": ms, "value": rays / ms / 1e3, "unit": "Mrays/s", "rays_per_frame": rays,
+            "bound": "valu_f64", "achieved": tops, "peak": VALU_F64_PEAK_TOPS, "frac": tops / VALU_F64_PEAK_TOPS,
+            "kernel": "lg::trace_kernel<false, false, false, true>", "algorithmic_flops_per_frame": flops,
+            "work_per_frame": {k: st[k] for k in ("nodes_tested", "spheres_tested", "cuboids_tested", "triangles_tested", "accel_entries", "hits")},
+            "traversal": "reference tree, pruned walk (lg_accel_set_prune default for a scene with a big mesh), megakernel",
+            "note": "one kernel per frame (megakernel): frame time = kernel time; byte-identical to the oracle in tests/test_gpu_configs.py"}
 
 
 def main():
@@ -142,10 +186,13 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="A/B: frames one after the other on one stream (no overlap)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (tiles staged through host memory)")
+    ap.add_argument("--all-gather", action="store_true",
+                    help="the end-of-frame collective is ONE all-gather (every rank ends with the film) instead of ONE gather to rank 0")
     ap.add_argument("--force-dist", action="store_true",
                     help="world size 1 with a process group and a real gather: RCCL rehearsal on a 1-GPU box")
     args = ap.parse_args()
 
+    exit_code = 0
     # stdout carries ONE line, the JSON record: whatever libraries print there (RCCL's version banner at communicator
     # creation, gloo's connection notes) is sent to stderr by pointing file descriptor 1 at it until the record is written
     sys.stdout.flush()
@@ -181,8 +228,6 @@ def main():
     t0 = time.perf_counter()
     acc = G.Accel(scene)  # host HLBVH build + flatten + upload (outside the timed region, reported below)
     accel_build_s = time.perf_counter() - t0
-    if os.environ.get("LASGUN_WAVEFRONT"):  # A/B: 0 = the earlier three-kernel pipeline over dense pixels
-        G.set_wavefront(acc, os.environ["LASGUN_WAVEFRONT"] == "1")
     if os.environ.get("LASGUN_PACKET"):  # A/B: one tree walk per wavefront
         G.set_packet(acc, os.environ["LASGUN_PACKET"] == "1")
     # LASGUN_NO_LDS_SCENE=1 (A/B): the traversal kernels read the scene tables through L1/L2 instead of LDS
@@ -192,7 +237,7 @@ def main():
     cur_stream = torch.cuda.current_stream()
     if balanced:
         ig = InterleavedGather(w, h, rank, world, BLOCK_ROWS, "cuda" if args.backend == "nccl" else "cpu", always_gather=args.force_dist,
-                               buffers=FRAMES_IN_FLIGHT + 1)
+                               buffers=FRAMES_IN_FLIGHT + 1, all_ranks=args.all_gather)
         cuda_tile = torch.zeros((h // world, w, 4), dtype=torch.uint8, device="cuda") if args.backend != "nccl" else None
         frame_streams = [torch.cuda.Stream() for _ in range(FRAMES_IN_FLIGHT)]
         overlap = [not args.sequential]
@@ -243,6 +288,7 @@ def main():
     full = finish()  # waits for the last gather (inside the timed region)
     fence()
     elapsed = time.perf_counter() - t0
+    timed_film = full.cpu().numpy().copy() if (rank == 0 and full is not None) else None  # the frame `value` was measured on
 
     # one frame at a time (render + gather, nothing else in flight): latency at this N
     was = overlap[0]
@@ -302,7 +348,7 @@ def main():
         print("verify: gathered %d-rank film == single-GPU film" % world, file=sys.stderr)
 
     extras = rank == 0 and world == 1 and not args.no_extras and not args.force_dist
-    e2e_ms = fast_info = probes = None
+    e2e_ms = fast_info = probes = mesh_info = None
     if extras:
         # PCIe-inclusive figure (never `value`): lg_capture into a HOST film = host BVH build + upload + render + 64 MiB D2H
         film = G.Film(w, h)
@@ -334,6 +380,7 @@ def main():
         del ref_film
         torch.cuda.empty_cache()
         probes = {"hbm_copy_GBps": G.probe_rate("hbm_copy"), "lds_read_GBps": G.probe_rate("lds_read")}
+        mesh_info = mesh_roofline(G, la, cur_stream) if args.size == 4096 else None
 
     if rank == 0:
         value = rays * args.steps / elapsed / 1e6
@@ -347,10 +394,10 @@ def main():
             # wavefront pipeline: lg::wf_trace_kernel<FAST, SHADOW, scene tables resident in LDS>, lg::wf_shade_kernel
             # wavefront pipeline: lg::wf_trace_kernel<FAST, SHADOW, scene tables resident in LDS, level-0 closest pass>, lg::wf_shade_kernel<KIND, L0>
             shadow = "shadow" in dom
-            kernel_name = ("lg::wf_trace_kernel<false, %s, %s, %s>" % ("true" if shadow else "false", "true" if lds_scene else "false", "false" if shadow else "true")
+            kernel_name = ("lg::wf_trace_kernel<false, %s, %s, %s, false>" % ("true" if shadow else "false", "true" if lds_scene else "false", "false" if shadow else "true")
                            if dom.startswith("trace<") else "lg::wf_shade_kernel<0, true>")
         else:  # megakernel (a share too small for the pipeline, e.g. a small --size over many ranks)
-            dom_ms, dst, kernel_name = frame_ms, st, "lg::trace_kernel<false, false, %s>" % ("true" if lds_scene else "false")
+            dom_ms, dst, kernel_name = frame_ms, st, "lg::trace_kernel<false, false, %s, false>" % ("true" if lds_scene else "false")
             per_kernel = {"trace_kernel": frame_ms}
         dom_bytes, dom_flops = algorithmic_bytes(dst), algorithmic_flops(dst)
         secs = dom_ms * 1e-3
@@ -365,6 +412,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "latency_ms": latency_ms,
+            "value_single_frame": rays / latency_ms / 1e3,  # Mrays/s of ONE frame issued alone (render + gather), nothing else in flight
             "config": {"workload": "configs[2]: %dx%d, Cornell shell + 1024 random plastic spheres (SplitMix64 0x1A560001), 1 spp, 1 point light" % (w, h),
                        "rays_per_frame": rays, "primary": total["primary_rays"], "shadow": total["shadow_rays"],
                        "parallelism": ("64-row blocks dealt round-robin over %d rank(s)%s; consecutive frames %s"
@@ -391,13 +439,23 @@ def main():
         }
         if fast_info is not None:
             out["fast_mode"] = fast_info
+        if mesh_info is not None:
+            out["roofline_mesh"] = mesh_info
+        check = None
         if world == 1 and not args.no_cpu_baseline and not args.force_dist and not args.no_extras:
-            out["cpu_baseline"] = cpu_baseline(w, h)
+            out["cpu_baseline"], check = cpu_baseline(w, h, timed_film)
+        out["bit_exact"] = check["bit_exact"] if check else None       # null: the oracle leg did not run (N > 1, --no-cpu-baseline)
+        out["mismatched_bytes"] = check["mismatched_bytes"] if check else None
+        out["bit_exact_check"] = check
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        if check is not None and not check["bit_exact"]:
+            exit_code = 3  # the metric says "bit-exact RGBA8 vs CPU": a frame that is not, is not a result
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -140,6 +140,10 @@ lg_multi *lg_multi_create(const lg_scene *, const int *device_ids, int count, ui
 void lg_multi_free(lg_multi *);
 int lg_multi_capture_device(lg_multi *, uint32_t width, uint32_t height, void *dev_rgba_on_root);
 int lg_multi_capture(lg_multi *, lg_film *);
+/* The all-gather form: EVERY rank's device receives the whole film -- dev_rgba[r] is width*height*4 bytes on
+ * rank r's device.  One ncclAllGather per device inside one group; contiguous tiles arrive in row order, interleaved blocks are
+ * put in row order by n strided device copies.  One device per rank (no repeats); the height must split evenly.  Synchronous. */
+int lg_multi_capture_device_all(lg_multi *, uint32_t width, uint32_t height, void *const *dev_rgba);
 int lg_multi_rank_count(const lg_multi *);
 lg_accel *lg_multi_accel(const lg_multi *, int rank);   /* rank's accel (to select traversal mode / organisation per rank) */
 int lg_multi_uses_rccl(const lg_multi *);                /* 1 when a communicator was created */
@@ -194,19 +198,19 @@ int lg_accel_set_mode(const lg_accel *, int mode);
  * reference's 254-triangle leaves are where it pays), off otherwise; 0 / 1: off / on. */
 int lg_accel_set_prune(const lg_accel *, int enabled);
 
-/* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes without
- * glass / mirror, with <= 32 lights and with at least 512 spheres / boxes (where node and sphere
- * tests dominate a ray) run as a three-kernel streaming pipeline (primary traversal + shading
- * frame, shadow traversal, shade) with per-pixel state in HBM when the launch covers at least
- * 2^20 pixels (2^23 when the scene carries a big mesh); everything else -- and everything when 0 -- runs in the
- * single persistent megakernel.  2 = use the pipeline wherever it is possible (tests). */
+/* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes with <= 32 lights and at least 512
+ * spheres / boxes (where node and sphere tests dominate a ray; glass / mirror over a big mesh excepted) run level by level in
+ * the WAVEFRONT pipeline (below) with per-ray state in HBM when the launch covers at least 2^20 pixels (2^23 when the scene
+ * carries a big mesh); everything else -- and everything when 0 -- runs in the single persistent megakernel.
+ * 2 = use the pipeline wherever it is possible (tests). */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
 
-/* Which pipeline "streaming" means.  1 (default): the WAVEFRONT pipeline -- li() level by level: per recursion level a
- * closest-hit pass (hits compacted into a queue, misses finished on the spot), an any-hit shadow pass and a shade pass
- * that appends the specular children to the next level's ray queue, then the levels are combined bottom-up in the
- * reference's (output + reflected) + refracted order.  It serves every scene, glass / mirror included.  0: the earlier
- * three-kernel pipeline over dense pixels (scenes without glass / mirror only; specular scenes then run in the megakernel). */
+/* The WAVEFRONT pipeline is li() level by level: per recursion level a closest-hit pass (hits compacted into a queue, misses
+ * finished on the spot), an any-hit shadow pass and a shade pass that appends the specular children to the next level's ray
+ * queue, then the levels are combined bottom-up in the reference's (output + reflected) + refracted order.  It serves every
+ * scene, glass / mirror included.  This switch used to select round 1's three-kernel pipeline over dense pixels instead
+ * (enabled = 0); that organisation equalled the wavefront pipeline on every measured scene and was retired in round 3 --
+ * the call is kept for source compatibility and changes nothing.  (lg_accel_set_packet still selects the packet organisation.) */
 int lg_accel_set_wavefront(const lg_accel *, int enabled);
 
 /* Wavefront pipeline, launches of 2 Mpixel and more: cut the launch into `bands` row bands (2..8) rendered on internal streams,

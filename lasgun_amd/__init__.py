@@ -56,6 +56,7 @@ _EXTRA = {
     "multi_free": (None, [_C.c_void_p]),
     "multi_capture_device": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
     "multi_capture": (_C.c_int, [_C.c_void_p, _C.c_void_p]),
+    "multi_capture_device_all": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.POINTER(_C.c_void_p)]),
     "multi_rank_count": (_C.c_int, [_C.c_void_p]),
     "multi_accel": (_C.c_void_p, [_C.c_void_p, _C.c_int]),
     "multi_uses_rccl": (_C.c_int, [_C.c_void_p]),
@@ -267,6 +268,12 @@ class HipApi(Api):
                 if api.call("multi_capture_device", self.h, int(w), int(h), _C.c_void_p(int(dev_ptr))):
                     raise LasgunError(api.last_error())
 
+            def capture_device_all(self, w, h, dev_ptrs):
+                """All-gather form: dev_ptrs[r] = a w*h*4-byte buffer on rank r's device; every one receives the whole film."""
+                arr = (_C.c_void_p * len(dev_ptrs))(*[int(p) for p in dev_ptrs])
+                if api.call("multi_capture_device_all", self.h, int(w), int(h), arr):
+                    raise LasgunError(api.last_error())
+
             def capture(self, film):
                 if api.call("multi_capture", self.h, film.h):
                     raise LasgunError(api.last_error())
@@ -295,6 +302,21 @@ class HipApi(Api):
         self.call("accel_info", accel.h, out)
         keys = ("nodes", "primrefs", "spheres", "cuboids", "triangles", "accels", "max_stack", "device_bytes")
         return dict(zip(keys, [int(v) for v in out]))
+
+
+def device_source_sha16():
+    """First 16 hex digits of the SHA-256 over the device sources (csrc/*.h, csrc/k_*.hip, in name order): the provenance
+    stamp of profiler counters -- bench.py reports a committed PMC figure only while the sources it was collected on are unchanged."""
+    import glob
+    import hashlib
+    src = _os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(_os.path.join(src, "*.h")) + glob.glob(_os.path.join(src, "k_*.hip"))):
+        if _os.path.basename(path) in ("host.h",):
+            continue
+        h.update(_os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _share_torch_hip_runtime():

@@ -17,7 +17,7 @@
 #include "host.h"
 
 namespace lg {
-// kernels.hip
+// k_mega.hip, k_wavefront.hip, k_packet.hip, k_probe.hip
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
 hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
 hipError_t launch_stream_fixup(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream);
@@ -28,8 +28,9 @@ hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t bl
 hipError_t launch_wf_shade(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t launch_wf_combine(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t wf_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
-hipError_t trace_set_lds_limit(size_t bytes);
-hipError_t stream_trace_ldss_prepare(size_t bytes);
+hipError_t mega_set_lds_limit(size_t bytes, bool ldss);
+hipError_t wf_set_lds_limit(size_t bytes, bool ldss);
+hipError_t packet_set_lds_limit(size_t bytes, bool ldss);
 hipError_t launch_kat(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d, double *out,
                       hipStream_t stream);
 hipError_t launch_kat_si(V3 o, V3 d, double t, V3 dpdu, V3 dpdv, double *out, hipStream_t stream);
@@ -319,10 +320,10 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     return P;
 }
 
-// The wavefront pipeline (kernels.hip): per chunk of the film and per supersample, levels 0 .. L-1 top-down (closest,
+// The wavefront pipeline (k_wavefront.hip): per chunk of the film and per supersample, levels 0 .. L-1 top-down (closest,
 // shadow, shade), then the combine passes bottom-up.  Queue capacities are worst case (level d holds at most 2^d rays per
 // pixel of the chunk), so the chunk is sized to the memory budget of the launch context: nothing can overflow.
-constexpr size_t WF_FULL_MIN_HOST = 48; // == WF_FULL_MIN of kernels.hip
+constexpr size_t WF_FULL_MIN_HOST = 48; // == WF_FULL_MIN of k_wavefront.hip
 static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c, hipStream_t stream) {
     const uint32_t levels = (a.flat.has_specular && P0.recursion > 0) ? P0.recursion + 1u : 1u;
     const uint32_t nsamples = P0.ss_root * P0.ss_root;
@@ -870,7 +871,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         }
         if (!a->fast_available) a->stack_depth_fast1 = a->stack_depth;
         size_t lds = (size_t)std::max(a->stack_depth, a->stack_depth_fast1) * 256 * 4;
-        if (lds > 64 * 1024) HIP_TRY(trace_set_lds_limit(lds));
+        if (lds > 64 * 1024) { HIP_TRY(mega_set_lds_limit(lds, false)); HIP_TRY(wf_set_lds_limit(lds, false)); HIP_TRY(packet_set_lds_limit(lds, false)); }
         int per_cu = 0, cus = 0;
         HIP_TRY(trace_occupancy(a->stack_depth, false, &per_cu));
         int per_cu_fast = 0;
@@ -942,7 +943,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                         if (r.second + i < np_soup)
                             std::memcpy(&img[((size_t)a->lds_soup_off + (size_t)(r.second + i) * 3) * 4], &fm.leaf_soup[r.first + i], 48);
                     }
-                // walk words of every record (words 16..19; kernels.hip, traverse_ref): the second formulation of the reference walk
+                // walk words of every record (words 16..19; walk.h, traverse_ref): the second formulation of the reference walk
                 // addresses nodes by their byte offset in the image and takes a leaf's slot range ready-made
                 for (const DAccel &A : fm.accels) {
                     const uint32_t tree0 = a->lds_node_off * 16u + A.lnode_base * LDS_NODE_STRIDE * 16u;
@@ -967,7 +968,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                 }
                 a->lds_image.upload(img);
                 a->lds_image_n16 = (uint32_t)n16;
-                HIP_TRY(stream_trace_ldss_prepare(LDS_MAX));
+                HIP_TRY(mega_set_lds_limit(LDS_MAX, true)); HIP_TRY(wf_set_lds_limit(LDS_MAX, true)); HIP_TRY(packet_set_lds_limit(LDS_MAX, true));
                 a->packet_lds = true;
                 if (stack_bytes + n16 * 16 <= LDS_MAX) a->ldss_blocks = (uint32_t)cus;
             }

@@ -201,7 +201,7 @@ struct DParams {
     uint32_t wf_level;          // level of this launch
     uint32_t wf_levels;         // number of levels (recursion + 1, or 1 for scenes without glass / mirror)
     uint32_t tile0;             // first tile of the chunk (level 0: pixel tile = tile0 + work tile)
-    uint32_t prune;             // reference traversal: the pruned walk (lg_accel_set_prune / the accel's default; kernels.hip, traverse_ref<.., PRUNE>)
+    uint32_t prune;             // reference traversal: the pruned walk (lg_accel_set_prune / the accel's default; walk.h, traverse_ref<.., PRUNE>)
     uint32_t *wf_counts;        // device counters: [d] rays of level d (d >= 1), [wf_levels + d] appended hits of level d
     unsigned long long wf_cap;      // capacity (rays) of this level's arrays
     unsigned long long wf_cap_next; // ... of the next level's

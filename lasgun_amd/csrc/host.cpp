@@ -789,7 +789,7 @@ struct Flattener {
     }
 
     // minv is EXACTLY the identity (1.0 and +0.0 bit patterns): the traversal may then skip inverse_transform_ray
-    // for rays whose components are finite and not -0 (kernels.hip, enter_accel: the product is the same bits)
+    // for rays whose components are finite and not -0 (walk.h, traverse_ref: the product is the same bits)
     static bool affine_is_identity(const Affine &m) {
         for (int c = 0; c < 4; ++c)
             for (int r = 0; r < 3; ++r) {

@@ -34,7 +34,7 @@ extern "C" void lg_set_last_error(const char *msg); // capi.cpp
 
 namespace {
 
-// ---- the six RCCL entry points this file needs (rccl.h: ncclResult_t is an int enum, ncclUint8 = 1) ----
+// ---- the RCCL entry points this file needs (rccl.h: ncclResult_t is an int enum, ncclUint8 = 1) ----
 typedef void *comm_t;
 struct Rccl {
     void *lib = nullptr;
@@ -44,6 +44,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, comm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
     bool load() {
@@ -58,6 +59,7 @@ struct Rccl {
     if (!field) { error = std::string("RCCL symbol missing: ") + sym; lib = nullptr; return false; }
         LG_SYM(CommInitAll, "ncclCommInitAll") LG_SYM(CommDestroy, "ncclCommDestroy") LG_SYM(GroupStart, "ncclGroupStart")
         LG_SYM(GroupEnd, "ncclGroupEnd") LG_SYM(Send, "ncclSend") LG_SYM(Recv, "ncclRecv") LG_SYM(GetErrorString, "ncclGetErrorString")
+        LG_SYM(AllGather, "ncclAllGather")
 #undef LG_SYM
         return true;
     }
@@ -69,6 +71,19 @@ constexpr int NCCL_UINT8 = 1;
 // multi-device state anew for every frame, like the reference rebuilds its BVH: one set per device list, kept for the
 // life of the process.  Calls on one set are serialised (g_rccl_mtx).
 std::map<std::vector<int>, std::vector<comm_t>> g_comms;
+
+// What an exchange must undo on every exit path (lg_multi_capture_device*).
+struct ExchangeGuard {
+    bool group_open = false;
+    std::vector<hipEvent_t> events;
+    int caller_device = -1;
+    ExchangeGuard() { if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1; }
+    ~ExchangeGuard() {
+        if (group_open) (void)g_rccl.GroupEnd();
+        for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+        if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    }
+};
 
 struct Share { // what one rank renders
     int device = 0;
@@ -181,6 +196,11 @@ int lg_multi_uses_rccl(const lg_multi *m) { return m->comms.empty() ? 0 : 1; }
 
 // The whole film into DEVICE memory of the root (the first device of the list).  Synchronous: on return the film is complete.
 int lg_multi_capture_device(lg_multi *m, uint32_t w, uint32_t h, void *dev_rgba_on_root) {
+    // declared in this order: on ANY exit path the guard first closes a still-open RCCL group (an error between GroupStart
+    // and GroupEnd would otherwise leave every later RCCL call of this thread -- PyTorch's included -- queued and never
+    // launched), destroys the events and puts the caller's device back; then the lock is released
+    std::unique_lock<std::mutex> rccl_lock(g_rccl_mtx, std::defer_lock);
+    ExchangeGuard guard;
     const uint32_t n = (uint32_t)m->shares.size();
     const size_t row_bytes = (size_t)w * 4;
     const bool interleaved = m->block_rows != 0 && h % (m->block_rows * n) == 0;
@@ -224,7 +244,6 @@ int lg_multi_capture_device(lg_multi *m, uint32_t w, uint32_t h, void *dev_rgba_
     HIP_OK(hipSetDevice(root.device));
     if (!m->recv_stream) HIP_OK(hipStreamCreateWithFlags(&m->recv_stream, hipStreamNonBlocking));
     hipStream_t root_stream = (hipStream_t)lg_accel_stream(root.accel);
-    std::vector<hipEvent_t> events;
     bool any_rccl = false;
     for (const Piece &p : pieces) if (m->shares[p.rank].device != root.device || m->force_rccl) any_rccl = true;
     if (any_rccl && m->comms.empty()) return mfail(m, "internal: no communicator");
@@ -236,12 +255,11 @@ int lg_multi_capture_device(lg_multi *m, uint32_t w, uint32_t h, void *dev_rgba_
         if (!has || s.device != root.device) continue;
         hipEvent_t ev;
         HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        guard.events.push_back(ev);
         HIP_OK(hipEventRecord(ev, (hipStream_t)lg_accel_stream(s.accel)));
         HIP_OK(hipStreamWaitEvent(m->recv_stream, ev, 0));
-        events.push_back(ev);
     }
-    std::unique_lock<std::mutex> rccl_lock(g_rccl_mtx, std::defer_lock);
-    if (any_rccl) { rccl_lock.lock(); NCCL_OK(g_rccl.GroupStart()); }
+    if (any_rccl) { rccl_lock.lock(); NCCL_OK(g_rccl.GroupStart()); guard.group_open = true; }
     for (const Piece &p : pieces) {
         Share &s = m->shares[p.rank];
         if (s.device == root.device && !m->force_rccl) continue; // copied below
@@ -253,7 +271,7 @@ int lg_multi_capture_device(lg_multi *m, uint32_t w, uint32_t h, void *dev_rgba_
         HIP_OK(hipSetDevice(root.device));
         NCCL_OK(g_rccl.Recv(film + p.film_off, p.bytes, NCCL_UINT8, s.comm_rank, m->comms[(size_t)root.comm_rank], m->recv_stream));
     }
-    if (any_rccl) NCCL_OK(g_rccl.GroupEnd());
+    if (any_rccl) { guard.group_open = false; NCCL_OK(g_rccl.GroupEnd()); }
     HIP_OK(hipSetDevice(root.device));
     if (!m->force_rccl)
         for (const Piece &p : pieces) {
@@ -263,13 +281,75 @@ int lg_multi_capture_device(lg_multi *m, uint32_t w, uint32_t h, void *dev_rgba_
         }
     HIP_OK(hipStreamSynchronize(m->recv_stream));
     HIP_OK(hipStreamSynchronize(root_stream)); // the root's own share, rendered in place
-    for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
     // the senders' streams have completed their sends once the root has received; make the tiles reusable explicitly
     for (uint32_t r = 1; r < n; ++r) {
         HIP_OK(hipSetDevice(m->shares[r].device));
         HIP_OK(hipStreamSynchronize((hipStream_t)lg_accel_stream(m->shares[r].accel)));
     }
-    HIP_OK(hipSetDevice(root.device));
+    return 0; // (the guard restores the caller's device)
+}
+
+// Every rank's device receives the WHOLE film ("equivalently ncclAllGather if every rank wants the image" --
+// a display per GPU, a later per-device pass over the full frame).  One device per rank (no repeats), equal shares: 64-row
+// blocks dealt round-robin, or contiguous row tiles of a height that n divides.  ONE ncclAllGather per device inside one
+// group, on that device's render stream; contiguous tiles land in row order as they arrive, interleaved blocks are put in
+// row order by n strided device copies per device.  dev_rgba[r] = a w*h*4-byte buffer on rank r's device.
+int lg_multi_capture_device_all(lg_multi *m, uint32_t w, uint32_t h, void *const *dev_rgba) {
+    std::unique_lock<std::mutex> rccl_lock(g_rccl_mtx, std::defer_lock);
+    ExchangeGuard guard;
+    const uint32_t n = (uint32_t)m->shares.size();
+    if (m->devices.size() != n) return mfail(m, "lg_multi_capture_device_all: one device per rank (a device may not repeat)");
+    const size_t row_bytes = (size_t)w * 4;
+    const uint32_t b = m->block_rows;
+    const bool interleaved = b != 0 && h % (b * n) == 0;
+    if (!interleaved && h % n != 0) return mfail(m, "lg_multi_capture_device_all: the film's height must be a multiple of the rank count");
+    const uint32_t rows = h / n;
+    const size_t tile_bytes = (size_t)rows * row_bytes;
+    if (n > 1 && m->comms.empty()) return mfail(m, "internal: no communicator");
+    std::vector<void *> gathered(n, nullptr); // interleaved: rank-major staging per device
+    for (uint32_t r = 0; r < n; ++r) {
+        Share &s = m->shares[r];
+        HIP_OK(hipSetDevice(s.device));
+        void *stream = lg_accel_stream(s.accel);
+        if (interleaved) {
+            const size_t need = tile_bytes * ((size_t)n + 1); // [own tile][n gathered tiles]
+            if (s.tile_bytes < need) {
+                if (s.tile) { HIP_OK(hipStreamSynchronize((hipStream_t)stream)); HIP_OK(hipFree(s.tile)); s.tile = nullptr; }
+                HIP_OK(hipMalloc(&s.tile, need));
+                s.tile_bytes = need;
+            }
+            gathered[r] = (uint8_t *)s.tile + tile_bytes;
+            if (lg_capture_interleaved_device(s.accel, w, h, b, n, r, s.tile, stream)) return mfail(m, lg_last_error());
+        } else { // rendered in place: rank r's tile is rows [r*rows, (r+1)*rows) of its own copy of the film
+            if (lg_capture_rows_device(s.accel, w, h, r * rows, (r + 1) * rows, 0, dev_rgba[r], stream)) return mfail(m, lg_last_error());
+        }
+    }
+    if (n > 1) {
+        rccl_lock.lock();
+        NCCL_OK(g_rccl.GroupStart());
+        guard.group_open = true;
+        for (uint32_t r = 0; r < n; ++r) {
+            Share &s = m->shares[r];
+            HIP_OK(hipSetDevice(s.device));
+            const void *send = interleaved ? s.tile : (const void *)((const uint8_t *)dev_rgba[r] + (size_t)r * tile_bytes); // (in place: RCCL allows send == recv + rank * count)
+            void *recv = interleaved ? gathered[r] : dev_rgba[r];
+            NCCL_OK(g_rccl.AllGather(send, recv, tile_bytes, NCCL_UINT8, m->comms[(size_t)s.comm_rank], (hipStream_t)lg_accel_stream(s.accel)));
+        }
+        guard.group_open = false;
+        NCCL_OK(g_rccl.GroupEnd());
+    }
+    for (uint32_t r = 0; r < n; ++r) {
+        Share &s = m->shares[r];
+        HIP_OK(hipSetDevice(s.device));
+        hipStream_t stream = (hipStream_t)lg_accel_stream(s.accel);
+        if (interleaved) { // rank q's compact tile holds image blocks q, q + n, ...: one strided copy per source rank
+            const uint8_t *src0 = n > 1 ? (const uint8_t *)gathered[r] : (const uint8_t *)s.tile;
+            for (uint32_t q = 0; q < n; ++q)
+                HIP_OK(hipMemcpy2DAsync((uint8_t *)dev_rgba[r] + (size_t)q * b * row_bytes, (size_t)n * b * row_bytes, src0 + (size_t)q * tile_bytes,
+                                        (size_t)b * row_bytes, (size_t)b * row_bytes, h / (b * n), hipMemcpyDeviceToDevice, stream));
+        }
+        HIP_OK(hipStreamSynchronize(stream));
+    }
     return 0;
 }
 

@@ -1,0 +1,349 @@
+// lasgun_amd/csrc/shade.h -- BxDFs, materials, the shading frame of a hit, camera rays, pixel addressing, quantisation.
+#pragma once
+#include "walk.h"
+
+namespace lg {
+// ------------------------------------------------------------------------------------------
+// BxDFs (core/bxdf/*.rs) in shading space
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double cos2_theta(V3 w) { return w.z * w.z; }
+__device__ __forceinline__ double abs_cos_theta(V3 w) { return fabs(w.z); }
+__device__ __forceinline__ double sin2_theta(V3 w) { return fmax_(1.0 - cos2_theta(w), 0.0); }
+__device__ __forceinline__ double sin_theta(V3 w) { return sqrt(sin2_theta(w)); }
+__device__ __forceinline__ double tan_theta(V3 w) { return sin_theta(w) / w.z; }
+__device__ __forceinline__ double tan2_theta(V3 w) { return sin2_theta(w) / cos2_theta(w); }
+__device__ __forceinline__ double cos_phi(V3 w) { double s = sin_theta(w); return s == 0.0 ? 1.0 : fmin_(fmax_(w.x / s, -1.0), 1.0); }
+__device__ __forceinline__ double sin_phi(V3 w) { double s = sin_theta(w); return s == 0.0 ? 0.0 : fmin_(fmax_(w.y / s, -1.0), 1.0); }
+
+__device__ __forceinline__ double fr_dielectric(double cos_i, double eta_i, double eta_t) { // fresnel.rs:37-64
+    cos_i = fmin_(fmax_(cos_i, -1.0), 1.0);
+    bool entering = cos_i > 0.0;
+    if (!entering) { double tmp = eta_i; eta_i = eta_t; eta_t = tmp; cos_i = fabs(cos_i); }
+    double sin_i = sqrt(fmax_(1.0 - cos_i * cos_i, 0.0));
+    double sin_t = eta_i / eta_t * sin_i;
+    if (sin_t >= 1.0) return 1.0;
+    double cos_t = sqrt(fmax_(1.0 - sin_t * sin_t, 0.0));
+    double r_parl = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+    double r_perp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+    return (r_parl * r_parl + r_perp * r_perp) * 0.5;
+}
+__device__ __forceinline__ V3 fr_conductor(double cos_i, V3 eta_i, V3 eta_t, V3 k) { // fresnel.rs:69-91
+    cos_i = fmin_(fmax_(cos_i, -1.0), 1.0);
+    V3 eta = div_ew(eta_t, eta_i);
+    V3 etak = div_ew(k, eta_i);
+    double c2 = cos_i * cos_i;
+    double s2 = 1.0 - c2;
+    V3 eta2 = mul_ew(eta, eta), etak2 = mul_ew(etak, etak);
+    V3 t0 = eta2 - etak2 - splat(s2);
+    V3 a2plusb2 = vsqrt(mul_ew(t0, t0) + 4.0 * mul_ew(eta2, etak2));
+    V3 t1 = a2plusb2 + splat(c2);
+    V3 a = vsqrt(0.5 * (a2plusb2 + t0));
+    V3 t2 = 2.0 * cos_i * a;
+    V3 rs = div_ew(t1 - t2, t1 + t2);
+    V3 t3 = c2 * a2plusb2 + splat(s2 * s2);
+    V3 t4 = t2 * s2;
+    V3 rp = div_ew(mul_ew(rs, t3 - t4), t3 + t4);
+    return 0.5 * (rp + rs);
+}
+__device__ __forceinline__ double tr_d(double ax, double ay, V3 wh) { // microfacet.rs:31-40
+    double tan2 = tan2_theta(wh);
+    if (isinf(tan2)) return 0.0;
+    double cos4 = cos2_theta(wh) * cos2_theta(wh);
+    double cp = cos_phi(wh), sp = sin_phi(wh);
+    double e = ((cp * cp) / (ax * ax) + (sp * sp) / (ay * ay)) * tan2;
+    return 1.0 / (PI * ax * ay * cos4 * (1.0 + e) * (1.0 + e));
+}
+__device__ __forceinline__ double tr_lambda(double ax, double ay, V3 w) { // microfacet.rs:55-66
+    double abs_tan = fabs(tan_theta(w));
+    if (isinf(abs_tan)) return 0.0;
+    double cp = cos_phi(w), sp = sin_phi(w);
+    double alpha = sqrt((cp * cp) * ax * ax + (sp * sp) * ay * ay);
+    double a2t2 = (alpha * abs_tan) * (alpha * abs_tan);
+    return (sqrt(1.0 + a2t2) - 1.0) / 2.0;
+}
+// microfacet::Reflection::f (microfacet.rs:101-115); conductor selects Substance::Conductor(1, eta, k)
+__device__ __forceinline__ V3 microfacet_f(V3 r, bool conductor, double d_eta_i, double d_eta_t, V3 c_eta, V3 c_k, double ax, double ay, V3 wo, V3 wi) {
+    double cos_o = abs_cos_theta(wo), cos_i = abs_cos_theta(wi);
+    V3 wh = wi + wo;
+    if (cos_i == 0.0 || cos_o == 0.0) return vzero();
+    if (wh.x == 0.0 && wh.y == 0.0 && wh.z == 0.0) return vzero();
+    wh = normalize(wh);
+    double ci = dot(wi, wh);
+    V3 spectrum = conductor ? fr_conductor(ci, splat(1.0), c_eta, c_k) : splat(fr_dielectric(ci, d_eta_i, d_eta_t));
+    double g = 1.0 / (1.0 + tr_lambda(ax, ay, wo) + tr_lambda(ax, ay, wi));
+    return mul_ew(r * tr_d(ax, ay, wh) * g, spectrum) / (4.0 * cos_i * cos_o);
+}
+__device__ __forceinline__ V3 oren_nayar_f(V3 r, double sigma_deg, V3 wo, V3 wi) { // diffuse.rs:29-56
+    double s = sigma_deg * (PI / 180.0), s2 = s * s;
+    double A = 1.0 - (s2 / 2.0 * (s2 + 0.33));
+    double B = 0.45 * s2 / (s2 + 0.09);
+    double sin_i = sin_theta(wi), sin_o = sin_theta(wo);
+    double max_cos = 0.0;
+    if (sin_i > 1e-4 && sin_o > 1e-4) {
+        double sp_i = sin_phi(wi), cp_i = cos_phi(wi), sp_o = sin_phi(wo), cp_o = cos_phi(wo);
+        double d_cos = cp_i * cp_o + sp_i * sp_o;
+        max_cos = fmax_(d_cos, 0.0);
+    }
+    double sin_alpha, tan_beta;
+    if (abs_cos_theta(wi) > abs_cos_theta(wo)) { sin_alpha = sin_o; tan_beta = sin_i / abs_cos_theta(wi); }
+    else { sin_alpha = sin_i; tan_beta = sin_o / abs_cos_theta(wo); }
+    return r * FRAC_1_PI * (A + B * max_cos * sin_alpha * tan_beta);
+}
+
+// Shading frame of one hit: what Material::scattering + BSDF::new keep (bsdf.rs:29-46)
+struct Shade {
+    V3 praw;   // interaction.p = ray.origin + ray.d * t (surface.rs:169)
+    V3 p;      // interaction.p + interaction.p_err (integrate.rs:40)
+    V3 pm;     // interaction.p - interaction.p_err (integrate.rs:127)
+    V3 wo, ng, ns, ss, ts;
+    int32_t mat;
+};
+
+// BSDF::f (bsdf.rs:73-92) with the BxDF list of Material::scattering (material/*.rs) inlined
+__device__ __forceinline__ V3 bsdf_f(const DMaterial &m, const Shade &sh, V3 wo, V3 wi) {
+    bool reflect = dot(wi, sh.ng) * dot(wo, sh.ng) > 0.0;
+    V3 wo_l{dot(wo, sh.ss), dot(wo, sh.ts), dot(wo, sh.ns)};
+    V3 wi_l{dot(wi, sh.ss), dot(wi, sh.ts), dot(wi, sh.ns)};
+    if (wo_l.z == 0.0) return vzero();
+    V3 f = vzero();
+    switch (m.kind) {
+    case MAT_MATTE: { // matte.rs:18-26 -- REFLECTION | DIFFUSE
+        if (reflect) {
+            V3 kd{m.p[0], m.p[1], m.p[2]};
+            f = f + (m.p[3] == 0.0 ? kd * FRAC_1_PI : oren_nayar_f(kd, m.p[3], wo_l, wi_l));
+        }
+        break;
+    }
+    case MAT_PLASTIC: { // plastic.rs:20-37 -- Lambertian then microfacet reflection, both REFLECTION
+        if (reflect) {
+            V3 kd{m.p[0], m.p[1], m.p[2]}, ks{m.p[3], m.p[4], m.p[5]};
+            if (vne(kd, vzero())) f = f + kd * FRAC_1_PI;
+            if (vne(ks, vzero())) f = f + microfacet_f(ks, false, 1.0, 1.5, vzero(), vzero(), m.p[6], m.p[6], wo_l, wi_l);
+        }
+        break;
+    }
+    case MAT_METAL: { // metal.rs:17-26
+        if (reflect) {
+            V3 eta{m.p[0], m.p[1], m.p[2]}, k{m.p[3], m.p[4], m.p[5]};
+            f = f + microfacet_f(splat(1.0), true, 0.0, 0.0, eta, k, m.p[6], m.p[7], wo_l, wi_l);
+        }
+        break;
+    }
+    case MAT_GLASS: { // glass.rs:33-56: specular BxDFs evaluate to zero (bxdf/mod.rs:172)
+        V3 kr{m.p[0], m.p[1], m.p[2]}, kt{m.p[3], m.p[4], m.p[5]};
+        if (reflect && vne(kr, vzero())) f = f + vzero();
+        if (!reflect && vne(kt, vzero())) f = f + vzero();
+        break;
+    }
+    default: // MAT_MIRROR, mirror.rs:15-17
+        if (reflect) f = f + vzero();
+        break;
+    }
+    return f;
+}
+
+struct Sample { // bxdf::LightSample
+    V3 spectrum, wi;
+    double pdf;
+};
+__device__ __forceinline__ V3 to_world(const Shade &sh, V3 v) { // bsdf.rs:165-171
+    return V3{sh.ss.x * v.x + sh.ts.x * v.y + sh.ns.x * v.z, sh.ss.y * v.x + sh.ts.y * v.y + sh.ns.y * v.z,
+              sh.ss.z * v.x + sh.ts.z * v.y + sh.ns.z * v.z};
+}
+__device__ __forceinline__ V3 clamp01(V3 v) {
+    return V3{fmin_(fmax_(v.x, 0.0), 1.0), fmin_(fmax_(v.y, 0.0), 1.0), fmin_(fmax_(v.z, 0.0), 1.0)};
+}
+// BSDF::sample_f(wo, (0.5, 0.5), REFLECTION | SPECULAR) (bsdf.rs:94-145, specular.rs:17-24):
+// only Mirror and Glass(kr != 0) own a matching component; exactly one, so comp = 0 and pdf / 1.
+__device__ __forceinline__ bool sample_specular_reflection(const DMaterial &m, const Shade &sh, Sample &s) {
+    bool glass = m.kind == MAT_GLASS;
+    if (!(m.kind == MAT_MIRROR || glass)) return false;
+    V3 r{m.p[0], m.p[1], m.p[2]};
+    if (glass && !vne(r, vzero())) return false; // component not present
+    V3 wo_l{dot(sh.wo, sh.ss), dot(sh.wo, sh.ts), dot(sh.wo, sh.ns)};
+    if (wo_l.z == 0.0) return false; // LightSample::zero(): pdf 0 -> caller returns zero
+    V3 wi_l{-wo_l.x, -wo_l.y, wo_l.z};
+    V3 fr = glass ? splat(fr_dielectric(wi_l.z, 1.0, m.p[6])) : splat(1.0);
+    V3 spectrum = mul_ew(fr, r) / abs_cos_theta(wi_l);
+    s.wi = to_world(sh, wi_l);
+    s.spectrum = clamp01(spectrum);
+    s.pdf = 1.0 / 1.0;
+    return true;
+}
+// BSDF::sample_f(wo, (0.5, 0.5), TRANSMISSION | SPECULAR) (specular.rs:43-63, bxdf/mod.rs:276-288)
+__device__ __forceinline__ bool sample_specular_transmission(const DMaterial &m, const Shade &sh, Sample &s) {
+    if (m.kind != MAT_GLASS) return false;
+    V3 kt{m.p[3], m.p[4], m.p[5]};
+    if (!vne(kt, vzero())) return false;
+    double eta_a = 1.0, eta_b = m.p[6];
+    V3 wo_l{dot(sh.wo, sh.ss), dot(sh.wo, sh.ts), dot(sh.wo, sh.ns)};
+    if (wo_l.z == 0.0) return false;
+    bool entering = wo_l.z > 0.0;
+    double eta_i = entering ? eta_a : eta_b, eta_t = entering ? eta_b : eta_a;
+    double eta = eta_i / eta_t;
+    // refract(wo, n = (0,0,1), eta)
+    V3 n{0.0, 0.0, 1.0};
+    double cos_i = dot(n, wo_l);
+    double sin2_i = fmax_(1.0 - cos_i * cos_i, 0.0);
+    double sin2_t = eta * eta * sin2_i;
+    if (sin2_t >= 1.0) return false; // total internal reflection: LightSample::zero()
+    double cos_t = sqrt(1.0 - sin2_t);
+    V3 wi_l = eta * -1.0 * wo_l + (eta * cos_i - cos_t) * n;
+    V3 spectrum = mul_ew(kt, splat(1.0) - splat(fr_dielectric(wi_l.z, eta_a, eta_b))) / abs_cos_theta(wi_l);
+    s.wi = to_world(sh, wi_l);
+    s.spectrum = clamp01(spectrum);
+    s.pdf = 1.0 / 1.0;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// the render kernel
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t to_byte(double c) { // img.rs:65-67
+    return (uint32_t)as_u8(round(fmin_(fmax_(c, 0.0), 1.0) * 255.0));
+}
+__device__ __forceinline__ V3 background(const DParams &P, V3 d) { // background.rs:25-34; powf(2.) == x*x
+    double a = fabs(dot(V3{0.0, 0.0, 1.0}, d));
+    double t = fmin_(sqrt(1.0 - a * a) / P.bg_scale, 1.0);
+    return V3{lerp(t, P.bg_inner.x, P.bg_outer.x), lerp(t, P.bg_inner.y, P.bg_outer.y), lerp(t, P.bg_inner.z, P.bg_outer.z)};
+}
+
+// frame fields
+enum { FR_ACC = 0, FR_SPEC_R = 3, FR_STATE = 6, FR_TO = 7, FR_TD = 10, FR_SPEC_T = 13, FR_A = 16, FR_PDF = 17 };
+__device__ __forceinline__ double &frame_at(const DParams &P, uint32_t depth, int field, unsigned long long gtid) {
+    return P.frames[((unsigned long long)depth * FRAME_DOUBLES + field) * P.frame_threads + gtid];
+}
+__device__ __forceinline__ void frame_put3(const DParams &P, uint32_t depth, int field, unsigned long long g, V3 v) {
+    frame_at(P, depth, field, g) = v.x; frame_at(P, depth, field + 1, g) = v.y; frame_at(P, depth, field + 2, g) = v.z;
+}
+__device__ __forceinline__ V3 frame_get3(const DParams &P, uint32_t depth, int field, unsigned long long g) {
+    return V3{frame_at(P, depth, field, g), frame_at(P, depth, field + 1, g), frame_at(P, depth, field + 2, g)};
+}
+
+// Which pixel a work item (tile, lane) renders and where its result goes (lib.rs:110-162 addresses pixels by
+// offset = y * w + x; the three modes are three ways of enumerating offsets).
+struct Pixel {
+    uint32_t x, y;
+    unsigned long long pix; // index into out_rgba (x4 bytes) / out_radiance (x3 doubles)
+    bool active;
+};
+__device__ __forceinline__ Pixel pixel_of(const DParams &P, uint32_t tile, uint32_t lane) {
+    Pixel px;
+    if (P.mode == 0) {
+        uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+        px.x = P.x0 + tx * 8u + (lane & 7u);
+        const uint32_t vy = P.y0 + ty * 8u + (lane >> 3); // row of the output buffer's addressing (== y unless rows are interleaved)
+        px.active = px.x < P.x1 && vy < P.y1;
+        px.y = P.ilv_n > 1u ? ((vy / P.ilv_b) * P.ilv_n + P.ilv_r) * P.ilv_b + vy % P.ilv_b : vy;
+        px.pix = (unsigned long long)(vy - P.out_row0) * P.out_pitch + (px.x - P.out_x0);
+    } else {
+        unsigned long long i = (unsigned long long)tile * 64ull + lane;
+        px.active = i < P.sub_count;
+        // mode 1: the strided subset {k + i*n} (lib.rs:152); mode 2: an explicit list of pixel offsets
+        unsigned long long off = P.mode == 1 ? P.sub_k + i * P.sub_n : (px.active ? P.pixel_list[i] : 0ull);
+        px.x = (uint32_t)(off % P.w);
+        px.y = (uint32_t)(off / P.w);
+        px.pix = P.out_compact ? i : off;
+    }
+    return px;
+}
+
+extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+
+// Shading frame of a hit from the ray that found it (resolve_hit + SurfaceInteraction::from,
+// surface.rs:158-183).  Pure function of (ray, best): recomputed after each shadow traversal
+// instead of being kept in registers across it, which is what lets 4-5 waves share a SIMD.
+__device__ __forceinline__ void shade_frame(const DParams &P, const Ray &ray, const Best &best, Shade &sh) {
+    Isect is;
+    sh.mat = resolve_hit(P, ray, best, is);
+    sh.wo = -normalize(ray.d);
+    sh.ng = face_forward(normalize(cross(is.gu, is.gv)), sh.wo);
+    sh.ns = is.has_n ? normalize(is.n) : normalize(cross(is.su, is.sv));
+    const double err = 2.220446049250313e-16 * 65536.0; // N::epsilon() * 2^16
+    V3 p = ray.o + ray.d * is.t;
+    V3 p_err = sh.ng * err;
+    sh.praw = p;
+    sh.p = p + p_err;
+    sh.pm = p - p_err;
+    sh.ss = normalize(is.su);    // si.surface.dpdu (bsdf.rs:34)
+    sh.ts = cross(sh.ns, sh.ss); // bsdf.rs:35
+}
+
+// Park / restore the shading frame in HBM across the shadow traversals ([field][lane]: coalesced).
+// What is stored are the very f64s shade_frame produced; wo, ts, p +- p_err are re-derived by
+// the same expressions, so the restored frame is bit-identical to a recomputed one.
+__device__ __forceinline__ void stash_put(const DParams &P, unsigned long long g, const Shade &sh) {
+    const unsigned long long n = P.frame_threads;
+    V3 p = sh.praw;
+    double *s = P.stash + g;
+    s[0 * n] = p.x; s[1 * n] = p.y; s[2 * n] = p.z;
+    s[3 * n] = sh.ng.x; s[4 * n] = sh.ng.y; s[5 * n] = sh.ng.z;
+    s[6 * n] = sh.ns.x; s[7 * n] = sh.ns.y; s[8 * n] = sh.ns.z;
+    s[9 * n] = sh.ss.x; s[10 * n] = sh.ss.y; s[11 * n] = sh.ss.z;
+    s[12 * n] = (double)sh.mat;
+}
+__device__ __forceinline__ void stash_get(const DParams &P, unsigned long long g, Shade &sh, const Ray &ray) {
+    const unsigned long long n = P.frame_threads;
+    const double *s = P.stash + g;
+    V3 p{s[0 * n], s[1 * n], s[2 * n]};
+    sh.ng = V3{s[3 * n], s[4 * n], s[5 * n]};
+    sh.ns = V3{s[6 * n], s[7 * n], s[8 * n]};
+    sh.ss = V3{s[9 * n], s[10 * n], s[11 * n]};
+    sh.mat = (int32_t)s[12 * n];
+    sh.wo = -normalize(ray.d);
+    const double err = 2.220446049250313e-16 * 65536.0;
+    V3 p_err = sh.ng * err;
+    sh.praw = p;
+    sh.p = p + p_err;
+    sh.pm = p - p_err;
+    sh.ts = cross(sh.ns, sh.ss);
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming pipeline: the same li() for scenes WITHOUT glass / mirror (no recursion), cut into
+// three kernels so that traversal (wants occupancy, 128 VGPRs) and shading (wants registers: trig,
+// microfacet, Fresnel) each get their own register allocation.  Per work item (pixel) the state
+// between kernels lives in HBM, SoA, indexed by widx = tile * 64 + lane:
+//   K1 primary   camera ray -> closest hit -> shade_frame           -> hit_ref, frame[13][n]
+//   K2 shadow    one any-hit traversal per light from frame.p       -> vis bits
+//   K3 shade     lights in order, ambient, sample sum, Img::set     -> film
+// (the shading frame used to be a kernel of its own between K1 and K2; see park_frame)
+// Every f64 is produced by the same expressions as in the megakernel; only their placement in
+// kernels differs.  Up to 32 lights; scenes with more use the megakernel.
+// ------------------------------------------------------------------------------------------
+// Camera::sample for sample `sidx` of pixel (x, y) (camera.rs:113-146)
+__device__ __forceinline__ Ray camera_ray(const DParams &P, uint32_t x, uint32_t y, uint32_t sidx) {
+    double img_plane_height = P.image_plane_height;
+    double img_plane_width = img_plane_height * P.aspect;
+    double pixel_size = img_plane_height * P.hinv;
+    double sample_separation = P.ss_distance * pixel_size;
+    double sox = ((double)x * P.winv - 0.5) * img_plane_width;
+    double soy = (0.5 - (double)(y + 1u) * P.hinv) * img_plane_height;
+    V3 cam_o = P.cam_origin + ((soy * P.pixel_separation) * P.cam_up) + ((sox * P.pixel_separation) * P.cam_aux);
+    V3 cam_d = P.cam_view + (soy * P.cam_up) + (sox * P.cam_aux);
+    V3 updiff = P.cam_up * sample_separation;
+    V3 auxdiff = P.cam_aux * sample_separation;
+    V3 halfdiff = updiff * 0.5 + auxdiff * 0.5;
+    const uint32_t dim = P.ss_root;
+    uint32_t si = sidx / dim, sj = sidx % dim;
+    V3 dd = cam_d + ((double)sj * updiff) + ((double)si * auxdiff) + halfdiff;
+    return ray_new(cam_o, dd);
+}
+
+// The shading frame of a primary hit, parked for the shadow and shade passes.  It is computed at the end of
+// the primary traversal pass (after the walk, so its registers are not live during it) rather than in a pass
+// of its own: one launch and one round trip of the hit record less (measured -2.7 % / -5 % per frame).
+__device__ __forceinline__ void park_frame(const DParams &P, unsigned long long widx, const Ray &ray, const Best &b) {
+    if (b.ref == NO_HIT) return;
+    Shade sh;
+    shade_frame(P, ray, b, sh);
+    const unsigned long long n = P.n_items;
+    double *f = P.frame + widx;
+    f[0 * n] = sh.praw.x; f[1 * n] = sh.praw.y; f[2 * n] = sh.praw.z;
+    f[3 * n] = sh.ng.x; f[4 * n] = sh.ng.y; f[5 * n] = sh.ng.z;
+    f[6 * n] = sh.ns.x; f[7 * n] = sh.ns.y; f[8 * n] = sh.ns.z;
+    f[9 * n] = sh.ss.x; f[10 * n] = sh.ss.y; f[11 * n] = sh.ss.z;
+    f[12 * n] = (double)sh.mat;
+}
+
+} // namespace lg

@@ -78,10 +78,14 @@ class InterleavedGather:
     done -- the film is not complete while its blocks are still rank-major.  Callers that alternate two render
     streams (bench.py) call both inside `with torch.cuda.stream(s)`."""
 
-    def __init__(self, width, height, rank, world, block_rows, device, group=None, always_gather=False, buffers=3):
+    def __init__(self, width, height, rank, world, block_rows, device, group=None, always_gather=False, buffers=3, all_ranks=False):
         assert interleave_ok(world, height, block_rows)
         self.w, self.h, self.rank, self.world, self.b, self.group = width, height, rank, world, block_rows, group
         self.collective = world > 1 or always_gather  # always_gather: run the collective even at world size 1 (rehearsal)
+        # all_ranks: ONE all-gather instead of ONE gather -- every rank ends with the whole film in row order (SURVEY.md 8(e):
+        # "equivalently ncclAllGather if every rank wants the image"); the default is the gather to rank 0
+        self.all_ranks = bool(all_ranks)
+        self.owner = self.all_ranks or rank == 0  # this rank assembles films
         self.rows = height // world
         # three buffer sets: the gather of frame k may take until frame k+3's render wants its buffers back
         self.nbuf = max(2, int(buffers))
@@ -92,7 +96,7 @@ class InterleavedGather:
         self.recv = None
         self.out = None
         self.cuda = torch.device(device).type == "cuda"
-        if rank == 0 and self.collective:
+        if self.owner and self.collective:
             self.recv = [torch.empty((world, self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(self.nbuf)]
             self.out = [torch.empty((height, width, 4), dtype=torch.uint8, device=device) for _ in range(self.nbuf)]
 
@@ -111,10 +115,16 @@ class InterleavedGather:
         i = self.k % self.nbuf
         self.k += 1
         if not self.collective:
+            if self.cuda:  # the buffer is handed out again after nbuf frames, possibly to another stream: order that use after this render
+                self.placed[i] = torch.cuda.Event()
+                self.placed[i].record()
             return
-        glist = [self.recv[i][r] for r in range(self.world)] if self.rank == 0 else None
-        work = dist.gather(self.tiles[i], gather_list=glist, dst=0, group=self.group, async_op=True)
-        if self.rank != 0:
+        if self.all_ranks:
+            work = dist.all_gather_into_tensor(self.recv[i].view(-1), self.tiles[i].view(-1), group=self.group, async_op=True)
+        else:
+            glist = [self.recv[i][r] for r in range(self.world)] if self.rank == 0 else None
+            work = dist.gather(self.tiles[i], gather_list=glist, dst=0, group=self.group, async_op=True)
+        if not self.owner:
             self.pending[i] = work
             return
         work.wait()  # (stream-level with RCCL: the current stream continues after the gather; the other stream renders meanwhile)
@@ -126,7 +136,7 @@ class InterleavedGather:
             self.placed[i].record()
 
     def finish(self):
-        """Wait for outstanding gathers; on rank 0 return the last frame's (height, width, 4) film."""
+        """Wait for outstanding gathers; on rank 0 (every rank with all_ranks) return the last frame's (height, width, 4) film."""
         for i in range(self.nbuf):
             if self.pending[i] is not None:
                 self.pending[i].wait()
@@ -134,7 +144,7 @@ class InterleavedGather:
             if self.placed[i] is not None:
                 self.placed[i].wait()
                 self.placed[i] = None
-        if self.rank != 0:
+        if not self.owner:
             return None
         last = (self.k - 1) % self.nbuf
         return self.out[last] if self.collective else self.tiles[last]

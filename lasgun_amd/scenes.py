@@ -641,3 +641,62 @@ def adversarial_prune_scene(api, seed):
         p = np.round(rng.uniform(-1.8, 1.8, 3) / snap) * snap if rng.random() < 0.5 else rng.uniform(-3, 3, 3)
         sc.add_point_light(p.tolist(), rng.uniform(0.3, 0.9, 3).tolist(), [1.0, 0.0, 0.0])
     return sc
+
+
+def exotic_obj():
+    """OBJ text in the forms the `obj` crate accepts beyond plain `f a b c`: comments, `o` / `g` statements, `v//vn` faces,
+    NEGATIVE (relative) indices for positions and normals, a 4- and a 5-vertex polygon (the reference keeps the first three
+    vertices of each, src/shape/triangle.rs:39-53), exponent notation and surplus whitespace."""
+    return """# a small tent: two quads, a pentagon and two triangles
+o tent
+v -1.0 0.0 -1.0
+v  1.0 0.0 -1.0
+v  1.0 0.0  1.0
+v -1.0 0.0  1.0
+v  0.0 1.2e0 0.0
+vn 0 1 0
+vn -0.7 0.7 0
+vn 0.7 0.7 0
+vn 0 0.7 0.7
+vn 0 0.7 -0.7
+g floor
+f 1//1 2//1 3//1 4//1
+g sides
+f -5//-4 -1//-4   -2//-4
+f 2//3 3//3 5//3
+f 3//4 4//4 5//4
+o fin
+g fin
+v 1.5 0.0 -0.5
+v 2.2 0.0 -0.2
+v 2.4 0.9 0.0
+v 1.9 1.4 0.2
+v 1.4 0.8 0.1
+vn 0.1 0.2 1.0
+f -5//-1 -4//-1 -3//-1 -2//-1 -1//-1
+f 1//5 5//5 2//5
+"""
+
+
+def exotic_obj_scene(api, smoothing=True):
+    """The `exotic_obj` mesh (negative indices, v//vn, 4- and 5-vertex polygons, o / g groups) under two lights, once as
+    parsed and once more in a rotated group, in front of a sphere: a render depends on every index being resolved as the
+    `obj` crate resolves it."""
+    scene = api.Scene.new()
+    scene.set_ambient_light([0.15, 0.15, 0.2])
+    scene.set_radial_background([0.3, 0.4, 0.6], [0.05, 0.05, 0.1], 0.6)
+    cam = scene.set_perspective_camera(50.0)
+    cam.look_at([1.0, 2.5, 6.0], [0.6, 0.4, 0.0], [0.0, 1.0, 0.0])
+    scene.set_mesh_smoothing(smoothing)
+    M = api.Material
+    mesh = scene.parse_obj(exotic_obj())
+    scene.add_point_light([3.0, 5.0, 4.0], [0.9, 0.85, 0.8], [1.0, 0.0, 0.0])
+    scene.add_point_light([-4.0, 3.0, 2.0], [0.3, 0.4, 0.6], [1.0, 0.0, 0.0])
+    scene.root.add_obj_of(mesh, M.plastic([0.8, 0.5, 0.3], [0.5, 0.5, 0.5], 0.3))
+    g = api.Aggregate.new()
+    g.rotate_y(140.0)
+    g.translate([-1.8, 0.2, -1.0])
+    g.add_obj_of(mesh, M.matte([0.4, 0.7, 0.5], 10.0))
+    scene.root.add_group(g)
+    scene.root.add_sphere([0.5, -50.0, 0.0], 49.9, M.matte([0.5, 0.5, 0.5], 0.0))
+    return scene

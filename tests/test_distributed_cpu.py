@@ -103,3 +103,42 @@ def test_two_rank_interleaved_gather_pipeline(tmp_path):
     o = oracle()
     want = o.render(S.cornell_scene(o, "glass"), (24, 32)).pixels()
     assert np.array_equal(np.load(out), want)
+
+
+def _allgather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_lib import oracle
+    from lasgun_amd import scenes as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        o = oracle()
+        w, h, b = 24, 32, 4
+        acc = o.Accel(S.cornell_scene(o, "glass"))
+        film = o.Film(w, h)
+        o.capture_subset(0, 1, acc, film)
+        mine = torch.from_numpy(film.pixels()[interleaved_rows(rank, world, h, b)].copy())
+        ig = InterleavedGather(w, h, rank, world, b, "cpu", all_ranks=True)
+        for frame in range(3):
+            t = ig.tile()
+            t.copy_(mine if frame == 2 else torch.zeros_like(mine))
+            ig.submit()
+        full = ig.finish()
+        assert full is not None  # EVERY rank owns a film
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_all_gather_gives_every_rank_the_film(tmp_path):
+    """The all-gather form of the end-of-frame exchange: ONE collective, every rank ends with the film."""
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_allgather_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from oracle_lib import oracle
+    from lasgun_amd import scenes as S
+    o = oracle()
+    want = o.render(S.cornell_scene(o, "glass"), (24, 32)).pixels()
+    for rank in range(2):
+        assert np.array_equal(np.load(str(tmp_path / ("rank%d.npy" % rank))), want), rank

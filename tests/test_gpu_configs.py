@@ -33,9 +33,9 @@ FULL = {
     "config5_mixed": (lambda api: S.mixed_scene(api), 8192, 4099, 1234),
 }
 # (label, streaming, wavefront, fast).  streaming 0 = megakernel; 2 = streamed wherever the organisation exists for the scene:
-# the wavefront pipeline takes every scene (glass / mirror: level by level), the three-kernel one only scenes without them
+# the wavefront pipeline takes every scene (glass / mirror: level by level)
 # prune: the pruned form of the reference walk (lg_accel_set_prune; these scenes' default) against the plain one
-ORGANISATIONS = [("megakernel", 0, True, False, False), ("wavefront", 2, True, False, False), ("pipeline3", 2, False, False, False),
+ORGANISATIONS = [("megakernel", 0, True, False, False), ("wavefront", 2, True, False, False),
                  ("megakernel-pruned", 0, True, False, True), ("wavefront-pruned", 2, True, False, True),
                  ("megakernel-fast", 0, True, True, False), ("wavefront-fast", 2, True, True, False)]
 

@@ -137,6 +137,9 @@ MID = {
     "kitchen_sink_persp": (lambda api: S.kitchen_sink_scene(api, "perspective"), 192, 160),
     "kitchen_sink_ortho": (lambda api: S.kitchen_sink_scene(api, "orthographic", recursion=4, supersampling=0), 160, 120),
     "kitchen_sink_rec0": (lambda api: S.kitchen_sink_scene(api, "perspective", recursion=0, supersampling=2), 96, 72),
+    # OBJ forms beyond `f a b c`: negative indices, v//vn, a 4- and a 5-vertex polygon (first three vertices), o / g groups
+    "exotic_obj_smooth": (lambda api: S.exotic_obj_scene(api, True), 160, 120),
+    "exotic_obj_flat": (lambda api: S.exotic_obj_scene(api, False), 96, 72),
     # ragged / tiny films: tiles cut by the right and bottom edges, and a single pixel
     "ragged_67x13": (lambda api: S.cornell_scene(api, "glass"), 67, 13),
     "ragged_5x131": (lambda api: S.spheres_scene(api, 64, seed=11), 5, 131),
@@ -265,10 +268,10 @@ def test_streaming_pipeline_and_megakernel_agree(name):
     builder, w, h = MID[name]
     acc = G.Accel(builder(G))
     outs = []
-    for streaming, wavefront in ((2, True), (2, False), (0, True)):  # 2 = streamed even for small films (wavefront / three-kernel), 0 = megakernel
+    for streaming, prune in ((2, False), (2, True), (0, False), (0, True)):  # 2 = the wavefront pipeline even for small films, 0 = megakernel; plain / pruned reference walk
         for fast in (False, True):
             G.set_streaming(acc, streaming)
-            G.set_wavefront(acc, wavefront)
+            G.set_prune(acc, prune)
             G.set_mode(acc, fast)
             film = G.Film(w, h)
             G.capture_subset(0, 1, acc, film)
@@ -687,3 +690,29 @@ def test_bench_multi_gpu_path_over_rccl_world1():
     assert "verify: gathered 1-rank film == single-GPU film" in p.stderr
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["primary"] == 1024 * 1024
+
+
+@pytest.mark.parametrize("collective", ["gather", "all-gather"])
+def test_bench_two_ranks_end_to_end_under_torchrun(collective):
+    """The driver's own launch line for N > 1, with two ranks sharing this box's one GPU and gloo carrying the tiles:
+    `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --backend gloo`.  Rank 0's gathered film must equal
+    the single-rank film (LASGUN_BENCH_VERIFY) and the record must describe a two-rank run.  The ranks are child processes: this
+    process starts them and reads their output, nothing is exec'ed from a process that has touched the GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LASGUN_BENCH_VERIFY="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    port = str(29600 + (os.getpid() % 300) + (0 if collective == "gather" else 301))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "512", "--steps", "3", "--warmup", "1"]
+    if collective == "all-gather":
+        cmd.append("--all-gather")
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "verify: gathered 2-rank film == single-GPU film" in p.stderr, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["primary"] == 512 * 512 and "2 rank(s)" in line["config"]["parallelism"]
+    assert line["bit_exact"] is None  # the oracle leg belongs to N = 1

@@ -18,10 +18,12 @@ def newest(pattern):
 
 
 import hashlib
+import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 out = {"kernels": {}, "kernel_stats": [],
-       # the source these passes were collected on: bench.py reports `traffic` from this file only while kernels.hip still has this hash
-       "kernels_hip_sha16": hashlib.sha256(open(os.path.join(ROOT, "lasgun_amd", "csrc", "kernels.hip"), "rb").read()).hexdigest()[:16]}
+       # the sources these passes were collected on: bench.py reports `traffic` from this file only while they still have this hash
+       "device_source_sha16": __import__("lasgun_amd").device_source_sha16()}
 ks = newest("prof/**/*kernel_stats.csv")
 if ks:
     rows = list(csv.DictReader(open(ks)))
