@@ -1,10 +1,12 @@
 #!/bin/bash
 # Round-end evidence run on the 1-GPU box: bench, rocprofv3 kernel stats, PMC passes, all configs.
-# usage (gpurun): bash tools/final_profile.sh  -> gpurun_out/final2/ ; then python3 tools/summarize_profiles.py gpurun_out/final2 profiles r02
+# usage (gpurun): bash tools/final_profile.sh  -> gpurun_out/final3/ ; then python3 tools/summarize_profiles.py gpurun_out/final3 profiles r03
 set -u
 export TMPDIR=/tmp
+# the profiler's preloaded library initialises HIP before bench.py can set this: the frames in flight need a hardware queue each
+export GPU_MAX_HW_QUEUES=16
 cd "${GRAFT_REPO_ROOT:?}"
-O=gpurun_out/final2; rm -rf "$O"; mkdir -p "$O"
+O=gpurun_out/final3; rm -rf "$O"; mkdir -p "$O"
 timeout -k 10 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"
 # per-kernel durations: frames one after the other (the form bench.py's roofline.kernel_ms_avg is measured in) ...
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -- python3 bench.py --steps 5 --warmup 1 --no-extras --sequential > "$O/prof.log" 2>&1; echo "stats rc=$?"
@@ -21,7 +23,10 @@ timeout -k 10 300 python3 tools/bench_configs.py > "$O/configs_parity.jsonl" 2>/
 timeout -k 10 300 python3 tools/bench_configs.py --fast > "$O/configs_fast.jsonl" 2>/dev/null
 timeout -k 10 300 python3 tools/bench_configs.py --org=megakernel > "$O/configs_megakernel.jsonl" 2>/dev/null
 timeout -k 10 300 python3 tools/bench_configs.py --org=wavefront > "$O/configs_wavefront.jsonl" 2>/dev/null
-timeout -k 10 300 python3 tools/bench_configs.py --org=pipeline3 "1a" "1b" "2P" "3 sph" > "$O/configs_pipeline3.jsonl" 2>/dev/null
+LASGUN_PRUNE=0 timeout -k 10 300 python3 tools/bench_configs.py > "$O/configs_unpruned.jsonl" 2>/dev/null
+LASGUN_PRUNE=1 timeout -k 10 300 python3 tools/bench_configs.py > "$O/configs_pruned.jsonl" 2>/dev/null
+timeout -k 10 300 python3 tools/bench_configs.py --org=packet "1a" "1b" "2P" "3 sph" > "$O/configs_packet.jsonl" 2>/dev/null
+timeout -k 10 200 python3 tools/share_time.py > "$O/share_time.jsonl" 2>/dev/null
 timeout -k 10 200 python3 tools/bench_multi.py --devices 0,0 --steps 5 > "$O/multi_2x_same_device.json" 2>/dev/null
 LASGUN_MULTI_FORCE_RCCL=1 timeout -k 10 200 python3 tools/bench_multi.py --devices 0,0 --steps 5 > "$O/multi_2x_same_device_rccl.json" 2>/dev/null
 tail -c 400 "$O/bench.json"

@@ -4,6 +4,7 @@
 set -eu
 cd "${GRAFT_REPO_ROOT:?}"
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16  # (the profiler initialises HIP before the program can set it)
 tag=$1; shift
 O=gpurun_out/pmcc_$tag; rm -rf "$O"; mkdir -p "$O"
 run() { name=$1; shift; rocprofv3 --pmc $1 --output-format csv -d "$O/$name" -- python3 "${CMD[@]}" > "$O/$name.log" 2>&1 || echo "pass $name failed" >> "$O/summary.txt"; }

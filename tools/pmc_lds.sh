@@ -1,6 +1,7 @@
 # LDS / SQ counter passes on the bench for the traversal kernels (each --pmc set is its own run; no trace flags with --pmc)
 set -eu
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16  # (the profiler initialises HIP before the program can set it)
 cd "${GRAFT_REPO_ROOT:?}"
 run() { name=$1; shift; LASGUN_PACKET=${LASGUN_PACKET:-0} rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmcl_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmcl_$name.log 2>&1; }
 run a SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU

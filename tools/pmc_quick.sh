@@ -4,6 +4,7 @@
 set -eu
 cd "${GRAFT_REPO_ROOT:?}"
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16  # (the profiler initialises HIP before the program can set it)
 tag=${1:-x}
 O=gpurun_out/pmcq_$tag; rm -rf "$O"; mkdir -p "$O"
 run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d "$O/$name" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > "$O/$name.log" 2>&1 || echo "pass $name failed" >> "$O/summary.txt"; }

@@ -1,6 +1,7 @@
 # SQ / cache counter passes on the bench (each --pmc set is its own run; no trace flags with --pmc)
 set -eu
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16  # (the profiler initialises HIP before the program can set it)
 cd "${GRAFT_REPO_ROOT:?}"
 run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$name.log 2>&1; }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
