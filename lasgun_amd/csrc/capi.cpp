@@ -194,6 +194,8 @@ struct lg_accel {
     DevBuf<uint32_t> tri_v, tri_n, tri_t;
     DevBuf<float> vpos, vnorm, vtex;
     DevBuf<DLeafRec> leaf_soup;
+    DevBuf<DChunk> chunks;
+    DevBuf<DLeafRec> leaf_soup2;
     DevBuf<uint32_t> sphere_ref_leaf, cuboid_ref_leaf, tri_ref_leaf, accel_ref_leaf;
     DevBuf<DAccel> accels;
     DevBuf<DMaterial> materials;
@@ -296,7 +298,7 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     DParams P{};
     P.nodes = a.nodes.p; P.nodes2 = a.nodes2.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
     P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
-    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
+    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.chunks = a.chunks.p; P.leaf_soup2 = a.leaf_soup2.p; P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
     P.tri_ref_leaf = a.tri_ref_leaf.p; P.accel_ref_leaf = a.accel_ref_leaf.p; P.accels = a.accels.p; P.materials = a.materials.p;
     P.lights = a.lights.p;
     P.nlights = (uint32_t)a.flat.lights.size();
@@ -834,7 +836,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         const FlatScene &f = a->flat;
         a->nodes.upload(f.nodes); a->nodes2.upload(f.nodes2); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
-        a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->sphere_ref_leaf.upload(f.sphere_ref_leaf); a->cuboid_ref_leaf.upload(f.cuboid_ref_leaf);
+        a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->chunks.upload(f.chunks); a->leaf_soup2.upload(f.leaf_soup2); a->sphere_ref_leaf.upload(f.sphere_ref_leaf); a->cuboid_ref_leaf.upload(f.cuboid_ref_leaf);
         a->tri_ref_leaf.upload(f.tri_ref_leaf); a->accel_ref_leaf.upload(f.accel_ref_leaf); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
         a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
         a->stats.alloc(2); // (the second record: iteration counters of the diagnostic build)
@@ -950,7 +952,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                     for (uint32_t i = 0, e = extent(nb, A.node_base, fm.nodes.size()); i < e; ++i) {
                         uint32_t *rec = &img[((size_t)(A.lnode_base + i) * LDS_NODE_STRIDE) * 4];
                         const DNode &nd = fm.nodes[A.node_base + i];
-                        if (nd.meta & NODE_LEAF) { rec[16] = A.lprim_base + nd.link; rec[17] = NODE_LEAF; rec[18] = rec[16] + (nd.meta & 0xFFFFu); }
+                        if (nd.meta & NODE_LEAF) { rec[16] = A.lprim_base + nd.link; rec[17] = NODE_LEAF; rec[18] = rec[16] + (nd.meta & 0xFFFFu); rec[19] = nd.pad; }
                         else { rec[16] = tree0 + nd.link * LDS_NODE_STRIDE * 16u; rec[17] = 1u << (nd.meta & 3u); rec[18] = 0u; }
                         rec[17] |= nd.meta & NODE_NOPRUNE;
                     }
@@ -1002,7 +1004,7 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.flat, y.flat);
     swap(x.nodes, y.nodes); swap(x.nodes2, y.nodes2); swap(x.primref, y.primref); swap(x.spheres, y.spheres); swap(x.sphere_mat, y.sphere_mat);
     swap(x.cuboids, y.cuboids); swap(x.cuboid_mat, y.cuboid_mat); swap(x.tri_v, y.tri_v); swap(x.tri_n, y.tri_n); swap(x.tri_t, y.tri_t);
-    swap(x.vpos, y.vpos); swap(x.vnorm, y.vnorm); swap(x.vtex, y.vtex); swap(x.leaf_soup, y.leaf_soup);
+    swap(x.vpos, y.vpos); swap(x.vnorm, y.vnorm); swap(x.vtex, y.vtex); swap(x.leaf_soup, y.leaf_soup); swap(x.chunks, y.chunks); swap(x.leaf_soup2, y.leaf_soup2);
     swap(x.sphere_ref_leaf, y.sphere_ref_leaf); swap(x.cuboid_ref_leaf, y.cuboid_ref_leaf); swap(x.tri_ref_leaf, y.tri_ref_leaf); swap(x.accel_ref_leaf, y.accel_ref_leaf);
     swap(x.accels, y.accels); swap(x.materials, y.materials); swap(x.lights, y.lights);
     swap(x.lds_image, y.lds_image);

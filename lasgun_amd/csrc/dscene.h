@@ -58,7 +58,7 @@ struct alignas(64) DNode {
     uint32_t link; // leaf: offset of its first primref (relative to the accel's prim_base); interior: second child (relative to node_base)
     uint32_t meta; // leaf: NODE_LEAF | nprims (u16, bvh.rs:440) ; interior: split axis
     uint32_t parent; // reference trees: the parent node (relative to node_base), NO_HIT at the root -- fast mode's candidate check walks leaf -> root
-    uint32_t pad;
+    uint32_t pad;    // leaves of a mesh's reference tree: index of the leaf's first culling record (DChunk) | number of its records << 24
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
@@ -87,6 +87,28 @@ struct alignas(16) DCuboid {
 struct alignas(16) DLeafRec { // 48-byte leaf-ordered geometry record (see header comment)
     uint32_t w[12];
 };
+// Pruned walk, inside the reference's fat mesh leaves (up to 254 triangles, bvh.rs:187,289): one record per run of <= 16
+// consecutive leaf_soup2 slots, made by the host from the triangles in those slots -- their bounds, a cone around their
+// normals and two shape numbers.  (The reference orders a leaf's triangles by a Morton code that ignores x, bvh.rs:575-579:
+// sixteen consecutive ones are no neighbours.  leaf_soup2 holds each leaf's triangles in spatial runs instead; the leaf loop
+// then decides exact ties in t by the ORIGINAL slot number, which is what the reference's first-come rule amounts to.)  The walk skips the 16 triangle tests when NONE of them could be accepted:
+// always by the ray's dominant axis; on all three axes only when the ray crosses every triangle of the record at an angle whose
+// sine is at least CHUNK_SMIN (the cone test) and the triangles are not degenerate at the ray's distance (hmin).
+struct alignas(64) DChunk {
+    float bmin[3], bmax[3]; // union of the triangles' bounds (vertex coordinates are f32: exact)
+    float axis[3];          // unit vector; every triangle normal of the record is within theta of it
+    float clim2;            // lateral culling is allowed when (axis . d)^2 >= clim2 * (d . d); 4 = never (wide cone, degenerate triangle)
+    float g2;               // max over the triangles of (longest edge)^2 / (smallest altitude)^3, rounded up
+    float hmin;             // smallest altitude of any triangle of the record, rounded down
+    uint32_t start, count;  // its run of leaf_soup2 slots
+    uint32_t pad[2];
+};
+static_assert(sizeof(DChunk) == 64, "DChunk is one 64-byte line");
+constexpr uint32_t CHUNK_SHIFT = 4u;            // at most 16 slots per record
+constexpr double CHUNK_SMIN = 0.1;              // |n . d| / |d| >= this for every triangle of a record that is culled laterally
+constexpr double CHUNK_KLAT = 0x1p-28;          // lateral margin (space) = this * R^2 * g2; derivation: 2688 u / CHUNK_SMIN^3 = 3.0e-10, x 12
+constexpr double CHUNK_HGATE = 0x1p-18;         // ... and only when hmin >= this * R (R: 1-norm distance from the ray origin to the record's far corner)
+
 struct DMaterial { // == lg_material of include/lasgun_hip.h
     int32_t kind;
     int32_t pad;
@@ -143,6 +165,9 @@ struct DParams {
     const float *vnorm;
     const float *vtex;
     const DLeafRec *leaf_soup; // slot j <-> primref[j]
+    const DLeafRec *leaf_soup2; // the triangle slots again, permuted WITHIN every leaf of a mesh's reference tree into a spatially
+                               // coherent order (word 9 = the slot it came from): what the pruned walk's leaf loop reads
+    const DChunk *chunks;      // culling records of the mesh leaves (DNode::pad), each with its run of leaf_soup2 slots
     // fast mode's candidate check (host.h): reference leaf of every sphere / cuboid / triangle / accel (parents: DNode::parent)
     const uint32_t *sphere_ref_leaf, *cuboid_ref_leaf, *tri_ref_leaf, *accel_ref_leaf;
     const DAccel *accels;

@@ -3,6 +3,7 @@
 #include "host.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -968,6 +969,155 @@ struct Flattener {
 };
 } // namespace
 
+// ---- culling records of the pruned walk (DChunk) --------------------------------------------------------
+// A fat leaf of a mesh's reference tree is cut into RUNS of <= 16 triangles that are neighbours in space and face the same way
+// (the reference's own order inside a leaf is a Morton order that ignores x, bvh.rs:575-579; a leaf is typically two to four
+// separate patches of the surface).  Recursive splitting of the leaf's triangle set: at the largest gap between centroids along
+// the widest axis when there is a clear one (patches fall apart there), at the median otherwise; a set of <= 16 triangles whose
+// normals stay within 35 degrees of their mean is a run.
+struct LeafTri {
+    uint32_t slot; // its slot in leaf_soup
+    V3 cen, n;     // centroid, unit normal (zero for a degenerate triangle)
+};
+static void cut_runs(std::vector<LeafTri> &t, size_t a, size_t b, std::vector<std::pair<size_t, size_t>> &runs) {
+    const size_t count = b - a;
+    if (count == 0) return;
+    if (count <= ((size_t)1 << CHUNK_SHIFT)) {
+        V3 sum{0, 0, 0};
+        for (size_t i = a; i < b; ++i) { V3 n = t[i].n; if (dot(n, t[a].n) < 0.0) n = V3{-n.x, -n.y, -n.z}; sum = sum + n; }
+        const double l = std::sqrt(dot(sum, sum));
+        double cmin = 1.0;
+        if (l > 0.0) for (size_t i = a; i < b; ++i) cmin = std::fmin(cmin, std::fabs(dot(t[i].n, sum)) / l);
+        if (count <= 2 || (l > 0.0 && cmin >= 0.82)) { runs.emplace_back(a, b); return; } // cos 35 degrees
+    }
+    V3 lo = t[a].cen, hi = lo;
+    for (size_t i = a; i < b; ++i) {
+        const V3 c = t[i].cen;
+        lo = V3{std::fmin(lo.x, c.x), std::fmin(lo.y, c.y), std::fmin(lo.z, c.z)};
+        hi = V3{std::fmax(hi.x, c.x), std::fmax(hi.y, c.y), std::fmax(hi.z, c.z)};
+    }
+    const V3 e = hi - lo;
+    const int axis = e.x >= e.y ? (e.x >= e.z ? 0 : 2) : (e.y >= e.z ? 1 : 2);
+    std::sort(t.begin() + (long)a, t.begin() + (long)b, [&](const LeafTri &p, const LeafTri &q) {
+        const double x = comp(p.cen, axis), y = comp(q.cen, axis);
+        return x < y || (x == y && p.slot < q.slot);
+    });
+    size_t cut = a + count / 2;
+    const double extent = comp(e, axis);
+    if (extent > 0.0) {
+        double gap = 0.0;
+        size_t at = cut;
+        for (size_t i = a + 1; i < b; ++i) {
+            const double g = comp(t[i].cen, axis) - comp(t[i - 1].cen, axis);
+            if (g > gap) { gap = g; at = i; }
+        }
+        if (gap > 4.0 * extent / (double)count) cut = at; // a clear gap: two patches
+    }
+    cut_runs(t, a, cut, runs);
+    cut_runs(t, cut, b, runs);
+}
+// leaf_soup2 (the triangles of every mesh leaf again, run after run; word 9 of a record = the slot it came from), the runs'
+// records, and in DNode::pad of every mesh leaf: index of its first record | number of its records << 24.
+static void build_chunks(FlatScene &out) {
+    out.leaf_soup2 = out.leaf_soup;
+    out.chunks.clear();
+    std::vector<char> done(out.nodes.size(), 0);
+    for (const DAccel &A : out.accels) {
+        if (!(A.flags & AF_MESH) || done[A.node_base]) continue;
+        std::vector<uint32_t> todo{0};
+        while (!todo.empty()) {
+            const uint32_t nidx = todo.back(); todo.pop_back();
+            done[A.node_base + nidx] = 1;
+            DNode &nd = out.nodes[A.node_base + nidx];
+            if (!(nd.meta & NODE_LEAF)) { todo.push_back(nidx + 1); todo.push_back(nd.link); continue; }
+            const size_t first = (size_t)A.prim_base + nd.link, count = nd.meta & 0xFFFFu;
+            std::vector<LeafTri> tris(count);
+            for (size_t i = 0; i < count; ++i) {
+                float p[9];
+                std::memcpy(p, out.leaf_soup[first + i].w, sizeof p);
+                const V3 v0{p[0], p[1], p[2]}, v1{p[3], p[4], p[5]}, v2{p[6], p[7], p[8]};
+                V3 n = cross(v1 - v0, v2 - v0);
+                const double l = std::sqrt(dot(n, n));
+                n = l > 0.0 && std::isfinite(l) ? n * (1.0 / l) : V3{0, 0, 0};
+                tris[i] = LeafTri{(uint32_t)(first + i), (v0 + v1 + v2) * (1.0 / 3.0), n};
+            }
+            std::vector<std::pair<size_t, size_t>> runs;
+            cut_runs(tris, 0, count, runs);
+            if (out.chunks.size() >= (1u << 24) || runs.size() > 255) throw Error("too many culling records");
+            nd.pad = (uint32_t)out.chunks.size() | ((uint32_t)runs.size() << 24);
+            for (size_t i = 0; i < count; ++i) {
+                DLeafRec r = out.leaf_soup[tris[i].slot];
+                r.w[9] = tris[i].slot;
+                out.leaf_soup2[first + i] = r;
+            }
+            for (const auto &run : runs) {
+                DChunk k{};
+                k.start = (uint32_t)(first + run.first);
+                k.count = (uint32_t)(run.second - run.first);
+                float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                double g2 = 0.0, hmin = INFINITY;
+                std::vector<V3> normals;
+                bool degenerate = false;
+                V3 nsum{0, 0, 0};
+                for (size_t s = first + run.first; s < first + run.second; ++s) {
+                    float p[9];
+                    std::memcpy(p, out.leaf_soup2[s].w, sizeof p);
+                    V3 v[3];
+                    for (int i = 0; i < 3; ++i) {
+                        v[i] = V3{(double)p[3 * i], (double)p[3 * i + 1], (double)p[3 * i + 2]};
+                        for (int ax = 0; ax < 3; ++ax) { mn[ax] = std::fmin(mn[ax], p[3 * i + ax]); mx[ax] = std::fmax(mx[ax], p[3 * i + ax]); }
+                    }
+                    const V3 e0 = v[1] - v[0], e1 = v[2] - v[1], e2 = v[0] - v[2];
+                    const V3 n = cross(e0, V3{-e2.x, -e2.y, -e2.z});
+                    const double twice_area = std::sqrt(dot(n, n));
+                    const double lmax = std::sqrt(std::fmax(dot(e0, e0), std::fmax(dot(e1, e1), dot(e2, e2))));
+                    const double h = twice_area / lmax; // the smallest altitude
+                    if (!(twice_area > 0.0) || !std::isfinite(twice_area) || !(h > 0.0)) { degenerate = true; continue; }
+                    V3 nu = n * (1.0 / twice_area);
+                    if (!normals.empty() && dot(nu, normals[0]) < 0.0) nu = V3{-nu.x, -nu.y, -nu.z}; // only |n . d| matters: one hemisphere, whatever the winding
+                    normals.push_back(nu);
+                    nsum = nsum + nu;
+                    g2 = std::fmax(g2, lmax * lmax / (h * h * h));
+                    hmin = std::fmin(hmin, h);
+                }
+                for (int ax = 0; ax < 3; ++ax) { k.bmin[ax] = mn[ax]; k.bmax[ax] = mx[ax]; }
+                k.clim2 = 4.0f; k.g2 = INFINITY; k.hmin = 0.0f; // (4 = no lateral culling for this record)
+                k.axis[0] = k.axis[1] = 0.0f; k.axis[2] = 1.0f;
+                const double nl = std::sqrt(dot(nsum, nsum));
+                if (!normals.empty() && !degenerate && nl > 1e-6 && std::isfinite(g2)) {
+                    // the axis as the kernel will see it (f32, not exactly unit): the cone's half-angle is measured against THAT vector
+                    const float ax[3] = {(float)(nsum.x / nl), (float)(nsum.y / nl), (float)(nsum.z / nl)};
+                    const double al = std::sqrt((double)ax[0] * ax[0] + (double)ax[1] * ax[1] + (double)ax[2] * ax[2]);
+                    double cmin = 1.0; // smallest cosine between a normal and the axis
+                    for (const V3 &n : normals) cmin = std::fmin(cmin, (n.x * ax[0] + n.y * ax[1] + n.z * ax[2]) / al);
+                    const double theta = std::acos(std::fmax(-1.0, std::fmin(1.0, cmin))) + 1e-3; // + slack for the roundings above
+                    const double room = std::acos(CHUNK_SMIN) - theta; // a direction within `room` of the axis meets every triangle at >= asin(CHUNK_SMIN)
+                    if (room > 1e-3) {
+                        const double clim = std::cos(room) * al; // (axis . d)^2 >= clim2 * (d . d), with the axis's own length folded in
+                        k.axis[0] = ax[0]; k.axis[1] = ax[1]; k.axis[2] = ax[2];
+                        k.clim2 = std::nextafterf((float)(clim * clim * (1.0 + 1e-6)), INFINITY);
+                        k.g2 = std::nextafterf((float)(g2 * (1.0 + 1e-6)), INFINITY);
+                        k.hmin = std::nextafterf((float)(hmin * (1.0 - 1e-6)), 0.0f);
+                    }
+                }
+                out.chunks.push_back(k);
+            }
+        }
+    }
+    if (std::getenv("LASGUN_DEBUG_CHUNKS")) { // what the runs look like: sizes, and how much room their cones leave
+        size_t n = out.chunks.size(), never = 0, tris = 0, hist[6] = {0, 0, 0, 0, 0, 0};
+        for (const DChunk &k : out.chunks) {
+            tris += k.count;
+            if (k.clim2 >= 4.0f) { ++never; continue; }
+            const double room = std::acos(std::sqrt((double)k.clim2)) * 57.29578;
+            ++hist[room < 30 ? 0 : room < 45 ? 1 : room < 60 ? 2 : room < 70 ? 3 : room < 80 ? 4 : 5];
+        }
+        std::fprintf(stderr, "[lasgun] culling records: %zu over %zu triangles (%.1f per record); no lateral culling: %zu; room <30: %zu, <45: %zu, <60: %zu, <70: %zu, <80: %zu, >=80: %zu\n",
+                     n, tris, n ? (double)tris / (double)n : 0.0, never, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+    }
+    out.chunks.resize(out.chunks.size() + 2, DChunk{});
+}
+
 void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     out = FlatScene();
     Flattener fl{scene, out, {}, with_fast};
@@ -982,6 +1132,7 @@ void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     out.max_stack_fast1 = fneed1;
     if (out.primref.size() > 80000000u) throw Error("too many primitive slots for the 32-bit record offsets of the triangle stream");
     out.leaf_soup.resize(out.primref.size() + 2, DLeafRec{}); // two spare records: the mesh leaf loop keeps the next slot in flight
+    build_chunks(out);
     out.sphere_ref_leaf.resize(out.spheres.size(), NO_HIT);
     out.cuboid_ref_leaf.resize(out.cuboids.size(), NO_HIT);
     out.tri_ref_leaf.resize(out.tri_v.size() / 3, NO_HIT);

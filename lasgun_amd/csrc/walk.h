@@ -353,7 +353,7 @@ __device__ __forceinline__ Ray local_ray(const DParams &P, const Ray &wray, uint
 // either kind start in 16 different bank groups.
 struct NodeRec {
     double bmin[3], bmax[3];
-    uint32_t link, meta;
+    uint32_t link, meta, pad;
 };
 __device__ __forceinline__ double u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 template <bool LDSS>
@@ -367,13 +367,13 @@ __device__ __forceinline__ NodeRec load_node(const DParams &P, const uint4 *scn,
         const uint2 d = *reinterpret_cast<const uint2 *>(q4 + 3);
         n.bmin[0] = a.x; n.bmin[1] = a.y; n.bmin[2] = b.x;
         n.bmax[0] = b.y; n.bmax[1] = c.x; n.bmax[2] = c.y;
-        n.link = d.x; n.meta = d.y;
+        n.link = d.x; n.meta = d.y; n.pad = 0u;
     } else {
         // one 64-byte record = four 16-byte loads from a single line, all issued before the slab test
         const DNode *nd = P.nodes + idx;
         n.bmin[0] = nd->bmin[0]; n.bmin[1] = nd->bmin[1]; n.bmin[2] = nd->bmin[2];
         n.bmax[0] = nd->bmax[0]; n.bmax[1] = nd->bmax[1]; n.bmax[2] = nd->bmax[2];
-        n.link = nd->link; n.meta = nd->meta;
+        n.link = nd->link; n.meta = nd->meta; n.pad = nd->pad;
     }
     return n;
 }
@@ -590,12 +590,65 @@ __device__ __forceinline__ bool tri_rec_t(const LeafRec &r, V3 o, double sx, dou
     h.t = tscaled * invdet;
     return true;
 }
-template <int KZ, bool LDSS, bool FAST = false, bool COUNT = false>
-__device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, const V3 o, const TriSetup tri, uint32_t li, const uint32_t le,
-                                           const uint32_t soup_delta, const uint32_t accel, const bool anyhit, Best &best, bool &tie, Counters &cnt) {
+// What the pruned walk knows when it opens a fat leaf: the limit (already scaled by 1 + PRUNE_LIMIT_REL), the dominant axis's
+// margin in t (eps * |1/d_kz|) and d . d.
+struct LeafCull {
+    double lb, ekz, dd;
+    uint32_t records;      // DNode::pad of the leaf: first record | number of records << 24
+};
+// One culling record (DChunk) against the ray: true = none of its <= 16 triangles can be accepted, the tests are skipped.
+// (t1, t2) per axis are the slab test's own expressions on the record's box.  Dominant axis: an accepted t is a convex
+// combination of plane parameters that lie between the box's two (section 3.5), so it lies in [tmin_kz - ekz, tmax_kz + ekz]: outside
+// [0, limit] nothing is accepted.  All axes, when the ray meets every triangle of the record at an angle of sine >= CHUNK_SMIN
+// and the triangles are not degenerate at its distance: the accepted hit point lies within m = CHUNK_KLAT * R^2 * g2 of the
+// triangle (the edge functions' rounding, 48 u R^2, moves the projected origin by at most that over an altitude), so t lies in
+// every axis's [tmin_i - m |1/d_i|, tmax_i + m |1/d_i|]: an empty intersection, one beyond the limit or one before 0 accepts nothing.
+#ifdef LG_CHUNK_DEBUG
+static __device__ int g_dbg_gate_dummy;
+#define g_dbg_gate lc_dbg_gate
+#endif
+template <int KZ>
+__device__ __forceinline__ bool chunk_culled(const DChunk *rec, const Ray &ray, const LeafCull &lc, uint32_t &run_start, uint32_t &run_count
+#ifdef LG_CHUNK_DEBUG
+                                             , int &lc_dbg_gate
+#endif
+) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(rec);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    const uint2 sc = *reinterpret_cast<const uint2 *>(q + 3);
+    run_start = sc.x; run_count = sc.y;
+    const double bmin[3] = {rec_f32(a.x), rec_f32(a.y), rec_f32(a.z)}, bmax[3] = {rec_f32(a.w), rec_f32(b.x), rec_f32(b.y)};
+    const V3 ax{rec_f32(b.z), rec_f32(b.w), rec_f32(c.x)};
+    const double clim2 = rec_f32(c.y), g2 = rec_f32(c.z), hmin = rec_f32(c.w);
+    const double ox = bmin[0] - ray.o.x, px = bmax[0] - ray.o.x, oy = bmin[1] - ray.o.y, py = bmax[1] - ray.o.y, oz = bmin[2] - ray.o.z, pz = bmax[2] - ray.o.z;
+    double t1 = ox * ray.dinv.x, t2 = px * ray.dinv.x;
+    const double nx = fmin_(t1, t2), fx = fmax_(t1, t2);
+    t1 = oy * ray.dinv.y; t2 = py * ray.dinv.y;
+    const double ny = fmin_(t1, t2), fy = fmax_(t1, t2);
+    t1 = oz * ray.dinv.z; t2 = pz * ray.dinv.z;
+    const double nz = fmin_(t1, t2), fz = fmax_(t1, t2);
+    const double nk = KZ == 0 ? nx : KZ == 1 ? ny : nz, fk = KZ == 0 ? fx : KZ == 1 ? fy : fz;
+    bool skip = nk > lc.lb + lc.ekz || fk < -lc.ekz; // (NaN parameters compare false)
+    const double ad = dot(ax, ray.d);
+    const double R = (fmax_(fabs(ox), fabs(px)) + fmax_(fabs(oy), fabs(py))) + fmax_(fabs(oz), fabs(pz)); // >= the distance to any vertex
+#ifdef LG_CHUNK_DEBUG
+    if (ad * ad >= clim2 * lc.dd) g_dbg_gate = 1; else g_dbg_gate = 0;
+#endif
+    if (ad * ad >= clim2 * lc.dd && hmin >= CHUNK_HGATE * R) {
+        const double m = (CHUNK_KLAT * g2) * (R * R);
+        const double ex = m * fabs(ray.dinv.x), ey = m * fabs(ray.dinv.y), ez = m * fabs(ray.dinv.z);
+        const double tn = fmax_(fmax_(nx - ex, ny - ey), nz - ez), tf = fmin_(fmin_(fx + ex, fy + ey), fz + ez); // (inf - inf = NaN: ignored)
+        skip = skip || tn > tf || tf < 0.0 || tn > lc.lb;
+    }
+    return skip;
+}
+template <int KZ, bool LDSS, bool FAST = false, bool COUNT = false, bool PRUNE = false>
+__device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, const Ray &ray, const TriSetup tri, uint32_t li, const uint32_t le,
+                                           const uint32_t soup_delta, const uint32_t accel, const bool anyhit, Best &best, bool &tie, Counters &cnt,
+                                           LeafCull lc) {
+    const V3 o = ray.o;
     const char *base = reinterpret_cast<const char *>(P.leaf_soup);
     constexpr uint32_t REC = (uint32_t)sizeof(DLeafRec);
-    uint32_t off = (li + soup_delta) * REC; // (the array holds < 2^32 / 48 slots: checked by the host)
 #define LG_TRI(R, SLOT)                                                                                                  \
     do {                                                                                                                 \
         TriHit h_;                                                                                                       \
@@ -609,6 +662,79 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
+    if (PRUNE && lc.ekz < INFINITY) { // (a level or ray outside the stated ranges: the plain loop below, in the reference's order)
+        // The leaf in runs of <= 16 slots of leaf_soup2 counted from its first slot (one culling record per run), where the
+        // leaf's triangles stand in a k-d order: a run whose record is culled is stepped over.  The reference scans the leaf in
+        // order[] sequence and keeps the FIRST of several triangles with exactly the same t (triangle.rs:251: `t >= isect.t`
+        // rejects); scanning in another order gives the same winner when a tie goes to the lower original slot -- the final hit
+        // is the lexicographic minimum of (t, slot) either way.  (No t is NaN inside the stated ranges.)
+        const char *base2 = reinterpret_cast<const char *>(P.leaf_soup2);
+        uint32_t rec = lc.records & 0x00FFFFFFu;                 // the next record to look at
+        const uint32_t rec_end = rec + (lc.records >> 24);
+        uint32_t s = 0, run_end = 0;                              // the run being tested: leaf_soup2 slots [s, run_end)
+        uint32_t leaf_slot = NO_HIT; // original slot of the hit this leaf has given so far
+#define LG_TRI2(R)                                                                                                       \
+    do {                                                                                                                 \
+        TriHit h_;                                                                                                       \
+        if (COUNT) cnt.triangles++;                                                                                      \
+        if (tri_rec_t<KZ>(R, o, tri.sx, tri.sy, tri.sz, h_)) {                                                           \
+            const uint32_t from_ = (R).c.y;                                                                              \
+            if (h_.t < best.t || (h_.t == best.t && leaf_slot != NO_HIT && from_ < leaf_slot)) {                         \
+                best.t = h_.t; best.ref = load_primref<LDSS>(P, scn, from_ - soup_delta); best.accel = accel;            \
+                leaf_slot = from_;                                                                                       \
+                if (!anyhit) lc.lb = h_.t + h_.t * PRUNE_LIMIT_REL;                                                      \
+                if (COUNT) dbg_event(P, 6.0, (double)best.ref, h_.t, (double)accel);                                     \
+                if (anyhit && h_.t < 1.0) done = true; /* point.rs:49 */                                                 \
+            }                                                                                                            \
+        }                                                                                                                \
+    } while (0)
+        // Two wave-uniform phases, like the walk itself: every lane first steps over culled runs until it stands in one that
+        // survives (or its leaf ends), then the lanes that stand in a run test it, two triangles per trip with the next record in
+        // flight.  A lane's own loop nest would make the whole wave pay for every run that ANY lane keeps.
+        bool in_run = false, done = false;
+        uint32_t off = 0;
+        LeafRec ra;
+        ra.a = ra.b = ra.c = uint4{0u, 0u, 0u, 0u};
+        for (;;) {
+            bool seeking = wave_any(!in_run && rec < rec_end);
+            while (seeking) {
+                if (!in_run && rec < rec_end) {
+                    if (COUNT) cnt.nodes++; // (a record test is counted with the node tests)
+                    uint32_t start, count;
+#ifdef LG_CHUNK_DEBUG
+                    int gate_ = 0;
+                    const bool culled_ = chunk_culled<KZ>(P.chunks + rec, ray, lc, start, count, gate_);
+                    if (COUNT) { cnt.cuboids++; if (LG_CHUNK_DEBUG == 1 ? gate_ != 0 : LG_CHUNK_DEBUG == 2 ? !culled_ : (!culled_ && gate_)) cnt.spheres++; }
+#else
+                    const bool culled_ = chunk_culled<KZ>(P.chunks + rec, ray, lc, start, count);
+#endif
+                    ++rec;
+                    if (!culled_) { in_run = true; s = start; run_end = start + count; off = s * REC; ra = load_rec_at(base2, off); } // (the array holds < 2^32 / 48 slots: checked by the host)
+                }
+                seeking = wave_any(!in_run && rec < rec_end);
+            }
+            bool testing = wave_any(in_run);
+            if (!testing) break;
+            while (testing) {
+                if (in_run) {
+                    const bool two = s + 1u < run_end;
+                    const LeafRec rb = load_rec_at(base2, off + REC); // (two spare records behind the last slot: always readable)
+                    LG_TRI2(ra);
+                    if (two && !done) LG_TRI2(rb);
+                    s += two ? 2u : 1u;
+                    off += 2u * REC;
+                    if (done) { rec = rec_end; in_run = false; } // an occluded any-hit ray: nothing more to find
+                    else if (s >= run_end) in_run = false;
+                    else ra = load_rec_at(base2, off);
+                }
+                testing = wave_any(in_run);
+            }
+        }
+        return done;
+#undef LG_TRI2
+        return false;
+    }
+    uint32_t off = (li + soup_delta) * REC; // (the array holds < 2^32 / 48 slots: checked by the host)
     LeafRec ra = load_rec_at(base, off);
     for (; li + 1u < le; li += 2u) {
         const LeafRec rb = load_rec_at(base, off + REC);
@@ -674,7 +800,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     double dd = dot(ray.d, ray.d);      // a of every sphere's quadratic at this level
     double four_a = 4.0 * dd;           // 4.0 * a of its discriminant b*b - 4.0*a*c (core/math.rs:16: (4.0 * a) * c)
     uint32_t negmask = neg_mask(ray);   // dir_is_neg (bvh.rs:463)
-    uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0;
+    uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0, lcb = 0;
     uint32_t state = ST_NODE;
     // ---- PRUNE: per-axis limits of the level the lane is in, and the level's margin
     V3 plim{INFINITY, INFINITY, INFINITY};
@@ -720,14 +846,14 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
             if (state == ST_NODE) {
                 // the record's walk words: interior -> (second child's cursor, 1 << split axis, -), leaf -> (first slot, NODE_LEAF, last slot + 1)
                 double bmin[3], bmax[3];
-                uint32_t w_link, w_meta, w_end;
+                uint32_t w_link, w_meta, w_end, w_chunk;
                 if (LDSS) {
                     const char *rec = reinterpret_cast<const char *>(scn) + cur;
                     const double2 *q = reinterpret_cast<const double2 *>(rec);
                     const double2 a = q[0], b = q[1], c = q[2]; // four ds_read_b128
                     const uint4 d = *reinterpret_cast<const uint4 *>(rec + LDS_NODE_WALK_OFF);
                     bmin[0] = a.x; bmin[1] = a.y; bmin[2] = b.x; bmax[0] = b.y; bmax[1] = c.x; bmax[2] = c.y;
-                    w_link = d.x; w_meta = d.y; w_end = d.z;
+                    w_link = d.x; w_meta = d.y; w_end = d.z; w_chunk = d.w;
                 } else {
                     const NodeRec nd = load_node<false>(P, scn, cur);
                     bmin[0] = nd.bmin[0]; bmin[1] = nd.bmin[1]; bmin[2] = nd.bmin[2]; bmax[0] = nd.bmax[0]; bmax[1] = nd.bmax[1]; bmax[2] = nd.bmax[2];
@@ -735,6 +861,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     w_link = (lf ? L.prim_base : L.node_base) + nd.link;
                     w_meta = (lf ? NODE_LEAF : 1u << (nd.meta & 3u)) | (nd.meta & NODE_NOPRUNE);
                     w_end = w_link + (nd.meta & 0xFFFFu);
+                    w_chunk = nd.pad;
                 }
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
                 bool hit;
@@ -763,6 +890,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 cur = interior_hit ? near_node : popped;
                 sp = sp + (interior_hit ? 1u : 0u) - (pop && can_pop ? 1u : 0u);
                 li = w_link; le = w_end; // (read in ST_LEAF only)
+                if (PRUNE) lcb = w_chunk;
                 state = leaf_hit ? ST_LEAF : (pop && !can_pop) ? ST_LEVEL_DONE : ST_NODE;
             }
 #ifdef LG_STAMPS
@@ -780,9 +908,15 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
             if (!FAST) tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
             bool done;
-            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
-            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
-            else done = mesh_leaf2<2, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
+            LeafCull lc{INFINITY, INFINITY, dd, lcb};
+            if (PRUNE) { // the level's limits, as prune_limits made them: the dominant axis carries lb + eps * |1/d_kz|
+                const double lim = anyhit ? 1.0 : best.t;
+                lc.lb = lim + lim * PRUNE_LIMIT_REL;
+                lc.ekz = peps * fabs(tri.kz == 0 ? ray.dinv.x : tri.kz == 1 ? ray.dinv.y : ray.dinv.z);
+            }
+            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
+            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
+            else done = mesh_leaf2<2, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
             if (FAST) limit = prune_limit(best.t, anyhit);
             if (PRUNE && !anyhit) prune_limits(best.t);
             if (done) state = ST_DONE;
@@ -1025,9 +1159,10 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
         if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
             if (!FAST) tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
             bool done;
-            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
-            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
-            else done = mesh_leaf2<2, LDSS, FAST, COUNT>(P, scn, ray.o, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt);
+            const LeafCull lc{INFINITY, INFINITY, dd, 0u};
+            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST, COUNT>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
+            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST, COUNT>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
+            else done = mesh_leaf2<2, LDSS, FAST, COUNT>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
             if (FAST) limit = prune_limit(best.t, anyhit);
             if (done) state = ST_DONE;
             else if (sp != base) { --sp; const uint32_t e = stk[sp * stride]; cur = e & ~STK_LEAF; state = (e & STK_LEAF) ? ST_OPEN : ST_NODE; }
