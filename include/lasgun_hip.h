@@ -191,7 +191,7 @@ int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t
 int lg_accel_set_mode(const lg_accel *, int mode);
 /* Pruned form of the reference traversal (mode 0 only): the reference's tree and visit order, but a node is skipped when on
  * some axis the ray reaches its slab only beyond the best accepted hit (closest hit) or beyond the light (shadow rays) by
- * more than a margin derived from the rounding of the reference's own intersection formulas (DESIGN.md section 3.5): every
+ * more than a margin derived from the rounding of the reference's own intersection formulas (DESIGN.md section 3.4): every
  * primitive below such a node would be rejected by the reference's `t >= isect.t` (sphere.rs:86, cuboid.rs:95,
  * triangle.rs:251), so every pixel is what the unpruned walk gives.  Nodes over a nested BVHAccel are never skipped; inside a
  * mesh only the ray's dominant axis counts.  -1 (default): on for scenes that carry a mesh of >= 256 triangles (the

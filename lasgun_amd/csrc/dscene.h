@@ -31,12 +31,12 @@ constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
 constexpr uint32_t WF_NONE = 0xFFFFFFFFu, WF_MISS = 0xFFFFFFFEu; // wavefront pipeline: no such child / the ray hit nothing
 constexpr int MAX_CHAIN = 8;      // scene-graph nesting levels (root = 1)
 constexpr uint32_t NODE_LEAF = 0x80000000u;
-// reference trees: a leaf below this node holds a nested BVHAccel -- the pruned walk (DESIGN.md section 3.5) never skips such a
+// reference trees: a leaf below this node holds a nested BVHAccel -- the pruned walk (DESIGN.md section 3.4) never skips such a
 // node, because its bounds on a primitive's t are stated per level, for spheres, boxes and triangles only
 constexpr uint32_t NODE_NOPRUNE = 0x40000000u;
 // Margins of the pruned walk, in units of the level's size S = |o - centre|_1 + (sum of the root box's extents):
 // a primitive's accepted hit point o + t*d lies within  e0 + S*(PRUNE_E1 + e2*S)  of its bounds box (per axis; triangles: on the
-// ray's dominant axis only).  u = 2^-53; the derivations (DESIGN.md 3.5) give 114 u W^2 / r for a sphere, 4 u (|b| + |o|) for a
+// ray's dominant axis only).  u = 2^-53; the derivations (DESIGN.md 3.4) give 114 u W^2 / r for a sphere, 4 u (|b| + |o|) for a
 // box, 12 u S for a triangle; the constants below keep a factor >= 8 above them.
 constexpr double PRUNE_E1 = 0x1p-46;          // per unit of S (boxes: 4u, triangles: 12u)
 constexpr double PRUNE_E0_PER_COORD = 0x1p-46; // e0 = this * (largest |coordinate| of the level's boxes): box rounding u|c -+ r|, 8u|b|
@@ -91,7 +91,7 @@ struct alignas(16) DLeafRec { // 48-byte leaf-ordered geometry record (see heade
 // consecutive leaf_soup2 slots, made by the host from the triangles in those slots -- their bounds, a cone around their
 // normals and two shape numbers.  (The reference orders a leaf's triangles by a Morton code that ignores x, bvh.rs:575-579:
 // sixteen consecutive ones are no neighbours.  leaf_soup2 holds each leaf's triangles in spatial runs instead; the leaf loop
-// then decides exact ties in t by the ORIGINAL slot number, which is what the reference's first-come rule amounts to.)  The walk skips the 16 triangle tests when NONE of them could be accepted (DESIGN.md 3.5):
+// then decides exact ties in t by the ORIGINAL slot number, which is what the reference's first-come rule amounts to.)  The walk skips the 16 triangle tests when NONE of them could be accepted (DESIGN.md 3.4):
 // always by the ray's dominant axis; on all three axes only when the ray crosses every triangle of the record at an angle whose
 // sine is at least CHUNK_SMIN (the cone test) and the triangles are not degenerate at the ray's distance (hmin).
 struct alignas(64) DChunk {
@@ -104,7 +104,9 @@ struct alignas(64) DChunk {
     uint32_t pad[2];
 };
 static_assert(sizeof(DChunk) == 64, "DChunk is one 64-byte line");
-constexpr uint32_t CHUNK_SHIFT = 4u;            // at most 16 slots per record
+constexpr uint32_t CHUNK_SHIFT = 4u;            // at most 16 slots per run
+constexpr uint32_t CHUNK_GROUP = 4u;            // runs per group record
+constexpr uint32_t CHUNK_IS_GROUP = 0xFFFFFFFFu; // DChunk::start of a group record; its count = the run records behind it
 constexpr double CHUNK_SMIN = 0.1;              // |n . d| / |d| >= this for every triangle of a record that is culled laterally
 constexpr double CHUNK_KLAT = 0x1p-28;          // lateral margin (space) = this * R^2 * g2; derivation: 2688 u / CHUNK_SMIN^3 = 3.0e-10, x 12
 constexpr double CHUNK_HGATE = 0x1p-18;         // ... and only when hmin >= this * R (R: 1-norm distance from the ray origin to the record's far corner)

@@ -601,7 +601,7 @@ struct Flattener {
         return worst;
     }
 
-    // Constants of the pruned walk for one BVHAccel level (DAccel::prune, DESIGN.md section 3.5), from its root box, the
+    // Constants of the pruned walk for one BVHAccel level (DAccel::prune, DESIGN.md section 3.4), from its root box, the
     // largest coordinate magnitude of its boxes and its smallest sphere radius (0 = the level holds no sphere).
     static void prune_constants(const Bounds &root, double cmax, double rmin, bool has_sphere, double out6[6]) {
         const V3 ext = root.max - root.min;
@@ -969,7 +969,7 @@ struct Flattener {
 };
 } // namespace
 
-// ---- culling records of the pruned walk (DChunk, DESIGN.md section 3.5) --------------------------------------------------------
+// ---- culling records of the pruned walk (DChunk, DESIGN.md section 3.4) --------------------------------------------------------
 // A fat leaf of a mesh's reference tree is cut into RUNS of <= 16 triangles that are neighbours in space and face the same way
 // (the reference's own order inside a leaf is a Morton order that ignores x, bvh.rs:575-579; a leaf is typically two to four
 // separate patches of the surface).  Recursive splitting of the leaf's triangle set: at the largest gap between centroids along
@@ -1016,6 +1016,59 @@ static void cut_runs(std::vector<LeafTri> &t, size_t a, size_t b, std::vector<st
     cut_runs(t, a, cut, runs);
     cut_runs(t, cut, b, runs);
 }
+// One culling record over the triangles in leaf_soup2 slots [a, b): bounds, normal cone, shape numbers.
+static DChunk make_record(const FlatScene &out, size_t a, size_t b) {
+    DChunk k{};
+    k.start = (uint32_t)a;
+    k.count = (uint32_t)(b - a);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double g2 = 0.0, hmin = INFINITY;
+    std::vector<V3> normals;
+    bool degenerate = false;
+    V3 nsum{0, 0, 0};
+    for (size_t s = a; s < b; ++s) {
+        float p[9];
+        std::memcpy(p, out.leaf_soup2[s].w, sizeof p);
+        V3 v[3];
+        for (int i = 0; i < 3; ++i) {
+            v[i] = V3{(double)p[3 * i], (double)p[3 * i + 1], (double)p[3 * i + 2]};
+            for (int ax = 0; ax < 3; ++ax) { mn[ax] = std::fmin(mn[ax], p[3 * i + ax]); mx[ax] = std::fmax(mx[ax], p[3 * i + ax]); }
+        }
+        const V3 e0 = v[1] - v[0], e1 = v[2] - v[1], e2 = v[0] - v[2];
+        const V3 n = cross(e0, V3{-e2.x, -e2.y, -e2.z});
+        const double twice_area = std::sqrt(dot(n, n));
+        const double lmax = std::sqrt(std::fmax(dot(e0, e0), std::fmax(dot(e1, e1), dot(e2, e2))));
+        const double h = twice_area / lmax; // the smallest altitude
+        if (!(twice_area > 0.0) || !std::isfinite(twice_area) || !(h > 0.0)) { degenerate = true; continue; }
+        V3 nu = n * (1.0 / twice_area);
+        if (!normals.empty() && dot(nu, normals[0]) < 0.0) nu = V3{-nu.x, -nu.y, -nu.z}; // only |n . d| matters: one hemisphere, whatever the winding
+        normals.push_back(nu);
+        nsum = nsum + nu;
+        g2 = std::fmax(g2, lmax * lmax / (h * h * h));
+        hmin = std::fmin(hmin, h);
+    }
+    for (int ax = 0; ax < 3; ++ax) { k.bmin[ax] = mn[ax]; k.bmax[ax] = mx[ax]; }
+    k.clim2 = 4.0f; k.g2 = INFINITY; k.hmin = 0.0f; // (4 = no lateral culling for this record)
+    k.axis[0] = k.axis[1] = 0.0f; k.axis[2] = 1.0f;
+    const double nl = std::sqrt(dot(nsum, nsum));
+    if (!normals.empty() && !degenerate && nl > 1e-6 && std::isfinite(g2)) {
+        // the axis as the kernel will see it (f32, not exactly unit): the cone's half-angle is measured against THAT vector
+        const float ax[3] = {(float)(nsum.x / nl), (float)(nsum.y / nl), (float)(nsum.z / nl)};
+        const double al = std::sqrt((double)ax[0] * ax[0] + (double)ax[1] * ax[1] + (double)ax[2] * ax[2]);
+        double cmin = 1.0; // smallest cosine between a normal and the axis
+        for (const V3 &n : normals) cmin = std::fmin(cmin, (n.x * ax[0] + n.y * ax[1] + n.z * ax[2]) / al);
+        const double theta = std::acos(std::fmax(-1.0, std::fmin(1.0, cmin))) + 1e-3; // + slack for the roundings above
+        const double room = std::acos(CHUNK_SMIN) - theta; // a direction within `room` of the axis meets every triangle at >= asin(CHUNK_SMIN)
+        if (room > 1e-3) {
+            const double clim = std::cos(room) * al; // (axis . d)^2 >= clim2 * (d . d), with the axis's own length folded in
+            k.axis[0] = ax[0]; k.axis[1] = ax[1]; k.axis[2] = ax[2];
+            k.clim2 = std::nextafterf((float)(clim * clim * (1.0 + 1e-6)), INFINITY);
+            k.g2 = std::nextafterf((float)(g2 * (1.0 + 1e-6)), INFINITY);
+            k.hmin = std::nextafterf((float)(hmin * (1.0 - 1e-6)), 0.0f);
+        }
+    }
+    return k;
+}
 // leaf_soup2 (the triangles of every mesh leaf again, run after run; word 9 of a record = the slot it came from), the runs'
 // records, and in DNode::pad of every mesh leaf: index of its first record | number of its records << 24.
 static void build_chunks(FlatScene &out) {
@@ -1043,65 +1096,30 @@ static void build_chunks(FlatScene &out) {
             }
             std::vector<std::pair<size_t, size_t>> runs;
             cut_runs(tris, 0, count, runs);
-            if (out.chunks.size() >= (1u << 24) || runs.size() > 255) throw Error("too many culling records");
-            nd.pad = (uint32_t)out.chunks.size() | ((uint32_t)runs.size() << 24);
+            if (out.chunks.size() >= (1u << 24) - 512u) throw Error("too many culling records");
+            nd.pad = (uint32_t)out.chunks.size();
             for (size_t i = 0; i < count; ++i) {
                 DLeafRec r = out.leaf_soup[tris[i].slot];
                 r.w[9] = tris[i].slot;
                 out.leaf_soup2[first + i] = r;
             }
-            for (const auto &run : runs) {
-                DChunk k{};
-                k.start = (uint32_t)(first + run.first);
-                k.count = (uint32_t)(run.second - run.first);
-                float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-                double g2 = 0.0, hmin = INFINITY;
-                std::vector<V3> normals;
-                bool degenerate = false;
-                V3 nsum{0, 0, 0};
-                for (size_t s = first + run.first; s < first + run.second; ++s) {
-                    float p[9];
-                    std::memcpy(p, out.leaf_soup2[s].w, sizeof p);
-                    V3 v[3];
-                    for (int i = 0; i < 3; ++i) {
-                        v[i] = V3{(double)p[3 * i], (double)p[3 * i + 1], (double)p[3 * i + 2]};
-                        for (int ax = 0; ax < 3; ++ax) { mn[ax] = std::fmin(mn[ax], p[3 * i + ax]); mx[ax] = std::fmax(mx[ax], p[3 * i + ax]); }
-                    }
-                    const V3 e0 = v[1] - v[0], e1 = v[2] - v[1], e2 = v[0] - v[2];
-                    const V3 n = cross(e0, V3{-e2.x, -e2.y, -e2.z});
-                    const double twice_area = std::sqrt(dot(n, n));
-                    const double lmax = std::sqrt(std::fmax(dot(e0, e0), std::fmax(dot(e1, e1), dot(e2, e2))));
-                    const double h = twice_area / lmax; // the smallest altitude
-                    if (!(twice_area > 0.0) || !std::isfinite(twice_area) || !(h > 0.0)) { degenerate = true; continue; }
-                    V3 nu = n * (1.0 / twice_area);
-                    if (!normals.empty() && dot(nu, normals[0]) < 0.0) nu = V3{-nu.x, -nu.y, -nu.z}; // only |n . d| matters: one hemisphere, whatever the winding
-                    normals.push_back(nu);
-                    nsum = nsum + nu;
-                    g2 = std::fmax(g2, lmax * lmax / (h * h * h));
-                    hmin = std::fmin(hmin, h);
+            // the leaf's record stream: runs in groups of <= CHUNK_GROUP, every group of two or more behind a GROUP record over the
+            // triangles of all its runs (start = CHUNK_IS_GROUP, count = how many run records follow it: a culled group is
+            // stepped over whole)
+            size_t nrec = 0;
+            for (size_t g = 0; g < runs.size(); g += CHUNK_GROUP) {
+                const size_t ge = std::min(runs.size(), g + CHUNK_GROUP);
+                if (ge - g >= 2) {
+                    DChunk gk = make_record(out, first + runs[g].first, first + runs[ge - 1].second);
+                    gk.start = CHUNK_IS_GROUP;
+                    gk.count = (uint32_t)(ge - g);
+                    out.chunks.push_back(gk);
+                    ++nrec;
                 }
-                for (int ax = 0; ax < 3; ++ax) { k.bmin[ax] = mn[ax]; k.bmax[ax] = mx[ax]; }
-                k.clim2 = 4.0f; k.g2 = INFINITY; k.hmin = 0.0f; // (4 = no lateral culling for this record)
-                k.axis[0] = k.axis[1] = 0.0f; k.axis[2] = 1.0f;
-                const double nl = std::sqrt(dot(nsum, nsum));
-                if (!normals.empty() && !degenerate && nl > 1e-6 && std::isfinite(g2)) {
-                    // the axis as the kernel will see it (f32, not exactly unit): the cone's half-angle is measured against THAT vector
-                    const float ax[3] = {(float)(nsum.x / nl), (float)(nsum.y / nl), (float)(nsum.z / nl)};
-                    const double al = std::sqrt((double)ax[0] * ax[0] + (double)ax[1] * ax[1] + (double)ax[2] * ax[2]);
-                    double cmin = 1.0; // smallest cosine between a normal and the axis
-                    for (const V3 &n : normals) cmin = std::fmin(cmin, (n.x * ax[0] + n.y * ax[1] + n.z * ax[2]) / al);
-                    const double theta = std::acos(std::fmax(-1.0, std::fmin(1.0, cmin))) + 1e-3; // + slack for the roundings above
-                    const double room = std::acos(CHUNK_SMIN) - theta; // a direction within `room` of the axis meets every triangle at >= asin(CHUNK_SMIN)
-                    if (room > 1e-3) {
-                        const double clim = std::cos(room) * al; // (axis . d)^2 >= clim2 * (d . d), with the axis's own length folded in
-                        k.axis[0] = ax[0]; k.axis[1] = ax[1]; k.axis[2] = ax[2];
-                        k.clim2 = std::nextafterf((float)(clim * clim * (1.0 + 1e-6)), INFINITY);
-                        k.g2 = std::nextafterf((float)(g2 * (1.0 + 1e-6)), INFINITY);
-                        k.hmin = std::nextafterf((float)(hmin * (1.0 - 1e-6)), 0.0f);
-                    }
-                }
-                out.chunks.push_back(k);
+                for (size_t r = g; r < ge; ++r) { out.chunks.push_back(make_record(out, first + runs[r].first, first + runs[r].second)); ++nrec; }
             }
+            if (nrec > 255) throw Error("too many culling records in one leaf");
+            nd.pad |= (uint32_t)nrec << 24;
         }
     }
     if (std::getenv("LASGUN_DEBUG_CHUNKS")) { // what the runs look like: sizes, and how much room their cones leave

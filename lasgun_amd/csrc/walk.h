@@ -598,7 +598,7 @@ struct LeafCull {
 };
 // One culling record (DChunk) against the ray: true = none of its <= 16 triangles can be accepted, the tests are skipped.
 // (t1, t2) per axis are the slab test's own expressions on the record's box.  Dominant axis: an accepted t is a convex
-// combination of plane parameters that lie between the box's two (section 3.5), so it lies in [tmin_kz - ekz, tmax_kz + ekz]: outside
+// combination of plane parameters that lie between the box's two (section 3.4), so it lies in [tmin_kz - ekz, tmax_kz + ekz]: outside
 // [0, limit] nothing is accepted.  All axes, when the ray meets every triangle of the record at an angle of sine >= CHUNK_SMIN
 // and the triangles are not degenerate at its distance: the accepted hit point lies within m = CHUNK_KLAT * R^2 * g2 of the
 // triangle (the edge functions' rounding, 48 u R^2, moves the projected origin by at most that over an altitude), so t lies in
@@ -709,7 +709,8 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
                     const bool culled_ = chunk_culled<KZ>(P.chunks + rec, ray, lc, start, count);
 #endif
                     ++rec;
-                    if (!culled_) { in_run = true; s = start; run_end = start + count; off = s * REC; ra = load_rec_at(base2, off); } // (the array holds < 2^32 / 48 slots: checked by the host)
+                    if (start == CHUNK_IS_GROUP) { if (culled_) rec += count; } // a group record: culled, its runs are stepped over; kept, they come next
+                    else if (!culled_) { in_run = true; s = start; run_end = start + count; off = s * REC; ra = load_rec_at(base2, off); } // (the array holds < 2^32 / 48 slots: checked by the host)
                 }
                 seeking = wave_any(!in_run && rec < rec_end);
             }
@@ -762,7 +763,7 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 // visit order decides, raise `tie`; the caller (walk() below) then puts the winner to the reference tree's own box tests
 // (ref_candidate) and re-traces with the reference walk when either fails.
 //
-// PRUNE (the reference tree, the reference's visit order; DESIGN.md section 3.5 has the derivations): a node is skipped when,
+// PRUNE (the reference tree, the reference's visit order; DESIGN.md section 3.4 has the derivations): a node is skipped when,
 // on some axis, the ray enters its slab only at a parameter beyond the limit -- the best accepted t so far (closest hit) or 1
 // (any-hit) -- by more than that axis's margin.  Every primitive below such a node would be rejected by the reference's own
 // `t >= isect.t` (sphere.rs:86, cuboid.rs:95, triangle.rs:251) or could not bring isect.t below 1 (point.rs:49), so the lane's
