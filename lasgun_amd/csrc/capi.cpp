@@ -280,8 +280,8 @@ static lg_accel::LaunchCtx &ctx_for(const lg_accel &a, hipStream_t stream) {
     if (a.ctxs.size() < MAX_LAUNCH_CTXS) {
         a.ctxs.emplace_back(new lg_accel::LaunchCtx());
         c = a.ctxs.back().get();
-        c->tile_counter.alloc(4);
-        HIP_TRY(hipMemset(c->tile_counter.p, 0, 4 * sizeof(uint32_t)));
+        c->tile_counter.alloc(TILE_COUNTER_WORDS);
+        HIP_TRY(hipMemset(c->tile_counter.p, 0, TILE_COUNTER_WORDS * sizeof(uint32_t)));
     } else {
         c = a.ctxs[0].get();
         for (auto &x : a.ctxs) if (x->last_use < c->last_use) c = x.get();
@@ -380,7 +380,7 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
     unsigned long long n0 = 0;
     size_t need = 0, hit_cap = 0, hit_len = 0;
     const uint32_t nlaunch = 4 * levels;
-    const uint32_t CL = 64; // the queue counts (3 per level) in the first 256 bytes, then every tile counter on a line of its own
+    const uint32_t CL = TILE_COUNTER_WORDS; // the queue counts (3 per level) in the first block, then a block of tile heads per launch (one head per XCD, each on a line of its own)
     auto size_chunk = [&] {
         n0 = chunk_tiles * 64ull;
         need = (size_t)n0 * per_pixel + 4096 * (3 * levels + 4);
@@ -629,7 +629,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         P.stats = a.stats.p;
         HIP_TRY(hipMemsetAsync(a.stats.p, 0, sizeof(DStats), stream));
     }
-    HIP_TRY(hipMemsetAsync(c.tile_counter.p, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(c.tile_counter.p, 0, TILE_COUNTER_WORDS * sizeof(uint32_t), stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (a.profiling) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));

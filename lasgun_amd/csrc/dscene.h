@@ -30,6 +30,10 @@ constexpr uint32_t PRIM_INDEX_MASK = 0x3FFFFFFFu;
 constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
 constexpr uint32_t WF_NONE = 0xFFFFFFFFu, WF_MISS = 0xFFFFFFFEu; // wavefront pipeline: no such child / the ray hit nothing
 constexpr int MAX_CHAIN = 8;      // scene-graph nesting levels (root = 1)
+// tile counters of a persistent kernel (kcommon.h, claim_tile): [0..15] plain words (the packet kernels' three), then one head word per XCD, 64 bytes apart
+constexpr uint32_t TILE_HEADS = 8u, TILE_HEAD_STRIDE = 16u;
+constexpr uint32_t TILE_COUNTER_WORDS = 16u + TILE_HEADS * TILE_HEAD_STRIDE;
+constexpr uint32_t NO_TILE = 0xFFFFFFFFu;
 constexpr uint32_t NODE_LEAF = 0x80000000u;
 // reference trees: a leaf below this node holds a nested BVHAccel -- the pruned walk never skips such a
 // node, because its bounds on a primitive's t are stated per level, for spheres, boxes and triangles only

@@ -132,11 +132,20 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
         scn = dst;
     }
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)cnt;
+    // Tiles are claimed XCD by XCD (kcommon.h, claim_tile) where the scene sits in LDS and the claim itself is what waves queue on:
+    // headline frame 3.39 + 3.52 -> 3.10 + 3.19 ms for the two traversal passes.  With the tables in L2 (mesh scenes) the bands
+    // measured no better than one head word (config 5: 68.4 vs 69.4 ms), so those forms keep the single word.
+    uint32_t band = LDSS ? xcc_id() : 0u, bands_left = TILE_HEADS;
     for (;;) {
-        uint32_t tile = 0;
-        if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
-        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-        if (tile >= ntiles) break; // every wave reaches this exit
+        uint32_t tile;
+        if (LDSS) tile = claim_tile(P.tile_counter, ntiles, band, bands_left);
+        else {
+            tile = 0u;
+            if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
+            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+            if (tile >= ntiles) tile = NO_TILE;
+        }
+        if (tile == NO_TILE) break; // every wave reaches this exit
         if (!SHADOW) {
             const unsigned long long i = (unsigned long long)tile * lpt + lane;
             Pixel px;
