@@ -96,24 +96,30 @@ struct alignas(16) DLeafRec { // 48-byte leaf-ordered geometry record (see heade
 // normals and two shape numbers.  (The reference orders a leaf's triangles by a Morton code that ignores x, bvh.rs:575-579:
 // sixteen consecutive ones are no neighbours.  leaf_soup2 holds each leaf's triangles in spatial runs instead; the leaf loop
 // then decides exact ties in t by the ORIGINAL slot number, which is what the reference's first-come rule amounts to.)  The walk skips the 16 triangle tests when NONE of them could be accepted:
-// always by the ray's dominant axis; on all three axes only when the ray crosses every triangle of the record at an angle whose
-// sine is at least CHUNK_SMIN (the cone test) and the triangles are not degenerate at the ray's distance (hmin).
+// always by the ray's dominant axis; on all three axes with a margin that grows with 1 / sigma^3, sigma a lower bound (from the
+// cone) of the sine of the angle at which the ray crosses the record's triangles -- never for a ray that may lie in a triangle's plane.
 struct alignas(64) DChunk {
     float bmin[3], bmax[3]; // union of the triangles' bounds (vertex coordinates are f32: exact)
-    float axis[3];          // unit vector; every triangle normal of the record is within theta of it
-    float clim2;            // lateral culling is allowed when (axis . d)^2 >= clim2 * (d . d); 4 = never (wide cone, degenerate triangle)
+    float axis[3];          // unit vector; every triangle normal of the record is within theta of it (or of its opposite)
+    float cos_t;            // cos(theta), rounded down; -1 = no lateral culling for this record (wide cone, degenerate triangle)
     float g2;               // max over the triangles of (longest edge)^2 / (smallest altitude)^3, rounded up
     float hmin;             // smallest altitude of any triangle of the record, rounded down
     uint32_t start, count;  // its run of leaf_soup2 slots
-    uint32_t pad[2];
+    float sin_t;            // sin(theta), rounded up
+    uint32_t pad;
 };
 static_assert(sizeof(DChunk) == 64, "DChunk is one 64-byte line");
 constexpr uint32_t CHUNK_SHIFT = 4u;            // at most 16 slots per run
 constexpr uint32_t CHUNK_GROUP = 4u;            // runs per group record
 constexpr uint32_t CHUNK_IS_GROUP = 0xFFFFFFFFu; // DChunk::start of a group record; its count = the run records behind it
-constexpr double CHUNK_SMIN = 0.1;              // |n . d| / |d| >= this for every triangle of a record that is culled laterally
-constexpr double CHUNK_KLAT = 0x1p-28;          // lateral margin (space) = this * R^2 * g2; derivation: 2688 u / CHUNK_SMIN^3 = 3.0e-10, x 12
-constexpr double CHUNK_HGATE = 0x1p-18;         // ... and only when hmin >= this * R (R: 1-norm distance from the ray origin to the record's far corner)
+// Lateral culling of a record: with sigma <= |n . d| / |d| for every triangle of the record (from the cone and the ray:
+// cos(alpha + theta), alpha the angle between the ray and the cone's axis), the accepted hit point lies within
+// m = CHUNK_K0 * R^2 * g2 / sigma^3 of the triangle (derivation: 4608 u = 5.1e-13, x 7), R the 1-norm distance from the ray's
+// origin to the record's far corner; used when sigma >= CHUNK_SIGMA_MIN and hmin^2 * sigma >= CHUNK_HGATE * R^2 (the projected
+// triangle's area must dominate the edge functions' rounding: 384 u = 4.3e-14).
+constexpr float CHUNK_K0 = 0x1p-38f;
+constexpr float CHUNK_SIGMA_MIN = 1e-3f;
+constexpr float CHUNK_HGATE = 0x1p-40f;
 
 struct DMaterial { // == lg_material of include/lasgun_hip.h
     int32_t kind;

@@ -1048,21 +1048,21 @@ static DChunk make_record(const FlatScene &out, size_t a, size_t b) {
         hmin = std::fmin(hmin, h);
     }
     for (int ax = 0; ax < 3; ++ax) { k.bmin[ax] = mn[ax]; k.bmax[ax] = mx[ax]; }
-    k.clim2 = 4.0f; k.g2 = INFINITY; k.hmin = 0.0f; // (4 = no lateral culling for this record)
+    k.cos_t = -1.0f; k.sin_t = 1.0f; k.g2 = INFINITY; k.hmin = 0.0f; // (-1 = no lateral culling for this record)
     k.axis[0] = k.axis[1] = 0.0f; k.axis[2] = 1.0f;
     const double nl = std::sqrt(dot(nsum, nsum));
     if (!normals.empty() && !degenerate && nl > 1e-6 && std::isfinite(g2)) {
-        // the axis as the kernel will see it (f32, not exactly unit): the cone's half-angle is measured against THAT vector
+        // the axis as the kernel will see it (f32, not exactly unit): the cone's half-angle is measured against THAT vector,
+        // and the kernel's |axis . d| / |d| differs from the cosine by the axis's length (1 +- 1e-7): 1e-3 rad of slack covers both
         const float ax[3] = {(float)(nsum.x / nl), (float)(nsum.y / nl), (float)(nsum.z / nl)};
         const double al = std::sqrt((double)ax[0] * ax[0] + (double)ax[1] * ax[1] + (double)ax[2] * ax[2]);
         double cmin = 1.0; // smallest cosine between a normal and the axis
         for (const V3 &n : normals) cmin = std::fmin(cmin, (n.x * ax[0] + n.y * ax[1] + n.z * ax[2]) / al);
-        const double theta = std::acos(std::fmax(-1.0, std::fmin(1.0, cmin))) + 1e-3; // + slack for the roundings above
-        const double room = std::acos(CHUNK_SMIN) - theta; // a direction within `room` of the axis meets every triangle at >= asin(CHUNK_SMIN)
-        if (room > 1e-3) {
-            const double clim = std::cos(room) * al; // (axis . d)^2 >= clim2 * (d . d), with the axis's own length folded in
+        const double theta = std::acos(std::fmax(-1.0, std::fmin(1.0, cmin))) + 1e-3;
+        if (theta < 1.5) {
             k.axis[0] = ax[0]; k.axis[1] = ax[1]; k.axis[2] = ax[2];
-            k.clim2 = std::nextafterf((float)(clim * clim * (1.0 + 1e-6)), INFINITY);
+            k.cos_t = std::nextafterf((float)(std::cos(theta) * (1.0 - 1e-6)), -INFINITY);
+            k.sin_t = std::nextafterf((float)(std::sin(theta) * (1.0 + 1e-6)), INFINITY);
             k.g2 = std::nextafterf((float)(g2 * (1.0 + 1e-6)), INFINITY);
             k.hmin = std::nextafterf((float)(hmin * (1.0 - 1e-6)), 0.0f);
         }
@@ -1126,8 +1126,8 @@ static void build_chunks(FlatScene &out) {
         size_t n = out.chunks.size(), never = 0, tris = 0, hist[6] = {0, 0, 0, 0, 0, 0};
         for (const DChunk &k : out.chunks) {
             tris += k.count;
-            if (k.clim2 >= 4.0f) { ++never; continue; }
-            const double room = std::acos(std::sqrt((double)k.clim2)) * 57.29578;
+            if (k.cos_t < 0.0f) { ++never; continue; }
+            const double room = 90.0 - std::acos((double)k.cos_t) * 57.29578; // how far from the axis a ray may point before it is edge-on to some triangle
             ++hist[room < 30 ? 0 : room < 45 ? 1 : room < 60 ? 2 : room < 70 ? 3 : room < 80 ? 4 : 5];
         }
         std::fprintf(stderr, "[lasgun] culling records: %zu over %zu triangles (%.1f per record); no lateral culling: %zu; room <30: %zu, <45: %zu, <60: %zu, <70: %zu, <80: %zu, >=80: %zu\n",

@@ -599,8 +599,8 @@ struct LeafCull {
 // One culling record (DChunk) against the ray: true = none of its <= 16 triangles can be accepted, the tests are skipped.
 // (t1, t2) per axis are the slab test's own expressions on the record's box.  Dominant axis: an accepted t is a convex
 // combination of plane parameters that lie between the box's two (section 3.4), so it lies in [tmin_kz - ekz, tmax_kz + ekz]: outside
-// [0, limit] nothing is accepted.  All axes, when the ray meets every triangle of the record at an angle of sine >= CHUNK_SMIN
-// and the triangles are not degenerate at its distance: the accepted hit point lies within m = CHUNK_KLAT * R^2 * g2 of the
+// [0, limit] nothing is accepted.  All axes, when the ray meets every triangle of the record at an angle of sine >= sigma > 0
+// and the triangles are not degenerate at its distance: the accepted hit point lies within m = CHUNK_K0 * R^2 * g2 / sigma^3 of the
 // triangle (the edge functions' rounding, 48 u R^2, moves the projected origin by at most that over an altitude), so t lies in
 // every axis's [tmin_i - m |1/d_i|, tmax_i + m |1/d_i|]: an empty intersection, one beyond the limit or one before 0 accepts nothing.
 #ifdef LG_CHUNK_DEBUG
@@ -615,11 +615,10 @@ __device__ __forceinline__ bool chunk_culled(const DChunk *rec, const Ray &ray, 
 ) {
     const uint4 *q = reinterpret_cast<const uint4 *>(rec);
     const uint4 a = q[0], b = q[1], c = q[2];
-    const uint2 sc = *reinterpret_cast<const uint2 *>(q + 3);
-    run_start = sc.x; run_count = sc.y;
+    run_start = q[3].x; run_count = q[3].y;
     const double bmin[3] = {rec_f32(a.x), rec_f32(a.y), rec_f32(a.z)}, bmax[3] = {rec_f32(a.w), rec_f32(b.x), rec_f32(b.y)};
     const V3 ax{rec_f32(b.z), rec_f32(b.w), rec_f32(c.x)};
-    const double clim2 = rec_f32(c.y), g2 = rec_f32(c.z), hmin = rec_f32(c.w);
+    const float cos_t = __uint_as_float(c.y), g2 = __uint_as_float(c.z), hmin = __uint_as_float(c.w), sin_t = __uint_as_float(q[3].z);
     const double ox = bmin[0] - ray.o.x, px = bmax[0] - ray.o.x, oy = bmin[1] - ray.o.y, py = bmax[1] - ray.o.y, oz = bmin[2] - ray.o.z, pz = bmax[2] - ray.o.z;
     double t1 = ox * ray.dinv.x, t2 = px * ray.dinv.x;
     const double nx = fmin_(t1, t2), fx = fmax_(t1, t2);
@@ -629,13 +628,18 @@ __device__ __forceinline__ bool chunk_culled(const DChunk *rec, const Ray &ray, 
     const double nz = fmin_(t1, t2), fz = fmax_(t1, t2);
     const double nk = KZ == 0 ? nx : KZ == 1 ? ny : nz, fk = KZ == 0 ? fx : KZ == 1 ? fy : fz;
     bool skip = nk > lc.lb + lc.ekz || fk < -lc.ekz; // (NaN parameters compare false)
-    const double ad = dot(ax, ray.d);
-    const double R = (fmax_(fabs(ox), fabs(px)) + fmax_(fabs(oy), fabs(py))) + fmax_(fabs(oz), fabs(pz)); // >= the distance to any vertex
+    // sigma: a lower bound of |n . d| / |d| over the record's triangles -- cos(alpha + theta) with cos(alpha) = |axis . d| / |d|, in
+    // f32 with every rounding pushed towards a smaller sigma (a larger margin)
+    const float ca = fminf(fabsf((float)dot(ax, ray.d)) * __frsqrt_rn((float)lc.dd) * (1.0f - 4e-6f), 1.0f);
+    const float sa = sqrtf(fmaxf(1.0f - ca * ca, 0.0f)) * (1.0f + 4e-6f) + 1e-6f;
+    const float sigma = (ca * cos_t - sa * sin_t) - 1e-5f;
+    const float Rf = (float)((fmax_(fabs(ox), fabs(px)) + fmax_(fabs(oy), fabs(py))) + fmax_(fabs(oz), fabs(pz))) * (1.0f + 1e-6f); // >= the 1-norm distance to any vertex
 #ifdef LG_CHUNK_DEBUG
-    if (ad * ad >= clim2 * lc.dd) g_dbg_gate = 1; else g_dbg_gate = 0;
+    lc_dbg_gate = sigma >= CHUNK_SIGMA_MIN ? 1 : 0;
 #endif
-    if (ad * ad >= clim2 * lc.dd && hmin >= CHUNK_HGATE * R) {
-        const double m = (CHUNK_KLAT * g2) * (R * R);
+    if (sigma >= CHUNK_SIGMA_MIN && hmin * hmin * sigma >= CHUNK_HGATE * Rf * Rf) {
+        const float inv = __frcp_rn(sigma) * (1.0f + 1e-6f);
+        const double m = (double)(((CHUNK_K0 * g2) * (inv * inv * inv)) * (Rf * Rf) * (1.0f + 1e-5f));
         const double ex = m * fabs(ray.dinv.x), ey = m * fabs(ray.dinv.y), ez = m * fabs(ray.dinv.z);
         const double tn = fmax_(fmax_(nx - ex, ny - ey), nz - ez), tf = fmin_(fmin_(fx + ex, fy + ey), fz + ez); // (inf - inf = NaN: ignored)
         skip = skip || tn > tf || tf < 0.0 || tn > lc.lb;
