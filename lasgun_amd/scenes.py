@@ -550,16 +550,29 @@ def adversarial_mesh_scene(api, seed):
     return sc
 
 
-def _slab_mesh_obj(rng, n_quads, snap):
+def _slab_mesh_obj(rng, n_quads, snap, normals=False):
     """OBJ text: axis-aligned quads in planes whose offsets are multiples of `snap` (rays of an axis-aligned orthographic
-    camera on the same lattice lie IN those planes: triangles seen exactly edge-on), generic triangles, and long thin ones."""
-    lines, nv = [], 0
+    camera on the same lattice lie IN those planes: triangles seen exactly edge-on), generic triangles, and long thin ones.
+    With `normals` every triangle corner carries a shading normal of its own: two triangles that meet in an edge then shade
+    differently, so WHICH of them wins an exact tie in t (a ray through the shared edge) shows in the picture."""
+    lines, faces, nv, nn = [], [], 0, 0
     def quad(p, e1, e2):
-        nonlocal nv
+        nonlocal nv, nn
         for v in (p, p + e1, p + e1 + e2, p + e2):
             lines.append("v %.9g %.9g %.9g" % tuple(v))
-        lines.append("f %d %d %d" % (nv + 1, nv + 2, nv + 3))
-        lines.append("f %d %d %d" % (nv + 1, nv + 3, nv + 4))
+        for tri in ((1, 2, 3), (1, 3, 4)):
+            if normals:
+                face_n = np.cross(e1, e2)
+                face_n = face_n / (np.linalg.norm(face_n) or 1.0)
+                ids = []
+                for _ in range(3):
+                    n = face_n + rng.uniform(-0.4, 0.4, 3)
+                    lines.append("vn %.6f %.6f %.6f" % tuple(n))
+                    nn += 1
+                    ids.append(nn)
+                faces.append("f %d//%d %d//%d %d//%d" % (nv + tri[0], ids[0], nv + tri[1], ids[1], nv + tri[2], ids[2]))
+            else:
+                faces.append("f %d %d %d" % (nv + tri[0], nv + tri[1], nv + tri[2]))
         nv += 4
     import numpy as np
     for i in range(n_quads):
@@ -574,7 +587,7 @@ def _slab_mesh_obj(rng, n_quads, snap):
             e1 = rng.uniform(-0.5, 0.5, 3)
             e2 = rng.uniform(-0.5, 0.5, 3) * (10.0 ** rng.uniform(-6, 0))
             quad(p, e1, e2)
-    return "\n".join(lines) + "\n"
+    return "\n".join(lines + faces) + "\n"
 
 
 def adversarial_prune_scene(api, seed):
@@ -609,7 +622,7 @@ def adversarial_prune_scene(api, seed):
     mats = [M.matte(rng.uniform(0.2, 1, 3).tolist(), 0.0), M.plastic(rng.uniform(0.2, 1, 3).tolist(), [0.5, 0.5, 0.5], 0.3),
             M.mirror([0.6, 0.6, 0.6]), M.glass([0.9, 0.9, 0.9], [0.9, 0.9, 0.9], 1.3)]
     nmat = 4 if rng.random() < 0.4 else 2
-    mesh = sc.parse_obj(_slab_mesh_obj(rng, int(rng.integers(300, 700)), snap))
+    mesh = sc.parse_obj(_slab_mesh_obj(rng, int(rng.integers(300, 700)), snap, normals=bool(rng.random() < 0.5)))
     root = sc.root
     if rng.random() < 0.5:
         root.add_obj_of(mesh, mats[0])                       # the mesh accel directly in the root (identity all the way)
@@ -699,4 +712,43 @@ def exotic_obj_scene(api, smoothing=True):
     g.add_obj_of(mesh, M.matte([0.4, 0.7, 0.5], 10.0))
     scene.root.add_group(g)
     scene.root.add_sphere([0.5, -50.0, 0.0], 49.9, M.matte([0.5, 0.5, 0.5], 0.0))
+    return scene
+
+
+def tie_mesh_scene(api, n=24, seed=5):
+    """A flat n x n grid of quads (2 n^2 triangles, several fat leaves of the reference tree) whose corners carry random shading
+    normals of their own, under an orthographic camera on the grid's lattice: at a 128 x 128 film every fourth row and column of
+    rays passes exactly through edges and corners shared by two to six triangles -- exact ties in t, which the reference gives to the triangle
+    that comes first in its leaf's order[] (and, across leaves, in its visit order).  The picture shows who won."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    step = 1.0 / 8.0
+    lines, faces, nn = ["o grid"], [], 0
+    for j in range(n + 1):
+        for i in range(n + 1):
+            lines.append("v %.9g %.9g 0" % ((i - n / 2) * step, (j - n / 2) * step))
+    def vid(i, j):
+        return j * (n + 1) + i + 1
+    for j in range(n):
+        for i in range(n):
+            for tri in ((vid(i, j), vid(i + 1, j), vid(i + 1, j + 1)), (vid(i, j), vid(i + 1, j + 1), vid(i, j + 1))):
+                ids = []
+                for _ in range(3):
+                    v = np.array([0.0, 0.0, 1.0]) + rng.uniform(-0.5, 0.5, 3)
+                    lines.append("vn %.6f %.6f %.6f" % tuple(v))
+                    nn += 1
+                    ids.append(nn)
+                faces.append("f %d//%d %d//%d %d//%d" % (tri[0], ids[0], tri[1], ids[1], tri[2], ids[2]))
+    scene = api.Scene.new()
+    scene.set_ambient_light([0.2, 0.2, 0.2])
+    cam = scene.set_orthographic_camera(4.0)   # image plane 4 high: 128 rows of 1/32 -- every fourth row and column of rays runs along grid lines
+    cam.look_at([0.0, 0.0, 4.0], [0.0, 0.0, 0.0], [0.0, 1.0, 0.0])
+    mesh = scene.parse_obj("\n".join(lines + faces) + "\n")
+    scene.add_point_light([1.0, 2.0, 3.0], [0.9, 0.9, 0.9], [1.0, 0.0, 0.0])
+    scene.add_point_light([-2.0, -1.0, 2.5], [0.4, 0.5, 0.7], [1.0, 0.0, 0.0])
+    scene.root.add_obj_of(mesh, api.Material.plastic([0.8, 0.6, 0.3], [0.5, 0.5, 0.5], 0.3))
+    g = api.Aggregate.new()
+    g.translate([0.25, -0.125, -0.5])   # a second copy behind the first, also on the lattice
+    g.add_obj_of(mesh, api.Material.matte([0.3, 0.6, 0.8], 0.0))
+    scene.root.add_group(g)
     return scene

@@ -716,3 +716,30 @@ def test_bench_two_ranks_end_to_end_under_torchrun(collective):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["primary"] == 512 * 512 and "2 rank(s)" in line["config"]["parallelism"]
     assert line["bit_exact"] is None  # the oracle leg belongs to N = 1
+
+
+def test_exact_ties_inside_fat_leaves_go_to_the_reference_winner():
+    """Rays through edges and corners shared by two to six triangles of a mesh with per-corner shading normals: the winner of an
+    exact tie in t shows in the picture.  The pruned walk scans a fat leaf run by run instead of in the reference's order and gives
+    a tie to the lower original slot; plain walk, pruned walk (megakernel and wavefront pipeline) and fast mode must all paint
+    the oracle's picture -- bytes and radiance bits."""
+    w = h = 128
+    o = oracle()
+    oacc = o.Accel(S.tie_mesh_scene(o))
+    ofilm = o.Film(w, h)
+    o.capture_subset_mt(0, 1, oacc, ofilm, 8)
+    o.set_trig_mode(1)
+    try:
+        orad = o.capture_radiance(oacc, w, h, nthreads=8)
+    finally:
+        o.set_trig_mode(0)
+    assert len(np.unique(ofilm.pixels().reshape(-1, 4), axis=0)) > 1000
+    acc = G.Accel(S.tie_mesh_scene(G))
+    assert G.accel_info(acc)["triangles"] == 2 * 24 * 24
+    for streaming in (0, 2):
+        for prune, fast in ((False, False), (True, False), (False, True)):
+            G.set_streaming(acc, streaming); G.set_prune(acc, prune); G.set_mode(acc, fast)
+            film = G.Film(w, h)
+            G.capture_subset(0, 1, acc, film)
+            assert np.array_equal(film.pixels(), ofilm.pixels()), (streaming, prune, fast)
+            assert np.array_equal(bits(G.capture_radiance(acc, w, h)), bits(orad)), (streaming, prune, fast)

@@ -366,7 +366,7 @@ def kitchen_like(api):
     return scene
 
 
-@pytest.mark.parametrize("gen", ["random", "adversarial", "adversarial_mesh"])
+@pytest.mark.parametrize("gen", ["random", "adversarial", "adversarial_mesh", "adversarial_prune"])
 def test_render_through_the_python_bvh(gen):
     """The same comparison with the witness finding its hits through ITS OWN restatement of the BVH and of
     BVHAccel::intersect (tests/pyref_bvh.py) instead of by brute force: scenes with duplicated and face-sharing primitives
@@ -374,7 +374,8 @@ def test_render_through_the_python_bvh(gen):
     Every pixel must agree to the bit (a NaN matches a NaN)."""
     import os
     import pyref_bvh
-    builder = {"random": S.random_scene, "adversarial": S.adversarial_scene, "adversarial_mesh": S.adversarial_mesh_scene}[gen]
+    builder = {"random": S.random_scene, "adversarial": S.adversarial_scene, "adversarial_mesh": S.adversarial_mesh_scene,
+               "adversarial_prune": S.adversarial_prune_scene}[gen]
     nseeds = int(os.environ.get("LASGUN_WITNESS_SEEDS", "6"))
     o = oracle()
     w, h = 24, 18
@@ -417,3 +418,18 @@ def test_exotic_obj_forms_against_the_python_witness(smoothing):
     assert (prad.view(np.uint64) == orad.view(np.uint64)).all()
     assert np.array_equal(np.asarray(prgba, dtype=np.uint8), ofilm.pixels())
     assert len(np.unique(ofilm.pixels().reshape(-1, 4), axis=0)) > 200  # the mesh is in view, lit and shaded
+
+
+def test_exact_ties_against_the_python_witness():
+    """The tie scene of the GPU suite (rays through shared edges and corners of a mesh whose corners carry shading normals of
+    their own): oracle and witness must give every tie to the same triangle -- the witness walks its own BVH in the reference's order."""
+    import pyref_bvh
+    o = oracle()
+    w = h = 64
+    oacc = o.Accel(S.tie_mesh_scene(o, n=12))
+    orad = np.asarray(o.capture_radiance(oacc, w, h, nthreads=8))
+    scene = S.tie_mesh_scene(pyref.Api, n=12)
+    pyref_bvh.install(scene)
+    prad, _ = pyref.render(scene, w, h)
+    prad = np.asarray(prad, dtype=np.float64)
+    assert (prad.view(np.uint64) == orad.view(np.uint64)).all()
