@@ -164,6 +164,17 @@ def mesh_roofline(G, la, stream):
     rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
     flops = algorithmic_flops(st)
     tops = flops / (ms * 1e-3) / 1e12
+    # the same frame as the reference walks it (no node or run skipped): its work, and how long this build's plain walk takes over it
+    G.set_prune(acc, False)
+    st_ref = G.capture_stats(acc, size, size, 0, size)
+    G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    ms_plain = (time.perf_counter() - t0) * 1e3
+    G.set_prune(acc, None)
+    flops_ref = algorithmic_flops(st_ref)
     del film
     torch.cuda.empty_cache()
     return {"workload": "configs[3]: 4096x4096, 100,352-triangle torus (glass) in a transformed group + mirror sphere in the Cornell shell, recursion 3",
@@ -172,7 +183,12 @@ def mesh_roofline(G, la, stream):
             "kernel": "lg::trace_kernel<false, false, false, true>", "algorithmic_flops_per_frame": flops,
             "work_per_frame": {k: st[k] for k in ("nodes_tested", "spheres_tested", "cuboids_tested", "triangles_tested", "accel_entries", "hits")},
             "traversal": "reference tree, pruned walk (lg_accel_set_prune default for a scene with a big mesh), megakernel",
-            "note": "one kernel per frame (megakernel): frame time = kernel time; byte-identical to the oracle in tests/test_gpu_configs.py"}
+            "plain_walk": {"ms_per_frame": ms_plain, "algorithmic_flops_per_frame": flops_ref, "frac": flops_ref / (ms_plain * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS,
+                           "triangles_tested": st_ref["triangles_tested"], "nodes_tested": st_ref["nodes_tested"]},
+            "reference_work_rate_frac": flops_ref / (ms * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS,
+            "note": "one kernel per frame (megakernel): frame time = kernel time; byte-identical to the oracle in tests/test_gpu_configs.py.  `frac` prices "
+                    "the tests the pruned walk still makes (the kernel then waits on L2, not on the VALU); `plain_walk` is the same frame with every test "
+                    "the reference makes, `reference_work_rate_frac` that work over the pruned walk's time (what skipping buys, not a roofline fraction)"}
 
 
 def main():

@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r02_bench.json, produced by `python bench.py` on the GPU box) carries
+"""The committed bench line (profiles/r03_bench.json, produced by `python bench.py` on the GPU box) carries
 every field of the driver's contract; BASELINE.json's metric string is the one bench.py prints."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r02_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r03_bench.json")) as f:
         rows = [l for l in f.read().splitlines() if l.startswith("{")]
     return json.loads(rows[-1])
 
@@ -29,6 +29,11 @@ def test_bench_line_has_the_contract_fields():
     assert r["traffic"] is None or r["traffic_source"]
     assert "hbm_algorithmic" in r and "lds" in r and r["hbm_algorithmic"]["measured_copy_peak"] > 1000.0
     assert d["latency_ms"] > 0.0 and d["config"]["rays_per_frame"] == d["config"]["primary"] + d["config"]["shadow"]
+    # the line proves its own "bit-exact RGBA8 vs CPU": the timed frame against the oracle film, in the same run
+    assert d["bit_exact"] is True and d["mismatched_bytes"] == 0 and d["bit_exact_check"]["checked_pixels"] >= 65536
+    assert d["value_single_frame"] > 100.0 and abs(d["value_single_frame"] - d["config"]["rays_per_frame"] / d["latency_ms"] / 1e3) < 1e-6 * d["value_single_frame"]
+    m = d["roofline_mesh"]
+    assert m["bound"] == "valu_f64" and 0.0 < m["frac"] < 1.0 and m["work_per_frame"]["triangles_tested"] > 0 and m["ms_per_frame"] > 0.0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
