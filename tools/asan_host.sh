@@ -1,7 +1,7 @@
 #!/bin/bash
 # Host side (scene description, OBJ reader, HLBVH builder, flattening, C ABI) under AddressSanitizer + UBSan on the CPU:
 # builds lasgun_amd/csrc/{host,capi,multi}.cpp with -fsanitize=address,undefined, links them with the device object, and
-# runs tests/test_host.py plus the flattening of 450 random / adversarial scenes and the full-size configs through it.
+# runs tests/test_host.py plus the flattening of 600 random / adversarial scenes and the full-size configs through it.
 # (GPU sanitizers are not available on the pool; the kernels are covered by the parity suite and the fuzz campaign.)
 set -eu
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -20,12 +20,12 @@ python3 - <<'PY'
 import lasgun_amd as la
 G, S, n = la.api, la.scenes, 0
 for seed in range(150):
-    for gen in (S.random_scene, S.adversarial_scene, S.adversarial_mesh_scene):
+    for gen in (S.random_scene, S.adversarial_scene, S.adversarial_mesh_scene, S.adversarial_prune_scene):
         try:
             G.host_build_dump(gen(G, seed)); n += 1
         except la.LasgunError:
             pass
-for b in (lambda: S.mesh_scene(G), lambda: S.mixed_scene(G), lambda: S.spheres_scene(G), lambda: S.kitchen_sink_scene(G), lambda: S.instanced_scene(G)):
+for b in (lambda: S.mesh_scene(G), lambda: S.mixed_scene(G), lambda: S.spheres_scene(G), lambda: S.kitchen_sink_scene(G), lambda: S.instanced_scene(G), lambda: S.tie_mesh_scene(G), lambda: S.exotic_obj_scene(G)):
     G.host_build_dump(b()); n += 1
 print("flattened", n, "scenes under ASan + UBSan: no report")
 PY
