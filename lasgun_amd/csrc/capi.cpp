@@ -425,6 +425,7 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
             break;
         } catch (const Error &e) {
             if (std::string(e.what()).find("hipMalloc") == std::string::npos || chunk_tiles <= 1) throw;
+            (void)hipGetLastError(); // (the failed allocation's error must not be what the next launch reports)
             chunk_tiles = (chunk_tiles + 1) / 2;
             a.wf_budget = std::max<size_t>(a.wf_budget / 2, 64ull << 20); // (later launches start from what fitted)
             size_chunk();

@@ -235,3 +235,55 @@ def test_wavefront_bands_on_internal_streams_leave_the_film_unchanged():
             G.capture_rows_device(acc, w, h, 0, h, film.data_ptr(), row0=0, stream=s.cuda_stream)
             s.synchronize()
             assert torch.equal(film, ref), bands
+
+
+@pytest.mark.parametrize("w, h, block_rows", [(128, 256, 64), (96, 80, 0)])
+def test_multi_device_all_gather_form_single_rank(w, h, block_rows):
+    """lg_multi_capture_device_all, the all-gather form (every rank's device ends with the whole film), at the one size a 1-GPU
+    box can run it -- one rank, one device: interleaved blocks (put in row order by the strided copies) and a contiguous tile
+    (rendered in place).  A repeated device is refused: a communicator has one rank per device."""
+    import torch
+    scene = S.kitchen_sink_scene(G)
+    one = G.Film(w, h)
+    G.capture(scene, one)
+    m = G.Multi(scene, [0], block_rows)
+    dev = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):
+        m.capture_device_all(w, h, [dev.data_ptr()])
+        assert np.array_equal(dev.cpu().numpy(), one.pixels())
+    m.close()
+    m2 = G.Multi(scene, [0, 0], block_rows)
+    with pytest.raises(la.LasgunError):
+        m2.capture_device_all(w, h, [dev.data_ptr(), dev.data_ptr()])
+    m2.close()
+
+
+def test_capture_takes_every_visible_device_by_default_and_prune_switch():
+    """A process that never names a device (like a program written against the reference) gets every visible one from
+    lg_capture (lib.rs:58-62: every core); and lg_accel_set_prune takes -1 / 0 / 1 only, the film is the same in each."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+            "os.environ['LASGUN_DEBUG'] = '1'\n"
+            "import numpy as np, lasgun_amd as la\n"
+            "from oracle_lib import oracle\n"
+            "G = la.api; S = la.scenes; o = oracle()\n"
+            "film = G.Film(96, 64); G.capture(S.cornell_scene(G, 'glass'), film)   # no set_device / set_devices before\n"
+            "want = o.render(S.cornell_scene(o, 'glass'), (96, 64)).pixels()\n"
+            "assert np.array_equal(film.pixels(), want)\n"
+            "print('default devices ok')\n") % (root, root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0 and "default devices ok" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+    acc = G.Accel(S.mesh_scene(G, 32, 24, "glass"))
+    films = []
+    for v in (None, False, True, -1):
+        G.set_prune(acc, v)
+        f = G.Film(80, 60)
+        G.capture_subset(0, 1, acc, f)
+        films.append(f.pixels())
+    assert all(np.array_equal(films[0], x) for x in films[1:])
+    with pytest.raises(la.LasgunError):
+        if G.call("accel_set_prune", acc.h, 2):
+            raise la.LasgunError(G.last_error())
