@@ -180,7 +180,7 @@ int lg_capture_rect(const lg_accel *, uint32_t width, uint32_t height, uint32_t 
 int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, lg_stats *out);
 
 /* Traversal mode of an accel.  0 (default) = the reference's own traversal over the reference's
- * own BVH: the parity path.  1 = opt-in FAST mode: a binned-SAH BVH (<= 4 primitives per leaf)
+ * own BVH: the parity path.  1 = opt-in FAST mode: a binned-SAH BVH (one primitive per leaf)
  * over the same primitives, front-to-back with pruning beyond the best hit; same primitive tests
  * and arithmetic.  Its winner is put to the reference tree's own box tests (leaf to root, through every
  * nested accel); a winner that fails them, or an exact tie in t, re-traces the ray with the reference
@@ -254,6 +254,11 @@ void lg_aggregate_get_transform(lg_aggregate *, double m[16], double minv[16]);
 /* Host-only HLBVH build + flatten of a scene, no device needed: structure dump + counts
  * (nodes, primrefs, spheres, cuboids, triangles, accels, max_stack, has_specular). */
 int lg_host_build_dump(const lg_scene *, const double **f, size_t *nf, const int64_t **i, size_t *ni, uint64_t info[8]);
+/* Host-only self-check of the fast mode's wide node records against the binary fast trees they are collapsed from (no device):
+ * out = { records, children, leaves reached, deepest stack of a walk that pushes every child but one, violations, the stack
+ * depth the flattening reserved, 0, 0 }.  Violations: a child box not containing its node's box, a leaf reached twice or
+ * never, a dangling link. */
+int lg_host_check_wide_records(const lg_scene *, uint64_t out[8]);
 
 /* One pixel traced by a single lane (sample 0): out = { t, primref, accel instance, number of lights, then per light
  * the shadow ray's { t, primref }, then the shadow rays' origin (3) } -- primref is 4294967295 for "no hit"; out_len >=

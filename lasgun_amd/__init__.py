@@ -64,6 +64,7 @@ _EXTRA = {
     "trace_pixel": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_int, _C.POINTER(_C.c_double), _C.c_size_t]),
     "host_build_dump": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.POINTER(_C.c_double)), _C.POINTER(_C.c_size_t),
                                    _C.POINTER(_C.POINTER(_C.c_int64)), _C.POINTER(_C.c_size_t), _C.c_uint64 * 8]),
+    "host_check_wide_records": (_C.c_int, [_C.c_void_p, _C.c_uint64 * 8]),
 }
 
 
@@ -234,6 +235,14 @@ class HipApi(Api):
         i = _np.ctypeslib.as_array(pi, shape=(ni.value,)).copy()
         keys = ("nodes", "primrefs", "spheres", "cuboids", "triangles", "accels", "max_stack", "has_specular")
         return f, i, dict(zip(keys, [int(v) for v in info]))
+
+    def host_check_wide_records(self, scene):
+        """Host-only self-check of the fast mode's wide node records (no GPU needed): dict of counts; `violations` must be 0."""
+        out = (_C.c_uint64 * 8)()
+        if self.call("host_check_wide_records", scene.h, out):
+            raise LasgunError(self.last_error())
+        keys = ("records", "children", "leaves", "deepest_stack", "violations", "reserved_stack")
+        return dict(zip(keys, [int(v) for v in out]))
 
     def Multi(self, scene, devices, block_rows=64):
         """One film on several GPUs of this process, gathered on devices[0] over xGMI with one grouped RCCL exchange

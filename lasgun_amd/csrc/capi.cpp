@@ -7,8 +7,10 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -185,7 +187,7 @@ struct lg_accel {
     int device = 0; // the HIP device this accel's tables and launches live on
     FlatScene flat;
     DevBuf<DNode> nodes;
-    DevBuf<DNode2> nodes2;
+    DevBuf<DNode4> nodes4;
     DevBuf<uint32_t> primref;
     DevBuf<DSphere> spheres;
     DevBuf<int32_t> sphere_mat;
@@ -296,7 +298,7 @@ static lg_accel::LaunchCtx &ctx_for(const lg_accel &a, hipStream_t stream) {
 static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     const Scene &s = *a.scene;
     DParams P{};
-    P.nodes = a.nodes.p; P.nodes2 = a.nodes2.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
+    P.nodes = a.nodes.p; P.nodes4 = a.nodes4.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
     P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
     P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.chunks = a.chunks.p; P.leaf_soup2 = a.leaf_soup2.p; P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
     P.tri_ref_leaf = a.tri_ref_leaf.p; P.accel_ref_leaf = a.accel_ref_leaf.p; P.accels = a.accels.p; P.materials = a.materials.p;
@@ -835,13 +837,13 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         flatten_scene(*a->scene, a->flat, with_fast); // host HLBVH build + flatten (throws on what the reference would panic on)
         use_device(a->device);
         const FlatScene &f = a->flat;
-        a->nodes.upload(f.nodes); a->nodes2.upload(f.nodes2); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
+        a->nodes.upload(f.nodes); a->nodes4.upload(f.nodes4); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
         a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->chunks.upload(f.chunks); a->leaf_soup2.upload(f.leaf_soup2); a->sphere_ref_leaf.upload(f.sphere_ref_leaf); a->cuboid_ref_leaf.upload(f.cuboid_ref_leaf);
         a->tri_ref_leaf.upload(f.tri_ref_leaf); a->accel_ref_leaf.upload(f.accel_ref_leaf); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
         a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
         a->stats.alloc(2); // (the second record: iteration counters of the diagnostic build)
-        a->device_bytes = f.nodes.size() * (sizeof(DNode) + sizeof(DNode2)) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
+        a->device_bytes = f.nodes.size() * sizeof(DNode) + f.nodes4.size() * sizeof(DNode4) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
                           f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 + f.leaf_soup.size() * sizeof(DLeafRec) +
                           f.accels.size() * sizeof(DAccel) + f.materials.size() * sizeof(DMaterial);
         if (!a->stream) HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
@@ -1003,7 +1005,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
 static void swap_tables(lg_accel &x, lg_accel &y) {
     using std::swap;
     swap(x.flat, y.flat);
-    swap(x.nodes, y.nodes); swap(x.nodes2, y.nodes2); swap(x.primref, y.primref); swap(x.spheres, y.spheres); swap(x.sphere_mat, y.sphere_mat);
+    swap(x.nodes, y.nodes); swap(x.nodes4, y.nodes4); swap(x.primref, y.primref); swap(x.spheres, y.spheres); swap(x.sphere_mat, y.sphere_mat);
     swap(x.cuboids, y.cuboids); swap(x.cuboid_mat, y.cuboid_mat); swap(x.tri_v, y.tri_v); swap(x.tri_n, y.tri_n); swap(x.tri_t, y.tri_t);
     swap(x.vpos, y.vpos); swap(x.vnorm, y.vnorm); swap(x.vtex, y.vtex); swap(x.leaf_soup, y.leaf_soup); swap(x.chunks, y.chunks); swap(x.leaf_soup2, y.leaf_soup2);
     swap(x.sphere_ref_leaf, y.sphere_ref_leaf); swap(x.cuboid_ref_leaf, y.cuboid_ref_leaf); swap(x.tri_ref_leaf, y.tri_ref_leaf); swap(x.accel_ref_leaf, y.accel_ref_leaf);
@@ -1419,6 +1421,70 @@ int lg_host_build_dump(const lg_scene *s, const double **f, size_t *nf, const in
         *i = flat.dump_i.data(); *ni = flat.dump_i.size();
         info[0] = flat.nodes.size(); info[1] = flat.primref.size(); info[2] = flat.spheres.size(); info[3] = flat.cuboids.size();
         info[4] = flat.tri_v.size() / 3; info[5] = flat.accels.size(); info[6] = flat.max_stack; info[7] = flat.has_specular ? 1 : 0;
+    });
+}
+// Host-only self-check of the fast mode's wide records (DNode4) against the binary fast trees they were collapsed from:
+// out[0] records, out[1] children, out[2] leaves reached, out[3] the deepest stack a walk that pushes every child but one would need
+// (frames of nested accels not counted), out[4] violations (a child box that does not contain its node's f64 box, a leaf reached
+// twice or never, a link that is not a node of the tree), out[5] = FlatScene::max_stack_fast1.
+int lg_host_check_wide_records(const lg_scene *s, uint64_t out[8]) {
+    return guarded([&] {
+        FlatScene flat;
+        flatten_scene(s->s, flat, true);
+        for (int k = 0; k < 8; ++k) out[k] = 0;
+        out[5] = flat.max_stack_fast1;
+        std::vector<uint32_t> seen_tree;
+        for (const DAccel &A : flat.accels) {
+            if (std::find(seen_tree.begin(), seen_tree.end(), A.fnode_base) != seen_tree.end()) continue; // (mesh instances share a tree)
+            seen_tree.push_back(A.fnode_base);
+            // the binary tree: its nodes (children follow their parent; DNode::link = second child) and its leaves by first slot
+            std::map<uint32_t, uint32_t> leaf_by_start; // first slot -> node
+            std::set<uint32_t> interior;
+            std::vector<uint32_t> bin{0u};
+            while (!bin.empty()) {
+                const uint32_t i = bin.back(); bin.pop_back();
+                const DNode &d = flat.nodes[A.fnode_base + i];
+                if (d.meta & NODE_LEAF) leaf_by_start[d.link] = i;
+                else { interior.insert(i); bin.push_back(i + 1u); bin.push_back(d.link); }
+            }
+            if (flat.nodes[A.fnode_base].meta & NODE_LEAF) continue; // a single leaf: no record
+            std::map<uint32_t, int> reached;
+            struct It { uint32_t node, depth; };
+            std::vector<It> st{{0u, 0u}};
+            auto contains = [](const float box[6], const DNode &d) {
+                for (int a = 0; a < 3; ++a)
+                    if (!((double)box[a] <= d.bmin[a]) || !((double)box[3 + a] >= d.bmax[a])) return false;
+                return true;
+            };
+            while (!st.empty()) {
+                const It it = st.back(); st.pop_back();
+                const DNode4 &w = flat.nodes4[A.fnode_base + it.node];
+                out[0]++;
+                uint32_t k = 0;
+                for (int c = 0; c < WIDE; ++c) k += w.link[c] != NO_HIT ? 1u : 0u;
+                if (k < 2u) out[4]++;
+                out[3] = std::max<uint64_t>(out[3], it.depth + k - 1u);
+                for (int c = 0; c < WIDE; ++c) {
+                    if (w.link[c] == NO_HIT) continue;
+                    out[1]++;
+                    uint32_t node;
+                    if (w.link[c] & WIDE_LEAF) {
+                        const uint32_t start = w.link[c] & WIDE_START_MASK, cnt = (w.link[c] >> WIDE_COUNT_SHIFT) & 7u;
+                        auto f = leaf_by_start.find(start);
+                        if (f == leaf_by_start.end() || (flat.nodes[A.fnode_base + f->second].meta & 0xFFFFu) != cnt) { out[4]++; continue; }
+                        node = f->second;
+                        if (reached[start]++) out[4]++;
+                        out[2]++;
+                    } else {
+                        node = w.link[c];
+                        if (!interior.count(node)) { out[4]++; continue; }
+                        st.push_back({node, it.depth + k - 1u});
+                    }
+                    if (!contains(w.box[c], flat.nodes[A.fnode_base + node])) out[4]++;
+                }
+            }
+            if (reached.size() != leaf_by_start.size()) out[4]++;
+        }
     });
 }
 int lg_accel_info(const lg_accel *a, uint64_t out[8]) {

@@ -66,21 +66,20 @@ struct alignas(64) DNode {
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
-// Child-pair record of an INTERIOR node (same index as its DNode): the bounds of BOTH children,
-// so one 128-byte fetch feeds two slab tests and the two tests overlap in the pipeline.  The
-// reference tests a child's box when it visits that child (bvh.rs:472-473); testing it one step
-// earlier, at the parent, is the same pure function of (box, ray) -- nodes are never culled by
-// t -- so every box is still tested exactly once and leaves are still processed near-child-first.
-struct alignas(128) DNode2 {
-    double b0min[3], b0max[3]; // first child  (node + 1)
-    double b1min[3], b1max[3]; // second child (node.link)
-    uint32_t link0, meta0;     // copies of the children's DNode.link / DNode.meta
-    uint32_t link1, meta1;
-    uint32_t axis;             // this node's split axis (dir_is_neg[axis] picks the near child)
-    uint32_t second;           // index of the second child (relative to node_base)
-    uint32_t pad[2];
+// Wide record of an INTERIOR node of a FAST tree (same index as its DNode; only the nodes a wide node was collapsed from are
+// filled in): up to WIDE children -- the node's two children with the larger ones opened in turn (host.cpp, wide_records) --
+// each with its box in f32 rounded OUTWARD from the fast tree's (already inflated) f64 box, and a link word: bit 31 = leaf,
+// then bits 28-30 = its primitive count and bits 0-27 its first slot (relative to the accel's prim_base), else the child's node
+// index (relative to node_base); NO_HIT = no such child.  One 128-byte fetch feeds four slab tests and the walk is half as
+// deep in dependent fetches as a binary walk.
+constexpr int WIDE = 4;
+constexpr uint32_t WIDE_LEAF = 0x80000000u, WIDE_COUNT_SHIFT = 28u, WIDE_START_MASK = 0x0FFFFFFFu;
+struct alignas(128) DNode4 {
+    float box[WIDE][6]; // min x y z, max x y z
+    uint32_t link[WIDE];
+    uint32_t pad[4];
 };
-static_assert(sizeof(DNode2) == 128, "DNode2 must be 128 bytes");
+static_assert(sizeof(DNode4) == 128, "DNode4 must be 128 bytes");
 
 struct alignas(32) DSphere {
     double cx, cy, cz, r;
@@ -144,7 +143,7 @@ struct alignas(16) DAccel {
     uint32_t flags;
     uint32_t nchain;  // number of accels on the path root..self
     uint32_t chain[MAX_CHAIN];
-    uint32_t fnode_base; // the optional fast tree (binned SAH, <= 4 primitives per leaf) over the SAME primitives
+    uint32_t fnode_base; // the optional fast tree (binned SAH, one primitive per leaf) over the SAME primitives
     uint32_t fprim_base;
     uint32_t lnode_base; // reference tree again, in the compact numbering of the LDS-resident scene image (DParams::lds_image)
     uint32_t lprim_base;
@@ -164,7 +163,7 @@ constexpr int STASH_DOUBLES = 13; // p(3) ng(3) ns(3) ss(3) material id
 struct DParams {
     // ---- scene tables
     const DNode *nodes;
-    const DNode2 *nodes2; // valid at interior-node indices
+    const DNode4 *nodes4; // fast trees: valid at the interior nodes wide records were made for
     const uint32_t *primref;
     const DSphere *spheres;
     const int32_t *sphere_mat;

@@ -3,6 +3,8 @@
 #include "host.h"
 
 #include <algorithm>
+#include <cfloat>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -450,13 +452,17 @@ class Builder {
 };
 
 // ------------------------------------------------------------------------------------------
-// Fast tree (NOT in the reference): binned-SAH BVH with <= 4 primitives per leaf over the same
+// Fast tree (NOT in the reference): binned-SAH BVH with one primitive per leaf over the same
 // primitive boxes, emitted in the same pre-order format as the reference tree so the device
 // tables and node records are shared.  Used only by the opt-in fast traversal mode.
 // ------------------------------------------------------------------------------------------
 class FastBuilder {
   public:
-    explicit FastBuilder(const std::vector<Bounds> &pb) : pb_(pb) {}
+    // leaf_max: primitives per leaf.  Measured under the wide walk (config 3 / 4 / 4m / 5, ms): 4 -> 8.17 / 18.9 / 10.4 / 36.9,
+    // 2 -> 7.97 / 18.0 / 9.87 / 35.9, 1 -> 7.98 / 17.3 / 9.42 / 36.3 -- a primitive test costs more than a box test, and a
+    // nested accel that shares a leaf with a wall is entered (ray transform, three divisions, a level frame) by every ray
+    // that reaches the wall: with the mesh's tree at 1, config 4 takes 17.3 / 18.8 / 19.6 ms with the aggregates' at 1 / 2 / 4.
+    FastBuilder(const std::vector<Bounds> &pb, size_t leaf_max) : pb_(pb), LEAF_MAX(leaf_max) {}
     BuiltBVH run() {
         size_t n = pb_.size();
         idx_.resize(n);
@@ -469,7 +475,6 @@ class FastBuilder {
     }
 
   private:
-    static constexpr size_t LEAF_MAX = 4;
     uint32_t build(size_t s, size_t e) {
         uint32_t my = (uint32_t)out_.nodes.size();
         out_.nodes.push_back(LinNode{b_none(), true, 0, 0});
@@ -536,6 +541,7 @@ class FastBuilder {
         return my;
     }
     const std::vector<Bounds> &pb_;
+    const size_t LEAF_MAX;
     std::vector<uint32_t> idx_;
     std::vector<V3> cen_;
     BuiltBVH out_;
@@ -548,7 +554,7 @@ struct MeshTables { // per scene mesh, shared by all its instances
     bool built = false;
     uint32_t node_base = 0, prim_base = 0, nnodes = 0, norder = 0;
     uint32_t max_stack = 0;
-    uint32_t fnode_base = 0, fprim_base = 0, fmax_stack = 0, fmax_stack1 = 0;
+    uint32_t fnode_base = 0, fprim_base = 0, fmax_stack1 = 0;
     Bounds root_bounds{};
     double cmax = 0.0; // largest |coordinate| of its triangle boxes
     uint32_t tri_base = 0;
@@ -650,20 +656,94 @@ struct Flattener {
             if (noprune && (*noprune)[out.nodes.size() - node_base]) d.meta |= NODE_NOPRUNE;
             out.nodes.push_back(d);
         }
-        // child-pair records for the interior nodes
-        out.nodes2.resize(out.nodes.size(), DNode2{});
-        for (size_t i = 0; i < bvh.nodes.size(); ++i) {
-            const LinNode &n = bvh.nodes[i];
-            if (n.leaf) continue;
-            const DNode &c0 = out.nodes[node_base + i + 1], &c1 = out.nodes[node_base + n.c];
-            DNode2 &p = out.nodes2[node_base + i];
-            std::memcpy(p.b0min, c0.bmin, 24); std::memcpy(p.b0max, c0.bmax, 24);
-            std::memcpy(p.b1min, c1.bmin, 24); std::memcpy(p.b1max, c1.bmax, 24);
-            p.link0 = c0.link; p.meta0 = c0.meta; p.link1 = c1.link; p.meta1 = c1.meta;
-            p.axis = n.a & 3u; p.second = n.c;
-        }
     }
 
+    // f64 -> f32 rounded toward -inf / +inf (a NaN stays a NaN; beyond the f32 range: the largest finite value or the infinity)
+    static float f32_down(double x) {
+        if (x != x) return (float)x;
+        if (x > (double)FLT_MAX) return FLT_MAX;
+        if (x < -(double)FLT_MAX) return -INFINITY;
+        float f = (float)x;
+        if ((double)f > x) f = std::nextafterf(f, -INFINITY);
+        return f;
+    }
+    static float f32_up(double x) {
+        if (x != x) return (float)x;
+        if (x < -(double)FLT_MAX) return -FLT_MAX;
+        if (x > (double)FLT_MAX) return INFINITY;
+        float f = (float)x;
+        if ((double)f < x) f = std::nextafterf(f, INFINITY);
+        return f;
+    }
+    // Wide records (DNode4, dscene.h) of the FAST tree just appended at node_base: the root's two children, then the interior child
+    // with the largest box opened in place until WIDE children stand (or only leaves are left); every interior child gets a record
+    // of its own the same way.  Returns the wide walk's worst-case stack use: at a record with k children up to k - 1 are pending
+    // while the walk is below the remaining one (extra_in_order[slot] = what a nested accel in that leaf slot needs on top).
+    uint32_t wide_records(const BuiltBVH &bvh, uint32_t node_base, const std::vector<uint32_t> &extra_in_order) {
+        out.nodes4.resize(out.nodes.size(), DNode4{});
+        const std::vector<LinNode> &N = bvh.nodes;
+        auto leaf_extra = [&](const LinNode &n) {
+            uint32_t e = 0;
+            for (uint32_t k = 0; k < (n.c & 0xFFFFu); ++k) e = std::max(e, extra_in_order[n.a + k]);
+            return e;
+        };
+        if (N[0].leaf) return leaf_extra(N[0]);
+        std::vector<char> made(N.size(), 0);
+        std::vector<uint32_t> todo{0u};
+        while (!todo.empty()) {
+            const uint32_t i = todo.back(); todo.pop_back();
+            made[i] = 1;
+            std::vector<uint32_t> kids{i + 1u, N[i].c};
+            while (kids.size() < (size_t)WIDE) {
+                int pick = -1;
+                double area = -1.0;
+                for (size_t k = 0; k < kids.size(); ++k) {
+                    if (N[kids[k]].leaf) continue;
+                    const double a = b_area(N[kids[k]].b);
+                    if (pick < 0 || a > area) { pick = (int)k; area = a; } // (a NaN area never replaces the pick)
+                }
+                if (pick < 0) break;
+                const uint32_t c = kids[(size_t)pick];
+                kids[(size_t)pick] = c + 1u;
+                kids.insert(kids.begin() + pick + 1, N[c].c);
+            }
+            DNode4 &w = out.nodes4[node_base + i];
+            for (int k = 0; k < WIDE; ++k) {
+                w.link[k] = NO_HIT;
+                for (int a = 0; a < 6; ++a) w.box[k][a] = 0.0f;
+            }
+            for (size_t k = 0; k < kids.size(); ++k) {
+                const LinNode &c = N[kids[k]];
+                const DNode &d = out.nodes[node_base + kids[k]];
+                for (int a = 0; a < 3; ++a) { w.box[k][a] = f32_down(d.bmin[a]); w.box[k][3 + a] = f32_up(d.bmax[a]); }
+                if (c.leaf) {
+                    const uint32_t cnt = c.c & 0xFFFFu;
+                    if (cnt > 7u || c.a > WIDE_START_MASK) throw Error("fast tree: leaf does not fit a wide record's link word");
+                    w.link[k] = WIDE_LEAF | (cnt << WIDE_COUNT_SHIFT) | c.a;
+                } else {
+                    w.link[k] = kids[k];
+                    todo.push_back(kids[k]);
+                }
+            }
+        }
+        std::vector<uint32_t> need(N.size(), 0u);
+        for (size_t i = N.size(); i-- > 0;) { // children follow their parent in the linear order
+            if (!made[i]) continue;
+            const DNode4 &w = out.nodes4[node_base + i];
+            uint32_t k = 0, below = 0;
+            for (int c = 0; c < WIDE; ++c) {
+                if (w.link[c] == NO_HIT) continue;
+                ++k;
+                if (w.link[c] & WIDE_LEAF) {
+                    const uint32_t start = w.link[c] & WIDE_START_MASK, cnt = (w.link[c] >> WIDE_COUNT_SHIFT) & 7u;
+                    for (uint32_t j = 0; j < cnt; ++j) below = std::max(below, extra_in_order[start + j]);
+                }
+                else below = std::max(below, need[w.link[c]]);
+            }
+            need[i] = k - 1u + below;
+        }
+        return need[0];
+    }
     // parents of the reference tree just appended at node_base (fast mode's candidate check walks leaf -> root)
     void record_parents(const BuiltBVH &bvh, uint32_t node_base) {
         for (size_t i = 0; i < bvh.nodes.size(); ++i) out.nodes[node_base + i].parent = NO_HIT;
@@ -771,7 +851,7 @@ struct Flattener {
         mt.max_stack = stack_need(mt.bvh.nodes, refs, [](uint32_t) { return 0u; });
         if (with_fast) { // fast tree over the same triangles
             const std::vector<Bounds> pbf = inflated(pb);
-            BuiltBVH fb = FastBuilder(pbf).run();
+            BuiltBVH fb = FastBuilder(pbf, 1).run();
             append_nodes(fb, mt.fnode_base);
             mt.fprim_base = (uint32_t)out.primref.size();
             out.leaf_soup.resize(mt.fprim_base, DLeafRec{});
@@ -782,8 +862,7 @@ struct Flattener {
                     std::memcpy(&rec.w[3 * k], &obj.position[3 * (size_t)obj.tri[3 * (size_t)o + k].v], 12);
                 out.leaf_soup.push_back(rec);
             }
-            mt.fmax_stack1 = stack_need(fb.nodes, refs, [](uint32_t) { return 0u; }); // the second formulation: one word per pending child
-            mt.fmax_stack = 2 * mt.fmax_stack1;
+            mt.fmax_stack1 = wide_records(fb, mt.fnode_base, refs); // the wide walk: up to WIDE - 1 pending children per record
         }
         mt.built = true;
         return mt;
@@ -811,7 +890,7 @@ struct Flattener {
     }
 
     // returns accel id; sets bound = BVHAccel::bound() (bvh.rs:457-459) and need = stack entries
-    uint32_t mesh_instance(uint32_t mesh, bool has_mat, const Material &mat, int32_t parent, Bounds &bound, uint32_t &need, uint32_t &fneed, uint32_t &fneed1) {
+    uint32_t mesh_instance(uint32_t mesh, bool has_mat, const Material &mat, int32_t parent, Bounds &bound, uint32_t &need, uint32_t &fneed1) {
         uint32_t id = (uint32_t)out.accels.size();
         out.accels.emplace_back();
         MeshTables &mt = mesh_tables(mesh);
@@ -828,12 +907,11 @@ struct Flattener {
         dump(mt.bvh, has_mat, false, idt);
         bound = b_transform(idt.m, mt.root_bounds);
         need = mt.max_stack;
-        fneed = mt.fmax_stack;
         fneed1 = mt.fmax_stack1;
         return id;
     }
 
-    uint32_t aggregate(const Aggregate &agg, int32_t parent, Bounds &bound, uint32_t &need, uint32_t &fneed, uint32_t &fneed1) { // bvh.rs:150-162
+    uint32_t aggregate(const Aggregate &agg, int32_t parent, Bounds &bound, uint32_t &need, uint32_t &fneed1) { // bvh.rs:150-162
         uint32_t id = (uint32_t)out.accels.size();
         out.accels.emplace_back();
         {
@@ -851,7 +929,7 @@ struct Flattener {
         std::vector<double> child_f; std::vector<int64_t> child_i;
         std::swap(child_f, out.dump_f); std::swap(child_i, out.dump_i); // children dump into fresh vectors
         std::vector<Bounds> pb(n);
-        std::vector<uint32_t> ref(n), extra(n, 0), fextra(n, 0), fextra1(n, 0);
+        std::vector<uint32_t> ref(n), extra(n, 0), fextra1(n, 0);
         std::vector<DLeafRec> rec(n, DLeafRec{});
         for (size_t i = 0; i < n; ++i) {
             const SceneNode &nd = agg.contents[i];
@@ -881,21 +959,19 @@ struct Flattener {
                 break;
             }
             case SceneNode::MESH: {
-                uint32_t cn = 0, fcn = 0, fcn1 = 0;
-                uint32_t cid = mesh_instance(nd.obj, nd.has_mat, nd.mat, (int32_t)id, pb[i], cn, fcn, fcn1);
+                uint32_t cn = 0, fcn1 = 0;
+                uint32_t cid = mesh_instance(nd.obj, nd.has_mat, nd.mat, (int32_t)id, pb[i], cn, fcn1);
                 fextra1[i] = 3 + fcn1;
                 ref[i] = (PK_ACCEL << 30) | cid;
                 extra[i] = 3 + cn;
-                fextra[i] = 3 + fcn;
                 break;
             }
             case SceneNode::GROUP: {
-                uint32_t cn = 0, fcn = 0, fcn1 = 0;
-                uint32_t cid = aggregate(*nd.group, (int32_t)id, pb[i], cn, fcn, fcn1);
+                uint32_t cn = 0, fcn1 = 0;
+                uint32_t cid = aggregate(*nd.group, (int32_t)id, pb[i], cn, fcn1);
                 fextra1[i] = 3 + fcn1;
                 ref[i] = (PK_ACCEL << 30) | cid;
                 extra[i] = 3 + cn;
-                fextra[i] = 3 + fcn;
                 break;
             }
             }
@@ -934,29 +1010,23 @@ struct Flattener {
         out.accels[id].prim_base = prim_base;
         need = stack_need(bvh.nodes, extra_in_order, [](uint32_t e) { return e; });
         bound = b_transform(agg.transform.m, bvh.nodes[0].b);
-        fneed = 0; fneed1 = 0;
+        fneed1 = 0;
         if (with_fast) { // fast tree over the same primitives (child accels included as primitives)
             const std::vector<Bounds> pbf = inflated(pb);
-            BuiltBVH fb = FastBuilder(pbf).run();
+            BuiltBVH fb = FastBuilder(pbf, 1).run();
             uint32_t fnode_base;
             append_nodes(fb, fnode_base);
             uint32_t fprim_base = (uint32_t)out.primref.size();
             out.leaf_soup.resize(fprim_base, DLeafRec{});
-            std::vector<uint32_t> fextra_in_order(fb.order.size());
+            std::vector<uint32_t> one(fb.order.size()); // per slot: what a nested accel there needs on the stack (3-word level frame + its own walk)
             for (size_t i = 0; i < fb.order.size(); ++i) {
                 out.primref.push_back(ref[fb.order[i]]);
                 out.leaf_soup.push_back(rec[fb.order[i]]);
-                fextra_in_order[i] = fextra[fb.order[i]];
+                one[i] = fextra1[fb.order[i]];
             }
             out.accels[id].fnode_base = fnode_base;
             out.accels[id].fprim_base = fprim_base;
-            // two words per pending child in the fast traversal; nested entries cost what they cost below
-            std::vector<uint32_t> half(fextra_in_order.size());
-            for (size_t i = 0; i < half.size(); ++i) half[i] = (fextra_in_order[i] + 1) / 2;
-            fneed = 2 * stack_need(fb.nodes, half, [](uint32_t e) { return e; });
-            std::vector<uint32_t> one(fb.order.size());
-            for (size_t i = 0; i < one.size(); ++i) one[i] = fextra1[fb.order[i]];
-            fneed1 = stack_need(fb.nodes, one, [](uint32_t e) { return e; }); // second formulation: one word per pending child, 3-word level frames
+            fneed1 = wide_records(fb, fnode_base, one);
         }
         // stitch the dump: [prefix][this accel][children]
         std::swap(child_f, out.dump_f); std::swap(child_i, out.dump_i); // out.* = prefix again, child_* = children
@@ -1143,10 +1213,9 @@ void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     fl.meshes.resize(scene.meshes.size());
     out.default_material = fl.add_material(material_default());
     Bounds b;
-    uint32_t need = 0, fneed = 0, fneed1 = 0;
-    fl.aggregate(*scene.root, -1, b, need, fneed, fneed1);
+    uint32_t need = 0, fneed1 = 0;
+    fl.aggregate(*scene.root, -1, b, need, fneed1);
     out.max_stack = need;
-    out.max_stack_fast = fneed;
     out.max_stack_fast1 = fneed1;
     if (out.primref.size() > 80000000u) throw Error("too many primitive slots for the 32-bit record offsets of the triangle stream");
     out.leaf_soup.resize(out.primref.size() + 2, DLeafRec{}); // two spare records: the mesh leaf loop keeps the next slot in flight

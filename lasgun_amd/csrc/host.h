@@ -107,7 +107,7 @@ struct Scene {
 // ---- flattened scene (host copies of the device tables) ----------------------------------
 struct FlatScene {
     std::vector<DNode> nodes;
-    std::vector<DNode2> nodes2;
+    std::vector<DNode4> nodes4; // wide records of the fast trees' interior nodes (empty without fast trees)
     std::vector<uint32_t> primref;
     std::vector<DSphere> spheres;
     std::vector<int32_t> sphere_mat;
@@ -127,8 +127,7 @@ struct FlatScene {
     std::vector<DLight> lights;
     int32_t default_material = 0;
     uint32_t max_stack = 0;      // worst-case per-lane traversal stack entries
-    uint32_t max_stack_fast = 0; // same for the fast tree (two words per pending child)
-    uint32_t max_stack_fast1 = 0; // the fast tree walked by the second formulation (one word per pending child)
+    uint32_t max_stack_fast1 = 0; // the fast trees under the wide walk (one word per pending child, 3-word level frames)
     bool has_specular = false;   // any glass / mirror material present
     bool has_fast = false;       // the fast mode's trees are part of the tables
     // structure dump in the same format as the oracle's orc_accel_dump (build-parity tests)

@@ -378,16 +378,6 @@ __device__ __forceinline__ NodeRec load_node(const DParams &P, const uint4 *scn,
     return n;
 }
 template <bool LDSS>
-__device__ __forceinline__ void load_node_link(const DParams &P, const uint4 *scn, uint32_t idx, uint32_t &link, uint32_t &meta) {
-    if (LDSS) {
-        uint2 d = *reinterpret_cast<const uint2 *>(scn + (P.lds_node_off + ((idx << 2) + idx) + 3u));
-        link = d.x; meta = d.y;
-    } else {
-        const DNode *nd = P.nodes + idx;
-        link = nd->link; meta = nd->meta;
-    }
-}
-template <bool LDSS>
 __device__ __forceinline__ uint32_t load_primref(const DParams &P, const uint4 *scn, uint32_t i) {
     if (LDSS) return reinterpret_cast<const uint32_t *>(scn + P.lds_prim_off)[i];
     return P.primref[i];
@@ -761,7 +751,7 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 #else
 #define LG_STAMP(i) do { } while (0)
 #endif
-// FAST (lg_accel_set_mode(1), opt-in, NOT the reference's traversal): the same walk over the binned-SAH trees with <= 4 primitives
+// FAST (lg_accel_set_mode(1), opt-in, NOT the reference's traversal): the same walk over the binned-SAH trees with one primitive
 // per leaf, near child first by dir_is_neg[axis] as before, and a node is skipped when its slab tnear lies beyond the best hit so
 // far (closest) or beyond the light (any-hit) -- margins as in prune_limit().  Exact ties in t (and NaN t), where the reference's
 // visit order decides, raise `tie`; the caller (walk() below) then puts the winner to the reference tree's own box tests
@@ -796,7 +786,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     Lvl L;
     lvl_set<LDSS, FAST>(P, scn, L, 0u);
     double limit = prune_limit(INFINITY, anyhit); // FAST: nodes whose tnear lies beyond this are skipped
-    TriSetup tri;                                  // FAST: per mesh level (its leaves hold <= 4 triangles: per leaf the three divides would dominate)
+    TriSetup tri;                                  // FAST: per mesh level (its leaves hold one triangle: per leaf the three divides would dominate)
     tri.kz = 0; tri.sx = 0.0; tri.sy = 0.0; tri.sz = 0.0;
     // ---- the root accel's local ray (bvh.rs:462), kept for the returns
     Ray root = wray;
@@ -1080,13 +1070,12 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
 #endif
 }
 
-// Fast mode's walk with CHILD-PAIR records (nodes2): `cur` is an interior node whose own box is known to be hit; one 128-byte
-// record holds both children's boxes and leaf words, so a step tests two boxes per dependent fetch -- the fast walk waits on
-// those fetches, not on the VALU (half the fetches of the one-node-per-step form).  The nearer hit child (by slab tnear) is
-// taken, the other is pushed (one word: node index, bit 31 = it is a leaf); a popped leaf entry fetches its slot range
-// (ST_OPEN).  Everything else -- levels, leaves, pruning margins, tie / NaN flags -- is traverse_ref<false, true>.
-constexpr uint32_t ST_OPEN = 5u;
-constexpr uint32_t STK_LEAF = 0x80000000u;
+// Fast mode's walk over WIDE records (DNode4, dscene.h): `cur` is an interior node of the fast tree whose own box is known to be
+// hit; one 128-byte record holds the boxes and link words of up to four nodes below it, so a step tests four boxes per dependent
+// fetch -- the fast walk waits on those fetches, not on the VALU.  The nearest hit child (by slab tnear) is taken, the others are
+// pushed (one word each, the record's link word: a leaf carries its slot range, so a popped leaf needs no fetch of its own).
+// Everything else -- levels, leaves, pruning margins, tie / NaN flags -- is traverse_ref<false, true>.
+
 // the root node of a level: its own box, once (bvh.rs:472-473 for node 0)
 template <bool COUNT>
 __device__ __forceinline__ void fast_level_root(const DParams &P, const Lvl &L, const Ray &ray, const double limit, uint32_t &state, uint32_t &cur,
@@ -1111,7 +1100,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
     Lvl L;
     lvl_set<LDSS, FAST>(P, scn, L, 0u);
     double limit = prune_limit(INFINITY, anyhit); // FAST: nodes whose tnear lies beyond this are skipped
-    TriSetup tri;                                  // FAST: per mesh level (its leaves hold <= 4 triangles: per leaf the three divides would dominate)
+    TriSetup tri;                                  // FAST: per mesh level (its leaves hold one triangle: per leaf the three divides would dominate)
     tri.kz = 0; tri.sx = 0.0; tri.sy = 0.0; tri.sz = 0.0;
     // ---- the root accel's local ray (bvh.rs:462), kept for the returns
     Ray root = wray;
@@ -1123,6 +1112,10 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
     uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0;
     uint32_t state = ST_NODE;
     fast_level_root<COUNT>(P, L, ray, limit, state, cur, li, le, cnt);
+    auto take = [&](const uint32_t e) { // a pending child comes off the stack
+        if (e & WIDE_LEAF) { li = L.prim_base + (e & WIDE_START_MASK); le = li + ((e >> WIDE_COUNT_SHIFT) & 7u); state = ST_LEAF; }
+        else { cur = L.node_base + e; state = ST_NODE; }
+    };
     for (;;) {
         // ---- phase A: interior nodes, two children per step, until no lane of the wave is at a node
         // (loops are written with their wave-uniform condition in a variable tested at the bottom: hipcc then keeps the
@@ -1130,32 +1123,48 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
         bool more_nodes = wave_any(state == ST_NODE);
         while (more_nodes) {
             if (state == ST_NODE) {
-                const DNode2 *nd = P.nodes2 + cur;
-                const double b0min[3] = {nd->b0min[0], nd->b0min[1], nd->b0min[2]}, b0max[3] = {nd->b0max[0], nd->b0max[1], nd->b0max[2]};
-                const double b1min[3] = {nd->b1min[0], nd->b1min[1], nd->b1min[2]}, b1max[3] = {nd->b1max[0], nd->b1max[1], nd->b1max[2]};
-                const uint32_t link0 = nd->link0, meta0 = nd->meta0, link1 = nd->link1, meta1 = nd->meta1, second = L.node_base + nd->second;
+                // one wide record: four child boxes (f32, rounded outward by the host; widened exactly) and their link words
+                const uint4 *q = reinterpret_cast<const uint4 *>(P.nodes4 + cur);
+                const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4], w5 = q[5], lk = q[6];
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
-                if (COUNT) cnt.nodes += 2u; // both children's boxes
-                // a primitive's computed t can undershoot its box's tnear by the error of its own formula: for a sphere
-                // the quadratic's cancellation, ~sqrt(eps) of the distance to its centre, which lies inside the box
-                double tn0, tf0, tn1, tf1;
-                bool hit0 = slab_intersects_nc_t(b0min, b0max, ray, tn0, tf0);
-                bool hit1 = slab_intersects_nc_t(b1min, b1max, ray, tn1, tf1);
-                hit0 = hit0 && !(tn0 - 4e-8 * fabs(tf0) > limit);
-                hit1 = hit1 && !(tn1 - 4e-8 * fabs(tf1) > limit);
-                const bool swap = hit1 && (!hit0 || tn1 < tn0); // the nearer hit child first
-                const bool any = hit0 || hit1, both = hit0 && hit1;
-                const uint32_t first = cur + 1u;
-                const uint32_t near_idx = swap ? second : first, far_idx = swap ? first : second;
-                const uint32_t near_link = swap ? link1 : link0, near_meta = swap ? meta1 : meta0, far_meta = swap ? meta0 : meta1;
-                const bool near_leaf = (near_meta & NODE_LEAF) != 0u;
-                const bool can_pop = sp != base;
-                stk[sp * stride] = far_idx | ((far_meta & NODE_LEAF) ? STK_LEAF : 0u); // counts only if sp advances
-                const uint32_t next = any ? near_idx : (popped & ~STK_LEAF);
-                sp = sp + (both ? 1u : 0u) - (!any && can_pop ? 1u : 0u);
-                li = L.prim_base + near_link; le = li + (near_meta & 0xFFFFu); // (read in ST_LEAF only)
-                cur = next;
-                state = any ? (near_leaf ? ST_LEAF : ST_NODE) : !can_pop ? ST_LEVEL_DONE : (popped & STK_LEAF) ? ST_OPEN : ST_NODE;
+                const uint32_t bw[24] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w,
+                                         w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w};
+                const uint32_t link[WIDE] = {lk.x, lk.y, lk.z, lk.w};
+                if (COUNT) cnt.nodes += (uint32_t)WIDE;
+                double tn[WIDE];
+                bool hit[WIDE];
+#pragma unroll
+                for (int k = 0; k < WIDE; ++k) {
+                    const double mn[3] = {(double)__uint_as_float(bw[6 * k]), (double)__uint_as_float(bw[6 * k + 1]), (double)__uint_as_float(bw[6 * k + 2])};
+                    const double mx[3] = {(double)__uint_as_float(bw[6 * k + 3]), (double)__uint_as_float(bw[6 * k + 4]), (double)__uint_as_float(bw[6 * k + 5])};
+                    double tf;
+                    hit[k] = slab_intersects_nc_t(mn, mx, ray, tn[k], tf);
+                    // (a primitive's computed t can undershoot its box's tnear by the error of its own formula: for a sphere the
+                    // quadratic's cancellation, ~sqrt(eps) of the distance to its centre, which lies inside the box)
+                    hit[k] = hit[k] && !(tn[k] - 4e-8 * fabs(tf) > limit) && link[k] != NO_HIT;
+                }
+                // the nearest hit child is taken, the others are pushed in record order
+                int near = -1;
+                double near_t = INFINITY;
+#pragma unroll
+                for (int k = 0; k < WIDE; ++k) {
+                    const bool better = hit[k] && (near < 0 || tn[k] < near_t);
+                    near = better ? k : near;
+                    near_t = better ? tn[k] : near_t;
+                }
+                const bool any = near >= 0, can_pop = sp != base;
+                uint32_t taken = popped;
+#pragma unroll
+                for (int k = 0; k < WIDE; ++k) {
+                    const bool push = hit[k] && k != near;
+                    stk[sp * stride] = link[k]; // counts only if sp advances
+                    sp += push ? 1u : 0u;
+                    taken = (k == near) ? link[k] : taken;
+                }
+                sp -= (!any && can_pop) ? 1u : 0u;
+                if (!any && !can_pop) state = ST_LEVEL_DONE;
+                else if (taken & WIDE_LEAF) { li = L.prim_base + (taken & WIDE_START_MASK); le = li + ((taken >> WIDE_COUNT_SHIFT) & 7u); state = ST_LEAF; }
+                else cur = L.node_base + taken;
             }
             more_nodes = wave_any(state == ST_NODE);
         }
@@ -1170,7 +1179,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
             else done = mesh_leaf2<2, LDSS, FAST, COUNT>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
             if (FAST) limit = prune_limit(best.t, anyhit);
             if (done) state = ST_DONE;
-            else if (sp != base) { --sp; const uint32_t e = stk[sp * stride]; cur = e & ~STK_LEAF; state = (e & STK_LEAF) ? ST_OPEN : ST_NODE; }
+            else if (sp != base) { --sp; take(stk[sp * stride]); }
             else state = ST_LEVEL_DONE;
         }
         bool more_prims = wave_any(state == ST_LEAF);
@@ -1233,7 +1242,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
                     if (anyhit && t < 1.0) state = ST_DONE; // occluded: point.rs:49 only asks isect.t < 1.0
                 }
                 if (state == ST_LEAF && li >= le) { // leaf exhausted: next pending node of this level, or the level is done
-                    if (sp != base) { --sp; cur = popped & ~STK_LEAF; state = (popped & STK_LEAF) ? ST_OPEN : ST_NODE; }
+                    if (sp != base) { --sp; take(popped); }
                     else state = ST_LEVEL_DONE;
                 }
             }
@@ -1253,13 +1262,6 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
             }
             if (FAST && (L.flags & AF_MESH)) tri = tri_setup(ray);
             fast_level_root<COUNT>(P, L, ray, limit, state, cur, li, le, cnt);
-        }
-        // ---- a pending child that is a leaf (pushed with its box already tested): its slot range
-        if (state == ST_OPEN) {
-            uint32_t link, meta;
-            load_node_link<false>(P, scn, cur, link, meta);
-            li = L.prim_base + link; le = li + (meta & 0xFFFFu);
-            state = ST_LEAF;
         }
         // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
         while (state == ST_LEVEL_DONE) { // (a lane comes back through every level that is exhausted with it)
@@ -1293,7 +1295,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
                     negmask = neg_mask(ray);
                 }
                 if (li < le) state = ST_LEAF;
-                else if (sp != base) { --sp; const uint32_t e = stk[sp * stride]; cur = e & ~STK_LEAF; state = (e & STK_LEAF) ? ST_OPEN : ST_NODE; }
+                else if (sp != base) { --sp; take(stk[sp * stride]); }
                 else state = ST_LEVEL_DONE; // the parent level is exhausted as well
             }
         }

@@ -55,6 +55,18 @@ def test_host_bvh_build_matches_oracle_bit_for_bit(name):
     assert info["max_stack"] <= 64 * 8
 
 
+@pytest.mark.parametrize("name", list(BUILD_CASES))
+def test_wide_records_of_the_fast_trees_cover_their_binary_trees(name):
+    """Fast mode's wide node records (DNode4): every leaf of the binary fast tree is reached exactly once, every child box
+    (f32, rounded outward) contains its node's f64 box, and the stack the flattening reserves covers the deepest walk."""
+    r = la.api.host_check_wide_records(BUILD_CASES[name][0](la.api))
+    assert r["violations"] == 0, r
+    assert r["children"] >= 2 * r["records"] and r["children"] <= 4 * r["records"]
+    assert r["deepest_stack"] <= r["reserved_stack"], r
+    if name == "mesh_100k":
+        assert r["leaves"] > 20000 and r["children"] > 2.5 * r["records"], r
+
+
 def test_transform_concat_matches_oracle():
     o = oracle()
     outs = []
