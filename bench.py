@@ -306,6 +306,16 @@ def main():
     elapsed = time.perf_counter() - t0
     timed_film = full.cpu().numpy().copy() if (rank == 0 and full is not None) else None  # the frame `value` was measured on
 
+    # the same K steps twice more (not `value`: the spread between back-to-back blocks of the same run, reported beside it)
+    repeats = [elapsed]
+    for _ in range(2):
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        finish()
+        fence()
+        repeats.append(time.perf_counter() - t1)
+
     # one frame at a time (render + gather, nothing else in flight): latency at this N
     was = overlap[0]
     overlap[0] = False
@@ -346,12 +356,13 @@ def main():
     keys = sorted(st)
     rdev = "cuda" if args.backend == "nccl" else "cpu"
     vec = torch.tensor([st[k] for k in keys] + [0], dtype=torch.float64, device=rdev)
-    tmax = torch.tensor([elapsed, kernel_ms / max(launches, 1), latency_ms], dtype=torch.float64, device=rdev)
+    tmax = torch.tensor([elapsed, kernel_ms / max(launches, 1), latency_ms] + repeats, dtype=torch.float64, device=rdev)
     if multi:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total = {k: int(v) for k, v in zip(keys, vec.tolist())}
     elapsed, latency_ms = float(tmax[0]), float(tmax[2])
+    repeats = [float(x) for x in tmax[3:]]
     # the metric counts primary + shadow rays; config 3 has no specular material, so there are no secondary rays
     assert total["secondary_rays"] == 0, "the headline workload must not cast secondary rays"
     rays = total["primary_rays"] + total["shadow_rays"]
@@ -428,6 +439,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "latency_ms": latency_ms,
+            "value_repeats": [rays * args.steps / r / 1e6 for r in repeats],  # [0] is `value`; the other two: the same K steps again
             "value_single_frame": rays / latency_ms / 1e3,  # Mrays/s of ONE frame issued alone (render + gather), nothing else in flight
             "config": {"workload": "configs[2]: %dx%d, Cornell shell + 1024 random plastic spheres (SplitMix64 0x1A560001), 1 spp, 1 point light" % (w, h),
                        "rays_per_frame": rays, "primary": total["primary_rays"], "shadow": total["shadow_rays"],

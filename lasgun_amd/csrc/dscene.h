@@ -90,7 +90,7 @@ struct alignas(16) DCuboid {
 struct alignas(16) DLeafRec { // 48-byte leaf-ordered geometry record (see header comment)
     uint32_t w[12];
 };
-// Pruned walk, inside the reference's fat mesh leaves (up to 254 triangles, bvh.rs:187,289): one record per run of <= 16
+// Pruned walk, inside the reference's fat mesh leaves (up to 254 triangles, bvh.rs:187,289): one record per run of <= 32
 // consecutive leaf_soup2 slots, made by the host from the triangles in those slots -- their bounds, a cone around their
 // normals and two shape numbers.  (The reference orders a leaf's triangles by a Morton code that ignores x, bvh.rs:575-579:
 // sixteen consecutive ones are no neighbours.  leaf_soup2 holds each leaf's triangles in spatial runs instead; the leaf loop
@@ -108,8 +108,9 @@ struct alignas(64) DChunk {
     uint32_t pad;
 };
 static_assert(sizeof(DChunk) == 64, "DChunk is one 64-byte line");
-constexpr uint32_t CHUNK_SHIFT = 4u;            // at most 16 slots per run
-constexpr uint32_t CHUNK_GROUP = 4u;            // runs per group record
+constexpr uint32_t CHUNK_SHIFT = 5u;            // at most 32 slots per run (measured, config 4 / 4m / 5 in ms: 16 slots in groups of 4: 44.2 / 16.1 / 62.7;
+                                                // 32 in groups of 2: 42.0 / 15.6 / 61.7; 8 in 4: 48.7 / 17.6 / 64.8; a binary hierarchy of groups: no change)
+constexpr uint32_t CHUNK_GROUP = 2u;            // runs per group record
 constexpr uint32_t CHUNK_IS_GROUP = 0xFFFFFFFFu; // DChunk::start of a group record; its count = the run records behind it
 // Lateral culling of a record: with sigma <= |n . d| / |d| for every triangle of the record (from the cone and the ray:
 // cos(alpha + theta), alpha the angle between the ray and the cone's axis), the accepted hit point lies within

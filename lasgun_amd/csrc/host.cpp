@@ -1040,10 +1040,10 @@ struct Flattener {
 } // namespace
 
 // ---- culling records of the pruned walk (DChunk) --------------------------------------------------------
-// A fat leaf of a mesh's reference tree is cut into RUNS of <= 16 triangles that are neighbours in space and face the same way
+// A fat leaf of a mesh's reference tree is cut into RUNS of <= 32 triangles that are neighbours in space and face the same way
 // (the reference's own order inside a leaf is a Morton order that ignores x, bvh.rs:575-579; a leaf is typically two to four
 // separate patches of the surface).  Recursive splitting of the leaf's triangle set: at the largest gap between centroids along
-// the widest axis when there is a clear one (patches fall apart there), at the median otherwise; a set of <= 16 triangles whose
+// the widest axis when there is a clear one (patches fall apart there), at the median otherwise; a set of <= 32 triangles whose
 // normals stay within 35 degrees of their mean is a run.
 struct LeafTri {
     uint32_t slot; // its slot in leaf_soup

@@ -586,7 +586,7 @@ struct LeafCull {
     double lb, ekz, dd;
     uint32_t records;      // DNode::pad of the leaf: first record | number of records << 24
 };
-// One culling record (DChunk) against the ray: true = none of its <= 16 triangles can be accepted, the tests are skipped.
+// One culling record (DChunk) against the ray: true = none of its triangles (<= 32 for a run) can be accepted, the tests are skipped.
 // (t1, t2) per axis are the slab test's own expressions on the record's box.  Dominant axis: an accepted t is a convex
 // combination of plane parameters that lie between the box's two (section 3.4), so it lies in [tmin_kz - ekz, tmax_kz + ekz]: outside
 // [0, limit] nothing is accepted.  All axes, when the ray meets every triangle of the record at an angle of sine >= sigma > 0
@@ -657,7 +657,7 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
         }                                                                                                                \
     } while (0)
     if (PRUNE && lc.ekz < INFINITY) { // (a level or ray outside the stated ranges: the plain loop below, in the reference's order)
-        // The leaf in runs of <= 16 slots of leaf_soup2 counted from its first slot (one culling record per run), where the
+        // The leaf in runs of <= 32 slots of leaf_soup2 counted from its first slot (one culling record per run), where the
         // leaf's triangles stand in a k-d order: a run whose record is culled is stepped over.  The reference scans the leaf in
         // order[] sequence and keeps the FIRST of several triangles with exactly the same t (triangle.rs:251: `t >= isect.t`
         // rejects); scanning in another order gives the same winner when a tie goes to the lower original slot -- the final hit
