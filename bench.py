@@ -309,6 +309,10 @@ def main():
     # the same K steps twice more (not `value`: the spread between back-to-back blocks of the same run, reported beside it)
     repeats = [elapsed]
     for _ in range(2):
+        for _ in range(args.warmup):  # (the film's D2H copy above left the GPU idle: the same warm-up as before the first block)
+            step()
+        finish()
+        fence()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
