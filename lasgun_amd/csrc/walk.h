@@ -345,6 +345,15 @@ __device__ __forceinline__ Ray local_ray(const DParams &P, const Ray &wray, uint
     return r;
 }
 
+// The same record through the SCALAR cache: for an address every active lane shares (the caller checks).  The scene tables are
+// never written while a kernel runs, so the constant address space's promise holds; one 48- or 64-byte scalar fetch then stands
+// for 64 lanes' fetches of the same line through the vector L1.
+typedef uint32_t lg_u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) lg_u32x4 *lg_const_u4;
+__device__ __forceinline__ uint4 load_const_u4(lg_const_u4 q, int i) {
+    const lg_u32x4 v = q[i];
+    return uint4{v.x, v.y, v.z, v.w};
+}
 // ---- scene table access: HBM/L2 tables, or (LDSS) the copy a 1024-lane workgroup holds in LDS.
 // Lanes of a wave read DIFFERENT records, 56 bytes per node visit: through the vector L1 that is
 // 64 B/clk per CU and the traversal kernels were bound by it as much as by VALU issue; the LDS
@@ -353,7 +362,7 @@ __device__ __forceinline__ Ray local_ray(const DParams &P, const Ray &wray, uint
 // either kind start in 16 different bank groups.
 struct NodeRec {
     double bmin[3], bmax[3];
-    uint32_t link, meta, pad;
+    uint32_t link, meta, parent, pad;
 };
 __device__ __forceinline__ double u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 template <bool LDSS>
@@ -367,14 +376,23 @@ __device__ __forceinline__ NodeRec load_node(const DParams &P, const uint4 *scn,
         const uint2 d = *reinterpret_cast<const uint2 *>(q4 + 3);
         n.bmin[0] = a.x; n.bmin[1] = a.y; n.bmin[2] = b.x;
         n.bmax[0] = b.y; n.bmax[1] = c.x; n.bmax[2] = c.y;
-        n.link = d.x; n.meta = d.y; n.pad = 0u;
+        n.link = d.x; n.meta = d.y; n.parent = 0u; n.pad = 0u;
     } else {
         // one 64-byte record = four 16-byte loads from a single line, all issued before the slab test
         const DNode *nd = P.nodes + idx;
         n.bmin[0] = nd->bmin[0]; n.bmin[1] = nd->bmin[1]; n.bmin[2] = nd->bmin[2];
         n.bmax[0] = nd->bmax[0]; n.bmax[1] = nd->bmax[1]; n.bmax[2] = nd->bmax[2];
-        n.link = nd->link; n.meta = nd->meta; n.pad = nd->pad;
+        n.link = nd->link; n.meta = nd->meta; n.parent = nd->parent; n.pad = nd->pad;
     }
+    return n;
+}
+__device__ __forceinline__ NodeRec load_node_uniform(const DParams &P, uint32_t idx) { // (idx: the same for every active lane)
+    lg_const_u4 q = (lg_const_u4)(uintptr_t)(P.nodes + idx);
+    const uint4 a = load_const_u4(q, 0), b = load_const_u4(q, 1), c = load_const_u4(q, 2), d = load_const_u4(q, 3);
+    NodeRec n;
+    n.bmin[0] = u2d(a.x, a.y); n.bmin[1] = u2d(a.z, a.w); n.bmin[2] = u2d(b.x, b.y);
+    n.bmax[0] = u2d(b.z, b.w); n.bmax[1] = u2d(c.x, c.y); n.bmax[2] = u2d(c.z, c.w);
+    n.link = d.x; n.meta = d.y; n.parent = d.z; n.pad = d.w;
     return n;
 }
 template <bool LDSS>
@@ -436,10 +454,13 @@ __device__ __forceinline__ bool ref_path_hit(const DParams &P, uint32_t node_bas
     uint32_t n = leaf;
     if (n == NO_HIT) return false; // a primitive beyond its leaf's u16 count: the reference never reaches it
     for (;;) {
-        const DNode *nd = P.nodes + (node_base + n);
-        const double bmin[3] = {nd->bmin[0], nd->bmin[1], nd->bmin[2]}, bmax[3] = {nd->bmax[0], nd->bmax[1], nd->bmax[2]};
-        n = nd->parent; // same 64-byte record: one fetch per step
-        if (!slab_intersects(bmin, bmax, ray)) return false;
+        // (neighbouring rays mostly hit primitives of the same reference leaf and then climb the same nodes: one scalar fetch)
+        const uint32_t i = node_base + n, i0 = __builtin_amdgcn_readfirstlane(i);
+        NodeRec nd;
+        if (__builtin_amdgcn_ballot_w64(i != i0) == 0ull) nd = load_node_uniform(P, i0);
+        else nd = load_node<false>(P, nullptr, i);
+        n = nd.parent; // same 64-byte record: one fetch per step
+        if (!slab_intersects(nd.bmin, nd.bmax, ray)) return false;
         if (n == NO_HIT) return true;
     }
 }
@@ -558,6 +579,10 @@ __device__ __forceinline__ LeafRec load_rec_at(const char *base, uint32_t off) {
     const uint4 *q = reinterpret_cast<const uint4 *>(base + off);
     return LeafRec{q[0], q[1], q[2]};
 }
+__device__ __forceinline__ LeafRec load_rec_uniform(const char *base, uint32_t off) {
+    lg_const_u4 q = (lg_const_u4)(uintptr_t)(base + off);
+    return LeafRec{load_const_u4(q, 0), load_const_u4(q, 1), load_const_u4(q, 2)};
+}
 template <int KZ>
 __device__ __forceinline__ bool tri_rec_t(const LeafRec &r, V3 o, double sx, double sy, double sz, TriHit &h) {
     const V3 p0{rec_f32(r.a.x), rec_f32(r.a.y), rec_f32(r.a.z)}, p1{rec_f32(r.a.w), rec_f32(r.b.x), rec_f32(r.b.y)},
@@ -597,18 +622,26 @@ struct LeafCull {
 static __device__ int g_dbg_gate_dummy;
 #define g_dbg_gate lc_dbg_gate
 #endif
+struct ChunkRec { uint4 a, b, c, d; }; // one DChunk as loaded: four 16-byte words of one line
+__device__ __forceinline__ ChunkRec load_chunk(const DChunk *rec) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(rec);
+    return ChunkRec{q[0], q[1], q[2], q[3]};
+}
+__device__ __forceinline__ ChunkRec load_chunk_uniform(const DChunk *rec) { // (see load_rec_uniform)
+    lg_const_u4 q = (lg_const_u4)(uintptr_t)rec;
+    return ChunkRec{load_const_u4(q, 0), load_const_u4(q, 1), load_const_u4(q, 2), load_const_u4(q, 3)};
+}
 template <int KZ>
-__device__ __forceinline__ bool chunk_culled(const DChunk *rec, const Ray &ray, const LeafCull &lc, uint32_t &run_start, uint32_t &run_count
+__device__ __forceinline__ bool chunk_culled(const ChunkRec &k, const Ray &ray, const LeafCull &lc, uint32_t &run_start, uint32_t &run_count
 #ifdef LG_CHUNK_DEBUG
                                              , int &lc_dbg_gate
 #endif
 ) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(rec);
-    const uint4 a = q[0], b = q[1], c = q[2];
-    run_start = q[3].x; run_count = q[3].y;
+    const uint4 a = k.a, b = k.b, c = k.c;
+    run_start = k.d.x; run_count = k.d.y;
     const double bmin[3] = {rec_f32(a.x), rec_f32(a.y), rec_f32(a.z)}, bmax[3] = {rec_f32(a.w), rec_f32(b.x), rec_f32(b.y)};
     const V3 ax{rec_f32(b.z), rec_f32(b.w), rec_f32(c.x)};
-    const float cos_t = __uint_as_float(c.y), g2 = __uint_as_float(c.z), hmin = __uint_as_float(c.w), sin_t = __uint_as_float(q[3].z);
+    const float cos_t = __uint_as_float(c.y), g2 = __uint_as_float(c.z), hmin = __uint_as_float(c.w), sin_t = __uint_as_float(k.d.z);
     const double ox = bmin[0] - ray.o.x, px = bmax[0] - ray.o.x, oy = bmin[1] - ray.o.y, py = bmax[1] - ray.o.y, oz = bmin[2] - ray.o.z, pz = bmax[2] - ray.o.z;
     double t1 = ox * ray.dinv.x, t2 = px * ray.dinv.x;
     const double nx = fmin_(t1, t2), fx = fmax_(t1, t2);
@@ -685,26 +718,30 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
         // Two wave-uniform phases, like the walk itself: every lane first steps over culled runs until it stands in one that
         // survives (or its leaf ends), then the lanes that stand in a run test it, two triangles per trip with the next record in
         // flight.  A lane's own loop nest would make the whole wave pay for every run that ANY lane keeps.
+        // When every lane that takes a step stands at the same record (the lanes of a coherent wave in the same leaf mostly do),
+        // the record comes through the scalar cache (load_*_uniform) instead of 64 times through the vector L1, whose request
+        // rate this loop is otherwise bound by.
         bool in_run = false, done = false;
         uint32_t off = 0;
-        LeafRec ra;
-        ra.a = ra.b = ra.c = uint4{0u, 0u, 0u, 0u};
         for (;;) {
             bool seeking = wave_any(!in_run && rec < rec_end);
             while (seeking) {
                 if (!in_run && rec < rec_end) {
                     if (COUNT) cnt.nodes++; // (a record test is counted with the node tests)
                     uint32_t start, count;
+                    bool culled_;
+                    const uint32_t rec0 = __builtin_amdgcn_readfirstlane(rec);
 #ifdef LG_CHUNK_DEBUG
                     int gate_ = 0;
-                    const bool culled_ = chunk_culled<KZ>(P.chunks + rec, ray, lc, start, count, gate_);
+                    culled_ = chunk_culled<KZ>(load_chunk(P.chunks + rec), ray, lc, start, count, gate_);
                     if (COUNT) { cnt.cuboids++; if (LG_CHUNK_DEBUG == 1 ? gate_ != 0 : LG_CHUNK_DEBUG == 2 ? !culled_ : (!culled_ && gate_)) cnt.spheres++; }
 #else
-                    const bool culled_ = chunk_culled<KZ>(P.chunks + rec, ray, lc, start, count);
+                    if (__builtin_amdgcn_ballot_w64(rec != rec0) == 0ull) culled_ = chunk_culled<KZ>(load_chunk_uniform(P.chunks + rec0), ray, lc, start, count);
+                    else culled_ = chunk_culled<KZ>(load_chunk(P.chunks + rec), ray, lc, start, count);
 #endif
                     ++rec;
                     if (start == CHUNK_IS_GROUP) { if (culled_) rec += count; } // a group record: culled, its runs are stepped over; kept, they come next
-                    else if (!culled_) { in_run = true; s = start; run_end = start + count; off = s * REC; ra = load_rec_at(base2, off); } // (the array holds < 2^32 / 48 slots: checked by the host)
+                    else if (!culled_) { in_run = true; s = start; run_end = start + count; off = s * REC; } // (the array holds < 2^32 / 48 slots: checked by the host)
                 }
                 seeking = wave_any(!in_run && rec < rec_end);
             }
@@ -713,14 +750,20 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
             while (testing) {
                 if (in_run) {
                     const bool two = s + 1u < run_end;
-                    const LeafRec rb = load_rec_at(base2, off + REC); // (two spare records behind the last slot: always readable)
-                    LG_TRI2(ra);
-                    if (two && !done) LG_TRI2(rb);
+                    const uint32_t off0 = __builtin_amdgcn_readfirstlane(off);
+                    if (__builtin_amdgcn_ballot_w64(off != off0) == 0ull) { // two triangles per trip (two spare records behind the last slot: always readable)
+                        const LeafRec ra = load_rec_uniform(base2, off0), rb = load_rec_uniform(base2, off0 + REC);
+                        LG_TRI2(ra);
+                        if (two && !done) LG_TRI2(rb);
+                    } else {
+                        const LeafRec ra = load_rec_at(base2, off), rb = load_rec_at(base2, off + REC);
+                        LG_TRI2(ra);
+                        if (two && !done) LG_TRI2(rb);
+                    }
                     s += two ? 2u : 1u;
                     off += 2u * REC;
                     if (done) { rec = rec_end; in_run = false; } // an occluded any-hit ray: nothing more to find
                     else if (s >= run_end) in_run = false;
-                    else ra = load_rec_at(base2, off);
                 }
                 testing = wave_any(in_run);
             }
@@ -850,7 +893,11 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     bmin[0] = a.x; bmin[1] = a.y; bmin[2] = b.x; bmax[0] = b.y; bmax[1] = c.x; bmax[2] = c.y;
                     w_link = d.x; w_meta = d.y; w_end = d.z; w_chunk = d.w;
                 } else {
-                    const NodeRec nd = load_node<false>(P, scn, cur);
+                    // (lanes of a coherent wave are mostly at the same node near the root: one scalar fetch then)
+                    const uint32_t cur0 = __builtin_amdgcn_readfirstlane(cur);
+                    NodeRec nd;
+                    if (__builtin_amdgcn_ballot_w64(cur != cur0) == 0ull) nd = load_node_uniform(P, cur0);
+                    else nd = load_node<false>(P, scn, cur);
                     bmin[0] = nd.bmin[0]; bmin[1] = nd.bmin[1]; bmin[2] = nd.bmin[2]; bmax[0] = nd.bmax[0]; bmax[1] = nd.bmax[1]; bmax[2] = nd.bmax[2];
                     const bool lf = (nd.meta & NODE_LEAF) != 0u;
                     w_link = (lf ? L.prim_base : L.node_base) + nd.link;
@@ -1124,8 +1171,17 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
         while (more_nodes) {
             if (state == ST_NODE) {
                 // one wide record: four child boxes (f32, rounded outward by the host; widened exactly) and their link words
-                const uint4 *q = reinterpret_cast<const uint4 *>(P.nodes4 + cur);
-                const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4], w5 = q[5], lk = q[6];
+                // (lanes of a coherent wave are mostly at the same record near the root: it then comes through the scalar cache)
+                uint4 w0, w1, w2, w3, w4, w5, lk;
+                const uint32_t cur0 = __builtin_amdgcn_readfirstlane(cur);
+                if (__builtin_amdgcn_ballot_w64(cur != cur0) == 0ull) {
+                    lg_const_u4 q = (lg_const_u4)(uintptr_t)(P.nodes4 + cur0);
+                    w0 = load_const_u4(q, 0); w1 = load_const_u4(q, 1); w2 = load_const_u4(q, 2); w3 = load_const_u4(q, 3);
+                    w4 = load_const_u4(q, 4); w5 = load_const_u4(q, 5); lk = load_const_u4(q, 6);
+                } else {
+                    const uint4 *q = reinterpret_cast<const uint4 *>(P.nodes4 + cur);
+                    w0 = q[0]; w1 = q[1]; w2 = q[2]; w3 = q[3]; w4 = q[4]; w5 = q[5]; lk = q[6];
+                }
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
                 const uint32_t bw[24] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w,
                                          w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w};
