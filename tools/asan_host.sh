@@ -1,7 +1,8 @@
 #!/bin/bash
 # Host side (scene description, OBJ reader, HLBVH builder, flattening, C ABI) under AddressSanitizer + UBSan on the CPU:
 # builds lasgun_amd/csrc/{host,capi,multi}.cpp with -fsanitize=address,undefined, links them with the device object, and
-# runs tests/test_host.py plus the flattening of 600 random / adversarial scenes and the full-size configs through it.
+# runs tests/test_host.py plus the flattening of 600 random / adversarial scenes (reference trees, and fast trees with their wide records) and the
+# full-size configs through it.
 # (GPU sanitizers are not available on the pool; the kernels are covered by the parity suite and the fuzz campaign.)
 set -eu
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -23,6 +24,8 @@ for seed in range(150):
     for gen in (S.random_scene, S.adversarial_scene, S.adversarial_mesh_scene, S.adversarial_prune_scene):
         try:
             G.host_build_dump(gen(G, seed)); n += 1
+            r = G.host_check_wide_records(gen(G, seed))  # the fast trees and their wide records too
+            assert r["violations"] == 0 and r["deepest_stack"] <= r["reserved_stack"], (gen.__name__, seed, r)
         except la.LasgunError:
             pass
 for b in (lambda: S.mesh_scene(G), lambda: S.mixed_scene(G), lambda: S.spheres_scene(G), lambda: S.kitchen_sink_scene(G), lambda: S.instanced_scene(G), lambda: S.tie_mesh_scene(G), lambda: S.exotic_obj_scene(G)):
