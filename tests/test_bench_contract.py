@@ -32,6 +32,8 @@ def test_bench_line_has_the_contract_fields():
     # the line proves its own "bit-exact RGBA8 vs CPU": the timed frame against the oracle film, in the same run
     assert d["bit_exact"] is True and d["mismatched_bytes"] == 0 and d["bit_exact_check"]["checked_pixels"] >= 65536
     assert d["value_single_frame"] > 100.0 and abs(d["value_single_frame"] - d["config"]["rays_per_frame"] / d["latency_ms"] / 1e3) < 1e-6 * d["value_single_frame"]
+    # the spread of the run: the same K steps timed three times back to back, the first of them being `value`
+    assert len(d["value_repeats"]) == 3 and d["value_repeats"][0] == d["value"] and min(d["value_repeats"]) > 0.9 * d["value"]
     m = d["roofline_mesh"]
     assert m["bound"] == "valu_f64" and 0.0 < m["frac"] < 1.0 and m["work_per_frame"]["triangles_tested"] > 0 and m["ms_per_frame"] > 0.0
     c = d["cpu_baseline"]
