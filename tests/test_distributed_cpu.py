@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -141,4 +142,29 @@ def test_two_rank_all_gather_gives_every_rank_the_film(tmp_path):
     o = oracle()
     want = o.render(S.cornell_scene(o, "glass"), (24, 32)).pixels()
     for rank in range(2):
+        assert np.array_equal(np.load(str(tmp_path / ("rank%d.npy" % rank))), want), rank
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_more_ranks_interleaved_gather_pipeline(tmp_path, world):
+    """The driver's N = 4 and N = 8 layouts rehearsed on CPU: 4-row blocks dealt round-robin over `world` gloo ranks (two groups of
+    blocks per rank at 4, one at 8), three frames through the buffer rotation, ONE gather per frame, film == the oracle's."""
+    out = str(tmp_path / "ilv.npy")
+    port = 35500 + (os.getpid() % 2000) + world
+    mp.spawn(_ilv_worker, args=(world, port, out), nprocs=world, join=True)
+    from oracle_lib import oracle
+    from lasgun_amd import scenes as S
+    o = oracle()
+    want = o.render(S.cornell_scene(o, "glass"), (24, 32)).pixels()
+    assert np.array_equal(np.load(out), want)
+
+
+def test_four_rank_all_gather_gives_every_rank_the_film(tmp_path):
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_allgather_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    from oracle_lib import oracle
+    from lasgun_amd import scenes as S
+    o = oracle()
+    want = o.render(S.cornell_scene(o, "glass"), (24, 32)).pixels()
+    for rank in range(4):
         assert np.array_equal(np.load(str(tmp_path / ("rank%d.npy" % rank))), want), rank
