@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What one rank's share of the headline frame costs at N = 1, 2, 4, 8 (one GPU, no gather): the fixed per-frame costs
-that bound strong scaling.  usage: python tools/share_time.py [size]"""
+that bound strong scaling.  usage: python tools/share_time.py [size] [megakernel]"""
 import json
 import os
 import sys
@@ -14,6 +14,8 @@ G = la.api
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 G.set_device(0)
 acc = G.Accel(la.scenes.spheres_scene(G))
+if len(sys.argv) > 2 and sys.argv[2] == "megakernel":  # A/B: one launch per frame instead of three
+    G.set_streaming(acc, 0)
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 for world in (1, 2, 4, 8):
     tiles = [torch.zeros((size // world, size, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
