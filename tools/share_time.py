@@ -16,15 +16,16 @@ G.set_device(0)
 acc = G.Accel(la.scenes.spheres_scene(G))
 if len(sys.argv) > 2 and sys.argv[2] == "megakernel":  # A/B: one launch per frame instead of three
     G.set_streaming(acc, 0)
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+NS = int(os.environ.get("LASGUN_SHARE_STREAMS", "2"))  # frames in flight in the overlapped form (bench.py keeps four)
+streams = [torch.cuda.Stream() for _ in range(NS)]
 for world in (1, 2, 4, 8):
-    tiles = [torch.zeros((size // world, size, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    out = {"world": world}
+    tiles = [torch.zeros((size // world, size, 4), dtype=torch.uint8, device="cuda") for _ in range(NS)]
+    out = {"world": world, "frames_in_flight": NS}
     for overlap in (False, True):
         def frame(k):
-            s = streams[k % 2] if overlap else streams[0]
-            G.capture_interleaved_device(acc, size, size, 64, world, 0, tiles[k % 2].data_ptr(), stream=s.cuda_stream)
-        for k in range(4):
+            s = streams[k % NS] if overlap else streams[0]
+            G.capture_interleaved_device(acc, size, size, 64, world, 0, tiles[k % NS].data_ptr(), stream=s.cuda_stream)
+        for k in range(2 * NS):
             frame(k)
         torch.cuda.synchronize()
         n = 20
