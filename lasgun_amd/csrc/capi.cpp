@@ -300,7 +300,7 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     DParams P{};
     P.nodes = a.nodes.p; P.nodes4 = a.nodes4.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
     P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
-    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.chunks = a.chunks.p; P.leaf_soup2 = a.leaf_soup2.p; P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
+    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.chunks = a.chunks.p; P.leaf_soup2 = a.leaf_soup2.n ? a.leaf_soup2.p : a.leaf_soup.p; /* (a scene without a mesh has no second soup) */ P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
     P.tri_ref_leaf = a.tri_ref_leaf.p; P.accel_ref_leaf = a.accel_ref_leaf.p; P.accels = a.accels.p; P.materials = a.materials.p;
     P.lights = a.lights.p;
     P.nlights = (uint32_t)a.flat.lights.size();
@@ -845,6 +845,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         a->stats.alloc(2); // (the second record: iteration counters of the diagnostic build)
         a->device_bytes = f.nodes.size() * sizeof(DNode) + f.nodes4.size() * sizeof(DNode4) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
                           f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 + f.leaf_soup.size() * sizeof(DLeafRec) +
+                          f.leaf_soup2.size() * sizeof(DLeafRec) + f.chunks.size() * sizeof(DChunk) +
                           f.accels.size() * sizeof(DAccel) + f.materials.size() * sizeof(DMaterial);
         if (!a->stream) HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
         // per-lane LDS stack: worst case of this scene graph, +2 guard entries

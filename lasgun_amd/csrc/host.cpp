@@ -1049,6 +1049,7 @@ struct LeafTri {
     uint32_t slot; // its slot in leaf_soup
     V3 cen, n;     // centroid, unit normal (zero for a degenerate triangle)
 };
+constexpr size_t CHUNK_MIN_RUN = 2; // sets this small are never split further
 static void cut_runs(std::vector<LeafTri> &t, size_t a, size_t b, std::vector<std::pair<size_t, size_t>> &runs) {
     const size_t count = b - a;
     if (count == 0) return;
@@ -1058,7 +1059,9 @@ static void cut_runs(std::vector<LeafTri> &t, size_t a, size_t b, std::vector<st
         const double l = std::sqrt(dot(sum, sum));
         double cmin = 1.0;
         if (l > 0.0) for (size_t i = a; i < b; ++i) cmin = std::fmin(cmin, std::fabs(dot(t[i].n, sum)) / l);
-        if (count <= 2 || (l > 0.0 && cmin >= 0.82)) { runs.emplace_back(a, b); return; } // cos 35 degrees
+        // (cos 35 degrees.  A set of <= CHUNK_MIN_RUN triangles is a run whatever its normals do: make_record measures every
+        // run's cone itself and leaves lateral culling off when it is too wide, so this only bounds the number of records)
+        if (count <= CHUNK_MIN_RUN || (l > 0.0 && cmin >= 0.82)) { runs.emplace_back(a, b); return; }
     }
     V3 lo = t[a].cen, hi = lo;
     for (size_t i = a; i < b; ++i) {
@@ -1142,8 +1145,12 @@ static DChunk make_record(const FlatScene &out, size_t a, size_t b) {
 // leaf_soup2 (the triangles of every mesh leaf again, run after run; word 9 of a record = the slot it came from), the runs'
 // records, and in DNode::pad of every mesh leaf: index of its first record | number of its records << 24.
 static void build_chunks(FlatScene &out) {
-    out.leaf_soup2 = out.leaf_soup;
     out.chunks.clear();
+    out.leaf_soup2.clear();
+    bool any_mesh = false;
+    for (const DAccel &A : out.accels) any_mesh = any_mesh || (A.flags & AF_MESH) != 0u;
+    if (!any_mesh) return; // (the pruned walk reads leaf_soup2 / chunks in mesh leaves only; capi.cpp points them at leaf_soup then)
+    out.leaf_soup2 = out.leaf_soup;
     std::vector<char> done(out.nodes.size(), 0);
     for (const DAccel &A : out.accels) {
         if (!(A.flags & AF_MESH) || done[A.node_base]) continue;
@@ -1166,7 +1173,17 @@ static void build_chunks(FlatScene &out) {
             }
             std::vector<std::pair<size_t, size_t>> runs;
             cut_runs(tris, 0, count, runs);
-            if (out.chunks.size() >= (1u << 24) - 512u) throw Error("too many culling records");
+            // The records are an optimisation: a leaf whose cut does not fit the 8-bit record count of DNode::pad (a soup of
+            // incoherent triangles, a geometric progression of centroids: the gap rule peels one triangle per cut) is cut into
+            // plain runs of <= 32 consecutive triangles of the sorted set instead (<= 8 runs + 4 group records), and a mesh
+            // beyond the 24-bit record index leaves its remaining leaves without records: pad = 0, and the leaf loop walks
+            // such a leaf in the reference's order over the reference's soup (walk.h, mesh_leaf2).
+            auto records_of = [](size_t nruns) { return nruns + nruns / CHUNK_GROUP; }; // one record per run, one per group of CHUNK_GROUP (= 2) runs
+            if (records_of(runs.size()) > 255) {
+                runs.clear();
+                for (size_t r0 = 0; r0 < count; r0 += (size_t)1 << CHUNK_SHIFT) runs.emplace_back(r0, std::min(count, r0 + ((size_t)1 << CHUNK_SHIFT)));
+            }
+            if (out.chunks.size() + records_of(runs.size()) + 2 >= (1u << 24)) { nd.pad = 0u; continue; }
             nd.pad = (uint32_t)out.chunks.size();
             for (size_t i = 0; i < count; ++i) {
                 DLeafRec r = out.leaf_soup[tris[i].slot];
@@ -1188,7 +1205,7 @@ static void build_chunks(FlatScene &out) {
                 }
                 for (size_t r = g; r < ge; ++r) { out.chunks.push_back(make_record(out, first + runs[r].first, first + runs[r].second)); ++nrec; }
             }
-            if (nrec > 255) throw Error("too many culling records in one leaf");
+            if (nrec > 255) throw Error("internal: a leaf's culling records exceed their 8-bit count"); // (cannot happen: see records_of above)
             nd.pad |= (uint32_t)nrec << 24;
         }
     }

@@ -689,7 +689,7 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
-    if (PRUNE && lc.ekz < INFINITY) { // (a level or ray outside the stated ranges: the plain loop below, in the reference's order)
+    if (PRUNE && lc.ekz < INFINITY && (lc.records >> 24) != 0u) { // (a level or ray outside the stated ranges, or a leaf the host gave no records: the plain loop below, in the reference's order)
         // The leaf in runs of <= 32 slots of leaf_soup2 counted from its first slot (one culling record per run), where the
         // leaf's triangles stand in a k-d order: a run whose record is culled is stepped over.  The reference scans the leaf in
         // order[] sequence and keeps the FIRST of several triangles with exactly the same t (triangle.rs:251: `t >= isect.t`

@@ -656,6 +656,40 @@ def adversarial_prune_scene(api, seed):
     return sc
 
 
+def progression_soup_scene(api, seed):
+    """A triangle soup whose centroids form a geometric progression along x (ratio 1.2 or 1.3) with random orientations:
+    inside one fat leaf of the reference tree no run of three or more triangles is coherent and every largest-gap cut peels
+    one triangle off -- the host's culling records (host.cpp, build_chunks) must fall back to plain runs instead of failing
+    (round 3 refused such a scene: "too many culling records in one leaf").  Seen from the side, with spheres among it."""
+    import numpy as np
+    G = api; M = api.Material
+    rng = np.random.default_rng(seed + 300000)
+    ratio = float(rng.choice([1.2, 1.3]))
+    n = int(rng.integers(250, 520))
+    lines = []
+    for i in range(n):
+        cx = ratio ** (i % 254) * 1e-20 * (1.0 if i < 254 else -1.0)   # f32 range: 1.3^253 * 1e-20 ~ 7e8
+        c = np.array([cx, float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))])
+        size = max(abs(cx) * 0.4, 0.05)
+        for _ in range(3):
+            lines.append("v %.9g %.9g %.9g" % tuple(c + rng.uniform(-1, 1, 3) * size))
+        lines.append("f %d %d %d" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    sc = G.Scene.new()
+    cam = sc.set_perspective_camera(float(rng.uniform(40, 80)))
+    cam.look_at([float(rng.uniform(-2, 2)), float(rng.uniform(-1, 1)), 6.0], [0.0, 0.0, 0.0], [0, 1, 0])
+    sc.set_ambient_light([0.2, 0.2, 0.2])
+    sc.set_max_recursion_depth(int(rng.integers(0, 3)))
+    mats = [M.matte(rng.uniform(0.2, 1, 3).tolist(), 0.0), M.plastic(rng.uniform(0.2, 1, 3).tolist(), [0.5, 0.5, 0.5], 0.3),
+            M.mirror([0.6, 0.6, 0.6])]
+    mesh = sc.parse_obj("\n".join(lines) + "\n")
+    sc.root.add_obj_of(mesh, mats[int(rng.integers(3))])
+    for i in range(int(rng.integers(2, 12))):
+        sc.root.add_sphere(rng.uniform(-1.5, 1.5, 3).tolist(), float(10.0 ** rng.uniform(-1.5, -0.3)), mats[i % 3])
+    for i in range(int(rng.integers(1, 3))):
+        sc.add_point_light(rng.uniform(-4, 4, 3).tolist(), rng.uniform(0.3, 0.9, 3).tolist(), [1.0, 0.0, 0.0])
+    return sc
+
+
 def exotic_obj():
     """OBJ text in the forms the `obj` crate accepts beyond plain `f a b c`: comments, `o` / `g` statements, `v//vn` faces,
     NEGATIVE (relative) indices for positions and normals, a 4- and a 5-vertex polygon (the reference keeps the first three

@@ -36,7 +36,13 @@ GENERATORS = {
     "adversarial": (S.adversarial_scene, (64, 48)),
     "adversarial_mesh": (S.adversarial_mesh_scene, (64, 48)),
     "adversarial_prune": (S.adversarial_prune_scene, (64, 48)),
+    "progression_soup": (S.progression_soup_scene, (64, 48)),
 }
+# Generators that build knife-edge scenes on purpose (spheres touching in a point, rays through the tangent points): there one ulp
+# of atan2 / acos -- glibc's against the portable algorithm the device and the oracle's second mode share -- can turn into another
+# pixel value.  Everywhere else the device film must equal the GLIBC oracle's film byte for byte.
+KNIFE_EDGE = {"adversarial_prune"}
+LIBM_PIXELS_PER_SCENE = 8  # budget of libm-sensitive pixels in one knife-edge scene (measured: 31 pixels in 49,600 scenes, at most 2 in one)
 # (streaming, fast, packet, prune): megakernel and wavefront pipeline in either traversal mode, three-kernel pipeline with the
 # packet walk, and the pruned form of the reference walk in megakernel and wavefront pipeline
 ORGANISATIONS = ((0, False, False, False), (0, True, False, False), (2, False, False, False), (2, True, False, False), (2, False, True, False),
@@ -72,7 +78,12 @@ def test_fuzz_campaign(gen):
             orad = o.capture_radiance(oacc, w, h, nthreads=8)
         finally:
             o.set_trig_mode(0)
-        done["libm_sensitive_pixels"] += int((ofilm_libm.pixels() != ofilm.pixels()).any(axis=-1).sum())
+        libm_sensitive = (ofilm_libm.pixels() != ofilm.pixels()).any(axis=-1)  # pixels on which the two oracle modes disagree
+        done["libm_sensitive_pixels"] += int(libm_sensitive.sum())
+        if gen in KNIFE_EDGE:
+            assert int(libm_sensitive.sum()) <= LIBM_PIXELS_PER_SCENE, (gen, seed, int(libm_sensitive.sum()))
+        else:
+            assert not libm_sensitive.any(), ("the portable-trig oracle left the glibc oracle's bytes", gen, seed, int(libm_sensitive.sum()))
         acc = G.Accel(build(G, seed))
         done["scenes"] += 1
         done["nan_pixels"] += int(np.isnan(np.asarray(orad)).any(axis=-1).sum())
@@ -92,6 +103,11 @@ def test_fuzz_campaign(gen):
             done["renders"] += 1
             if not (np.array_equal(film.pixels(), ofilm.pixels()) and same_f64(rad, orad)):
                 done["mismatches"].append([seed, streaming, fast, packet, prune])
+            # against the glibc oracle (what the Rust binary calls): a device pixel may differ from it ONLY where the oracle's own two
+            # trig modes differ -- a real device error can never hide in the "libm-sensitive" bucket
+            differs = (film.pixels() != ofilm_libm.pixels()).any(axis=-1)
+            if (differs & ~libm_sensitive).any():
+                done["mismatches"].append([seed, streaming, fast, packet, prune, "vs-libm"])
         if done["scenes"] % 25 == 0:
             print("fuzz %s: %d scenes, %d renders, %d mismatches" % (gen, done["scenes"], done["renders"], len(done["mismatches"])), flush=True)
     log = os.environ.get("LASGUN_FUZZ_LOG")

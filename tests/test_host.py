@@ -67,6 +67,17 @@ def test_wide_records_of_the_fast_trees_cover_their_binary_trees(name):
         assert r["leaves"] > 20000 and r["children"] > 2.5 * r["records"], r
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_incoherent_fat_leaves_build(seed):
+    """A soup whose centroids form a geometric progression with random orientations (round 3's builder threw "too many culling
+    records in one leaf" on it): the culling records are an optimisation and must never fail the build; the reference tree
+    still equals the oracle's."""
+    f, i, info = la.api.host_build_dump(S.progression_soup_scene(la.api, seed))
+    o = oracle()
+    of, oi = o.Accel(S.progression_soup_scene(o, seed)).dump()
+    assert np.array_equal(i, oi) and np.array_equal(f.view(np.uint64), of.view(np.uint64))
+
+
 def test_transform_concat_matches_oracle():
     o = oracle()
     outs = []

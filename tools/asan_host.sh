@@ -21,7 +21,7 @@ python3 - <<'PY'
 import lasgun_amd as la
 G, S, n = la.api, la.scenes, 0
 for seed in range(150):
-    for gen in (S.random_scene, S.adversarial_scene, S.adversarial_mesh_scene, S.adversarial_prune_scene):
+    for gen in (S.random_scene, S.adversarial_scene, S.adversarial_mesh_scene, S.adversarial_prune_scene, S.progression_soup_scene):
         try:
             G.host_build_dump(gen(G, seed)); n += 1
             r = G.host_check_wide_records(gen(G, seed))  # the fast trees and their wide records too
