@@ -202,7 +202,14 @@ int lg_accel_set_prune(const lg_accel *, int enabled);
  * spheres / boxes (where node and sphere tests dominate a ray; glass / mirror over a big mesh excepted) run level by level in
  * the WAVEFRONT pipeline (below) with per-ray state in HBM when the launch covers at least 2^20 pixels (2^23 when the scene
  * carries a big mesh); everything else -- and everything when 0 -- runs in the single persistent megakernel.
- * 2 = use the pipeline wherever it is possible (tests). */
+ * 2 = use the pipeline wherever it is possible (tests).
+ * 3 = the QUEUE organisation wherever it is possible (reference traversal, <= 32 lights, recursion depth <= 7): ONE persistent
+ * launch per chunk of the film whose waves pull 64-ray packets from per-level ray queues -- level 0's packets are the 8x8 pixel
+ * tiles, level d + 1's are filled by level d's glass / mirror hits -- deepest level first, each packet taken through closest hit,
+ * shadow rays and shading by the wave that claimed it; the levels are combined bottom-up as in the wavefront pipeline.  It is
+ * the default for scenes with glass / mirror over a big mesh (long, uneven walks; sparse deep levels), where the megakernel
+ * runs deep levels with a few lanes per wave and the level-by-level pipeline ends every launch with its slowest wave's tail.
+ * Returns non-zero (lg_last_error) for any other value. */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
 
 /* The WAVEFRONT pipeline is li() level by level: per recursion level a closest-hit pass (hits compacted into a queue, misses

@@ -90,8 +90,11 @@ class HipApi(Api):
             raise LasgunError(self.last_error())
 
     def set_streaming(self, accel, enabled):
-        """True (default) = three-kernel streaming pipeline where the scene allows it; False = megakernel only."""
-        self.call("accel_set_streaming", accel.h, int(enabled) if enabled in (0, 1, 2) else (1 if enabled else 0))
+        """Kernel organisation (include/lasgun_hip.h, lg_accel_set_streaming): 1 / True = the accel's defaults, 0 / False = the
+        megakernel only, 2 = the level-by-level wavefront pipeline wherever possible, 3 = the queue organisation (every recursion
+        level in one persistent launch) wherever possible.  Same bytes out in every organisation."""
+        if self.call("accel_set_streaming", accel.h, int(enabled) if enabled in (0, 1, 2, 3) else (1 if enabled else 0)):
+            raise LasgunError(self.last_error())
 
     def set_wf_split(self, accel, bands):
         """Bands of a big wavefront launch on internal streams (0 = default; include/lasgun_hip.h, lg_accel_set_wf_split)."""

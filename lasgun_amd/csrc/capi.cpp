@@ -30,6 +30,9 @@ hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t bl
 hipError_t launch_wf_shade(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t launch_wf_combine(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t wf_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
+hipError_t launch_queue(const DParams &P, uint32_t blocks, hipStream_t stream);
+hipError_t queue_occupancy(uint32_t stack_depth, int *blocks_per_cu);
+hipError_t queue_set_lds_limit(size_t bytes, bool ldss);
 hipError_t mega_set_lds_limit(size_t bytes, bool ldss);
 hipError_t wf_set_lds_limit(size_t bytes, bool ldss);
 hipError_t packet_set_lds_limit(size_t bytes, bool ldss);
@@ -214,6 +217,7 @@ struct lg_accel {
         DevBuf<uint32_t> st_hit_ref, st_vis, st_tie_flag, st_tie_tiles;
         DevBuf<uint8_t> wf_mem;                                // wavefront pipeline: every per-level array of a chunk, carved from one allocation
         DevBuf<uint32_t> wf_counters;                          // its queue counts and per-launch tile counters
+        bool queue_used = false;                               // the queue organisation ran on it: wf_counters holds its control words (QC_ERROR is checked after a synchronise)
     };
     mutable std::vector<std::unique_ptr<LaunchCtx>> ctxs;
     // wavefront pipeline, big launches: the frame is cut into bands rendered on internal streams (each with a launch context
@@ -231,6 +235,11 @@ struct lg_accel {
     bool streaming_pays = false;
     unsigned long long streaming_min_items = 1ull << 20;
     uint32_t wf_blocks = 1, wf_blocks_fast = 1;   // grids of the wavefront pipeline's 256-lane traversal kernels
+    uint32_t queue_blocks = 1;                    // grid of the queue organisation's persistent kernel (256-lane form)
+    mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
+    bool queue_default = false;                   // glass / mirror over a big mesh: long uneven walks, sparse deep levels (k_queue.hip)
+    mutable size_t queue_budget = 0;              // bytes one launch context may hold for it (0 = from the free memory at first use)
+    unsigned long long queue_min_items = 1ull << 16; // launches below this many pixels stay with the megakernel
     mutable bool wavefront = true;               // lg_accel_set_wavefront: level-by-level pipeline instead of the three-kernel one
     mutable size_t wf_budget = 0;                 // bytes one launch context may hold for it (0 = from the free memory at first use)
     // LDS-resident scene (reference tree only): the tables in their LDS layout, when they fit beside the stacks
@@ -294,6 +303,18 @@ static lg_accel::LaunchCtx &ctx_for(const lg_accel &a, hipStream_t stream) {
     return *c;
 }
 
+// Wait for the accel's stream; then, if the queue organisation ran, look at its error word: a wave that gave up waiting for
+// work that never came (a scheduler bug) must fail the call, not leave a half-rendered film behind.  Caller holds a.mtx.
+static void sync_checked(const lg_accel &a) {
+    HIP_TRY(hipStreamSynchronize(a.stream));
+    for (auto &c : a.ctxs) {
+        if (!c->queue_used || !c->wf_counters.p) continue;
+        uint32_t w = 0u;
+        HIP_TRY(hipMemcpy(&w, c->wf_counters.p + QC_ERROR, sizeof w, hipMemcpyDeviceToHost));
+        if (w != 0u) throw Error("queue organisation: a wave gave up waiting for work (scheduler stalled); the film is incomplete");
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     const Scene &s = *a.scene;
@@ -317,6 +338,10 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     P.pixel_separation = s.camera.pixel_separation;
     P.ss_distance = s.camera.ss_distance;
     P.ss_root = s.camera.ss_root;
+    {   // LASGUN_SLAB_SIGNS=0: the reference's slab formula as written in every node step (A/B, tests)
+        static const bool signs = [] { const char *e = std::getenv("LASGUN_SLAB_SIGNS"); return !(e && e[0] == '0'); }();
+        P.boxes_finite = a.flat.boxes_finite && signs ? 1u : 0u;
+    }
     P.bg_inner = s.bg_inner; P.bg_outer = s.bg_outer; P.bg_scale = s.bg_scale;
     P.ambient = s.ambient;
     P.w = w; P.h = h;
@@ -522,11 +547,139 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
     if (a.profiling) { HIP_TRY(hipEventRecord(e1, stream)); a.events.emplace_back(e0, e1); }
 }
 
+// The queue organisation (k_queue.hip): per chunk of the film and per supersample ONE persistent launch that runs every recursion
+// level -- its waves pull 64-ray packets from per-level queues, deepest level first -- then the combine passes bottom-up, shared
+// with the level-by-level pipeline.  Queue capacities are worst case (level d: 2^d rays per pixel of the chunk), so nothing can
+// overflow; a recursive scene may take a large share of the HBM for it (a 4096^2 frame at recursion 3: 26 GB of 288) and keeps ONE
+// chunk in flight per launch context.
+static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c, hipStream_t stream) {
+    const uint32_t levels = (a.flat.has_specular && P0.recursion > 0) ? P0.recursion + 1u : 1u;
+    const uint32_t nsamples = P0.ss_root * P0.ss_root;
+    auto level_bytes = [&](uint32_t d) -> size_t { // per ray of level d
+        size_t b = 0;
+        if (d >= 1) b += 6 * 8;                       // ray queue
+        if (levels > 1) b += 3 * 8;                   // output / li
+        if (d + 1 < levels) b += 8 * 8 + 2 * 4;       // children's weights and indices
+        return b;
+    };
+    size_t per_pixel = (nsamples > 1 ? 3 * 8 : 0) + 1;
+    for (uint32_t d = 0; d < levels; ++d) per_pixel += level_bytes(d) << d;
+    if (a.queue_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        // a recursive scene: up to a quarter of the free memory (at most 48 GiB) per launch context, so that a 4096^2 frame is one
+        // launch; others need a few bytes per pixel and take the wavefront pipeline's share (an allocation that fails halves the chunk)
+        size_t budget = levels > 1 ? free_b / 4 : free_b / 16;
+        const size_t cap = levels > 1 ? (48ull << 30) : (8ull << 30);
+        const char *env = std::getenv("LASGUN_QUEUE_BUDGET_MB");
+        const bool from_env = env && std::atoll(env) > 0;
+        if (from_env) budget = (size_t)std::atoll(env) << 20; // (as given: tests cut small films into many chunks with it)
+        else if (budget > cap) budget = cap;
+        a.queue_budget = !from_env && budget < (64ull << 20) ? (64ull << 20) : budget;
+    }
+    unsigned long long chunk_tiles = a.queue_budget / (per_pixel * 64);
+    const unsigned long long cap_limit = (0xFFFFFF00ull >> (levels - 1)) / 64ull; // ray indices are 32-bit
+    if (chunk_tiles > cap_limit) chunk_tiles = cap_limit;
+    if (chunk_tiles < 1) chunk_tiles = 1;
+    if (chunk_tiles > P0.ntiles) chunk_tiles = P0.ntiles;
+    const bool ldss = a.lds_scene && a.ldss_blocks;
+    const uint32_t blocks_cap = ldss ? a.ldss_blocks : a.queue_blocks;
+    const unsigned long long threads = (unsigned long long)blocks_cap * (ldss ? 1024ull : 256ull);
+    unsigned long long n0 = 0;
+    size_t need = 0, nready = 0;
+    struct Carved {
+        std::vector<double *> q, out, spec;
+        std::vector<uint32_t *> child;
+        double *accum = nullptr;
+    } K;
+    for (;;) { // memory that is not there: halve the chunk and carve again
+        try {
+            n0 = chunk_tiles * 64ull;
+            need = (size_t)n0 * per_pixel + 4096 * (4 * levels + 4);
+            nready = (size_t)chunk_tiles * ((1ull << levels) - 2ull) + (size_t)levels * QR_SLACK; // one word per packet of the levels >= 1, + slack per level
+            if (c.wf_mem.n < need) { HIP_TRY(hipDeviceSynchronize()); c.wf_mem.alloc(need); }
+            if (c.wf_counters.n < QC_WORDS + nready) { HIP_TRY(hipDeviceSynchronize()); c.wf_counters.alloc(QC_WORDS + nready); }
+            if (P0.nlights > 0 && c.stash.n < (size_t)threads * STASH_DOUBLES) { HIP_TRY(hipDeviceSynchronize()); c.stash.alloc((size_t)threads * STASH_DOUBLES); }
+            break;
+        } catch (const Error &e) {
+            if (std::string(e.what()).find("hipMalloc") == std::string::npos || chunk_tiles <= 1) throw;
+            (void)hipGetLastError();
+            chunk_tiles = (chunk_tiles + 1) / 2;
+            a.queue_budget = std::max<size_t>(a.queue_budget / 2, 64ull << 20);
+            if (std::getenv("LASGUN_DEBUG")) std::fprintf(stderr, "[lasgun] queue: %s -- chunks of %llu tiles instead\n", e.what(), chunk_tiles);
+        }
+    }
+    {
+        K.q.assign(levels, nullptr); K.out.assign(levels, nullptr); K.spec.assign(levels, nullptr); K.child.assign(levels, nullptr);
+        uint8_t *cur = c.wf_mem.p;
+        auto take = [&](size_t bytes) { uint8_t *p = cur; cur += (bytes + 255) & ~(size_t)255; return p; };
+        for (uint32_t d = 0; d < levels; ++d) {
+            const size_t cap = (size_t)n0 << d;
+            if (d >= 1) K.q[d] = (double *)take(cap * 6 * 8);
+            if (levels > 1) K.out[d] = (double *)take(cap * 3 * 8);
+            if (d + 1 < levels) { K.spec[d] = (double *)take(cap * 8 * 8); K.child[d] = (uint32_t *)take(cap * 2 * 4); }
+        }
+        K.accum = nsamples > 1 ? (double *)take((size_t)n0 * 3 * 8) : nullptr;
+    }
+    c.queue_used = true;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (a.profiling) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
+    auto timed = [&](int kind, auto &&launch) { // HIP events around ONE kernel on its launch stream
+        hipEvent_t k0 = nullptr, k1 = nullptr;
+        if (a.profiling) { HIP_TRY(hipEventCreate(&k0)); HIP_TRY(hipEventCreate(&k1)); HIP_TRY(hipEventRecord(k0, stream)); }
+        HIP_TRY(launch());
+        if (a.profiling) { HIP_TRY(hipEventRecord(k1, stream)); a.kind_events[kind].emplace_back(k0, k1); }
+    };
+    if (std::getenv("LASGUN_DEBUG"))
+        std::fprintf(stderr, "[lasgun] queue: levels %u, %llu tiles in chunks of %llu (%.1f MiB), grid %u x %u, stack %u\n", levels,
+                     (unsigned long long)P0.ntiles, chunk_tiles, need / 1048576.0, blocks_cap, ldss ? 1024u : 256u, a.stack_depth);
+    const uint32_t flat_cap = a.cus * 16u;
+    for (unsigned long long t0 = 0; t0 < P0.ntiles; t0 += chunk_tiles) {
+        DParams P = P0;
+        P.tile0 = (uint32_t)t0;
+        P.ntiles = (uint32_t)std::min<unsigned long long>(chunk_tiles, P0.ntiles - t0);
+        P.n_items = n0; // SoA stride of level 0's arrays and of the sample accumulator
+        P.accum = K.accum;
+        P.wf_levels = levels;
+        P.q_ctl = c.wf_counters.p; P.q_ready = c.wf_counters.p + QC_WORDS;
+        for (uint32_t d = 0; d < levels; ++d) { P.q_rays[d] = K.q[d]; P.q_out[d] = K.out[d]; P.q_spec[d] = K.spec[d]; P.q_child[d] = K.child[d]; }
+        P.stash = c.stash.p; P.frame_threads = threads;
+        if (ldss) {
+            P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
+            P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
+        }
+        const uint32_t blocks = ldss ? blocks_cap : std::min(blocks_cap, (P.ntiles + 3u) / 4u);
+        const size_t nready_now = nready;
+        for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
+            P.sample_index = sidx;
+            HIP_TRY(hipMemsetAsync(c.wf_counters.p, 0, (QC_WORDS + (levels > 1 ? nready_now : 0)) * sizeof(uint32_t), stream));
+            timed(4, [&] { return launch_queue(P, blocks, stream); });
+            for (uint32_t d = levels - 1; d-- > 0;) { // bottom-up: li of level d's rays from their children's (integrate.rs:79, 103, 129)
+                P.wf_level = d;
+                P.wf_cap = (unsigned long long)n0 << d; P.wf_cap_next = (unsigned long long)n0 << (d + 1);
+                P.wf_out = K.out[d]; P.wf_spec = K.spec[d]; P.wf_child = K.child[d]; P.wf_out_next = K.out[d + 1];
+                const uint32_t flat_blocks0 = (uint32_t)(((unsigned long long)P.ntiles * 64ull + 255ull) / 256ull);
+                timed(1, [&] { return launch_wf_combine(P, d == 0 ? flat_blocks0 : flat_cap, stream); });
+            }
+        }
+    }
+    if (a.profiling) { HIP_TRY(hipEventRecord(e1, stream)); a.events.emplace_back(e0, e1); }
+}
+
 // Enqueue one render on `stream`.  Caller holds a.mtx.
 static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t stream) {
     if (P.ntiles == 0) return;
     lg_accel::LaunchCtx &c = ctx_for(a, stream);
     P.tile_counter = c.tile_counter.p;
+    // ---- queue organisation: every recursion level in one persistent launch (reference traversal, <= 32 lights, <= 7 levels of
+    // recursion; not the counting variant).  Forced by lg_accel_set_streaming(3); the default for glass / mirror over a big mesh.
+    {
+        const uint32_t levels = (a.flat.has_specular && P.recursion > 0) ? P.recursion + 1u : 1u;
+        const bool can = !stats && !a.fast && P.nlights <= 32 && levels <= QC_MAX_LEVELS;
+        const bool want = a.queue == 1 || (a.queue < 0 && a.streaming && !a.streaming_forced && !a.packet && a.queue_default &&
+                                           (unsigned long long)P.ntiles * 64ull >= a.queue_min_items);
+        if (can && want) { enqueue_queue(a, P, c, stream); return; }
+    }
     // ---- wavefront pipeline: li() level by level (any scene with <= 32 lights; not the counting variant, not the packet walk)
     if (a.streaming && !stats && P.nlights <= 32 && P.recursion < 20 && !(a.packet && !a.fast) &&
         (a.streaming_forced || (a.streaming_pays && (unsigned long long)P.ntiles * 64ull >= a.streaming_min_items))) {
@@ -877,7 +1030,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         }
         if (!a->fast_available) a->stack_depth_fast1 = a->stack_depth;
         size_t lds = (size_t)std::max(a->stack_depth, a->stack_depth_fast1) * 256 * 4;
-        if (lds > 64 * 1024) { HIP_TRY(mega_set_lds_limit(lds, false)); HIP_TRY(wf_set_lds_limit(lds, false)); HIP_TRY(packet_set_lds_limit(lds, false)); }
+        if (lds > 64 * 1024) { HIP_TRY(mega_set_lds_limit(lds, false)); HIP_TRY(wf_set_lds_limit(lds, false)); HIP_TRY(packet_set_lds_limit(lds, false)); HIP_TRY(queue_set_lds_limit(lds, false)); }
         int per_cu = 0, cus = 0;
         HIP_TRY(trace_occupancy(a->stack_depth, false, &per_cu));
         int per_cu_fast = 0;
@@ -893,6 +1046,9 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         HIP_TRY(wf_trace_occupancy(a->stack_depth_fast1, true, &wbf));
         a->wf_blocks = (uint32_t)((wb < 1 ? 1 : wb) * cus);
         a->wf_blocks_fast = (uint32_t)((wbf < 1 ? 1 : wbf) * cus);
+        int qb = 0;
+        HIP_TRY(queue_occupancy(a->stack_depth, &qb));
+        a->queue_blocks = (uint32_t)((qb < 1 ? 1 : qb) * cus);
         int pk = 0;
         HIP_TRY(stream_packet_occupancy(a->stack_depth, &pk));
         a->packet_blocks = (uint32_t)((pk < 1 ? 1 : pk) * cus);
@@ -974,7 +1130,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                 }
                 a->lds_image.upload(img);
                 a->lds_image_n16 = (uint32_t)n16;
-                HIP_TRY(mega_set_lds_limit(LDS_MAX, true)); HIP_TRY(wf_set_lds_limit(LDS_MAX, true)); HIP_TRY(packet_set_lds_limit(LDS_MAX, true));
+                HIP_TRY(mega_set_lds_limit(LDS_MAX, true)); HIP_TRY(wf_set_lds_limit(LDS_MAX, true)); HIP_TRY(packet_set_lds_limit(LDS_MAX, true)); HIP_TRY(queue_set_lds_limit(LDS_MAX, true));
                 a->packet_lds = true;
                 if (stack_bytes + n16 * 16 <= LDS_MAX) a->ldss_blocks = (uint32_t)cus;
             }
@@ -1062,7 +1218,7 @@ void lg_accel_free(lg_accel *a) {
 }
 void *lg_accel_stream(const lg_accel *a) { return (void *)a->stream; }
 int lg_accel_synchronize(const lg_accel *a) {
-    return guarded([&] { HIP_TRY(hipStreamSynchronize(a->stream)); });
+    return guarded([&] { std::lock_guard<std::mutex> g(a->mtx); use_device(a->device); sync_checked(*a); });
 }
 
 int lg_capture_rows_device(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t row0, void *dev_rgba, void *hip_stream) {
@@ -1130,11 +1286,11 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) {
             enqueue(*a, P, false, a->stream);
             if (whole) HIP_TRY(hipMemcpyAsync(film->px, buf.p, (size_t)area * 4, hipMemcpyDeviceToHost, a->stream));
         }
-        if (whole) { use_device(a->device); HIP_TRY(hipStreamSynchronize(a->stream)); return; }
+        if (whole) { use_device(a->device); sync_checked(*a); return; }
         std::vector<uint32_t> host((size_t)count);
         use_device(a->device);
         HIP_TRY(hipMemcpyAsync(host.data(), buf.p, (size_t)count * 4, hipMemcpyDeviceToHost, a->stream));
-        HIP_TRY(hipStreamSynchronize(a->stream));
+        sync_checked(*a);
         uint8_t *px = film->px;
         for (unsigned long long i = 0; i < count; ++i) std::memcpy(px + 4 * (k + i * n), &host[(size_t)i], 4);
     });
@@ -1164,7 +1320,7 @@ int lg_capture_pixels(const lg_accel *a, uint32_t w, uint32_t h, const uint64_t 
         enqueue(*a, P, false, a->stream);
         if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rgba.p, count * 4, hipMemcpyDeviceToHost, a->stream));
         if (rgb_out) HIP_TRY(hipMemcpyAsync(rgb_out, rad.p, count * 24, hipMemcpyDeviceToHost, a->stream));
-        HIP_TRY(hipStreamSynchronize(a->stream));
+        sync_checked(*a);
     });
 }
 // The crop [x0, x1) x [y0, y1) of a width x height film, compact and row-major: rgba_out (x1-x0)*(y1-y0)*4 bytes and/or
@@ -1186,7 +1342,7 @@ int lg_capture_rect(const lg_accel *a, uint32_t w, uint32_t h, uint32_t x0, uint
         enqueue(*a, P, false, a->stream);
         if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rgba.p, count * 4, hipMemcpyDeviceToHost, a->stream));
         if (rgb_out) HIP_TRY(hipMemcpyAsync(rgb_out, rad.p, count * 24, hipMemcpyDeviceToHost, a->stream));
-        HIP_TRY(hipStreamSynchronize(a->stream));
+        sync_checked(*a);
     });
 }
 // One device's share of a multi-device capture: rows of `film` rendered on `device` and copied home.
@@ -1216,7 +1372,7 @@ static int capture_share(const lg_scene *s, lg_film *film, int device, uint32_t 
                 HIP_TRY(hipMemcpyAsync(film->px + (size_t)y0 * row_bytes, a->staging.p, (size_t)(y1 - y0) * row_bytes, hipMemcpyDeviceToHost, a->stream));
             }
         }
-        HIP_TRY(hipStreamSynchronize(a->stream));
+        sync_checked(*a);
     });
     lg_accel_free(a);
     return rc;
@@ -1286,7 +1442,7 @@ int lg_capture_radiance(size_t k, size_t n, const lg_accel *a, uint32_t w, uint3
         std::lock_guard<std::mutex> g(a->mtx);
         use_device(a->device);
         size_t count = (size_t)w * h * 3;
-        if (a->staging_rad.n < count) { HIP_TRY(hipStreamSynchronize(a->stream)); a->staging_rad.alloc(count); }
+        if (a->staging_rad.n < count) { sync_checked(*a); a->staging_rad.alloc(count); }
         HIP_TRY(hipMemcpyAsync(a->staging_rad.p, rgb, count * 8, hipMemcpyHostToDevice, a->stream));
         DParams P = base_params(*a, w, h);
         if (n == 1 && k == 0) set_rect(P, 0, 0, w, h);
@@ -1295,7 +1451,7 @@ int lg_capture_radiance(size_t k, size_t n, const lg_accel *a, uint32_t w, uint3
         P.out_radiance = a->staging_rad.p;
         enqueue(*a, P, false, a->stream);
         HIP_TRY(hipMemcpyAsync(rgb, a->staging_rad.p, count * 8, hipMemcpyDeviceToHost, a->stream));
-        HIP_TRY(hipStreamSynchronize(a->stream));
+        sync_checked(*a);
     });
 }
 static int capture_stats_impl(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t filter, lg_stats *out);
@@ -1318,7 +1474,7 @@ static int capture_stats_impl(const lg_accel *a, uint32_t w, uint32_t h, uint32_
         enqueue(*a, P, true, a->stream);
         DStats s;
         HIP_TRY(hipMemcpyAsync(&s, a->stats.p, sizeof s, hipMemcpyDeviceToHost, a->stream));
-        HIP_TRY(hipStreamSynchronize(a->stream));
+        sync_checked(*a);
         *out = lg_stats{s.primary_rays, s.shadow_rays, s.secondary_rays, s.nodes_tested, s.spheres_tested, s.cuboids_tested,
                         s.triangles_tested, s.accel_entries, s.hits};
     });
@@ -1347,8 +1503,10 @@ int lg_accel_set_wf_split(const lg_accel *a, int bands) {
 }
 int lg_accel_set_streaming(const lg_accel *a, int enabled) {
     std::lock_guard<std::mutex> g(a->mtx);
+    if (enabled < 0 || enabled > 3) return fail("streaming must be 0 (megakernel), 1 (default), 2 (wavefront pipeline) or 3 (queue organisation)");
     a->streaming = enabled != 0;
     a->streaming_forced = enabled == 2; // 2 = use it whatever the scene and the launch size (tests)
+    a->queue = enabled == 3 ? 1 : enabled == 1 ? -1 : 0; // 3 = the queue organisation whatever the scene; 1 = the accel's defaults
     return 0;
 }
 int lg_accel_set_prune(const lg_accel *a, int enabled) {
@@ -1545,7 +1703,7 @@ int lg_trace_pixel(const lg_accel *a, uint32_t w, uint32_t h, uint32_t x, uint32
         HIP_TRY(launch_trace_pixel(P, fast != 0, fast ? a->stack_depth_fast1 : a->stack_depth, x, y, dout.p, a->stream));
         HIP_TRY(hipMemcpyAsync(out, dout.p, need * sizeof(double), hipMemcpyDeviceToHost, a->stream));
         if (P.dbg_log) HIP_TRY(hipMemcpyAsync(out + need, dlog.p, log_n * sizeof(double), hipMemcpyDeviceToHost, a->stream));
-        HIP_TRY(hipStreamSynchronize(a->stream));
+        sync_checked(*a);
     });
 }
 // Measured rates of the current device, GB/s: what 0 = HBM copy (16 B per lane, 1 GiB each way, read + written bytes),

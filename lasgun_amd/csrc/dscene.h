@@ -152,6 +152,19 @@ struct alignas(16) DAccel {
     double prune[6]; // pruned walk: centre of the root box (3), sum of its extents, e0, e2 (e0 = +inf: this level is never pruned)
 };
 
+// Control words of the queue organisation (DParams::q_ctl).  Every word that many waves hammer sits on a 128-byte line of its own
+// (agent-scope atomics and sc1 polls are served per line, ~88 per microsecond: MI355X_MICROARCH.md): header [QC_FINISHED] every
+// level is done, [QC_ERROR] a wave gave up waiting (a scheduler bug: reported by the host, never silent); then QC_LEVEL_WORDS
+// words per level d at QC_LEVEL0 + QC_LEVEL_WORDS * d: [QC_COUNT] rays appended so far, [QC_CLAIMED] packets handed out,
+// [QC_STATE, +1] one 64-bit word (packets of the level + 1) << 32 | packets done -- the high half is added when the count is final.
+// Ready words (DParams::q_ready), one per 64-ray packet of the levels >= 1: rays written so far; 64 = claimable; the last, partial
+// packet of a level is marked QR_LAST | its ray count once the level above has finished.
+constexpr uint32_t QC_FINISHED = 0u, QC_ERROR = 32u, QC_LEVEL0 = 128u, QC_LEVEL_WORDS = 128u, QC_COUNT = 0u, QC_CLAIMED = 32u, QC_STATE = 64u;
+constexpr uint32_t QC_MAX_LEVELS = 8u;
+constexpr uint32_t QC_WORDS = QC_LEVEL0 + QC_LEVEL_WORDS * QC_MAX_LEVELS;
+constexpr uint32_t QR_LAST = 0x80000000u;
+constexpr uint32_t QR_SLACK = 16u; // spare ready words behind every level's (the holder of a ticket beyond the level's capacity looks at the first: never raised)
+
 struct DStats { // per-launch counters (stats kernel variant only)
     unsigned long long primary_rays, shadow_rays, secondary_rays, nodes_tested, spheres_tested, cuboids_tested,
         triangles_tested, accel_entries, hits;
@@ -193,7 +206,7 @@ struct DParams {
     V3 cam_origin, cam_view, cam_up, cam_aux;
     double image_plane_height, pixel_separation, ss_distance;
     uint32_t ss_root;
-    uint32_t pad0;
+    uint32_t boxes_finite; // every node box of the scene is finite: the walk may take the sign-specialised slab test (walk.h, slab_intersects_sg)
     V3 bg_inner, bg_outer;
     double bg_scale;
     V3 ambient;
@@ -251,6 +264,16 @@ struct DParams {
     double *wf_q_next;          // [6][wf_cap_next]
     double *wf_out_next;        // [3][wf_cap_next] (the combine pass reads the children's values)
     uint32_t *wf_hq;            // [wf_hit_cap] ray index of hit h
+    // ---- queue organisation (k_queue.hip): ONE persistent launch runs every recursion level of a chunk.  Level d's rays live in
+    // q_rays[d] ([6][n_items << d]; level 0 = the chunk's pixels, no array), its results in q_out[d] / q_spec[d] / q_child[d] (the
+    // wavefront pipeline's layout: the combine pass is shared); q_ctl = control words (QC_*), q_ready = one word per 64-ray packet
+    // of every level >= 1: how many of its rays have been written
+    uint32_t *q_ctl;
+    uint32_t *q_ready;
+    double *q_rays[8];
+    double *q_out[8];
+    double *q_spec[8];
+    uint32_t *q_child[8];
     // packet organisation: lanes whose packet walk met an exact tie in t (or a NaN t) are re-traced privately
     uint32_t *tie_flag;         // [n_items] bit l: light l (shadow pass) / bit 0 (primary pass)
     uint32_t *tie_tiles;        // [ntiles] tiles with at least one flagged lane

@@ -1237,6 +1237,9 @@ void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     if (out.primref.size() > 80000000u) throw Error("too many primitive slots for the 32-bit record offsets of the triangle stream");
     out.leaf_soup.resize(out.primref.size() + 2, DLeafRec{}); // two spare records: the mesh leaf loop keeps the next slot in flight
     build_chunks(out);
+    out.boxes_finite = true;
+    for (const DNode &nd : out.nodes)
+        for (int k = 0; k < 3; ++k) out.boxes_finite = out.boxes_finite && std::isfinite(nd.bmin[k]) && std::isfinite(nd.bmax[k]);
     out.sphere_ref_leaf.resize(out.spheres.size(), NO_HIT);
     out.cuboid_ref_leaf.resize(out.cuboids.size(), NO_HIT);
     out.tri_ref_leaf.resize(out.tri_v.size() / 3, NO_HIT);

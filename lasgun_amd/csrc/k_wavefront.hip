@@ -36,27 +36,6 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want) {
     base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
     return base + lanes_below(mask);
 }
-// integrate(): sum over the pixel's samples, then * weight; Img::set (integrate.rs:16-20, img.rs:46-67)
-__device__ __forceinline__ void finish_pixel(const DParams &P, const Pixel &px, unsigned long long widx, V3 value) {
-    const uint32_t nsamples = P.ss_root * P.ss_root;
-    V3 color = vzero();
-    if (P.sample_index > 0) color = V3{P.accum[widx], P.accum[P.n_items + widx], P.accum[2 * P.n_items + widx]};
-    color = color + value;
-    if (P.sample_index + 1 < nsamples) {
-        P.accum[widx] = color.x; P.accum[P.n_items + widx] = color.y; P.accum[2 * P.n_items + widx] = color.z;
-        return;
-    }
-    const double weight = 1. / (double)nsamples;
-    color = color * weight;
-    const unsigned long long pix = px.pix;
-    if (P.out_rgba) {
-        uint32_t rgba = to_byte(color.x) | (to_byte(color.y) << 8) | (to_byte(color.z) << 16) | (255u << 24);
-        reinterpret_cast<uint32_t *>(P.out_rgba)[pix] = rgba;
-    }
-    if (P.out_radiance) {
-        P.out_radiance[3 * pix] = color.x; P.out_radiance[3 * pix + 1] = color.y; P.out_radiance[3 * pix + 2] = color.z;
-    }
-}
 __device__ __forceinline__ Ray wf_load_ray(const DParams &P, unsigned long long j) {
     const unsigned long long n = P.wf_cap;
     const double *q = P.wf_q + j;
@@ -79,7 +58,8 @@ struct HitSlots { // work tile t of a pass over the hit queue -> hit index of th
     uint32_t tiles_dense, tiles, lpt;
 };
 __device__ __forceinline__ unsigned long long wf_level_rays(const DParams &P, uint32_t level) {
-    return level == 0u ? (unsigned long long)P.ntiles * 64ull : P.wf_counts[level];
+    if (level == 0u) return (unsigned long long)P.ntiles * 64ull;
+    return P.q_ctl ? P.q_ctl[QC_LEVEL0 + QC_LEVEL_WORDS * level + QC_COUNT] : P.wf_counts[level]; // (the queue organisation keeps its own counts)
 }
 __device__ __forceinline__ HitSlots hit_slots(const DParams &P, uint32_t level, uint32_t lpt) {
     HitSlots s;
@@ -268,21 +248,7 @@ __global__ void __launch_bounds__(LG_BLOCK, 3) wf_shade_kernel(const DParams P) 
             sh.ts = cross(sh.ns, sh.ss);
             const DMaterial m = P.materials[sh.mat];
             const uint32_t vis = P.nlights ? P.vis[h] : 0u;
-            V3 nrm = sh.ns;
-            for (uint32_t l = 0; l < P.nlights; ++l) { // integrate.rs:47-66
-                if (!((vis >> l) & 1u)) continue;
-                const DLight L = P.lights[l];
-                V3 wi = V3{L.pos[0], L.pos[1], L.pos[2]} - sh.p;
-                double d = magnitude(wi);
-                double f_att = L.falloff[0] + L.falloff[1] * d + L.falloff[2] * d * d;
-                if (f_att == 0.0) continue;
-                wi = normalize(wi);
-                double wi_dot_n = dot(wi, nrm);
-                V3 fr = bsdf_f(m, sh, sh.wo, wi);
-                V3 li_col{L.intensity[0], L.intensity[1], L.intensity[2]};
-                output = output + (mul_ew(PI * li_col, fr) * wi_dot_n / f_att);
-            }
-            output = output + mul_ew(P.ambient, bsdf_f(m, sh, sh.wo, nrm)); // integrate.rs:67
+            output = shade_lights(P, m, sh, vis); // integrate.rs:47-67
             if (KIND == 1 && (m.kind == MAT_GLASS || m.kind == MAT_MIRROR)) { // depth < max recursion (integrate.rs:69-77)
                 if (sample_specular_transmission(m, sh, st))
                     has_t = !(st.pdf <= 0.0 || veq(st.spectrum, vzero()) || fabs(dot(st.wi, sh.ns)) == 0.0);
@@ -329,7 +295,7 @@ __global__ void __launch_bounds__(LG_BLOCK, 3) wf_shade_kernel(const DParams P) 
 // W4: li of this level's rays from their children's (integrate.rs:79, 103, 129); level 0 also quantises
 __global__ void __launch_bounds__(LG_BLOCK) wf_combine_kernel(const DParams P) {
     const uint32_t level = P.wf_level;
-    const unsigned long long n_work = level == 0u ? (unsigned long long)P.ntiles * 64ull : P.wf_counts[level];
+    const unsigned long long n_work = wf_level_rays(P, level);
     const unsigned long long n = P.wf_cap, nn = P.wf_cap_next;
     for (unsigned long long j = (unsigned long long)blockIdx.x * LG_BLOCK + threadIdx.x; j < n_work; j += (unsigned long long)gridDim.x * LG_BLOCK) {
         Pixel px;

@@ -299,6 +299,48 @@ __device__ __forceinline__ void stash_get(const DParams &P, unsigned long long g
     sh.ts = cross(sh.ns, sh.ss);
 }
 
+// integrate(): sum over the pixel's samples, then * weight; Img::set (integrate.rs:16-20, img.rs:46-67)
+__device__ __forceinline__ void finish_pixel(const DParams &P, const Pixel &px, unsigned long long widx, V3 value) {
+    const uint32_t nsamples = P.ss_root * P.ss_root;
+    V3 color = vzero();
+    if (P.sample_index > 0) color = V3{P.accum[widx], P.accum[P.n_items + widx], P.accum[2 * P.n_items + widx]};
+    color = color + value;
+    if (P.sample_index + 1 < nsamples) {
+        P.accum[widx] = color.x; P.accum[P.n_items + widx] = color.y; P.accum[2 * P.n_items + widx] = color.z;
+        return;
+    }
+    const double weight = 1. / (double)nsamples;
+    color = color * weight;
+    const unsigned long long pix = px.pix;
+    if (P.out_rgba) {
+        uint32_t rgba = to_byte(color.x) | (to_byte(color.y) << 8) | (to_byte(color.z) << 16) | (255u << 24);
+        reinterpret_cast<uint32_t *>(P.out_rgba)[pix] = rgba;
+    }
+    if (P.out_radiance) {
+        P.out_radiance[3 * pix] = color.x; P.out_radiance[3 * pix + 1] = color.y; P.out_radiance[3 * pix + 2] = color.z;
+    }
+}
+// li() of a hit up to its specular children: the lights in order, then the ambient term (integrate.rs:47-67).  `vis` bit l:
+// light l is visible from the hit (PointLight::sample, point.rs:49).  Shared by the level-by-level shade pass and the queue kernel.
+__device__ __forceinline__ V3 shade_lights(const DParams &P, const DMaterial &m, const Shade &sh, const uint32_t vis) {
+    V3 output = vzero();
+    const V3 nrm = sh.ns;
+    for (uint32_t l = 0; l < P.nlights; ++l) { // integrate.rs:47-66
+        if (!((vis >> l) & 1u)) continue;
+        const DLight L = P.lights[l];
+        V3 wi = V3{L.pos[0], L.pos[1], L.pos[2]} - sh.p;
+        double d = magnitude(wi);
+        double f_att = L.falloff[0] + L.falloff[1] * d + L.falloff[2] * d * d;
+        if (f_att == 0.0) continue;
+        wi = normalize(wi);
+        double wi_dot_n = dot(wi, nrm);
+        V3 fr = bsdf_f(m, sh, sh.wo, wi);
+        V3 li_col{L.intensity[0], L.intensity[1], L.intensity[2]};
+        output = output + (mul_ew(PI * li_col, fr) * wi_dot_n / f_att);
+    }
+    return output + mul_ew(P.ambient, bsdf_f(m, sh, sh.wo, nrm)); // integrate.rs:67
+}
+
 // ------------------------------------------------------------------------------------------
 // Streaming pipeline: the same li() for scenes WITHOUT glass / mirror (no recursion), cut into
 // three kernels so that traversal (wants occupancy, 128 VGPRs) and shading (wants registers: trig,

@@ -108,6 +108,28 @@ __device__ __forceinline__ bool slab_intersects_nc_axes(const double bmin[3], co
     return !(tnear > tfar) && !(tfar <= 0.0);
 }
 
+// slab_intersects_nc for a ray whose sign triple is known at compile time (SG: bit a set <=> dinv[a] < 0) -- the "plain" case:
+// every box coordinate finite (the host checks the scene: DParams::boxes_finite), the ray's origin finite, dinv finite and not
+// zero on every axis (ray_signs_plain).  Then fl(bmin - o) <= fl(bmax - o) (rounding is monotone; both may overflow to the same
+// infinity, neither is NaN), and multiplying by a finite non-zero dinv keeps (dinv > 0) or reverses (dinv < 0) that order, again
+// without a NaN (inf * 0 needs dinv = 0): min(t1, t2) and max(t1, t2) of cuboid.rs:113-117 ARE (t1, t2) or (t2, t1), up to the
+// sign of a zero when both are zeros -- and tnear / tfar only ever meet comparisons, which do not see that sign.  Six of the
+// ten min / max of a node step become register names.  Also hands back the per-axis entry parameters (the pruned walk's).
+template <int SG>
+__device__ __forceinline__ bool slab_intersects_sg(const double bmin[3], const double bmax[3], const Ray &r, double &tx, double &ty, double &tz) {
+    tx = (((SG & 1) ? bmax[0] : bmin[0]) - r.o.x) * r.dinv.x;
+    double tfar = (((SG & 1) ? bmin[0] : bmax[0]) - r.o.x) * r.dinv.x;
+    ty = (((SG & 2) ? bmax[1] : bmin[1]) - r.o.y) * r.dinv.y;
+    const double fy = (((SG & 2) ? bmin[1] : bmax[1]) - r.o.y) * r.dinv.y;
+    double tnear = fmax_(tx, ty);
+    tfar = fmin_(tfar, fy);
+    tz = (((SG & 4) ? bmax[2] : bmin[2]) - r.o.z) * r.dinv.z;
+    const double fz = (((SG & 4) ? bmin[2] : bmax[2]) - r.o.z) * r.dinv.z;
+    tnear = fmax_(tnear, tz);
+    tfar = fmin_(tfar, fz);
+    return !(tnear > tfar) && !(tfar <= 0.0);
+}
+
 // the same test, also handing back its tnear (used by the fast mode's front-to-back pruning)
 __device__ __forceinline__ bool slab_intersects_t(const double bmin[3], const double bmax[3], const Ray &r, double &tnear_out, double &tfar_out) {
     double t1 = (bmin[0] - r.o.x) * r.dinv.x, t2 = (bmax[0] - r.o.x) * r.dinv.x;
@@ -529,6 +551,16 @@ __device__ __forceinline__ bool ray_plain(const Ray &r) {
 __device__ __forceinline__ uint32_t neg_mask(const Ray &r) {
     return (r.dinv.x < 0.0 ? 1u : 0u) | (r.dinv.y < 0.0 ? 2u : 0u) | (r.dinv.z < 0.0 ? 4u : 0u);
 }
+// neg_mask, with bit 3 set when the ray is not "plain" in the sense of slab_intersects_sg: origin finite, dinv finite and non-zero
+// (v_cmp_class: normal or subnormal of either sign)
+constexpr uint32_t SIGNS_NOT_PLAIN = 8u;
+__device__ __forceinline__ uint32_t neg_mask_x(const Ray &r) {
+    const bool plain = __builtin_amdgcn_class(r.dinv.x, 0x008 | 0x010 | 0x080 | 0x100) && __builtin_amdgcn_class(r.dinv.y, 0x008 | 0x010 | 0x080 | 0x100) &&
+                       __builtin_amdgcn_class(r.dinv.z, 0x008 | 0x010 | 0x080 | 0x100) && __builtin_amdgcn_class(r.o.x, 0x1F8) &&
+                       __builtin_amdgcn_class(r.o.y, 0x1F8) && __builtin_amdgcn_class(r.o.z, 0x1F8);
+    return neg_mask(r) | (plain ? 0u : SIGNS_NOT_PLAIN);
+}
+template <int N> struct IntC { static constexpr int value = N; };
 constexpr uint32_t FRAME_SAME_RAY = 0x80000000u; // level frame, third word: the level was entered without changing the ray
 
 struct Lvl { // the accel level a lane is walking
@@ -837,7 +869,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     Ray ray = root;
     double dd = dot(ray.d, ray.d);      // a of every sphere's quadratic at this level
     double four_a = 4.0 * dd;           // 4.0 * a of its discriminant b*b - 4.0*a*c (core/math.rs:16: (4.0 * a) * c)
-    uint32_t negmask = neg_mask(ray);   // dir_is_neg (bvh.rs:463)
+    uint32_t negmask = neg_mask_x(ray); // dir_is_neg (bvh.rs:463), + SIGNS_NOT_PLAIN
     uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0, lcb = 0;
     uint32_t state = ST_NODE;
     // ---- PRUNE: per-axis limits of the level the lane is in, and the level's margin
@@ -876,7 +908,13 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         // ---- phase A: interior nodes (bvh.rs:471-505), until no lane of the wave is at a node
         // (loops are written with their wave-uniform condition in a variable tested at the bottom: hipcc then keeps the
         // loop-carried state in place instead of copying it in and out of the loop on every trip)
-        bool more_nodes = wave_any(state == ST_NODE);
+        // The step comes in nine forms: SG = 0..7 for a wave whose lanes at a node all carry the same sign triple of dinv and are
+        // "plain" (slab_intersects_sg: six of the slab test's ten min / max are then decided by the signs and cost nothing), SG = 8
+        // the reference's formula as written.  Which one runs is a scalar decision per entry into this phase: a lane's ray, and
+        // with it its signs, only changes between phases.
+        auto node_phase = [&](auto sgc) __attribute__((always_inline)) {
+        constexpr int SG = decltype(sgc)::value;
+        bool more_nodes = true;
         while (more_nodes) {
 #ifdef LG_STAMPS
             stamp_cnt[5] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_NODE));
@@ -917,13 +955,17 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     // the reference's test, and the node is skipped as well when on some axis the ray reaches its slab only beyond
                     // the limit (+ that axis's margin); never a node over a nested accel
                     double tx, ty, tz;
-                    hit = slab_intersects_nc_axes(bmin, bmax, ray, tx, ty, tz);
+                    if (SG < 8) hit = slab_intersects_sg<SG & 7>(bmin, bmax, ray, tx, ty, tz);
+                    else hit = slab_intersects_nc_axes(bmin, bmax, ray, tx, ty, tz);
                     const bool beyond = tx > plim.x || ty > plim.y || tz > plim.z; // (a NaN entry parameter compares false)
                     hit = hit && !(beyond && (w_meta & NODE_NOPRUNE) == 0u);
+                } else if (SG < 8) {
+                    double tx, ty, tz;
+                    hit = slab_intersects_sg<SG & 7>(bmin, bmax, ray, tx, ty, tz);
                 } else hit = slab_intersects_nc(bmin, bmax, ray);
                 if (COUNT) { cnt.nodes++; dbg_event(P, 2.0 + (hit ? 0.1 : 0.0), (double)L.accel, (double)cur, (double)w_meta); }
                 const bool leaf = (int32_t)w_meta < 0;            // n_primitives > 0 (bvh.rs:475): the builder emits no empty leaf
-                const bool neg = (negmask & w_meta) != 0u;        // dir_is_neg[axis] (bvh.rs:496)
+                const bool neg = ((SG < 8 ? (uint32_t)SG : negmask) & w_meta) != 0u; // dir_is_neg[axis] (bvh.rs:496); w_meta carries 1 << axis, never bit 3
                 const uint32_t first = cur + (LDSS ? LDS_NODE_BYTES : 1u), second = w_link; // the two children (interior nodes)
                 const uint32_t near_node = neg ? second : first, far_node = neg ? first : second;
                 const bool leaf_hit = hit && leaf, interior_hit = hit != leaf_hit;
@@ -940,6 +982,28 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
             stamp_cnt[6] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_DONE));
 #endif
             more_nodes = wave_any(state == ST_NODE);
+        }
+        };
+        {
+            const unsigned long long at_node = __builtin_amdgcn_ballot_w64(state == ST_NODE);
+            if (at_node != 0ull) {
+                uint32_t sg = SIGNS_NOT_PLAIN;
+                if (!FAST && P.boxes_finite) {
+                    const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)negmask, (int)__builtin_ctzll(at_node));
+                    if (__builtin_amdgcn_ballot_w64(state == ST_NODE && negmask != n0) == 0ull) sg = n0; // (>= 8: a ray that is not plain)
+                }
+                switch (sg) {
+                case 0u: node_phase(IntC<0>{}); break;
+                case 1u: node_phase(IntC<1>{}); break;
+                case 2u: node_phase(IntC<2>{}); break;
+                case 3u: node_phase(IntC<3>{}); break;
+                case 4u: node_phase(IntC<4>{}); break;
+                case 5u: node_phase(IntC<5>{}); break;
+                case 6u: node_phase(IntC<6>{}); break;
+                case 7u: node_phase(IntC<7>{}); break;
+                default: node_phase(IntC<8>{}); break;
+                }
+            }
         }
         LG_STAMP(1);
         // ---- phase B: leaf primitives in order[] sequence (bvh.rs:481-488)
@@ -1055,7 +1119,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 ray = accel_local_ray<LDSS>(P, scn, enter, ray);
                 dd = dot(ray.d, ray.d);
                 four_a = 4.0 * dd;
-                negmask = neg_mask(ray);
+                negmask = neg_mask_x(ray);
             }
             if (FAST && (L.flags & AF_MESH)) tri = tri_setup(ray);
             if (PRUNE) prune_level();
@@ -1092,7 +1156,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     }
                     dd = dot(ray.d, ray.d);
                     four_a = 4.0 * dd;
-                    negmask = neg_mask(ray);
+                    negmask = neg_mask_x(ray);
                 }
                 if (PRUNE) prune_level();
                 if (li < le) state = ST_LEAF;

@@ -37,7 +37,8 @@ FULL = {
 # prune: the pruned form of the reference walk (lg_accel_set_prune; these scenes' default) against the plain one
 ORGANISATIONS = [("megakernel", 0, True, False, False), ("wavefront", 2, True, False, False),
                  ("megakernel-pruned", 0, True, False, True), ("wavefront-pruned", 2, True, False, True),
-                 ("megakernel-fast", 0, True, True, False), ("wavefront-fast", 2, True, True, False)]
+                 ("megakernel-fast", 0, True, True, False), ("wavefront-fast", 2, True, True, False),
+                 ("queue", 3, True, False, False), ("queue-pruned", 3, True, False, True)]
 
 
 @pytest.mark.parametrize("name", list(FULL))
@@ -115,7 +116,7 @@ def test_rect_and_pixel_list_agree_with_the_film():
     """lg_capture_rect / lg_capture_pixels address the same pixels as the film (ragged sizes, every organisation)."""
     w, h = 203, 117
     acc = G.Accel(S.kitchen_sink_scene(G))
-    for streaming in (0, 2):
+    for streaming in (0, 2, 3):
         G.set_streaming(acc, streaming)
         film = G.Film(w, h)
         G.capture_subset(0, 1, acc, film)
@@ -143,7 +144,7 @@ def test_capture_subset_from_concurrent_threads():
     want = o.Film(w, h)
     o.capture_subset_mt(0, 1, o.Accel(S.cornell_scene(o, "glass")), want, 8)
     acc = G.Accel(S.cornell_scene(G, "glass"))
-    for streaming in (0, 2):
+    for streaming in (0, 2, 3):
         G.set_streaming(acc, streaming)
         for _ in range(3):
             buf = np.full((h, w, 4), 9, np.uint8)

@@ -44,9 +44,9 @@ GENERATORS = {
 KNIFE_EDGE = {"adversarial_prune"}
 LIBM_PIXELS_PER_SCENE = 8  # budget of libm-sensitive pixels in one knife-edge scene (measured: 31 pixels in 49,600 scenes, at most 2 in one)
 # (streaming, fast, packet, prune): megakernel and wavefront pipeline in either traversal mode, three-kernel pipeline with the
-# packet walk, and the pruned form of the reference walk in megakernel and wavefront pipeline
+# packet walk, the pruned form of the reference walk in megakernel and wavefront pipeline, and the queue organisation (3) with either walk
 ORGANISATIONS = ((0, False, False, False), (0, True, False, False), (2, False, False, False), (2, True, False, False), (2, False, True, False),
-                 (0, False, False, True), (2, False, False, True))
+                 (0, False, False, True), (2, False, False, True), (3, False, False, False), (3, False, False, True))
 
 
 @pytest.mark.parametrize("gen", sorted(GENERATORS))

@@ -1,0 +1,139 @@
+"""Multi-device paths over DISTINCT devices.  On a 1-GPU box every test here is skipped (the same paths run there against a
+repeated device: tests/test_gpu_configs.py, test_gpu_parity.py); on a node with 2, 4 or 8 GPUs they light up by themselves:
+lg_multi_capture / lg_multi_capture_device / lg_multi_capture_device_all and the default-device lg_capture over 2 / 4 / 8 devices
+against the single-device film and the CPU oracle -- interleaved 64-row blocks and contiguous row tiles, the RCCL exchange
+(ncclCommInitAll, one grouped send / recv into the root's film, all-gather form) and the LASGUN_CAPTURE_NO_RCCL=1 fall-through
+(one host thread and one D2H copy per device).  Reference: src/lib.rs:55-104 (the fan-out these replace), :110-162 (a pixel's
+value does not depend on the partition)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import lasgun_amd as la
+from oracle_lib import oracle
+
+pytestmark = pytest.mark.gpu
+G = la.api
+S = la.scenes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def ndev():
+    try:
+        return G.device_count()
+    except la.LasgunError:
+        return 0
+
+
+def need(n):
+    if ndev() < n:
+        pytest.skip("needs %d distinct HIP devices, this box has %d" % (n, ndev()))
+
+
+def oracle_film(builder, w, h):
+    o = oracle()
+    f = o.Film(w, h)
+    o.capture_subset_mt(0, 1, o.Accel(builder(o)), f, max(1, min(32, len(os.sched_getaffinity(0)))))
+    return f.pixels()
+
+
+SCENES = {"kitchen_sink": lambda api: S.kitchen_sink_scene(api), "cornell_glass": lambda api: S.cornell_scene(api, "glass")}
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+@pytest.mark.parametrize("block_rows, w, h", [(64, 256, 1024), (0, 203, 336)])
+@pytest.mark.parametrize("scene", sorted(SCENES))
+def test_multi_capture_over_distinct_devices(scene, block_rows, w, h, n):
+    """Every rank renders its share on ITS device, one grouped RCCL exchange (or device-to-device copies) puts the shares into the
+    root's film: device film, host film and -- for the interleaved blocks' case too -- the all-gather form, against the
+    single-device film and the oracle."""
+    need(n)
+    import torch
+    devices = list(range(n))
+    want = oracle_film(SCENES[scene], w, h)
+    G.set_devices([0])
+    try:
+        one = G.Film(w, h)
+        G.capture(SCENES[scene](G), one)
+        assert np.array_equal(one.pixels(), want)
+        m = G.Multi(SCENES[scene](G), devices, block_rows)
+        assert m.ranks == n
+        dev = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize(0)
+        for _ in range(2):  # tiles and communicators are reused
+            m.capture_device(w, h, dev.data_ptr())
+            assert np.array_equal(dev.cpu().numpy(), want)
+        host = G.Film.new_with_output(w, h, np.full((h, w, 4), 9, np.uint8))
+        m.capture(host)
+        assert np.array_equal(host.pixels(), want)
+        if m.uses_rccl:  # the all-gather form needs a communicator with one rank per device
+            bufs = [torch.full((h, w, 4), 7, dtype=torch.uint8, device="cuda:%d" % d) for d in devices]
+            for d in devices:
+                torch.cuda.synchronize(d)
+            m.capture_device_all(w, h, [b.data_ptr() for b in bufs])
+            for d, b in zip(devices, bufs):
+                assert np.array_equal(b.cpu().numpy(), want), d
+        m.close()
+    finally:
+        G.set_devices([0])
+
+
+def run_child(code, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+CHILD = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+         "os.environ['LASGUN_DEBUG'] = '1'\n"
+         "import numpy as np, lasgun_amd as la\n"
+         "from oracle_lib import oracle\n"
+         "G = la.api; S = la.scenes; o = oracle()\n"
+         "w, h = %d, %d\n"
+         "%s\n"
+         "film = G.Film(w, h); G.capture(S.cornell_scene(G, 'glass'), film)\n"
+         "want = o.render(S.cornell_scene(o, 'glass'), (w, h)).pixels()\n"
+         "assert np.array_equal(film.pixels(), want), int((film.pixels() != want).sum())\n"
+         "film2 = G.Film(w, h); G.capture(S.cornell_scene(G, 'glass'), film2)   # communicators are cached per device list\n"
+         "assert np.array_equal(film2.pixels(), want)\n"
+         "print('capture over', G.device_count(), 'devices ok')\n")
+
+
+@pytest.mark.parametrize("no_rccl", [False, True])
+@pytest.mark.parametrize("w, h", [(256, 1024), (131, 200)])
+def test_default_capture_splits_over_every_visible_device(w, h, no_rccl):
+    """A process that names no device: lg_capture takes every visible one (lib.rs:58-62: every core), over RCCL and over the
+    per-device fall-through -- fresh process each (the default is decided once per process)."""
+    need(2)
+    p = run_child(CHILD % (ROOT, ROOT, w, h, ""), {"LASGUN_CAPTURE_NO_RCCL": "1"} if no_rccl else None)
+    assert p.returncode == 0 and "devices ok" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_capture_over_a_named_device_list(n):
+    """lg_set_devices([0 .. n-1]) + lg_capture, fresh process, over RCCL and without."""
+    need(n)
+    for env in (None, {"LASGUN_CAPTURE_NO_RCCL": "1"}):
+        p = run_child(CHILD % (ROOT, ROOT, 192, 512, "G.set_devices(list(range(%d)))" % n), env)
+        assert p.returncode == 0 and "devices ok" in p.stdout, (env, p.stdout[-500:], p.stderr[-3000:])
+
+
+def test_bench_gathered_film_is_verified_at_n_ranks():
+    """bench.py's own launch line on as many GPUs as the box has (at most 4 here): the record carries
+    gathered_equals_single_gpu = true, the RCCL rank count and a bit_exact statement against the oracle."""
+    need(2)
+    import json
+    n = min(ndev(), 4)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(29650 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--size", "1024",
+           "--steps", "3", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["rccl_ranks"] == n and line["gathered_equals_single_gpu"] is True and line["bit_exact"] is True

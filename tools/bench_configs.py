@@ -26,7 +26,7 @@ CONFIGS = [
 
 def main():
     fast = "--fast" in sys.argv
-    org = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--org=")]  # default | megakernel | wavefront | packet
+    org = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--org=")]  # default | megakernel | wavefront | queue | packet
     org = org[0] if org else "default"
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     G.set_device(0)
@@ -42,6 +42,8 @@ def main():
             G.set_streaming(acc, 0)
         elif org == "wavefront":
             G.set_streaming(acc, 2)
+        elif org == "queue":
+            G.set_streaming(acc, 3)
         elif org == "packet":
             G.set_streaming(acc, 2); G.set_packet(acc, True)
         film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
