@@ -179,6 +179,20 @@ int lg_capture_rect(const lg_accel *, uint32_t width, uint32_t height, uint32_t 
 /* Work counters for rendering rows [y0, y1) (runs the counting kernel variant once). */
 int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, lg_stats *out);
 
+/* Audit of the pruned reference walk (lg_accel_set_prune) on real data: rows [y0, y1) are rendered once
+ * with the counting variant of the pruned walk, and every node and every run of triangles it SKIPS (although the reference's own
+ * box test passes) is also walked the reference's way.  A primitive found there that the reference would have ACCEPTED at that
+ * moment -- `t < isect.t` for a closest-hit ray (sphere.rs:86, cuboid.rs:95, triangle.rs:251), t < 1 for a shadow ray
+ * (point.rs:49) -- is a violation of the property the walk's exactness rests on: `violations` must be 0.  For the others,
+ * (t - limit) / margin is sampled (margin: the skipping rule's own, eps' * |1/d_axis|): min_slack_* = how much of the shipped
+ * margin the scene actually needed (+inf: no sample).  Reference traversal only (not the fast mode); the pruned walk is forced
+ * on for this render whatever the accel's setting. */
+typedef struct lg_prune_audit {
+    uint64_t skipped_nodes, skipped_runs, primitives, violations;
+    double min_slack_nodes, min_slack_runs;
+} lg_prune_audit;
+int lg_audit_prune(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, lg_prune_audit *out);
+
 /* Traversal mode of an accel.  0 (default) = the reference's own traversal over the reference's
  * own BVH: the parity path.  1 = opt-in FAST mode: a binned-SAH BVH (one primitive per leaf)
  * over the same primitives, front-to-back with pruning beyond the best hit; same primitive tests

@@ -45,6 +45,7 @@ _EXTRA = {
     "capture_radiance": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
     "capture_pixels": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p, _C.c_size_t, _C.c_void_p, _C.c_void_p]),
     "capture_rect": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_void_p, _C.c_void_p]),
+    "audit_prune": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
     "capture_stats": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.POINTER(CStats)]),
     "profile_enable": (None, [_C.c_void_p, _C.c_int]),
     "profile_read_kinds": (_C.c_int, [_C.c_void_p, _C.c_double * 5, _C.c_uint64 * 5]),
@@ -203,6 +204,17 @@ class HipApi(Api):
         if self.call("capture_stats", accel.h, w, h, y0, h if y1 is None else y1, _C.byref(s)):
             raise LasgunError(self.last_error())
         return s.as_dict()
+
+    def audit_prune(self, accel, w, h, y0=0, y1=None):
+        """Audit of the pruned reference walk on rows [y0, y1) (include/lasgun_hip.h, lg_audit_prune): every node / run it skips
+        is also walked the reference's way; `violations` (skipped primitives the reference would have accepted) must be 0."""
+        class _A(_C.Structure):
+            _fields_ = [("skipped_nodes", _C.c_uint64), ("skipped_runs", _C.c_uint64), ("primitives", _C.c_uint64), ("violations", _C.c_uint64),
+                        ("min_slack_nodes", _C.c_double), ("min_slack_runs", _C.c_double)]
+        r = _A()
+        if self.call("audit_prune", accel.h, w, h, y0, h if y1 is None else y1, _C.byref(r)):
+            raise LasgunError(self.last_error())
+        return {k: getattr(r, k) for k, _ in _A._fields_}
 
     def capture_stats_kind(self, accel, w, h, kind, y0=0, y1=None):
         """Work counters of one kind of traversal: 1 = closest-hit (primary/secondary), 2 = shadow."""

@@ -582,6 +582,12 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
     if (chunk_tiles > cap_limit) chunk_tiles = cap_limit;
     if (chunk_tiles < 1) chunk_tiles = 1;
     if (chunk_tiles > P0.ntiles) chunk_tiles = P0.ntiles;
+    if (chunk_tiles < P0.ntiles && P0.mode == 0u && P0.tiles_x != 0u && chunk_tiles >= (unsigned long long)P0.tiles_x * 32ull)
+        chunk_tiles -= chunk_tiles % ((unsigned long long)P0.tiles_x * 32ull); // whole rows of 32 x 32-tile blocks: the block order applies to every chunk
+    // level 0's work items: units of a few consecutive 8x8 tiles, whose specular children the wave compacts into packets of its own
+    // (LASGUN_QUEUE_UNIT: A/B)
+    static const uint32_t unit_tiles = [] { const char *e = std::getenv("LASGUN_QUEUE_UNIT"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 64 ? (uint32_t)v : 4u; }();
+    static const bool order_blocks = [] { const char *e = std::getenv("LASGUN_QUEUE_ORDER"); return !(e && e[0] == '0'); }(); // (0: tiles in row order, one claim counter: A/B)
     const bool ldss = a.lds_scene && a.ldss_blocks;
     const uint32_t blocks_cap = ldss ? a.ldss_blocks : a.queue_blocks;
     const unsigned long long threads = (unsigned long long)blocks_cap * (ldss ? 1024ull : 256ull);
@@ -642,13 +648,20 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
         P.accum = K.accum;
         P.wf_levels = levels;
         P.q_ctl = c.wf_counters.p; P.q_ready = c.wf_counters.p + QC_WORDS;
+        P.q_unit_tiles = levels > 1 ? unit_tiles : 1u;
+        // the tile sequence: rectangles whose chunk is whole tile rows go block by block, XCD by XCD (k_queue.hip, q_seq_tile)
+        P.q_order = (order_blocks && !ldss && P.mode == 0u && P.tiles_x != 0u && t0 % P.tiles_x == 0u && P.ntiles % P.tiles_x == 0u) ? 1u : 0u;
+        P.q_tiles_y = P.q_order ? P.ntiles / P.tiles_x : 0u;
+        P.q_blocks_x = P.q_order ? (P.tiles_x + 31u) / 32u : 0u;
+        P.q_seq_len = P.q_order ? P.q_blocks_x * ((P.q_tiles_y + 31u) / 32u) * 1024u : P.ntiles;
+        P.q_units = (P.q_seq_len + P.q_unit_tiles - 1u) / P.q_unit_tiles;
         for (uint32_t d = 0; d < levels; ++d) { P.q_rays[d] = K.q[d]; P.q_out[d] = K.out[d]; P.q_spec[d] = K.spec[d]; P.q_child[d] = K.child[d]; }
         P.stash = c.stash.p; P.frame_threads = threads;
         if (ldss) {
             P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
             P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
         }
-        const uint32_t blocks = ldss ? blocks_cap : std::min(blocks_cap, (P.ntiles + 3u) / 4u);
+        const uint32_t blocks = ldss ? blocks_cap : std::min(blocks_cap, (P.q_units + 3u) / 4u);
         const size_t nready_now = nready;
         for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
             P.sample_index = sidx;
@@ -1480,6 +1493,30 @@ static int capture_stats_impl(const lg_accel *a, uint32_t w, uint32_t h, uint32_
     });
 }
 
+int lg_audit_prune(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, lg_prune_audit *out) {
+    return guarded([&] {
+        if (y1 > h || y0 > y1) throw Error("bad row range");
+        if (!out) throw Error("out is NULL");
+        std::lock_guard<std::mutex> g(a->mtx);
+        if (a->fast) throw Error("the audit is of the pruned REFERENCE walk: not available in fast mode");
+        use_device(a->device);
+        DParams P = base_params(*a, w, h);
+        set_rect(P, 0, y0, w, y1);
+        P.out_row0 = y0;
+        P.prune = 1u; P.audit = std::getenv("LASGUN_AUDIT_SABOTAGE") ? 2u : 1u; // (2: the walk skips by an unsound rule on purpose -- the audit's self-test)
+        enqueue(*a, P, true, a->stream);
+        DStats s;
+        HIP_TRY(hipMemcpyAsync(&s, a->stats.p, sizeof s, hipMemcpyDeviceToHost, a->stream));
+        sync_checked(*a);
+        auto slack = [](unsigned long long stored) { // (complemented bits, 0 = no sample: k_mega.hip)
+            if (stored == 0ull) return (double)INFINITY;
+            const unsigned long long bits = ~stored;
+            double v; std::memcpy(&v, &bits, sizeof v);
+            return v;
+        };
+        *out = lg_prune_audit{s.audit_nodes, s.audit_runs, s.audit_prims, s.audit_violations, slack(s.audit_slack_nodes), slack(s.audit_slack_runs)};
+    });
+}
 int lg_accel_set_lds_scene(const lg_accel *a, int enabled) {
     std::lock_guard<std::mutex> lk(a->mtx);
     a->lds_scene = enabled != 0;

@@ -155,11 +155,12 @@ struct alignas(16) DAccel {
 // Control words of the queue organisation (DParams::q_ctl).  Every word that many waves hammer sits on a 128-byte line of its own
 // (agent-scope atomics and sc1 polls are served per line, ~88 per microsecond: MI355X_MICROARCH.md): header [QC_FINISHED] every
 // level is done, [QC_ERROR] a wave gave up waiting (a scheduler bug: reported by the host, never silent); then QC_LEVEL_WORDS
-// words per level d at QC_LEVEL0 + QC_LEVEL_WORDS * d: [QC_COUNT] rays appended so far, [QC_CLAIMED] packets handed out,
+// words per level d at QC_LEVEL0 + QC_LEVEL_WORDS * d: [QC_COUNT] packets reserved so far (level 0: unused), [QC_CLAIMED] tickets handed out (level 0: units),
 // [QC_STATE, +1] one 64-bit word (packets of the level + 1) << 32 | packets done -- the high half is added when the count is final.
-// Ready words (DParams::q_ready), one per 64-ray packet of the levels >= 1: rays written so far; 64 = claimable; the last, partial
-// packet of a level is marked QR_LAST | its ray count once the level above has finished.
-constexpr uint32_t QC_FINISHED = 0u, QC_ERROR = 32u, QC_LEVEL0 = 128u, QC_LEVEL_WORDS = 128u, QC_COUNT = 0u, QC_CLAIMED = 32u, QC_STATE = 64u;
+// Ready words (DParams::q_ready), one per 64-ray packet of the levels >= 1: QR_LAST | its ray count once the wave that filled it has
+// stored its rays (a packet has one producer and is published whole).
+constexpr uint32_t QC_FINISHED = 0u, QC_ERROR = 32u, QC_HEADS = 64u /* level 0: one claim counter per XCD band, 32 words apart */, QC_LEVEL0 = 384u,
+                   QC_LEVEL_WORDS = 128u, QC_COUNT = 0u, QC_CLAIMED = 32u, QC_STATE = 64u;
 constexpr uint32_t QC_MAX_LEVELS = 8u;
 constexpr uint32_t QC_WORDS = QC_LEVEL0 + QC_LEVEL_WORDS * QC_MAX_LEVELS;
 constexpr uint32_t QR_LAST = 0x80000000u;
@@ -168,6 +169,9 @@ constexpr uint32_t QR_SLACK = 16u; // spare ready words behind every level's (th
 struct DStats { // per-launch counters (stats kernel variant only)
     unsigned long long primary_rays, shadow_rays, secondary_rays, nodes_tested, spheres_tested, cuboids_tested,
         triangles_tested, accel_entries, hits;
+    // audit of the pruned walk (DParams::audit): skipped nodes / runs, primitives below them that yield a t, those the reference
+    // would have accepted (must be 0), smallest (t - limit) / margin among the rest (complemented f64 bits, kept with atomicMax; 0 = no sample)
+    unsigned long long audit_nodes, audit_runs, audit_prims, audit_violations, audit_slack_nodes, audit_slack_runs;
 };
 
 // Per-frame record of the explicit Whitted recursion stack (integrate.rs:69-79), in doubles.
@@ -270,6 +274,10 @@ struct DParams {
     // of every level >= 1: how many of its rays have been written
     uint32_t *q_ctl;
     uint32_t *q_ready;
+    uint32_t q_units, q_unit_tiles; // level 0's work items: units of q_unit_tiles consecutive 8x8 tiles of the tile SEQUENCE
+    // the tile sequence: q_order 0 = the tiles in row order (any addressing mode); 1 (rectangles) = blocks of 32 x 32 tiles in row
+    // order, Morton order inside a block, the sequence cut into 8 contiguous bands claimed XCD by XCD (k_queue.hip, q_seq_tile)
+    uint32_t q_order, q_blocks_x, q_tiles_y, q_seq_len;
     double *q_rays[8];
     double *q_out[8];
     double *q_spec[8];
@@ -288,6 +296,7 @@ struct DParams {
     uint32_t lds_accel_off;                 // LDS_ACCEL_UNITS units per accel: what the walk needs of a DAccel (see LDS_ACCEL_UNITS)
     unsigned long long *stamp_counts; // diagnostic build (-DLG_STAMPS) only
     uint32_t stats_filter;      // counting variant: 0 = all traversals, 1 = closest-hit (primary/secondary) only, 2 = shadow only
+    uint32_t audit;             // counting variant: also audit what the pruned walk skips (walk.h, audit_prim)
 };
 
 } // namespace lg

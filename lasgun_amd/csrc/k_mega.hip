@@ -236,6 +236,16 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
         atomicAdd(&P.stats->triangles_tested, (unsigned long long)cnt.triangles);
         atomicAdd(&P.stats->accel_entries, (unsigned long long)cnt.entries);
         atomicAdd(&P.stats->hits, (unsigned long long)cnt.hits);
+        if (P.audit) {
+            atomicAdd(&P.stats->audit_nodes, (unsigned long long)cnt.a_nodes);
+            atomicAdd(&P.stats->audit_runs, (unsigned long long)cnt.a_runs);
+            atomicAdd(&P.stats->audit_prims, (unsigned long long)cnt.a_prims);
+            atomicAdd(&P.stats->audit_violations, (unsigned long long)cnt.a_viol);
+            // (the slacks of non-violating primitives are >= 0, so their f64 bit patterns order like the numbers; the record starts
+            // zeroed, so the MINIMUM is kept as the maximum of the complemented bits: 0 = no sample)
+            atomicMax(&P.stats->audit_slack_nodes, ~(unsigned long long)__double_as_longlong(fmax_(cnt.a_slack_n, 0.0)));
+            atomicMax(&P.stats->audit_slack_runs, ~(unsigned long long)__double_as_longlong(fmax_(cnt.a_slack_r, 0.0)));
+        }
     }
 }
 

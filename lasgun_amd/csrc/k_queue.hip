@@ -6,29 +6,31 @@ namespace lg {
 // ------------------------------------------------------------------------------------------
 // Why a third organisation.  On scenes whose rays are long, uneven walks -- a 100k-triangle mesh in the
 // reference's 254-triangle leaves -- a wave is busy for a millisecond or more with one 8x8 tile.  The megakernel gives every lane
-// its pixel's whole ray tree (integrate.rs:23-132): deep levels run with a few lanes of the wave, the recursion state lives in
-// 300-500 spilled registers, and their scratch traffic competes with the scene tables for the L2.  The level-by-level pipeline
-// packs every level's rays into full waves, but each of its ~15 launches per chunk ends with a tail as long as its slowest wave.
-// Here ONE launch does both: its waves pull 64-ray PACKETS from per-level queues -- level 0's packets are the chunk's 8x8 pixel
-// tiles, level d + 1's are filled by level d's specular hits (ballot + prefix appends, as in wf_shade_kernel) -- and a packet is
-// taken through closest hit -> shading frame -> per-light any-hit -> radiance -> children by the wave that claimed it, with ONE
-// traversal call site in a wave-uniform job loop: what is live across a walk is a ray and a few words.  Deepest non-empty level
-// first, so the expensive secondary rays start early and the launch has one tail, not fifteen.  The levels are then combined
-// bottom-up by wf_combine_kernel (integrate.rs:79, 103, 129), exactly as in the level-by-level pipeline: same arrays, same order
-// of operations -- every f64 comes from the same expression in all three organisations.
+// its pixel's whole ray tree (integrate.rs:23-132): deep levels run with the few lanes of the tile that hit glass, the recursion
+// state lives in 300-500 spilled registers.  The level-by-level pipeline packs every level's rays into full waves, but each of its
+// ~15 launches per chunk ends with a tail as long as its slowest wave, and a queue filled by whoever appends next packs rays from
+// all over the film into one wave: incoherent, and the walk's wave-uniform phases then serialise (measured, round 4: such packets
+// cost 1.4 x the megakernel's sparse ones).  Here ONE launch does it: its waves pull work from per-level queues, deepest level
+// first -- level 0's work items are UNITS of a few neighbouring 8x8 pixel tiles, deeper levels' are 64-ray PACKETS -- and
+//   * a unit / packet is taken through closest hit -> shading frame -> per-light any-hit -> radiance -> children by the wave that
+//     claimed it, with ONE traversal call site in a wave-uniform job loop: what is live across a walk is a ray and a few words;
+//   * the specular children of a unit are COMPACTED BY THE WAVE ITSELF (ballot + prefix, as in wf_shade_kernel) into packets it
+//     owns until they are published: reflected and refracted rays apart, neighbours together -- full waves of coherent rays
+//     wherever a 32 x 8 pixel strip is mostly glass; a deeper packet's children go out as that packet's own one or two packets;
+//   * every published packet is complete (its ready word carries its ray count), so no wave ever waits for another's appends.
+// The levels are then combined bottom-up by wf_combine_kernel (integrate.rs:79, 103, 129), exactly as in the level-by-level
+// pipeline: same arrays, same order of operations -- every f64 comes from the same expression in all three organisations.
 //
-// Scheduling state (DParams::q_ctl, QC_*; every hot word on a 128-byte line of its own): per level a ray count (appends), a claim
-// counter and one 64-bit word (packets + 1) << 32 | packets done; per packet of the levels >= 1 a ready word.  A packet may be
-// claimed when its ready word says all its rays are written: 64, or QR_LAST | n for the last, partial packet of a level, set by
-// the wave that saw the level above complete.  Hand-off of the ray data between waves on different CUs / XCDs (MI355X_MICROARCH.md,
+// Scheduling state (DParams::q_ctl, QC_*; every hot word on a 128-byte line of its own): per level a packet count (reservations), a
+// ticket counter and one 64-bit word (packets + 1) << 32 | packets done; per packet of the levels >= 1 a ready word, QR_LAST | rays
+// once its rays are written.  Hand-off of the ray data between waves on different CUs / XCDs (MI355X_MICROARCH.md,
 // inter-workgroup visibility): the producer stores the rays WRITE-THROUGH (agent-scope relaxed atomic stores: global_store sc1;
 // a release fence would write back the XCD's whole dirty L2 -- megabytes of parked frames and results -- per packet), waits for
-// them (s_waitcnt vmcnt(0)), then raises the ready words with agent atomics; the consumer polls with relaxed agent loads, claims
-// by compare-and-swap, runs an agent-scope acquire and reads the rays.  Exactly one atomic operation on a level's 64-bit word
-// observes "count final and every packet done"; that wave marks the next level's last packet and publishes its packet count.
-// Level 0's packets are counted per wave and flushed when the wave turns to a deeper level or finds the tiles exhausted: one
-// atomic per tile (the claim), as in the megakernel.  Every wave leaves through QC_FINISHED (or, should the protocol ever stall,
-// through the poll limit with QC_ERROR set -- reported by the host, never silent).
+// them (s_waitcnt vmcnt(0)), then stores the ready word the same way; the consumer polls with relaxed agent loads, runs an
+// agent-scope acquire and reads the rays.  Exactly one atomic operation on a level's 64-bit word observes "count final and every
+// packet done"; that wave publishes the next level's packet count.  Level 0's units are counted per wave and flushed when the
+// wave turns to a deeper level or finds the units exhausted: one atomic per unit (the claim).  Every wave leaves through
+// QC_FINISHED (or, should the protocol ever stall, through the poll limit with QC_ERROR set -- reported by the host, never silent).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t q_lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -42,28 +44,100 @@ __device__ __forceinline__ uint32_t *q_ready(const DParams &P, uint32_t d) { // 
 constexpr uint32_t Q_EXIT = 0xFFFFFFFEu;
 constexpr uint32_t Q_POLL_LIMIT = 1u << 21; // polls of an idle wave (>= 30 microseconds each with the back-off) before it gives up: a minute or so
 
-// a level is complete: the next level's count is final; cascades through empty levels; the last level sets QC_FINISHED
+// a level is complete: the next level's packet count is final; cascades through empty levels; the last level sets QC_FINISHED
 __device__ __forceinline__ void q_level_complete(const DParams &P, uint32_t d) {
     for (;;) {
         if (d + 1u >= P.wf_levels) { __hip_atomic_store(P.q_ctl + QC_FINISHED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
         uint32_t *L = q_level(P, d + 1u);
-        // every append of level d's packets was performed before the "done" that led here (the appending lane waited for its
-        // atomics before counting its packet): the count is final, and so is the last packet's ready word
-        const uint32_t c = q_load(L + QC_COUNT);
-        const uint32_t npk = (c + 63u) >> 6;
-        if (c & 63u) atomicOr(q_ready(P, d + 1u) + (c >> 6), QR_LAST);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // every reservation of level d's work items was performed before the "done" that led here (a reservation returns its
+        // packet number to the lane that then counts the item): the count is final
+        const uint32_t npk = q_load(L + QC_COUNT);
         const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(L + QC_STATE), (unsigned long long)(npk + 1u) << 32);
         if ((uint32_t)old != npk) return; // packets of level d + 1 still out: the last of them will find the count final
         ++d;
     }
 }
-// `n` packets of level d have been taken through: count them; the one call that completes the level publishes the next
-__device__ __forceinline__ void q_packets_done(const DParams &P, uint32_t d, uint32_t n) {
+// `n` work items of level d have been taken through: count them; the one call that completes the level publishes the next
+__device__ __forceinline__ void q_items_done(const DParams &P, uint32_t d, uint32_t n) {
     const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(q_level(P, d) + QC_STATE), (unsigned long long)n);
     const uint32_t done = (uint32_t)old + n, target1 = (uint32_t)(old >> 32);
-    const bool complete = d == 0u ? done == P.ntiles : (target1 != 0u && done == target1 - 1u);
+    const bool complete = d == 0u ? done == P.q_units : (target1 != 0u && done == target1 - 1u);
     if (complete) q_level_complete(P, d);
+}
+
+// Level 0's tile sequence.  Which tiles are in flight together decides what the L2s must hold: 4096 waves on 4096 consecutive tiles
+// in row order cover a band of the film 64 pixels high and as wide as the film -- across the whole mesh -- and every XCD's L2 sees
+// all of it.  q_order 1: the film in blocks of 32 x 32 tiles (256 x 256 pixels), Morton order inside a block, and the sequence in
+// eight contiguous bands, one per XCD (HW_REG_XCC_ID; a wave whose band is exhausted moves on to the next for good): the 512 waves
+// of an XCD then work on half a block, a compact patch of the scene that its own 4 MiB L2 keeps.  Where a tile is rendered never
+// changes what is rendered.
+__device__ __forceinline__ uint32_t q_compact_bits(uint32_t x) { // bits 0, 2, 4, ... of x, packed
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    return (x | (x >> 8)) & 0x0000FFFFu;
+}
+__device__ __forceinline__ uint32_t q_seq_tile(const DParams &P, uint32_t s) { // sequence index -> tile of the chunk (NO_TILE: a hole of the block grid)
+    if (P.q_order == 0u) return s < P.ntiles ? s : NO_TILE;
+    const uint32_t block = s >> 10, w = s & 1023u;
+    const uint32_t tx = (block % P.q_blocks_x) * 32u + q_compact_bits(w), ty = (block / P.q_blocks_x) * 32u + q_compact_bits(w >> 1);
+    return tx < P.tiles_x && ty < P.q_tiles_y ? ty * P.tiles_x + tx : NO_TILE;
+}
+// the next unit of level 0 for this wave (lane 0 only); `band` / `left`: the wave's place among the XCD bands
+__device__ __forceinline__ uint32_t q_claim_unit(const DParams &P, uint32_t &band, uint32_t &left) {
+    if (P.q_order == 0u) {
+        if (left == 0u) return NO_TILE;
+        const uint32_t k = atomicAdd(q_level(P, 0u) + QC_CLAIMED, 1u);
+        if (k < P.q_units) return k;
+        left = 0u;
+        return NO_TILE;
+    }
+    while (left != 0u) {
+        const uint32_t lo = (uint32_t)(((unsigned long long)band * P.q_units) / TILE_HEADS), hi = (uint32_t)(((unsigned long long)(band + 1u) * P.q_units) / TILE_HEADS);
+        const uint32_t t = atomicAdd(P.q_ctl + QC_HEADS + band * 32u, 1u);
+        if (t < hi - lo) return lo + t;
+        band = (band + 1u) & (TILE_HEADS - 1u); // this band is done (for every wave: its head only grows)
+        --left;
+    }
+    return NO_TILE;
+}
+
+// A packet of the next level that this wave is filling: it owns the slot from the reservation to the publication.
+struct OpenPacket {
+    uint32_t pkt;  // its number in the level (NO_TILE: none open)
+    uint32_t fill; // rays placed so far
+};
+__device__ __forceinline__ uint32_t q_reserve(const DParams &P, uint32_t level, uint32_t lane) {
+    uint32_t k = 0u;
+    if (lane == 0u) k = atomicAdd(q_level(P, level) + QC_COUNT, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+}
+// Slots in `level` for the lanes of `mask` (at most 64): the open packet first, a newly reserved one for what does not fit.
+// Returns this lane's ray index in the level (meaningful for the lanes of `mask`); `full` = the packet that this call filled up
+// (NO_TILE: none) -- the caller publishes it once the rays are stored.
+__device__ __forceinline__ uint32_t q_place(const DParams &P, uint32_t level, OpenPacket &op, unsigned long long mask, uint32_t lane, uint32_t &full) {
+    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+    full = NO_TILE;
+    if (n == 0u) return 0u;
+    if (op.pkt == NO_TILE) { op.pkt = q_reserve(P, level, lane); op.fill = 0u; }
+    const uint32_t room = 64u - op.fill, rank = q_lanes_below(mask);
+    uint32_t idx = op.pkt * 64u + op.fill + rank;
+    if (n < room) op.fill += n;
+    else {
+        full = op.pkt;
+        if (n > room) {
+            const uint32_t k = q_reserve(P, level, lane);
+            if (rank >= room) idx = k * 64u + (rank - room);
+            op.pkt = k; op.fill = n - room;
+        } else { op.pkt = NO_TILE; op.fill = 0u; }
+    }
+    return idx;
+}
+// the rays of packet `pkt` of `level` are written and have left the wave (the caller waited for them): raise its ready word
+__device__ __forceinline__ void q_publish(const DParams &P, uint32_t level, uint32_t pkt, uint32_t rays, uint32_t lane) {
+    if (pkt != NO_TILE && rays != 0u && lane == 0u)
+        __hip_atomic_store(q_ready(P, level) + pkt, QR_LAST | rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <bool LDSS, bool PRUNE>
@@ -77,17 +151,17 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
         uint4 *dst = reinterpret_cast<uint4 *>(lds_stack + P.stack_depth * stride);
         const uint4 *src = reinterpret_cast<const uint4 *>(P.lds_image);
         for (uint32_t i = tid; i < P.lds_image_n16; i += stride) dst[i] = src[i];
-        __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling packets
+        __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling work
         scn = dst;
     }
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)cnt;
     uint32_t *const ctl = P.q_ctl;
     const uint32_t levels = P.wf_levels;
     uint32_t backoff = 1u, idle = 0u;
-    bool tiles_open = true;  // level 0 still has tiles (as far as this wave knows)
-    uint32_t done0 = 0u;     // level-0 packets this wave has taken through and not yet counted
+    uint32_t band = xcc_id(), bands_left = TILE_HEADS; // level 0 still has units while bands_left != 0 (as far as this wave knows)
+    uint32_t done0 = 0u;     // level-0 units this wave has taken through and not yet counted
     // Packets of the levels >= 1 are handed out by TICKET: a wave holds at most one ticket per level -- a fetch-add on the level's
-    // claim counter gives it packet number t, for good -- and looks at that packet's own ready word whenever it wants work; packet t
+    // ticket counter gives it packet number t, for good -- and looks at that packet's own ready word whenever it wants work; packet t
     // is taken through by the holder of ticket t and nobody else.  (A compare-and-swap on "the next ready packet" lets one wave
     // through per round trip and sends the losers away: 270k deep packets of a glass torus then cost a microsecond EACH, serially.
     // Tickets are one atomic per packet on the shared word and the polls go to words no other wave reads.)  A ticket beyond the
@@ -98,9 +172,9 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
     for (uint32_t d = 0u; d < QC_MAX_LEVELS; ++d) tk[d] = NO_TICKET;
     uint32_t closed = 0u; // bit d: level d has handed out its last packet: no more tickets
     for (;;) {
-        // ---- claim a packet: the deepest level whose ticket has come up (so that the expensive secondary rays start early and the
-        // launch ends with one short tail), else the next pixel tile
-        uint32_t lvl = NO_TILE, pkt = 0u, nrays = 64u;
+        // ---- claim work: the deepest level whose ticket has come up (so that the expensive secondary rays start early and the
+        // launch ends with one short tail), else the next unit of pixel tiles
+        uint32_t lvl = NO_TILE, item = 0u, nrays = 64u;
         if (lane == 0u) {
             if (levels > 1u) {
                 uint32_t rr[QC_MAX_LEVELS];
@@ -116,17 +190,16 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
                 for (uint32_t d = QC_MAX_LEVELS - 1u; d >= 1u; --d) {
                     if (lvl != NO_TILE || d >= levels) continue;
                     const uint32_t r = rr[d];
-                    if (!(r == 64u || (r & QR_LAST) != 0u)) continue; // (its rays are still being written, or it does not exist yet)
-                    lvl = d; pkt = tk[d]; nrays = r & 0xFFu;
+                    if ((r & QR_LAST) == 0u) continue; // (not published yet, or it does not exist)
+                    lvl = d; item = tk[d]; nrays = r & 0xFFu;
                     tk[d] = NO_TICKET;
                 }
             }
-            if (lvl == NO_TILE && tiles_open) {
-                const uint32_t k = atomicAdd(q_level(P, 0u) + QC_CLAIMED, 1u);
-                if (k < P.ntiles) { lvl = 0u; pkt = k; }
-                else tiles_open = false;
+            if (lvl == NO_TILE && bands_left != 0u) {
+                const uint32_t k = q_claim_unit(P, band, bands_left);
+                if (k != NO_TILE) { lvl = 0u; item = k; }
             }
-            if (lvl != 0u && done0 != 0u) { q_packets_done(P, 0u, done0); done0 = 0u; } // (this wave leaves level 0, for now or for good)
+            if (lvl != 0u && done0 != 0u) { q_items_done(P, 0u, done0); done0 = 0u; } // (this wave leaves level 0, for now or for good)
             if (lvl == NO_TILE) { // nothing to do right now: are the tickets still good?  is everything done?
 #pragma unroll
                 for (uint32_t d = 1u; d < QC_MAX_LEVELS; ++d) {
@@ -149,141 +222,140 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
             continue;
         }
         backoff = 1u; idle = 0u;
-        pkt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pkt);
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
         nrays = (uint32_t)__builtin_amdgcn_readfirstlane((int)nrays);
         const uint32_t d = lvl;
         const unsigned long long cap = P.n_items << d; // SoA stride of level d's arrays
-        const unsigned long long i = (unsigned long long)pkt * 64ull + lane; // this lane's ray of level d
+        // level 0: the unit's tiles one after the other; deeper: the one packet
+        const uint32_t first = d == 0u ? item * P.q_unit_tiles : item;
+        const uint32_t last = d == 0u ? (first + P.q_unit_tiles < P.q_seq_len ? first + P.q_unit_tiles : P.q_seq_len) : item + 1u;
+        OpenPacket op_r{NO_TILE, 0u}, op_t{NO_TILE, 0u}; // the next level's packets this wave is filling: reflected / refracted children
+        if (d != 0u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the rays were written by another wave, on any CU / XCD
 
-        // ---- the ray
-        Pixel px;
-        px.active = false; px.x = 0u; px.y = 0u; px.pix = 0ull;
-        Ray ray = ray_new(V3{0.0, 0.0, 0.0}, V3{0.0, 0.0, 1.0});
-        bool valid;
-        if (d == 0u) {
-            px = pixel_of(P, P.tile0 + pkt, lane);
-            valid = px.active;
-            if (valid) ray = camera_ray(P, px.x, px.y, P.sample_index);
-        } else {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the rays were written by other waves, on any CU / XCD
-            valid = lane < nrays;
-            if (valid) {
-                const double *q = P.q_rays[d] + i;
-                ray = ray_new(V3{q[0 * cap], q[1 * cap], q[2 * cap]}, V3{q[3 * cap], q[4 * cap], q[5 * cap]}); // Ray3::new (ray.rs:28-33)
+        for (uint32_t seq = first; seq < last; ++seq) {
+            const uint32_t pkt = d == 0u ? q_seq_tile(P, seq) : seq; // level 0: the tile behind this place of the sequence
+            if (pkt == NO_TILE) continue;
+            const unsigned long long i = (unsigned long long)pkt * 64ull + lane; // this lane's ray of level d
+            // ---- the ray
+            Pixel px;
+            px.active = false; px.x = 0u; px.y = 0u; px.pix = 0ull;
+            Ray ray = ray_new(V3{0.0, 0.0, 0.0}, V3{0.0, 0.0, 1.0});
+            bool valid;
+            if (d == 0u) {
+                px = pixel_of(P, P.tile0 + pkt, lane);
+                valid = px.active;
+                if (valid) ray = camera_ray(P, px.x, px.y, P.sample_index);
+            } else {
+                valid = lane < nrays;
+                if (valid) {
+                    const double *q = P.q_rays[d] + i;
+                    ray = ray_new(V3{q[0 * cap], q[1 * cap], q[2 * cap]}, V3{q[3 * cap], q[4 * cap], q[5 * cap]}); // Ray3::new (ray.rs:28-33)
+                } else if (d + 1u < levels) P.q_child[d][i] = WF_MISS; // a slot past the packet's rays: nothing for the combine pass to follow
             }
-        }
 
-        // ---- li() of the packet (integrate.rs:23-80): job 0 = closest hit, job 1 + l = any-hit towards light l (one call site)
-        bool hit = false;
-        uint32_t vis = 0u;
-        V3 hit_p = vzero();
-        Shade sh;
-        sh.mat = 0;
-        for (uint32_t job = 0u; job <= P.nlights; ++job) {
-            const bool shadow = job != 0u;
-            if (shadow && !wave_any(hit)) break;
-            Ray tray = ray;
-            if (shadow && hit) {
-                const DLight L = P.lights[job - 1u];
-                tray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
-            }
-            Best b;
-            b.ref = NO_HIT; b.t = INFINITY; b.accel = 0u;
-            if (shadow ? hit : valid) walk<LDSS, false, PRUNE>(P, tray, shadow, stack, stride, b, scn, cnt);
-            if (!shadow) {
-                hit = valid && b.ref != NO_HIT;
-                if (hit) {
-                    shade_frame(P, ray, b, sh); // resolve_hit + SurfaceInteraction::from, after the walk
-                    hit_p = sh.p;               // interaction.p + p_err (integrate.rs:40)
-                    if (P.nlights > 0u) stash_put(P, gtid, sh); // parked across the shadow walks
-                } else if (valid) { // integrate.rs:26-28
-                    const V3 value = background(P, normalize(ray.d));
-                    if (levels == 1u) finish_pixel(P, px, i, value);
-                    else {
-                        double *o = P.q_out[d] + i;
-                        o[0] = value.x; o[cap] = value.y; o[2 * cap] = value.z;
-                        if (d + 1u < levels) P.q_child[d][i] = WF_MISS;
-                    }
+            // ---- li() of the packet (integrate.rs:23-80): job 0 = closest hit, job 1 + l = any-hit towards light l (one call site)
+            bool hit = false;
+            uint32_t vis = 0u;
+            V3 hit_p = vzero();
+            Shade sh;
+            sh.mat = 0;
+            for (uint32_t job = 0u; job <= P.nlights; ++job) {
+                const bool shadow = job != 0u;
+                if (shadow && !wave_any(hit)) break;
+                Ray tray = ray;
+                if (shadow && hit) {
+                    const DLight L = P.lights[job - 1u];
+                    tray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
                 }
-            } else if (hit && !(b.t < 1.0)) vis |= 1u << (job - 1u); // point.rs:49
-        }
+                Best b;
+                b.ref = NO_HIT; b.t = INFINITY; b.accel = 0u;
+                if (shadow ? hit : valid) walk<LDSS, false, PRUNE>(P, tray, shadow, stack, stride, b, scn, cnt);
+                if (!shadow) {
+                    hit = valid && b.ref != NO_HIT;
+                    if (hit) {
+                        shade_frame(P, ray, b, sh); // resolve_hit + SurfaceInteraction::from, after the walk
+                        hit_p = sh.p;               // interaction.p + p_err (integrate.rs:40)
+                        if (P.nlights > 0u) stash_put(P, gtid, sh); // parked across the shadow walks
+                    } else if (valid) { // integrate.rs:26-28
+                        const V3 value = background(P, normalize(ray.d));
+                        if (levels == 1u) finish_pixel(P, px, i, value);
+                        else {
+                            double *o = P.q_out[d] + i;
+                            o[0] = value.x; o[cap] = value.y; o[2 * cap] = value.z;
+                            if (d + 1u < levels) P.q_child[d][i] = WF_MISS;
+                        }
+                    }
+                } else if (hit && !(b.t < 1.0)) vis |= 1u << (job - 1u); // point.rs:49
+            }
 
-        // ---- radiance of the hits, specular children (integrate.rs:47-77, 82-132)
-        bool has_r = false, has_t = false;
-        Sample sr, st;
-        V3 output = vzero();
-        if (hit) {
-            if (P.nlights > 0u) stash_get(P, gtid, sh, ray);
-            const DMaterial m = P.materials[sh.mat];
-            output = shade_lights(P, m, sh, vis);
-            if (d + 1u < levels && (m.kind == MAT_GLASS || m.kind == MAT_MIRROR)) { // depth < max recursion (integrate.rs:69-77)
-                if (sample_specular_transmission(m, sh, st))
-                    has_t = !(st.pdf <= 0.0 || veq(st.spectrum, vzero()) || fabs(dot(st.wi, sh.ns)) == 0.0);
-                if (sample_specular_reflection(m, sh, sr))
-                    has_r = !(sr.pdf <= 0.0 || veq(sr.spectrum, vzero()) || dot(sr.wi, sh.ns) <= 0.0);
-            }
-            if (levels == 1u) finish_pixel(P, px, i, output + vzero() + vzero()); // integrate.rs:79 with no children
-            else if (d + 1u >= levels) {
-                const V3 value = output + vzero() + vzero();
-                double *o = P.q_out[d] + i;
-                o[0] = value.x; o[cap] = value.y; o[2 * cap] = value.z;
-            }
-        }
-        if (d + 1u < levels) {
-            // children: one reservation per wave in the next level's queue, reflected rays first
-            const unsigned long long mr = __builtin_amdgcn_ballot_w64(has_r), mt = __builtin_amdgcn_ballot_w64(has_t);
-            const uint32_t nr = (uint32_t)__builtin_popcountll(mr), nt = (uint32_t)__builtin_popcountll(mt);
-            uint32_t base = 0u;
-            uint32_t *LN = q_level(P, d + 1u);
-            if (nr + nt != 0u) {
-                if (lane == 0u) base = atomicAdd(LN + QC_COUNT, nr + nt);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            }
-            const uint32_t cr = base + q_lanes_below(mr), ct = base + nr + q_lanes_below(mt);
+            // ---- radiance of the hits, specular children (integrate.rs:47-77, 82-132)
+            bool has_r = false, has_t = false;
+            Sample sr, st;
+            V3 output = vzero();
             if (hit) {
-                const unsigned long long nn = cap << 1;
-                double *o = P.q_out[d] + i;
-                o[0] = output.x; o[cap] = output.y; o[2 * cap] = output.z;
-                P.q_child[d][i] = has_r ? cr : WF_NONE;
-                P.q_child[d][cap + i] = has_t ? ct : WF_NONE;
-                double *sp = P.q_spec[d] + i;
-                if (has_r) {
-                    sp[0 * cap] = sr.spectrum.x; sp[1 * cap] = sr.spectrum.y; sp[2 * cap] = sr.spectrum.z;
-                    const V3 wr = -1.0 * sh.wo + 2.0 * dot(sh.wo, sh.ns) * sh.ns; // bxdf::util::reflect (integrate.rs:100)
-                    double *q = P.q_rays[d + 1u] + cr;
-                    q_store_wt(q + 0 * nn, sh.p.x); q_store_wt(q + 1 * nn, sh.p.y); q_store_wt(q + 2 * nn, sh.p.z);
-                    q_store_wt(q + 3 * nn, wr.x); q_store_wt(q + 4 * nn, wr.y); q_store_wt(q + 5 * nn, wr.z);
+                if (P.nlights > 0u) stash_get(P, gtid, sh, ray);
+                const DMaterial m = P.materials[sh.mat];
+                output = shade_lights(P, m, sh, vis);
+                if (d + 1u < levels && (m.kind == MAT_GLASS || m.kind == MAT_MIRROR)) { // depth < max recursion (integrate.rs:69-77)
+                    if (sample_specular_transmission(m, sh, st))
+                        has_t = !(st.pdf <= 0.0 || veq(st.spectrum, vzero()) || fabs(dot(st.wi, sh.ns)) == 0.0);
+                    if (sample_specular_reflection(m, sh, sr))
+                        has_r = !(sr.pdf <= 0.0 || veq(sr.spectrum, vzero()) || dot(sr.wi, sh.ns) <= 0.0);
                 }
-                if (has_t) {
-                    sp[3 * cap] = st.spectrum.x; sp[4 * cap] = st.spectrum.y; sp[5 * cap] = st.spectrum.z;
-                    sp[6 * cap] = fabs(dot(st.wi, sh.ns)); sp[7 * cap] = st.pdf;
-                    double *q = P.q_rays[d + 1u] + ct;
-                    q_store_wt(q + 0 * nn, sh.pm.x); q_store_wt(q + 1 * nn, sh.pm.y); q_store_wt(q + 2 * nn, sh.pm.z);
-                    q_store_wt(q + 3 * nn, st.wi.x); q_store_wt(q + 4 * nn, st.wi.y); q_store_wt(q + 5 * nn, st.wi.z);
+                if (levels == 1u) finish_pixel(P, px, i, output + vzero() + vzero()); // integrate.rs:79 with no children
+                else if (d + 1u >= levels) {
+                    const V3 value = output + vzero() + vzero();
+                    double *o = P.q_out[d] + i;
+                    o[0] = value.x; o[cap] = value.y; o[2 * cap] = value.z;
                 }
             }
-            if (nr + nt != 0u) {
-                // publish: the write-through stores above have left this wave, then the ready words of the packets the reservation
-                // [base, base + nr + nt) touches (at most three) are raised by what it put into each; the packet is counted only
-                // after those atomics have been performed (the count must never overtake them)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0u) {
-                    uint32_t *rd = q_ready(P, d + 1u);
-                    uint32_t lo = base;
-                    const uint32_t end = base + nr + nt;
-                    while (lo < end) {
-                        const uint32_t p = lo >> 6, hi = (p + 1u) << 6 < end ? (p + 1u) << 6 : end;
-                        atomicAdd(rd + p, hi - lo);
-                        lo = hi;
+            if (d + 1u < levels) {
+                // children into the packets this wave is filling at the next level: reflected and refracted rays apart
+                const unsigned long long mr = __builtin_amdgcn_ballot_w64(has_r), mt = __builtin_amdgcn_ballot_w64(has_t);
+                uint32_t full_r, full_t;
+                const uint32_t cr = q_place(P, d + 1u, op_r, mr, lane, full_r), ct = q_place(P, d + 1u, op_t, mt, lane, full_t);
+                if (hit) {
+                    const unsigned long long nn = cap << 1;
+                    double *o = P.q_out[d] + i;
+                    o[0] = output.x; o[cap] = output.y; o[2 * cap] = output.z;
+                    P.q_child[d][i] = has_r ? cr : WF_NONE;
+                    P.q_child[d][cap + i] = has_t ? ct : WF_NONE;
+                    double *sp = P.q_spec[d] + i;
+                    if (has_r) {
+                        sp[0 * cap] = sr.spectrum.x; sp[1 * cap] = sr.spectrum.y; sp[2 * cap] = sr.spectrum.z;
+                        const V3 wr = -1.0 * sh.wo + 2.0 * dot(sh.wo, sh.ns) * sh.ns; // bxdf::util::reflect (integrate.rs:100)
+                        double *q = P.q_rays[d + 1u] + cr;
+                        q_store_wt(q + 0 * nn, sh.p.x); q_store_wt(q + 1 * nn, sh.p.y); q_store_wt(q + 2 * nn, sh.p.z);
+                        q_store_wt(q + 3 * nn, wr.x); q_store_wt(q + 4 * nn, wr.y); q_store_wt(q + 5 * nn, wr.z);
+                    }
+                    if (has_t) {
+                        sp[3 * cap] = st.spectrum.x; sp[4 * cap] = st.spectrum.y; sp[5 * cap] = st.spectrum.z;
+                        sp[6 * cap] = fabs(dot(st.wi, sh.ns)); sp[7 * cap] = st.pdf;
+                        double *q = P.q_rays[d + 1u] + ct;
+                        q_store_wt(q + 0 * nn, sh.pm.x); q_store_wt(q + 1 * nn, sh.pm.y); q_store_wt(q + 2 * nn, sh.pm.z);
+                        q_store_wt(q + 3 * nn, st.wi.x); q_store_wt(q + 4 * nn, st.wi.y); q_store_wt(q + 5 * nn, st.wi.z);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (full_r != NO_TILE || full_t != NO_TILE) { // a packet filled up: its rays have left the wave, then its ready word
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    q_publish(P, d + 1u, full_r, 64u, lane);
+                    q_publish(P, d + 1u, full_t, 64u, lane);
+                }
             }
         }
-        // ---- the packet is through
+        // ---- the unit / packet is through: what is left in the open packets goes out as it is, then the item is counted (the
+        // reservations -- atomics that returned their packet numbers -- came first)
+        if (d + 1u < levels && (op_r.fill != 0u || op_t.fill != 0u)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            q_publish(P, d + 1u, op_r.pkt, op_r.fill, lane);
+            q_publish(P, d + 1u, op_t.pkt, op_t.fill, lane);
+        }
         if (lane == 0u) {
             if (d == 0u) ++done0; // counted when this wave next leaves level 0
-            else q_packets_done(P, d, 1u);
+            else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the ready words first)
+                q_items_done(P, d, 1u);
+            }
         }
     }
 }

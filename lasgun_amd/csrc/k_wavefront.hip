@@ -59,7 +59,7 @@ struct HitSlots { // work tile t of a pass over the hit queue -> hit index of th
 };
 __device__ __forceinline__ unsigned long long wf_level_rays(const DParams &P, uint32_t level) {
     if (level == 0u) return (unsigned long long)P.ntiles * 64ull;
-    return P.q_ctl ? P.q_ctl[QC_LEVEL0 + QC_LEVEL_WORDS * level + QC_COUNT] : P.wf_counts[level]; // (the queue organisation keeps its own counts)
+    return P.q_ctl ? (unsigned long long)P.q_ctl[QC_LEVEL0 + QC_LEVEL_WORDS * level + QC_COUNT] * 64ull : P.wf_counts[level]; // (the queue organisation counts 64-ray packets)
 }
 __device__ __forceinline__ HitSlots hit_slots(const DParams &P, uint32_t level, uint32_t lpt) {
     HitSlots s;

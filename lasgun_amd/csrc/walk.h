@@ -353,6 +353,11 @@ __device__ __forceinline__ void dbg_event(const DParams &P, double code, double 
 }
 struct Counters {
     uint32_t primary, shadow, secondary, nodes, spheres, cuboids, triangles, entries, hits;
+    // audit of the pruned walk (counting instantiations with DParams::audit; see audit_prim): nodes / runs it skipped although the
+    // reference's own box test passed, primitives below them put to the reference's tests, those the reference would have ACCEPTED
+    // (violations of property (P), DESIGN.md 3.4: must be 0), and the smallest (t - limit) / margin over the others
+    uint32_t a_nodes = 0u, a_runs = 0u, a_prims = 0u, a_viol = 0u;
+    double a_slack_n = INFINITY, a_slack_r = INFINITY;
 };
 
 __device__ __forceinline__ Affine load_affine(const Affine *p) { return *p; }
@@ -701,6 +706,94 @@ __device__ __forceinline__ bool chunk_culled(const ChunkRec &k, const Ray &ray, 
     }
     return skip;
 }
+// ---- audit of the pruned walk (diagnostic, counting instantiations only; lg_audit_prune) -----------------------------------------
+// Property (P) of DESIGN.md 3.4 on real data: a primitive under a node or in a run the pruned walk SKIPS must be one the reference
+// would have rejected at that moment -- `t >= isect.t` for a closest-hit ray (an exact tie inside the same fat leaf goes to the
+// lower original slot, as in mesh_leaf2), t >= 1 for a shadow ray (point.rs:49).  One that would have been accepted is a
+// violation; for the others (t - limit) / margin says how much of the shipped margin was needed.
+__device__ __forceinline__ void audit_prim(bool valid, double t, double limit, double margin, bool anyhit, bool tie_wins, Counters &cnt, double &slack) {
+    if (!valid) return;
+    cnt.a_prims++;
+    const bool accepted = anyhit ? !(t >= 1.0) : (!(t >= limit) || tie_wins);
+    if (accepted) { cnt.a_viol++; return; }
+    const double s = (t - limit) / margin;
+    if (s < slack) slack = s; // (margin == 0 or inf: +inf / 0 / NaN never lower the minimum)
+}
+// every primitive the reference reaches below node `top` of level L (its own box has passed the reference's test): no nested
+// accel can be among them (NODE_NOPRUNE keeps such nodes from being skipped)
+__device__ __noinline__ void audit_subtree(const DParams &P, uint32_t node_base, uint32_t prim_base, uint32_t top, const Ray &ray, double dd, double four_a,
+                                           double limit, double margin, bool anyhit, Counters &cnt) {
+    uint32_t st[64];
+    int sp = 0;
+    uint32_t n = top;
+    cnt.a_nodes++;
+    for (;;) {
+        const DNode *nd = P.nodes + n;
+        const bool h = n == top || slab_intersects_nc(nd->bmin, nd->bmax, ray); // cuboid.rs:104-121, as the reference walks it
+        if (h) {
+            if (nd->meta & NODE_LEAF) {
+                const uint32_t first = prim_base + nd->link, count = nd->meta & 0xFFFFu;
+                for (uint32_t slot = first; slot < first + count; ++slot) {
+                    const uint32_t ref = P.primref[slot], kind = ref >> 30;
+                    const uint4 *q = reinterpret_cast<const uint4 *>(P.leaf_soup + slot);
+                    const LeafRec g{q[0], q[1], q[2]};
+                    bool valid = false;
+                    double t = 0.0;
+                    if (kind == PK_SPHERE) { // as in traverse_ref
+                        const V3 cen{rec_f64(g.a.x, g.a.y), rec_f64(g.a.z, g.a.w), rec_f64(g.b.x, g.b.y)};
+                        const V3 l = ray.o - cen;
+                        const double b = 2.0 * dot(ray.d, l), c = dot(l, l) - rec_f64(g.c.x, g.c.y);
+                        if (dd == 0.0) { if (b != 0.0) { t = -c / b; valid = true; } }
+                        else {
+                            const double disc = b * b - four_a * c;
+                            if (!(disc < 0.0)) {
+                                const double qq = -(b + signum(b) * sqrt(disc)) / 2.0;
+                                const double r0 = qq / dd, r1 = (qq == 0.0) ? r0 : c / qq;
+                                const double t0 = fmin_(r0, r1), t1 = fmax_(r0, r1);
+                                t = t0 < 0.0 ? t1 : t0;
+                                valid = true;
+                            }
+                        }
+                        valid = valid && !(t < 0.0);
+                    } else if (kind == PK_CUBOID) {
+                        double mn[3] = {rec_f64(g.a.x, g.a.y), rec_f64(g.a.z, g.a.w), rec_f64(g.b.x, g.b.y)};
+                        double mx[3] = {rec_f64(g.b.z, g.b.w), rec_f64(g.c.x, g.c.y), rec_f64(g.c.z, g.c.w)};
+                        V3 d0, d1;
+                        valid = cuboid_hit<false>(mn, mx, ray, t, d0, d1);
+                    } else if (kind == PK_TRIANGLE) {
+                        const V3 p0{rec_f32(g.a.x), rec_f32(g.a.y), rec_f32(g.a.z)}, p1{rec_f32(g.a.w), rec_f32(g.b.x), rec_f32(g.b.y)},
+                            p2{rec_f32(g.b.z), rec_f32(g.b.w), rec_f32(g.c.x)};
+                        TriHit hh;
+                        valid = triangle_t(p0, p1, p2, ray, hh);
+                        t = hh.t;
+                    } else { cnt.a_viol++; } // a nested accel below a skipped node: the host's NODE_NOPRUNE marking failed
+                    audit_prim(valid, t, limit, margin, anyhit, false, cnt, cnt.a_slack_n);
+                }
+            } else {
+                st[sp++] = node_base + nd->link; // second child
+                n = n + 1u;                      // first child
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        n = st[--sp];
+    }
+}
+// the triangles of the leaf_soup2 slots [s0, s1) (a culled run, or the runs of a culled group) against the ray, the reference's way
+template <int KZ>
+__device__ __noinline__ void audit_run(const DParams &P, uint32_t s0, uint32_t s1, V3 o, TriSetup tri, double best_t, uint32_t best_ref, uint32_t leaf_slot,
+                                       double ekz, bool anyhit, Counters &cnt) {
+    cnt.a_runs++;
+    for (uint32_t s = s0; s < s1; ++s) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(P.leaf_soup2 + s);
+        const LeafRec r{q[0], q[1], q[2]};
+        TriHit hh;
+        const bool valid = tri_rec_t<KZ>(r, o, tri.sx, tri.sy, tri.sz, hh);
+        const bool tie_wins = valid && hh.t == best_t && best_ref != NO_HIT && leaf_slot != NO_HIT && r.c.y < leaf_slot;
+        audit_prim(valid, hh.t, anyhit ? 1.0 : best_t, ekz, anyhit, tie_wins, cnt, cnt.a_slack_r);
+    }
+}
+
 template <int KZ, bool LDSS, bool FAST = false, bool COUNT = false, bool PRUNE = false>
 __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, const Ray &ray, const TriSetup tri, uint32_t li, const uint32_t le,
                                            const uint32_t soup_delta, const uint32_t accel, const bool anyhit, Best &best, bool &tie, Counters &cnt,
@@ -771,6 +864,11 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
                     if (__builtin_amdgcn_ballot_w64(rec != rec0) == 0ull) culled_ = chunk_culled<KZ>(load_chunk_uniform(P.chunks + rec0), ray, lc, start, count);
                     else culled_ = chunk_culled<KZ>(load_chunk(P.chunks + rec), ray, lc, start, count);
 #endif
+                    if (COUNT && P.audit && culled_) { // what the skipped run (or the runs of the skipped group) would have given the reference
+                        uint32_t s0 = start, s1 = start + count;
+                        if (start == CHUNK_IS_GROUP) { s0 = P.chunks[rec + 1u].start; s1 = P.chunks[rec + count].start + P.chunks[rec + count].count; }
+                        audit_run<KZ>(P, s0, s1, o, tri, best.t, best.ref, leaf_slot, lc.ekz, anyhit, cnt);
+                    }
                     ++rec;
                     if (start == CHUNK_IS_GROUP) { if (culled_) rec += count; } // a group record: culled, its runs are stepped over; kept, they come next
                     else if (!culled_) { in_run = true; s = start; run_end = start + count; off = s * REC; } // (the array holds < 2^32 / 48 slots: checked by the host)
@@ -875,7 +973,10 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     // ---- PRUNE: per-axis limits of the level the lane is in, and the level's margin
     V3 plim{INFINITY, INFINITY, INFINITY};
     double peps = INFINITY;
-    auto prune_limits = [&](const double limit) { // limit >= 0 (every accepted t is), or +inf before the first hit
+    auto prune_limits = [&](const double limit_in) { // limit >= 0 (every accepted t is), or +inf before the first hit
+        // (audit == 2, counting instantiations only: the audit's own test -- a deliberately UNSOUND limit, half the real one, so
+        // that primitives the reference would accept do get skipped and lg_audit_prune must report them)
+        const double limit = (COUNT && P.audit == 2u) ? limit_in * 0.5 : limit_in;
         const double lb = limit + limit * PRUNE_LIMIT_REL;
         V3 m{lb + peps * fabs(ray.dinv.x), lb + peps * fabs(ray.dinv.y), lb + peps * fabs(ray.dinv.z)}; // (an axis with d == 0: +inf)
         if (L.flags & AF_MESH) { // triangles: the dominant axis alone (max_dimension as in tri_setup, triangle.rs:186)
@@ -958,6 +1059,13 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     if (SG < 8) hit = slab_intersects_sg<SG & 7>(bmin, bmax, ray, tx, ty, tz);
                     else hit = slab_intersects_nc_axes(bmin, bmax, ray, tx, ty, tz);
                     const bool beyond = tx > plim.x || ty > plim.y || tz > plim.z; // (a NaN entry parameter compares false)
+                    if (COUNT && !LDSS && P.audit && hit && beyond && (w_meta & NODE_NOPRUNE) == 0u) { // skipped although the reference would walk it
+                        double margin = INFINITY; // the smallest margin among the axes that said "beyond"
+                        if (tx > plim.x) margin = fmin_(margin, peps * fabs(ray.dinv.x));
+                        if (ty > plim.y) margin = fmin_(margin, peps * fabs(ray.dinv.y));
+                        if (tz > plim.z) margin = fmin_(margin, peps * fabs(ray.dinv.z));
+                        audit_subtree(P, L.node_base, L.prim_base, cur, ray, dd, four_a, anyhit ? 1.0 : best.t, margin, anyhit, cnt);
+                    }
                     hit = hit && !(beyond && (w_meta & NODE_NOPRUNE) == 0u);
                 } else if (SG < 8) {
                     double tx, ty, tz;

@@ -1,0 +1,91 @@
+"""Property (P) of the pruned reference walk, audited ON THE DEVICE on real data: every node and every run
+of triangles the walk skips is also walked the reference's way, and no primitive found there may be one the reference would have
+accepted at that moment (`t < isect.t`: sphere.rs:86, cuboid.rs:95, triangle.rs:251; t < 1 for a shadow ray: point.rs:49).
+Film equality (tests/test_gpu_configs.py, the fuzz campaign) only sees a violation that changes a byte; this sees every one.
+Also recorded: the smallest (t - limit) / margin over the skipped primitives -- how much of the shipped margins a scene needs."""
+import json
+import os
+
+import pytest
+
+import lasgun_amd as la
+
+pytestmark = pytest.mark.gpu
+G = la.api
+S = la.scenes
+
+
+def log(record):
+    path = os.environ.get("LASGUN_AUDIT_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(record) + "\n")
+
+
+def audit(name, acc, w, h, bands):
+    tot = None
+    for y0, y1 in bands:
+        r = G.audit_prune(acc, w, h, y0, y1)
+        if tot is None:
+            tot = r
+        else:
+            for k in ("skipped_nodes", "skipped_runs", "primitives", "violations"):
+                tot[k] += r[k]
+            for k in ("min_slack_nodes", "min_slack_runs"):
+                tot[k] = min(tot[k], r[k])
+    log(dict(tot, scene=name, film=[w, h], bands=bands))
+    assert tot["violations"] == 0, (name, tot)
+    return tot
+
+
+FULL = {
+    "config4_mesh_glass": (lambda: S.mesh_scene(G, 224, 224, "glass"), 4096),
+    "config4m_mesh_metal": (lambda: S.mesh_scene(G, 224, 224, "metal"), 4096),
+    "config5_mixed": (lambda: S.mixed_scene(G), 8192),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_configs_skip_nothing_the_reference_would_accept(name):
+    """Bands of 8 rows through the mesh, the mirror sphere, the top and the floor of the full-size BASELINE configs: primary,
+    shadow and (config 4) every level of specular rays."""
+    builder, size = FULL[name]
+    acc = G.Accel(builder())
+    bands = [(int(size * f), int(size * f) + 8) for f in (0.05, 0.3, 0.42, 0.5, 0.58, 0.7, 0.9)]
+    tot = audit(name, acc, size, size, bands)
+    assert tot["skipped_nodes"] > 10000 and tot["skipped_runs"] > 10000 and tot["primitives"] > 10000, tot  # the audit saw real work
+    assert tot["min_slack_nodes"] > 0.0 and tot["min_slack_runs"] > 0.0, tot
+
+
+def test_tie_scene_and_prune_generators_skip_nothing_the_reference_would_accept():
+    """Exact ties in t inside fat leaves (tie_mesh_scene), and the generator aimed at the pruning rules (slab meshes seen edge-on,
+    hits at the limit, spheres touching): whole small films."""
+    tot = audit("tie_mesh", G.Accel(S.tie_mesh_scene(G)), 128, 128, [(0, 128)])
+    assert tot["skipped_runs"] > 0
+    lo, hi = (int(v) for v in os.environ.get("LASGUN_AUDIT_SEEDS", "100:124").split(":"))
+    for gen in (S.adversarial_prune_scene, S.adversarial_mesh_scene, S.progression_soup_scene, S.random_scene):
+        for seed in range(lo, hi):
+            try:
+                acc = G.Accel(gen(G, seed))
+            except la.LasgunError:
+                continue  # (what the reference cannot build either)
+            audit("%s[%d]" % (gen.__name__, seed), acc, 64, 48, [(0, 48)])
+
+
+def test_the_audit_sees_violations_of_an_unsound_rule():
+    """The audit is not vacuous: LASGUN_AUDIT_SABOTAGE makes the counting walk skip by HALF the real limit (nowhere else: the
+    product kernels do not contain that line) -- primitives the reference would accept are then skipped, and the audit reports
+    them; without the switch the same scene has none, and its skipped subtrees are not empty."""
+    acc = G.Accel(S.mesh_scene(G, 64, 48, "glass"))
+    r = G.audit_prune(acc, 256, 256)
+    assert r["violations"] == 0 and r["primitives"] > 1000 and r["skipped_nodes"] > 1000, r
+    assert 0.0 < r["min_slack_nodes"] < float("inf"), r
+    os.environ["LASGUN_AUDIT_SABOTAGE"] = "1"
+    try:
+        bad = G.audit_prune(acc, 256, 256)
+    finally:
+        del os.environ["LASGUN_AUDIT_SABOTAGE"]
+    assert bad["violations"] > 100, bad
+    G.set_mode(acc, True)
+    with pytest.raises(la.LasgunError):
+        G.audit_prune(acc, 64, 64)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Config 4 (glass torus + mirror sphere) at recursion 0..3 in the megakernel and in the queue organisation: what each recursion
+level adds (ms, rays) -- where the queue organisation's time goes."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import lasgun_amd as la  # noqa: E402
+
+G, S = la.api, la.scenes
+size = int(os.environ.get("SIZE", "4096"))
+G.set_device(0)
+film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+for material in sys.argv[1:] or ["glass"]:
+    for rec in (0, 1, 2, 3):
+        scene = S.mesh_scene(G, 224, 224, material)
+        scene.set_max_recursion_depth(rec)
+        acc = G.Accel(scene)
+        row = {"material": material, "recursion": rec}
+        for org, code in (("megakernel", 0), ("queue", 3)):
+            G.set_streaming(acc, code)
+            G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)
+            torch.cuda.synchronize()
+            row[org + "_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+        st = G.capture_stats(acc, size, size)
+        row.update({k: st[k] for k in ("primary_rays", "shadow_rays", "secondary_rays", "hits", "nodes_tested", "triangles_tested")})
+        print(json.dumps(row), flush=True)
