@@ -24,7 +24,7 @@ Prints ONE JSON line on rank 0.
                 over the kernel's average duration, against 256 CUs x 4 SIMDs x 16 f64 lanes x 2.4 GHz).  The
                 SURVEY 8(d) byte figure is kept beside it (`hbm_algorithmic`: those bytes are served by the LDS-resident
                 scene and never reach HBM) together with the box's measured HBM copy rate and the LDS fraction (`lds`).
-  traffic       HBM bytes per launch of that kernel from rocprofv3 PMC passes of THIS source (profiles/r03_pmc.json
+  traffic       HBM bytes per launch of that kernel from rocprofv3 PMC passes of THIS source (profiles/r04_pmc.json
                 records the hash of the device sources it was collected on); null when they have changed since.
   cpu_baseline  the CPU oracle (a port: the Rust reference cannot be built here) timed on a bounded strided sample
                 of the same frame on this box's host cores (rank 0, N = 1 only).
@@ -149,12 +149,12 @@ def profiled_traffic(kernel_name, world, size):
     """HBM bytes per launch of `kernel_name` from the committed PMC passes, only if they were collected on these sources."""
     try:
         import lasgun_amd
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
         sha = lasgun_amd.device_source_sha16()
         t = pmc["kernels"].get(kernel_name)
         if t and pmc.get("device_source_sha16") == sha and world == 1 and size == 4096:
             # FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): doubled; both in KB
-            return (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0, "profiles/r03_pmc.json @ device sources " + sha
+            return (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0, "profiles/r04_pmc.json @ device sources " + sha
     except (OSError, KeyError, ValueError):
         pass
     return None, None
@@ -162,49 +162,64 @@ def profiled_traffic(kernel_name, world, size):
 
 def mesh_roofline(G, la, stream):
     """configs[3] (generated 100k-triangle torus of glass + mirror sphere, recursion 3, 4096^2) on this GPU, two untimed
-    frames after a warm-up: the triangle-test side of the path (the reference's 254-triangle leaves), in the traversal mode
-    the accel picks by default for such a scene (the pruned reference walk).  Counters from the counting instantiation of
-    the same walk."""
+    frames after a warm-up: the triangle-test side of the path (the reference's 254-triangle leaves), in the organisation and
+    traversal mode the accel picks by default for such a scene (round 4: the queue organisation -- every recursion level in one
+    persistent launch -- over the pruned reference walk).  Counters from the counting instantiation of the same walk."""
     size = 4096
     acc = G.Accel(la.scenes.mesh_scene(G, 224, 224, "glass"))
     film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
+
+    def frame_ms(reps=2):
+        G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    ms = frame_ms()
+    default_film = film.clone()
+    G.profile_enable(acc, True)
     G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(2):
-        G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 2 * 1e3
+    kinds = {k: v[0] / v[1] for k, v in G.profile_read_kinds(acc).items() if v[1]}
+    G.profile_read(acc)
+    G.profile_enable(acc, False)
+    kernel_ms = kinds.get("trace_kernel", ms)  # HIP events around the persistent kernel on its launch stream
     st = G.capture_stats(acc, size, size, 0, size)
     rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
     flops = algorithmic_flops(st)
-    tops = flops / (ms * 1e-3) / 1e12
-    # the same frame as the reference walks it (no node or run skipped): its work, and how long this build's plain walk takes over it
+    tops = flops / (kernel_ms * 1e-3) / 1e12
+    # the other organisations on the same frame (same bytes: checked), and the same frame as the reference walks it (no node or
+    # run skipped): its work, and how long this build's plain walk takes over it
+    G.set_streaming(acc, 0)
+    ms_mega = frame_ms()
+    same = bool(torch.equal(film, default_film))
+    G.set_streaming(acc, 1)
     G.set_prune(acc, False)
     st_ref = G.capture_stats(acc, size, size, 0, size)
-    G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
-    torch.cuda.synchronize()
-    ms_plain = (time.perf_counter() - t0) * 1e3
+    ms_plain = frame_ms(1)
     G.set_prune(acc, None)
     flops_ref = algorithmic_flops(st_ref)
-    del film
+    del film, default_film
     torch.cuda.empty_cache()
     return {"workload": "configs[3]: 4096x4096, 100,352-triangle torus (glass) in a transformed group + mirror sphere in the Cornell shell, recursion 3",
             "ms_per_frame": ms, "value": rays / ms / 1e3, "unit": "Mrays/s", "rays_per_frame": rays,
             "bound": "valu_f64", "achieved": tops, "peak": VALU_F64_PEAK_TOPS, "frac": tops / VALU_F64_PEAK_TOPS,
-            "kernel": "lg::trace_kernel<false, false, false, true>", "algorithmic_flops_per_frame": flops,
+            "kernel": "lg::queue_kernel<false, true>", "kernel_ms_avg": kernel_ms, "algorithmic_flops_per_frame": flops,
             "work_per_frame": {k: st[k] for k in ("nodes_tested", "spheres_tested", "cuboids_tested", "triangles_tested", "accel_entries", "hits")},
-            "traversal": "reference tree, pruned walk (lg_accel_set_prune default for a scene with a big mesh), megakernel",
+            "traversal": "reference tree, pruned walk (lg_accel_set_prune default for a scene with a big mesh), queue organisation (k_queue.hip: one persistent launch "
+                         "for all recursion levels + the bottom-up combine passes)",
+            "megakernel": {"ms_per_frame": ms_mega, "film_identical": same},
             "plain_walk": {"ms_per_frame": ms_plain, "algorithmic_flops_per_frame": flops_ref, "frac": flops_ref / (ms_plain * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS,
                            "triangles_tested": st_ref["triangles_tested"], "nodes_tested": st_ref["nodes_tested"]},
             "reference_work_rate_frac": flops_ref / (ms * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS,
-            "note": "one kernel per frame (megakernel): frame time = kernel time; byte-identical to the oracle in tests/test_gpu_configs.py.  `frac` prices "
-                    "the tests the pruned walk still makes (the kernel then waits on L2, not on the VALU); `plain_walk` is the same frame with every test "
-                    "the reference makes, `reference_work_rate_frac` that work over the pruned walk's time (what skipping buys, not a roofline fraction)"}
+            "note": "byte-identical to the oracle in tests/test_gpu_configs.py.  `frac` prices the tests the pruned walk still makes against the unfused f64 rate "
+                    "(profiles/r04_config4_pmc.txt: the kernel issues VALU instructions ~70 % of the time at ~59 % lane use -- it is bound by the instruction stream "
+                    "of its node, culling-record and triangle tests, not by L2); `plain_walk` is the same frame with every test the reference makes, "
+                    "`reference_work_rate_frac` that work over the pruned walk's time (what skipping buys, not a roofline fraction)"}
 
 
 def main():
@@ -260,8 +275,6 @@ def main():
     t0 = time.perf_counter()
     acc = G.Accel(scene)  # host HLBVH build + flatten + upload (outside the timed region, reported below)
     accel_build_s = time.perf_counter() - t0
-    if os.environ.get("LASGUN_PACKET"):  # A/B: one tree walk per wavefront
-        G.set_packet(acc, os.environ["LASGUN_PACKET"] == "1")
     # LASGUN_NO_LDS_SCENE=1 (A/B): the traversal kernels read the scene tables through L1/L2 instead of LDS
     lds_scene = G.set_lds_scene(acc, not os.environ.get("LASGUN_NO_LDS_SCENE")) and not os.environ.get("LASGUN_NO_LDS_SCENE")
     balanced = interleave_ok(world, h, BLOCK_ROWS)
@@ -446,10 +459,11 @@ def main():
             # wavefront pipeline: lg::wf_trace_kernel<FAST, SHADOW, scene tables resident in LDS>, lg::wf_shade_kernel
             # wavefront pipeline: lg::wf_trace_kernel<FAST, SHADOW, scene tables resident in LDS, level-0 closest pass>, lg::wf_shade_kernel<KIND, L0>
             shadow = "shadow" in dom
-            kernel_name = ("lg::wf_trace_kernel<false, %s, %s, %s, false>" % ("true" if shadow else "false", "true" if lds_scene else "false", "false" if shadow else "true")
+            pruned = "true" if G.get_prune(acc) else "false"  # (LASGUN_PRUNE / lg_accel_set_prune: the PRUNE template argument of the kernel that ran)
+            kernel_name = ("lg::wf_trace_kernel<false, %s, %s, %s, %s>" % ("true" if shadow else "false", "true" if lds_scene else "false", "false" if shadow else "true", pruned)
                            if dom.startswith("trace<") else "lg::wf_shade_kernel<0, true>")
         else:  # megakernel (a share too small for the pipeline, e.g. a small --size over many ranks)
-            dom_ms, dst, kernel_name = frame_ms, st, "lg::trace_kernel<false, false, %s, false>" % ("true" if lds_scene else "false")
+            dom_ms, dst, kernel_name = frame_ms, st, "lg::trace_kernel<false, false, %s, %s>" % ("true" if lds_scene else "false", "true" if G.get_prune(acc) else "false")
             per_kernel = {"trace_kernel": frame_ms}
         dom_bytes, dom_flops = algorithmic_bytes(dst), algorithmic_flops(dst)
         secs = dom_ms * 1e-3

@@ -211,6 +211,7 @@ int lg_accel_set_mode(const lg_accel *, int mode);
  * mesh only the ray's dominant axis counts.  -1 (default): on for scenes that carry a mesh of >= 256 triangles (the
  * reference's 254-triangle leaves are where it pays), off otherwise; 0 / 1: off / on. */
 int lg_accel_set_prune(const lg_accel *, int enabled);
+int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel default, LASGUN_PRUNE, lg_accel_set_prune, fast mode): 0 / 1 */
 
 /* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes with <= 32 lights and at least 512
  * spheres / boxes (where node and sphere tests dominate a ray; glass / mirror over a big mesh excepted) run level by level in
@@ -229,10 +230,8 @@ int lg_accel_set_streaming(const lg_accel *, int enabled);
 /* The WAVEFRONT pipeline is li() level by level: per recursion level a closest-hit pass (hits compacted into a queue, misses
  * finished on the spot), an any-hit shadow pass and a shade pass that appends the specular children to the next level's ray
  * queue, then the levels are combined bottom-up in the reference's (output + reflected) + refracted order.  It serves every
- * scene, glass / mirror included.  This switch used to select round 1's three-kernel pipeline over dense pixels instead
- * (enabled = 0); that organisation equalled the wavefront pipeline on every measured scene and was retired in round 3 --
- * the call is kept for source compatibility and changes nothing.  (lg_accel_set_packet still selects the packet organisation.) */
-int lg_accel_set_wavefront(const lg_accel *, int enabled);
+ * scene, glass / mirror included.  (lg_accel_set_wavefront and lg_accel_set_packet -- the switches of round 1's three-kernel
+ * pipeline and of the packet walk, both slower than this on every measured scene -- left the ABI in round 4.) */
 
 /* Wavefront pipeline, launches of 2 Mpixel and more: cut the launch into `bands` row bands (2..8) rendered on internal streams,
  * each with launch state of its own, so one band's closest pass fills the tails of another band's shadow and shade passes
@@ -251,19 +250,12 @@ int lg_accel_set_wf_split(const lg_accel *, int bands);
  * 1 when the accel's scene qualifies, 0 when it does not (the setting is then without effect). */
 int lg_accel_set_lds_scene(const lg_accel *, int enabled);
 
-/* Packet traversal (streaming pipeline, reference traversal): the 64 rays of a wavefront (an 8x8 pixel
- * tile, or its hit points towards one light) walk the reference tree ONCE together -- uniform node /
- * primitive fetches, one per-wave stack of (node, lane mask), near child by a vote of the lanes that hit
- * the node -- instead of 64 private walks.  Every lane sees exactly the reference's candidate set and
- * arithmetic; lanes that meet an exact tie in t (where the reference's visiting order decides) are
- * re-traced privately.  Same bytes out. */
-int lg_accel_set_packet(const lg_accel *, int enabled);
 
 /* Kernel timing with HIP events on the launch stream: enable, render, then read. */
 void lg_profile_enable(const lg_accel *, int enabled);
 int lg_profile_read(const lg_accel *, double *total_ms, uint64_t *launches); /* synchronises; resets the tally */
-/* Streaming pipeline: per-kernel HIP-event time.  kind 0 primary trace (+ shading frame; with the packet organisation
- * also its fix-up launch), 1 unused, 2 shadow trace, 3 shade; 4 = the megakernel. */
+/* Per-kernel HIP-event time.  kind 0 closest-hit trace (+ shading frame), 1 combine, 2 shadow trace, 3 shade; 4 = the megakernel
+ * or the queue organisation's persistent kernel. */
 int lg_profile_read_kinds(const lg_accel *, double ms[5], uint64_t launches[5]);
 /* lg_capture_stats restricted to one kind of traversal: 0 all, 1 closest-hit (primary/secondary), 2 shadow. */
 int lg_capture_stats_kind(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, int kind, lg_stats *out);

@@ -37,10 +37,9 @@ _EXTRA = {
     "accel_set_mode": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_prune": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_streaming": (_C.c_int, [_C.c_void_p, _C.c_int]),
+    "accel_get_prune": (_C.c_int, [_C.c_void_p]),
     "accel_set_lds_scene": (_C.c_int, [_C.c_void_p, _C.c_int]),
-    "accel_set_wavefront": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_wf_split": (_C.c_int, [_C.c_void_p, _C.c_int]),
-    "accel_set_packet": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
     "capture_radiance": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
     "capture_pixels": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p, _C.c_size_t, _C.c_void_p, _C.c_void_p]),
@@ -90,6 +89,10 @@ class HipApi(Api):
         if self.call("accel_set_prune", accel.h, -1 if enabled is None or enabled == -1 else (1 if enabled else 0)):
             raise LasgunError(self.last_error())
 
+    def get_prune(self, accel):
+        """Whether a render of this accel uses the pruned reference walk right now (accel default, LASGUN_PRUNE, set_prune, fast mode)."""
+        return bool(self.call("accel_get_prune", accel.h))
+
     def set_streaming(self, accel, enabled):
         """Kernel organisation (include/lasgun_hip.h, lg_accel_set_streaming): 1 / True = the accel's defaults, 0 / False = the
         megakernel only, 2 = the level-by-level wavefront pipeline wherever possible, 3 = the queue organisation (every recursion
@@ -100,15 +103,6 @@ class HipApi(Api):
     def set_wf_split(self, accel, bands):
         """Bands of a big wavefront launch on internal streams (0 = default; include/lasgun_hip.h, lg_accel_set_wf_split)."""
         self.call("accel_set_wf_split", accel.h, int(bands))
-
-    def set_wavefront(self, accel, enabled):
-        """True (default): "streaming" is the level-by-level wavefront pipeline (any scene); False: the earlier three-kernel
-        pipeline (scenes without glass / mirror; others fall back to the megakernel)."""
-        self.call("accel_set_wavefront", accel.h, 1 if enabled else 0)
-
-    def set_packet(self, accel, enabled):
-        """One tree walk per wavefront (packet traversal) in the streaming traversal kernels."""
-        self.call("accel_set_packet", accel.h, 1 if enabled else 0)
 
     def set_lds_scene(self, accel, enabled):
         """Scene tables resident in LDS for the streaming traversal kernels (default on); returns

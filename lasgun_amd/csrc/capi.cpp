@@ -19,13 +19,9 @@
 #include "host.h"
 
 namespace lg {
-// k_mega.hip, k_wavefront.hip, k_packet.hip, k_probe.hip
+// k_mega.hip, k_wavefront.hip, k_queue.hip, k_probe.hip
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
 hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
-hipError_t launch_stream_fixup(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream);
-hipError_t launch_stream_packet(const DParams &P, bool shadow, uint32_t blocks, hipStream_t stream);
-hipError_t stream_packet_occupancy(uint32_t stack_depth, int *blocks_per_cu);
-hipError_t launch_stream_shade(const DParams &P, hipStream_t stream);
 hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
 hipError_t launch_wf_shade(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t launch_wf_combine(const DParams &P, uint32_t blocks, hipStream_t stream);
@@ -35,7 +31,6 @@ hipError_t queue_occupancy(uint32_t stack_depth, int *blocks_per_cu);
 hipError_t queue_set_lds_limit(size_t bytes, bool ldss);
 hipError_t mega_set_lds_limit(size_t bytes, bool ldss);
 hipError_t wf_set_lds_limit(size_t bytes, bool ldss);
-hipError_t packet_set_lds_limit(size_t bytes, bool ldss);
 hipError_t launch_kat(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d, double *out,
                       hipStream_t stream);
 hipError_t launch_kat_si(V3 o, V3 d, double t, V3 dpdu, V3 dpdv, double *out, hipStream_t stream);
@@ -211,10 +206,8 @@ struct lg_accel {
     struct LaunchCtx {
         hipStream_t key = nullptr;
         unsigned long long last_use = 0;
-        DevBuf<uint32_t> tile_counter;                         // [0] next tile, [1] listed ties, [2] next listed tile
+        DevBuf<uint32_t> tile_counter;                         // [0] next tile; one head per XCD band behind it (TILE_COUNTER_WORDS)
         DevBuf<double> frames, stash;                          // megakernel: Whitted frame stack, parked shading frame
-        DevBuf<double> st_frame, st_accum;                     // streaming pipeline state (sized by the largest launch so far)
-        DevBuf<uint32_t> st_hit_ref, st_vis, st_tie_flag, st_tie_tiles;
         DevBuf<uint8_t> wf_mem;                                // wavefront pipeline: every per-level array of a chunk, carved from one allocation
         DevBuf<uint32_t> wf_counters;                          // its queue counts and per-launch tile counters
         bool queue_used = false;                               // the queue organisation ran on it: wf_counters holds its control words (QC_ERROR is checked after a synchronise)
@@ -240,17 +233,13 @@ struct lg_accel {
     bool queue_default = false;                   // glass / mirror over a big mesh: long uneven walks, sparse deep levels (k_queue.hip)
     mutable size_t queue_budget = 0;              // bytes one launch context may hold for it (0 = from the free memory at first use)
     unsigned long long queue_min_items = 1ull << 16; // launches below this many pixels stay with the megakernel
-    mutable bool wavefront = true;               // lg_accel_set_wavefront: level-by-level pipeline instead of the three-kernel one
     mutable size_t wf_budget = 0;                 // bytes one launch context may hold for it (0 = from the free memory at first use)
     // LDS-resident scene (reference tree only): the tables in their LDS layout, when they fit beside the stacks
     DevBuf<uint32_t> lds_image;
     uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_prim_off = 0, lds_soup_off = 0, lds_accel_off = 0;
     uint32_t ldss_blocks = 0;         // one 1024-lane workgroup per CU; 0 = variant unavailable for this scene
-    uint32_t packet_blocks = 1;       // grid of the 256-lane packet kernels
     uint32_t cus = 1;                 // compute units of the accel's device
-    bool packet_lds = false;          // the image fits beside the (64x smaller) per-wave stacks of the packet kernels
     mutable bool lds_scene = true;    // lg_accel_set_lds_scene
-    mutable bool packet = false;      // lg_accel_set_packet: one tree walk per wavefront in the streaming traversal kernels
     mutable DevBuf<DStats> stats;
     mutable DevBuf<uint8_t> staging;    // device film for host-film captures
     mutable DevBuf<double> staging_rad;
@@ -584,10 +573,14 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
     if (chunk_tiles > P0.ntiles) chunk_tiles = P0.ntiles;
     if (chunk_tiles < P0.ntiles && P0.mode == 0u && P0.tiles_x != 0u && chunk_tiles >= (unsigned long long)P0.tiles_x * 32ull)
         chunk_tiles -= chunk_tiles % ((unsigned long long)P0.tiles_x * 32ull); // whole rows of 32 x 32-tile blocks: the block order applies to every chunk
-    // level 0's work items: units of a few consecutive 8x8 tiles, whose specular children the wave compacts into packets of its own
-    // (LASGUN_QUEUE_UNIT: A/B)
-    static const uint32_t unit_tiles = [] { const char *e = std::getenv("LASGUN_QUEUE_UNIT"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 64 ? (uint32_t)v : 4u; }();
-    static const bool order_blocks = [] { const char *e = std::getenv("LASGUN_QUEUE_ORDER"); return !(e && e[0] == '0'); }(); // (0: tiles in row order, one claim counter: A/B)
+    // level 0's work items: units of consecutive 8x8 tiles whose specular children the wave compacts into packets of its own.  Default
+    // 1 (measured, config 4 / 4m in ms: 1 tile 39.0 / 16.4, 2: 40.0 / 17.0, 4: 41.0 / 18.5, 8: 44.6 / 22.2, 16: 51.7 / 31.6 -- a mesh tile is a
+    // millisecond of work, so longer units lengthen the launch's tail by more than fuller packets save); LASGUN_QUEUE_UNIT: A/B
+    static const uint32_t unit_tiles = [] { const char *e = std::getenv("LASGUN_QUEUE_UNIT"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 64 ? (uint32_t)v : 1u; }();
+    // LASGUN_QUEUE_ORDER=1 (A/B): 32 x 32-tile blocks in Morton order, claimed XCD by XCD -- measured no better than row order with one
+    // claim counter (config 4 / 4m / 5: 39.4 / 16.7 / 63.7 against 38.4 / 16.0 / 64.8 ms): which tiles are in flight together does not
+    // move these kernels, as round 3 found for the other organisations
+    static const bool order_blocks = [] { const char *e = std::getenv("LASGUN_QUEUE_ORDER"); return e && e[0] == '1'; }();
     const bool ldss = a.lds_scene && a.ldss_blocks;
     const uint32_t blocks_cap = ldss ? a.ldss_blocks : a.queue_blocks;
     const unsigned long long threads = (unsigned long long)blocks_cap * (ldss ? 1024ull : 256ull);
@@ -689,78 +682,14 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     {
         const uint32_t levels = (a.flat.has_specular && P.recursion > 0) ? P.recursion + 1u : 1u;
         const bool can = !stats && !a.fast && P.nlights <= 32 && levels <= QC_MAX_LEVELS;
-        const bool want = a.queue == 1 || (a.queue < 0 && a.streaming && !a.streaming_forced && !a.packet && a.queue_default &&
+        const bool want = a.queue == 1 || (a.queue < 0 && a.streaming && !a.streaming_forced && a.queue_default &&
                                            (unsigned long long)P.ntiles * 64ull >= a.queue_min_items);
         if (can && want) { enqueue_queue(a, P, c, stream); return; }
     }
-    // ---- wavefront pipeline: li() level by level (any scene with <= 32 lights; not the counting variant, not the packet walk)
-    if (a.streaming && !stats && P.nlights <= 32 && P.recursion < 20 && !(a.packet && !a.fast) &&
+    // ---- wavefront pipeline: li() level by level (any scene with <= 32 lights; not the counting variant)
+    if (a.streaming && !stats && P.nlights <= 32 && P.recursion < 20 &&
         (a.streaming_forced || (a.streaming_pays && (unsigned long long)P.ntiles * 64ull >= a.streaming_min_items))) {
         enqueue_wavefront(a, P, c, stream);
-        return;
-    }
-    // ---- packet organisation (opt-in, lg_accel_set_packet): one tree walk per wavefront + fix-up pass + shade; no glass / mirror
-    // (no recursion), <= 32 lights, not the counting variant
-    if (a.streaming && a.packet && !a.fast && !stats && !a.flat.has_specular && P.nlights <= 32 &&
-        (a.streaming_forced || (a.streaming_pays && (unsigned long long)P.ntiles * 64ull >= a.streaming_min_items))) {
-        const uint32_t nsamples = P.ss_root * P.ss_root;
-        P.n_items = (unsigned long long)P.ntiles * 64ull;
-        size_t n = (size_t)P.n_items;
-        if (c.st_hit_ref.n < n) {
-            HIP_TRY(hipDeviceSynchronize());
-            c.st_hit_ref.alloc(n); c.st_vis.alloc(n);
-            c.st_frame.alloc(n * STASH_DOUBLES);
-        }
-        if (nsamples > 1 && c.st_accum.n < 3 * n) { HIP_TRY(hipDeviceSynchronize()); c.st_accum.alloc(3 * n); }
-        P.hit_ref = c.st_hit_ref.p; P.vis = c.st_vis.p;
-        P.frame = c.st_frame.p; P.accum = c.st_accum.p;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (a.profiling) {
-            HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-            HIP_TRY(hipEventRecord(e0, stream));
-        }
-        auto timed = [&](int kind, auto &&launch) { // HIP events around ONE kernel on its launch stream
-            hipEvent_t k0 = nullptr, k1 = nullptr;
-            if (a.profiling) { HIP_TRY(hipEventCreate(&k0)); HIP_TRY(hipEventCreate(&k1)); HIP_TRY(hipEventRecord(k0, stream)); }
-            HIP_TRY(launch());
-            if (a.profiling) { HIP_TRY(hipEventRecord(k1, stream)); a.kind_events[kind].emplace_back(k0, k1); }
-        };
-#if defined(LG_PKT_STATS) || defined(LG_STAMPS)
-        P.stats = a.stats.p;
-#endif
-#ifdef LG_STAMPS
-        P.stamp_counts = reinterpret_cast<unsigned long long *>(a.stats.p + 1);
-#endif
-        uint32_t pblocks = 1, fblocks = 1;
-        {
-            if (c.st_tie_flag.n < n || c.st_tie_tiles.n < P.ntiles) { HIP_TRY(hipDeviceSynchronize()); c.st_tie_flag.alloc(n); c.st_tie_tiles.alloc(P.ntiles); }
-            P.tie_flag = c.st_tie_flag.p; P.tie_tiles = c.st_tie_tiles.p;
-            if (a.lds_scene && a.packet_lds) { // the image fits in LDS: one 1024-lane workgroup per CU
-                P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
-                P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
-                pblocks = a.cus;
-            } else {
-                pblocks = (P.ntiles + 3u) / 4u;
-                if (pblocks > a.packet_blocks) pblocks = a.packet_blocks;
-            }
-            fblocks = (P.ntiles + 3u) / 4u; if (fblocks > 256u) fblocks = 256u;
-        }
-        auto trace = [&](bool shadow) { // one tree walk per wavefront, then the lanes that met a tie again, privately
-            HIP_TRY(hipMemsetAsync(c.tile_counter.p, 0, 3 * sizeof(uint32_t), stream));
-            hipError_t e = launch_stream_packet(P, shadow, pblocks, stream);
-            if (e != hipSuccess) return e;
-            return launch_stream_fixup(P, shadow, fblocks, stream);
-        };
-        for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
-            P.sample_index = sidx;
-            timed(0, [&] { return trace(false); });
-            if (P.nlights > 0) timed(2, [&] { return trace(true); });
-            timed(3, [&] { return launch_stream_shade(P, stream); });
-        }
-        if (a.profiling) {
-            HIP_TRY(hipEventRecord(e1, stream));
-            a.events.emplace_back(e0, e1);
-        }
         return;
     }
     uint32_t cap = a.fast ? a.max_blocks_fast : a.max_blocks;
@@ -999,7 +928,7 @@ int lg_device_count(void) {
 // Called at creation without the fast trees -- they cost 5-10x the reference build and only mode 1 walks them -- and
 // once more, with them, by the first lg_accel_set_mode(accel, 1).
 static void build_and_upload(lg_accel *a, bool with_fast) {
-    a->ldss_blocks = 0; a->packet_lds = false; a->lds_image_n16 = 0; a->fast_available = true;
+    a->ldss_blocks = 0; a->lds_image_n16 = 0; a->fast_available = true;
         flatten_scene(*a->scene, a->flat, with_fast); // host HLBVH build + flatten (throws on what the reference would panic on)
         use_device(a->device);
         const FlatScene &f = a->flat;
@@ -1043,7 +972,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         }
         if (!a->fast_available) a->stack_depth_fast1 = a->stack_depth;
         size_t lds = (size_t)std::max(a->stack_depth, a->stack_depth_fast1) * 256 * 4;
-        if (lds > 64 * 1024) { HIP_TRY(mega_set_lds_limit(lds, false)); HIP_TRY(wf_set_lds_limit(lds, false)); HIP_TRY(packet_set_lds_limit(lds, false)); HIP_TRY(queue_set_lds_limit(lds, false)); }
+        if (lds > 64 * 1024) { HIP_TRY(mega_set_lds_limit(lds, false)); HIP_TRY(wf_set_lds_limit(lds, false)); HIP_TRY(queue_set_lds_limit(lds, false)); }
         int per_cu = 0, cus = 0;
         HIP_TRY(trace_occupancy(a->stack_depth, false, &per_cu));
         int per_cu_fast = 0;
@@ -1062,9 +991,6 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         int qb = 0;
         HIP_TRY(queue_occupancy(a->stack_depth, &qb));
         a->queue_blocks = (uint32_t)((qb < 1 ? 1 : qb) * cus);
-        int pk = 0;
-        HIP_TRY(stream_packet_occupancy(a->stack_depth, &pk));
-        a->packet_blocks = (uint32_t)((pk < 1 ? 1 : pk) * cus);
         a->cus = (uint32_t)cus;
         // LDS-resident scene: the REFERENCE tree's nodes (56 of 64 bytes, padded to 80 when that fits),
         // its primrefs, the spheres (padded to 48 when that fits) and cuboids, behind 1024 per-lane
@@ -1097,12 +1023,11 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
               }
             }
             const size_t stack_bytes = (size_t)a->stack_depth * 1024 * 4; // per-lane stacks of the private walks
-            const size_t wave_stacks = (size_t)a->stack_depth * 16 * 16;  // per-wave stacks of the packet walk
             const size_t prim16 = ((size_t)np + 3) / 4;
             // image: [nodes, LDS_NODE_STRIDE units each][primrefs][leaf records, 3 units per slot][accel records]
             const size_t accel16 = fm.accels.size() * LDS_ACCEL_UNITS;
             const size_t n16 = (size_t)nn * LDS_NODE_STRIDE + prim16 + (size_t)np_soup * 3 + accel16;
-            if (wave_stacks + n16 * 16 <= LDS_MAX) {
+            if (stack_bytes + n16 * 16 <= LDS_MAX) {
                 std::vector<uint32_t> img(n16 * 4, 0u);
                 a->lds_node_off = 0;
                 for (auto &r : nruns)
@@ -1143,9 +1068,8 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                 }
                 a->lds_image.upload(img);
                 a->lds_image_n16 = (uint32_t)n16;
-                HIP_TRY(mega_set_lds_limit(LDS_MAX, true)); HIP_TRY(wf_set_lds_limit(LDS_MAX, true)); HIP_TRY(packet_set_lds_limit(LDS_MAX, true)); HIP_TRY(queue_set_lds_limit(LDS_MAX, true));
-                a->packet_lds = true;
-                if (stack_bytes + n16 * 16 <= LDS_MAX) a->ldss_blocks = (uint32_t)cus;
+                HIP_TRY(mega_set_lds_limit(LDS_MAX, true)); HIP_TRY(wf_set_lds_limit(LDS_MAX, true)); HIP_TRY(queue_set_lds_limit(LDS_MAX, true));
+                a->ldss_blocks = (uint32_t)cus;
             }
             a->accels.upload(fm.accels); // again, now with the compact bases
         }
@@ -1164,6 +1088,9 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
             // (100k-triangle glass torus: 226 against 136 ms): those stay in the megakernel, where other tiles fill the gaps.
             a->prune_default = big_mesh >= 256; // the reference's mesh leaves hold up to 254 triangles (bvh.rs:187,289): skipping one pays for many node steps
             a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512 && !(f.has_specular && big_mesh >= 4096);
+            // glass / mirror over a big mesh: the queue organisation (round 4; config 4: 38.0 against the megakernel's 42.6 ms, and
+            // the level-by-level pipeline's 80; 4m: 15.8 / 15.9; launches of 2^16 pixels and more)
+            a->queue_default = f.has_specular && big_mesh >= 4096;
             a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 20);
         }
 }
@@ -1183,7 +1110,7 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.lds_image, y.lds_image);
     swap(x.lds_image_n16, y.lds_image_n16); swap(x.lds_node_off, y.lds_node_off); swap(x.lds_prim_off, y.lds_prim_off);
     swap(x.lds_soup_off, y.lds_soup_off); swap(x.lds_accel_off, y.lds_accel_off);
-    swap(x.ldss_blocks, y.ldss_blocks); swap(x.packet_blocks, y.packet_blocks); swap(x.packet_lds, y.packet_lds); swap(x.cus, y.cus);
+    swap(x.ldss_blocks, y.ldss_blocks); swap(x.cus, y.cus);
     swap(x.stack_depth, y.stack_depth); swap(x.stack_depth_fast1, y.stack_depth_fast1); swap(x.max_blocks, y.max_blocks); swap(x.max_blocks_fast, y.max_blocks_fast);
     swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast);
     swap(x.device_bytes, y.device_bytes); swap(x.fast_available, y.fast_available); swap(x.fast_refusal, y.fast_refusal);
@@ -1522,16 +1449,6 @@ int lg_accel_set_lds_scene(const lg_accel *a, int enabled) {
     a->lds_scene = enabled != 0;
     return a->ldss_blocks ? 1 : 0; // 1: the scene's tables fit in LDS (the variant exists for this accel)
 }
-int lg_accel_set_packet(const lg_accel *a, int enabled) {
-    std::lock_guard<std::mutex> lk(a->mtx);
-    a->packet = enabled != 0;
-    return 0;
-}
-int lg_accel_set_wavefront(const lg_accel *a, int enabled) {
-    std::lock_guard<std::mutex> g(a->mtx);
-    a->wavefront = enabled != 0;
-    return 0;
-}
 int lg_accel_set_wf_split(const lg_accel *a, int bands) {
     if (bands < 0 || bands > 8) return fail("bands must be 0 (default) .. 8 (more than 4 are rendered as 4)");
     std::lock_guard<std::mutex> g(a->mtx);
@@ -1545,6 +1462,10 @@ int lg_accel_set_streaming(const lg_accel *a, int enabled) {
     a->streaming_forced = enabled == 2; // 2 = use it whatever the scene and the launch size (tests)
     a->queue = enabled == 3 ? 1 : enabled == 1 ? -1 : 0; // 3 = the queue organisation whatever the scene; 1 = the accel's defaults
     return 0;
+}
+int lg_accel_get_prune(const lg_accel *a) { // the EFFECTIVE setting of the pruned walk: what a render of this accel uses right now
+    std::lock_guard<std::mutex> g(a->mtx);
+    return (int)base_params(*a, 8, 8).prune;
 }
 int lg_accel_set_prune(const lg_accel *a, int enabled) {
     if (enabled < -1 || enabled > 1) return fail("prune must be -1 (default), 0 or 1");

@@ -30,7 +30,7 @@ constexpr uint32_t PRIM_INDEX_MASK = 0x3FFFFFFFu;
 constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
 constexpr uint32_t WF_NONE = 0xFFFFFFFFu, WF_MISS = 0xFFFFFFFEu; // wavefront pipeline: no such child / the ray hit nothing
 constexpr int MAX_CHAIN = 8;      // scene-graph nesting levels (root = 1)
-// tile counters of a persistent kernel (kcommon.h, claim_tile): [0..15] plain words (the packet kernels' three), then one head word per XCD, 64 bytes apart
+// tile counters of a persistent kernel (kcommon.h, claim_tile): [0..15] plain words ([0]: the single-head forms' next tile), then one head word per XCD, 64 bytes apart
 constexpr uint32_t TILE_HEADS = 8u, TILE_HEAD_STRIDE = 16u;
 constexpr uint32_t TILE_COUNTER_WORDS = 16u + TILE_HEADS * TILE_HEAD_STRIDE;
 constexpr uint32_t NO_TILE = 0xFFFFFFFFu;
@@ -233,16 +233,14 @@ struct DParams {
     const unsigned long long *pixel_list; // mode 2
     uint8_t *out_rgba;
     double *out_radiance; // optional f64 RGB, same addressing as out_rgba (3 doubles per pixel)
-    uint32_t *tile_counter;   // [0] next tile, [1] number of tiles listed in tie_tiles, [2] next listed tile (fix-up pass)
+    uint32_t *tile_counter;   // [0] next tile; [16 + 16 * x] next tile of XCD band x (TILE_COUNTER_WORDS)
     double *frames;        // [recursion][FRAME_DOUBLES][nthreads]
     unsigned long long frame_threads;
     double *stash;         // [STASH_DOUBLES][nthreads]: shading frame parked across the shadow traversals
     DStats *stats;
     double *dbg_log;       // lg_trace_pixel only (counting instantiations): [0] = entries used, then 4 doubles per event
-    // ---- streaming pipeline (scenes without glass / mirror): per-work-item state in HBM, SoA,
-    // indexed by the dense work index widx = tile * 64 + lane
-    unsigned long long n_items; // ntiles * 64
-    uint32_t *hit_ref;          // [n_items] primref of the hit (NO_HIT = miss)
+    // ---- pipelines: per-work-item state in HBM, SoA, indexed by the dense work index widx = tile * 64 + lane
+    unsigned long long n_items; // pixels of a chunk (its tiles * 64): SoA stride of level 0's arrays
     double *frame;              // [STASH_DOUBLES][n_items] shading frame of the hit
     uint32_t *vis;              // [n_items] bit l set <=> light l is visible from the hit
     double *accum;              // [3][n_items] running sum over the pixel's samples (integrate.rs:17-18)
@@ -282,9 +280,6 @@ struct DParams {
     double *q_out[8];
     double *q_spec[8];
     uint32_t *q_child[8];
-    // packet organisation: lanes whose packet walk met an exact tie in t (or a NaN t) are re-traced privately
-    uint32_t *tie_flag;         // [n_items] bit l: light l (shadow pass) / bit 0 (primary pass)
-    uint32_t *tie_tiles;        // [ntiles] tiles with at least one flagged lane
     // ---- LDS-resident scene (scenes whose node / primref / sphere / cuboid tables fit beside the
     // stacks in the CU's 160 KB): `lds_image` holds those tables in their LDS layout; offsets and
     // strides are in 16-byte units from the start of the image

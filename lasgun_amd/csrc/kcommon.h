@@ -1,6 +1,6 @@
 // lasgun_amd/csrc/kcommon.h -- what every kernel file of the ray-trace path starts from: launch constants and the
 // per-lane stack in dynamic LDS.  (kernels.hip was one 3,100-line translation unit until round 3; it is now headers of
-// device code -- walk.h, packet.h, shade.h -- and one .hip file per kernel organisation, compiled side by side.)
+// device code -- walk.h, shade.h -- and one .hip file per kernel organisation, compiled side by side.)
 #pragma once
 #include <hip/hip_runtime.h>
 

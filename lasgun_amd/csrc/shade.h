@@ -341,18 +341,6 @@ __device__ __forceinline__ V3 shade_lights(const DParams &P, const DMaterial &m,
     return output + mul_ew(P.ambient, bsdf_f(m, sh, sh.wo, nrm)); // integrate.rs:67
 }
 
-// ------------------------------------------------------------------------------------------
-// Streaming pipeline: the same li() for scenes WITHOUT glass / mirror (no recursion), cut into
-// three kernels so that traversal (wants occupancy, 128 VGPRs) and shading (wants registers: trig,
-// microfacet, Fresnel) each get their own register allocation.  Per work item (pixel) the state
-// between kernels lives in HBM, SoA, indexed by widx = tile * 64 + lane:
-//   K1 primary   camera ray -> closest hit -> shade_frame           -> hit_ref, frame[13][n]
-//   K2 shadow    one any-hit traversal per light from frame.p       -> vis bits
-//   K3 shade     lights in order, ambient, sample sum, Img::set     -> film
-// (the shading frame used to be a kernel of its own between K1 and K2; see park_frame)
-// Every f64 is produced by the same expressions as in the megakernel; only their placement in
-// kernels differs.  Up to 32 lights; scenes with more use the megakernel.
-// ------------------------------------------------------------------------------------------
 // Camera::sample for sample `sidx` of pixel (x, y) (camera.rs:113-146)
 __device__ __forceinline__ Ray camera_ray(const DParams &P, uint32_t x, uint32_t y, uint32_t sidx) {
     double img_plane_height = P.image_plane_height;
@@ -370,22 +358,6 @@ __device__ __forceinline__ Ray camera_ray(const DParams &P, uint32_t x, uint32_t
     uint32_t si = sidx / dim, sj = sidx % dim;
     V3 dd = cam_d + ((double)sj * updiff) + ((double)si * auxdiff) + halfdiff;
     return ray_new(cam_o, dd);
-}
-
-// The shading frame of a primary hit, parked for the shadow and shade passes.  It is computed at the end of
-// the primary traversal pass (after the walk, so its registers are not live during it) rather than in a pass
-// of its own: one launch and one round trip of the hit record less (measured -2.7 % / -5 % per frame).
-__device__ __forceinline__ void park_frame(const DParams &P, unsigned long long widx, const Ray &ray, const Best &b) {
-    if (b.ref == NO_HIT) return;
-    Shade sh;
-    shade_frame(P, ray, b, sh);
-    const unsigned long long n = P.n_items;
-    double *f = P.frame + widx;
-    f[0 * n] = sh.praw.x; f[1 * n] = sh.praw.y; f[2 * n] = sh.praw.z;
-    f[3 * n] = sh.ng.x; f[4 * n] = sh.ng.y; f[5 * n] = sh.ng.z;
-    f[6 * n] = sh.ns.x; f[7 * n] = sh.ns.y; f[8 * n] = sh.ns.z;
-    f[9 * n] = sh.ss.x; f[10 * n] = sh.ss.y; f[11 * n] = sh.ss.z;
-    f[12 * n] = (double)sh.mat;
 }
 
 } // namespace lg

@@ -14,13 +14,12 @@
 //                                             compacted, frames parked) or per-light any-hit of its hits;
 //                                             LDSS = scene tables resident in LDS, one 1024-lane workgroup per CU
 //   wf_shade_kernel<KIND, L0>, wf_combine_kernel   radiance of a level's hits, specular children queued; levels combined bottom-up
-//   stream_packet_kernel<SHADOW, LDSS>        opt-in: ONE tree walk per wavefront (ballot / vote), stream_fixup_kernel<SHADOW>
-//                                             re-traces the lanes it flagged, stream_shade_kernel finishes the pixels
+//   queue_kernel<LDSS, PRUNE>                 every recursion level in one persistent launch (k_queue.hip)
 //   trace_pixel_kernel<FAST>                  one pixel by one lane, with an event log of the walk (lg_trace_pixel)
 //   kat_kernel, kat_si_kernel, math_kernel    probes behind the test hooks of the C ABI
 //
 // One traversal per mode: traverse_ref<LDSS, FAST, PRUNE, COUNT> (reference tree; FAST: the fast trees one node per step, an
-// A/B) and traverse_fast<COUNT> (fast trees, child pairs), both behind walk<>; traverse_packet<LDSS> for the packet kernels.
+// A/B) and traverse_fast<COUNT> (fast trees, wide records), both behind walk<>.
 //
 // What is restated from where (file:line under /root/reference):
 //   pixel loop / quantisation   src/lib.rs:110-162, src/img.rs:56-67

@@ -64,7 +64,6 @@ def test_full_size_config_vs_oracle_sample(name):
     first = None
     for label, streaming, wavefront, fast, prune in ORGANISATIONS:
         G.set_streaming(acc, streaming)
-        G.set_wavefront(acc, wavefront)
         G.set_mode(acc, fast)
         G.set_prune(acc, prune)
         film.zero_()
@@ -84,7 +83,6 @@ def test_full_size_config_vs_oracle_sample(name):
         else:
             assert torch.equal(film, first), (name, label)  # whole film, organisation against organisation
     G.set_streaming(acc, 1)
-    G.set_wavefront(acc, True)
     G.set_mode(acc, False)
     G.set_prune(acc, None)
     # ray accounting on two 32-row bands: through the torus (config 4 glass: its refractions) and through the mirror sphere
@@ -104,7 +102,6 @@ def test_full_size_config_crop_goldens(name):
     acc = G.Accel(builder(G))
     for label, streaming, wavefront, fast, prune in ORGANISATIONS:
         G.set_streaming(acc, streaming)
-        G.set_wavefront(acc, wavefront)
         G.set_mode(acc, fast)
         G.set_prune(acc, prune)
         rgba, rad = G.capture_rect(acc, w, h, x0, y0, x0 + cw, y0 + ch)

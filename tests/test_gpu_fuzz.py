@@ -43,9 +43,8 @@ GENERATORS = {
 # pixel value.  Everywhere else the device film must equal the GLIBC oracle's film byte for byte.
 KNIFE_EDGE = {"adversarial_prune"}
 LIBM_PIXELS_PER_SCENE = 8  # budget of libm-sensitive pixels in one knife-edge scene (measured: 31 pixels in 49,600 scenes, at most 2 in one)
-# (streaming, fast, packet, prune): megakernel and wavefront pipeline in either traversal mode, three-kernel pipeline with the
-# packet walk, the pruned form of the reference walk in megakernel and wavefront pipeline, and the queue organisation (3) with either walk
-ORGANISATIONS = ((0, False, False, False), (0, True, False, False), (2, False, False, False), (2, True, False, False), (2, False, True, False),
+# (streaming, fast, -, prune): megakernel and wavefront pipeline in either traversal mode, the pruned form of the reference walk in megakernel and wavefront pipeline, and the queue organisation (3) with either walk
+ORGANISATIONS = ((0, False, False, False), (0, True, False, False), (2, False, False, False), (2, True, False, False),
                  (0, False, False, True), (2, False, False, True), (3, False, False, False), (3, False, False, True))
 
 
@@ -96,7 +95,6 @@ def test_fuzz_campaign(gen):
                 assert fast and "inverse" in str(e), (seed, str(e))
                 done["fast_refused"] += 1
                 continue
-            G.set_packet(acc, packet)
             film = G.Film(w, h)
             G.capture_subset(0, 1, acc, film)
             rad = G.capture_radiance(acc, w, h)

@@ -228,7 +228,6 @@ def test_wavefront_pipeline_matches_oracle(name):
         o.set_trig_mode(0)
     acc = G.Accel(builder(G))
     G.set_streaming(acc, 2)  # streamed whatever the size of the launch
-    G.set_wavefront(acc, True)
     for fast in (False, True):
         G.set_mode(acc, fast)
         film = G.Film(w, h)
@@ -357,31 +356,6 @@ def test_lds_resident_scene_matches_global_tables(name):
     assert np.array_equal(outs[0][0], ofilm.pixels())
 
 
-@pytest.mark.parametrize("name", ["spheres_512", "spheres_seed7_300", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "instanced_mesh_176", "mesh_plastic_flat_128", "ragged_5x131", "one_pixel"])
-def test_packet_traversal_matches_private_walks(name):
-    """One tree walk per wavefront (lane masks, vote on the near child, tie lanes re-traced) vs 64 private
-    walks: same bytes, same radiance bits, with the scene tables in LDS and in HBM/L2; and vs the oracle."""
-    if name not in MID:
-        pytest.skip("no such scene")
-    builder, w, h = MID[name]
-    acc = G.Accel(builder(G))
-    G.set_streaming(acc, 2)
-    outs = []
-    for packet, lds in ((False, True), (True, True), (True, False)):
-        G.set_packet(acc, packet); G.set_lds_scene(acc, lds)
-        film = G.Film(w, h)
-        G.capture_subset(0, 1, acc, film)
-        sub = G.Film.new_with_output(w, h, np.full((h, w, 4), 7, np.uint8))
-        G.capture_subset(2, 5, acc, sub)
-        outs.append((film.pixels(), bits(G.capture_radiance(acc, w, h)), sub.pixels()))
-    for o_ in outs[1:]:
-        assert all(np.array_equal(a, b) for a, b in zip(outs[0], o_))
-    o = oracle()
-    ofilm = o.Film(w, h)
-    o.capture_subset_mt(0, 1, o.Accel(builder(o)), ofilm, 16)
-    assert np.array_equal(outs[1][0], ofilm.pixels())
-
-
 @pytest.mark.parametrize("nlights, w, h", [(3, 160, 96), (32, 96, 64), (33, 96, 64), (40, 64, 64)])
 def test_many_lights(nlights, w, h):
     """One any-hit pass per light; 32 lights is the last count the streaming pipeline's visibility word holds,
@@ -395,11 +369,11 @@ def test_many_lights(nlights, w, h):
     ofilm = o.Film(w, h)
     o.capture_subset_mt(0, 1, o.Accel(build(o)), ofilm, 16)
     acc = G.Accel(build(G))
-    for streaming, packet in ((0, False), (2, False), (2, True), (3, False)):
-        G.set_streaming(acc, streaming); G.set_packet(acc, packet)
+    for streaming in (0, 2, 3):
+        G.set_streaming(acc, streaming)
         film = G.Film(w, h)
         G.capture_subset(0, 1, acc, film)
-        assert np.array_equal(film.pixels(), ofilm.pixels()), (streaming, packet)
+        assert np.array_equal(film.pixels(), ofilm.pixels()), streaming
 
 
 @pytest.mark.parametrize("w, h", [(4096, 1), (1, 777), (3, 3), (8192, 2)])
@@ -472,11 +446,10 @@ def test_random_scene_parity(seed):
     finally:
         o.set_trig_mode(0)
     acc = G.Accel(S.random_scene(G, seed))
-    # megakernel, wavefront pipeline, both in either traversal mode; three-kernel pipeline with the packet walk (no glass / mirror only)
-    for streaming, fast, packet in ((0, False, False), (0, True, False), (2, False, False), (2, True, False), (2, False, True), (3, False, False)):
+    # megakernel and wavefront pipeline in either traversal mode, the queue organisation
+    for streaming, fast, packet in ((0, False, False), (0, True, False), (2, False, False), (2, True, False), (3, False, False)):
         G.set_streaming(acc, streaming)
         G.set_mode(acc, fast)
-        G.set_packet(acc, packet)
         film = G.Film(w, h)
         G.capture_subset(0, 1, acc, film)
         assert np.array_equal(film.pixels(), ofilm.pixels()), (seed, streaming, fast, packet)
@@ -639,8 +612,8 @@ def test_headline_4096_full_frame_vs_oracle():
     film = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
     for streaming, lds, fast, packet in ((1, True, False, False), (1, False, False, False), (0, True, False, False), (1, True, True, False),
-                                         (1, True, False, True), (1, False, False, True)):
-        G.set_streaming(acc, streaming); G.set_lds_scene(acc, lds); G.set_mode(acc, fast); G.set_packet(acc, packet)
+                                         (3, True, False, False), (3, False, False, False)):
+        G.set_streaming(acc, streaming); G.set_lds_scene(acc, lds); G.set_mode(acc, fast)
         film.zero_()
         torch.cuda.synchronize()  # the fill runs on torch's stream, the render on the accel's own
         G.capture_rows_device(acc, w, h, 0, h, film.data_ptr(), row0=0)
@@ -690,8 +663,8 @@ def test_adversarial_scenes_match_the_oracle(gen):
         finally:
             o.set_trig_mode(0)
         acc = G.Accel(ns_g[gen](seed))
-        for streaming, packet in ((0, False), (2, False), (2, True), (3, False)):
-            G.set_streaming(acc, streaming); G.set_packet(acc, packet)
+        for streaming, packet in ((0, False), (2, False), (3, False)):
+            G.set_streaming(acc, streaming)
             film = G.Film(w, h)
             G.capture_subset(0, 1, acc, film)
             assert np.array_equal(film.pixels(), ofilm.pixels()), (seed, streaming, packet)

@@ -12,7 +12,7 @@ src=$root/lasgun_amd/csrc
 for f in host capi multi; do
   g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$src/$f.cpp" -o "$b/$f.o" &
 done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$b/liblasgun_hip_asan.so" "$b/host.o" "$b/capi.o" "$b/multi.o" "$src/k_mega.o" "$src/k_wavefront.o" "$src/k_queue.o" "$src/k_packet.o" "$src/k_probe.o" -ldl -fsanitize=address,undefined 2>&1 | grep -v hip-link || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$b/liblasgun_hip_asan.so" "$b/host.o" "$b/capi.o" "$b/multi.o" "$src/k_mega.o" "$src/k_wavefront.o" "$src/k_queue.o" "$src/k_probe.o" -ldl -fsanitize=address,undefined 2>&1 | grep -v hip-link || true
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LASGUN_HIP_LIB="$b/liblasgun_hip_asan.so"
 cd "$root"

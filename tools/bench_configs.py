@@ -26,7 +26,7 @@ CONFIGS = [
 
 def main():
     fast = "--fast" in sys.argv
-    org = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--org=")]  # default | megakernel | wavefront | queue | packet
+    org = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--org=")]  # default | megakernel | wavefront | queue
     org = org[0] if org else "default"
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     G.set_device(0)
@@ -44,8 +44,6 @@ def main():
             G.set_streaming(acc, 2)
         elif org == "queue":
             G.set_streaming(acc, 3)
-        elif org == "packet":
-            G.set_streaming(acc, 2); G.set_packet(acc, True)
         film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
         stream = torch.cuda.current_stream().cuda_stream
         G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)

@@ -25,7 +25,7 @@ timeout -k 10 300 python3 tools/bench_configs.py --org=megakernel > "$O/configs_
 timeout -k 10 300 python3 tools/bench_configs.py --org=wavefront > "$O/configs_wavefront.jsonl" 2>/dev/null
 LASGUN_PRUNE=0 timeout -k 10 300 python3 tools/bench_configs.py > "$O/configs_unpruned.jsonl" 2>/dev/null
 LASGUN_PRUNE=1 timeout -k 10 300 python3 tools/bench_configs.py > "$O/configs_pruned.jsonl" 2>/dev/null
-timeout -k 10 300 python3 tools/bench_configs.py --org=packet "1a" "1b" "2P" "3 sph" > "$O/configs_packet.jsonl" 2>/dev/null
+timeout -k 10 300 python3 tools/bench_configs.py --org=queue > "$O/configs_queue.jsonl" 2>/dev/null
 timeout -k 10 200 python3 tools/share_time.py > "$O/share_time.jsonl" 2>/dev/null
 timeout -k 10 200 python3 tools/bench_multi.py --devices 0,0 --steps 5 > "$O/multi_2x_same_device.json" 2>/dev/null
 LASGUN_MULTI_FORCE_RCCL=1 timeout -k 10 200 python3 tools/bench_multi.py --devices 0,0 --steps 5 > "$O/multi_2x_same_device_rccl.json" 2>/dev/null
