@@ -24,7 +24,48 @@ CONFIGS = [
 ]
 
 
+def progressive(name, scene, size, n):
+    """The web worker's progressive form (www/renderer.ts:103-120): n shuffled capture_subset(k, n) calls into ONE film (each call
+    the pixels {k, k + n, ...} of the row-major image) against one whole frame."""
+    import random
+    acc = G.Accel(scene)
+    film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
+    ref = torch.zeros_like(film)
+    stream = torch.cuda.current_stream().cuda_stream
+    G.capture_rows_device(acc, size, size, 0, size, ref.data_ptr(), row0=0, stream=stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        G.capture_rows_device(acc, size, size, 0, size, ref.data_ptr(), row0=0, stream=stream)
+    torch.cuda.synchronize()
+    frame_ms = (time.perf_counter() - t0) / 3 * 1e3
+    order = list(range(n))
+    random.Random(7).shuffle(order)
+    for k in order[:2]:  # warm-up (launch contexts, kernels)
+        G.capture_subset_device(k, n, acc, size, size, film.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    film.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in order:
+        G.capture_subset_device(k, n, acc, size, size, film.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    prog_ms = (time.perf_counter() - t0) * 1e3
+    print(json.dumps({"config": name, "progressive_subsets": n, "frame_ms": round(frame_ms, 3), "progressive_ms": round(prog_ms, 3),
+                      "ratio": round(prog_ms / frame_ms, 3), "ms_per_subset": round(prog_ms / n, 4),
+                      "identical_to_frame": bool(torch.equal(film, ref))}), flush=True)
+
+
 def main():
+    prog = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--progressive=")]
+    if prog:
+        only = [a for a in sys.argv[1:] if not a.startswith("--")]
+        G.set_device(0)
+        for name, build, size in CONFIGS:
+            if only and not any(o in name for o in only):
+                continue
+            progressive(name, build(), size, int(prog[0]))
+        return
     fast = "--fast" in sys.argv
     org = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--org=")]  # default | megakernel | wavefront | queue
     org = org[0] if org else "default"
