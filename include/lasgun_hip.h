@@ -95,6 +95,10 @@ void lg_film_free(lg_film *);
 lg_accel *lg_accel_from(const lg_scene *);
 void lg_accel_free(lg_accel *);
 
+/* capture(&scene, &mut film) (lib.rs:55-104): builds the accel, renders every pixel, returns when the film is written.  Devices: the
+ * ones named with lg_set_devices / lg_set_device; a process that named none gets EVERY visible device for films of 2^18 pixels and
+ * more (the reference takes every core, lib.rs:58-62; `scene.threads` caps the count) -- one accel per device, one RCCL gather --
+ * and the HIP current device for smaller films (an accel and a communicator per GPU would cost more than the render). */
 int lg_capture(const lg_scene *, lg_film *);                                       /* lib.rs:55 */
 int lg_capture_subset(size_t k, size_t n, const lg_accel *, lg_film *);            /* lib.rs:110 */
 lg_film *lg_render(const lg_scene *, uint32_t width, uint32_t height);             /* lib.rs:46 */

@@ -397,7 +397,9 @@ class Api:
 
     # -- lib.rs entry points -------------------------------------------------
     def capture(self, scene, film):
-        """lib.rs:55 -- synchronous; on return every pixel of `film` is written."""
+        """lib.rs:55 -- synchronous; on return every pixel of `film` is written.  On the HIP library: split over the devices of
+        set_devices / set_device; a process that named none gets EVERY visible GPU for films of 2^18 pixels and more (an accel per
+        device, one RCCL gather) and the HIP current device for smaller ones (include/lasgun_hip.h, lg_capture)."""
         if self.call("capture", scene.h, film.h):
             raise LasgunError(self.last_error())
 

@@ -1325,9 +1325,15 @@ int lg_capture(const lg_scene *s, lg_film *film) { // lib.rs:55-104: the BVH is 
     // so the film is the same for any split.
     std::vector<int> devs = g_devices;
     if (devs.empty() && !g_device_chosen) {
-        int n_vis = 0;
-        if (hipGetDeviceCount(&n_vis) == hipSuccess)
-            for (int d = 0; d < n_vis; ++d) devs.push_back(d);
+        // the default: every visible device -- for films of 2^18 pixels and more.  A smaller film is a millisecond of work on one
+        // GPU; building an accel per device and a communicator over them for it would cost seconds (and every rank of a
+        // torchrun job that never named a device would do so on every GPU of the node): it stays on the HIP CURRENT device,
+        // which is also what a caller that chose its device through the HIP runtime itself expects
+        int n_vis = 0, cur = 0;
+        if ((unsigned long long)film->w * film->h >= (1ull << 18)) {
+            if (hipGetDeviceCount(&n_vis) == hipSuccess)
+                for (int d = 0; d < n_vis; ++d) devs.push_back(d);
+        } else if (hipGetDevice(&cur) == hipSuccess) devs.push_back(cur);
     }
     if (s->s.threads != 0 && devs.size() > s->s.threads) devs.resize(s->s.threads);
     if (devs.size() <= 1) {

@@ -103,10 +103,11 @@ CHILD = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, os.path.joi
 
 
 @pytest.mark.parametrize("no_rccl", [False, True])
-@pytest.mark.parametrize("w, h", [(256, 1024), (131, 200)])
+@pytest.mark.parametrize("w, h", [(256, 1024), (517, 640), (131, 200)])
 def test_default_capture_splits_over_every_visible_device(w, h, no_rccl):
-    """A process that names no device: lg_capture takes every visible one (lib.rs:58-62: every core), over RCCL and over the
-    per-device fall-through -- fresh process each (the default is decided once per process)."""
+    """A process that names no device: lg_capture takes every visible one for films of 2^18 pixels and more (lib.rs:58-62: every
+    core) -- interleaved blocks and contiguous tiles, over RCCL and over the per-device fall-through -- and the current device
+    for a smaller film; fresh process each."""
     need(2)
     p = run_child(CHILD % (ROOT, ROOT, w, h, ""), {"LASGUN_CAPTURE_NO_RCCL": "1"} if no_rccl else None)
     assert p.returncode == 0 and "devices ok" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
