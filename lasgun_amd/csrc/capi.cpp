@@ -21,13 +21,13 @@
 namespace lg {
 // k_mega.hip, k_wavefront.hip, k_queue.hip, k_probe.hip
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
-hipError_t trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
+hipError_t trace_occupancy(uint32_t stack_depth, bool fast, bool waves3, size_t extra_lds, int *blocks_per_cu);
 hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
 hipError_t launch_wf_shade(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t launch_wf_combine(const DParams &P, uint32_t blocks, hipStream_t stream);
-hipError_t wf_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu);
+hipError_t wf_trace_occupancy(uint32_t stack_depth, bool fast, size_t extra_lds, int *blocks_per_cu);
 hipError_t launch_queue(const DParams &P, uint32_t blocks, hipStream_t stream);
-hipError_t queue_occupancy(uint32_t stack_depth, int *blocks_per_cu);
+hipError_t queue_occupancy(uint32_t stack_depth, size_t extra_lds, int *blocks_per_cu);
 hipError_t queue_set_lds_limit(size_t bytes, bool ldss);
 hipError_t mega_set_lds_limit(size_t bytes, bool ldss);
 hipError_t wf_set_lds_limit(size_t bytes, bool ldss);
@@ -236,6 +236,8 @@ struct lg_accel {
     mutable size_t wf_budget = 0;                 // bytes one launch context may hold for it (0 = from the free memory at first use)
     // LDS-resident scene (reference tree only): the tables in their LDS layout, when they fit beside the stacks
     DevBuf<uint32_t> lds_image;
+    DevBuf<uint32_t> accel_image;     // scenes in L2: the accel records alone, in their LDS layout (DParams::accel_image); empty: too many accels
+    uint32_t accel_image_n16 = 0;
     uint32_t lds_image_n16 = 0, lds_node_off = 0, lds_prim_off = 0, lds_soup_off = 0, lds_accel_off = 0;
     uint32_t ldss_blocks = 0;         // one 1024-lane workgroup per CU; 0 = variant unavailable for this scene
     uint32_t cus = 1;                 // compute units of the accel's device
@@ -248,6 +250,8 @@ struct lg_accel {
     uint32_t stack_depth = 1;      // reference traversal
     uint32_t stack_depth_fast1 = 1; // fast traversal (one word per pending child; also deep enough for its reference re-trace)
     uint32_t max_blocks = 1;
+    uint32_t max_blocks3 = 1;      // grid of the megakernel's three-waves-per-SIMD instantiation
+    bool mega_waves3 = false;      // the scene carries a big mesh: the megakernel's 256-lane form runs at three waves per SIMD
     uint32_t max_blocks_fast = 1;
     uint64_t device_bytes = 0;
     mutable bool profiling = false;
@@ -317,6 +321,10 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     P.recursion = s.recursion;
     P.default_material = a.flat.default_material;
     P.stack_depth = a.stack_depth;
+    {   // LASGUN_ACCEL_LDS=0 (A/B): the accel records from the DAccel table in L2
+        static const bool accel_lds = [] { const char *e = std::getenv("LASGUN_ACCEL_LDS"); return !(e && e[0] == '0'); }();
+        P.accel_image = a.accel_image_n16 && accel_lds ? a.accel_image.p : nullptr; P.accel_image_n16 = a.accel_image_n16;
+    }
     {   // LASGUN_PRUNE=0|1 replaces the scene-dependent DEFAULT (test suites run whole under either); lg_accel_set_prune still wins
         static const int env_default = [] { const char *e = std::getenv("LASGUN_PRUNE"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();
         const bool dflt = env_default < 0 ? a.prune_default : env_default != 0;
@@ -692,7 +700,10 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         enqueue_wavefront(a, P, c, stream);
         return;
     }
-    uint32_t cap = a.fast ? a.max_blocks_fast : a.max_blocks;
+    static const int waves_env = [] { const char *e = std::getenv("LASGUN_MEGA_WAVES"); return e ? std::atoi(e) : 0; }(); // (3 / 4: A/B)
+    const bool waves3 = !stats && !a.fast && !(a.lds_scene && a.ldss_blocks) && (waves_env == 3 || (waves_env == 0 && a.mega_waves3));
+    P.mega_waves = waves3 ? 3u : 4u;
+    uint32_t cap = a.fast ? a.max_blocks_fast : waves3 ? a.max_blocks3 : a.max_blocks;
     uint32_t blocks = (P.ntiles + 3u) / 4u;
     if (blocks > cap) blocks = cap;
     uint32_t maxb = a.max_blocks > a.max_blocks_fast ? a.max_blocks : a.max_blocks_fast;
@@ -971,25 +982,37 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
             }
         }
         if (!a->fast_available) a->stack_depth_fast1 = a->stack_depth;
-        size_t lds = (size_t)std::max(a->stack_depth, a->stack_depth_fast1) * 256 * 4;
+        // Scenes whose tables stay in L2: the accel records (13 x 16 bytes each) go into LDS behind the stacks of the 256-lane
+        // kernels when that keeps four workgroups on a CU -- entering and leaving nested accels is a chain of dependent fetches of
+        // these records (37 % of the walk's cycles on config 4m when they come from L2)
+        a->accel_image_n16 = 0;
+        {
+            const size_t img = f.accels.size() * LDS_ACCEL_UNITS * 16;
+            if (f.accels.size() <= 64 && ((size_t)a->stack_depth * 256 * 4 + img) * 4 <= LDS_MAX) a->accel_image_n16 = (uint32_t)(f.accels.size() * LDS_ACCEL_UNITS);
+        }
+        const size_t extra_lds = (size_t)a->accel_image_n16 * 16;
+        size_t lds = (size_t)std::max(a->stack_depth, a->stack_depth_fast1) * 256 * 4 + extra_lds;
         if (lds > 64 * 1024) { HIP_TRY(mega_set_lds_limit(lds, false)); HIP_TRY(wf_set_lds_limit(lds, false)); HIP_TRY(queue_set_lds_limit(lds, false)); }
         int per_cu = 0, cus = 0;
-        HIP_TRY(trace_occupancy(a->stack_depth, false, &per_cu));
+        HIP_TRY(trace_occupancy(a->stack_depth, false, false, extra_lds, &per_cu));
+        int per_cu3 = 0;
+        HIP_TRY(trace_occupancy(a->stack_depth, false, true, extra_lds, &per_cu3));
         int per_cu_fast = 0;
-        HIP_TRY(trace_occupancy(a->stack_depth_fast1, true, &per_cu_fast));
+        HIP_TRY(trace_occupancy(a->stack_depth_fast1, true, false, 0, &per_cu_fast));
         if (per_cu_fast < 1) per_cu_fast = 1;
         a->max_blocks_fast = (uint32_t)per_cu_fast;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device));
         if (per_cu < 1) per_cu = 1;
         a->max_blocks = (uint32_t)(per_cu * cus);
+        a->max_blocks3 = (uint32_t)((per_cu3 < 1 ? 1 : per_cu3) * cus);
         a->max_blocks_fast *= (uint32_t)cus;
         int wb = 0, wbf = 0;
-        HIP_TRY(wf_trace_occupancy(a->stack_depth, false, &wb));
-        HIP_TRY(wf_trace_occupancy(a->stack_depth_fast1, true, &wbf));
+        HIP_TRY(wf_trace_occupancy(a->stack_depth, false, extra_lds, &wb));
+        HIP_TRY(wf_trace_occupancy(a->stack_depth_fast1, true, 0, &wbf));
         a->wf_blocks = (uint32_t)((wb < 1 ? 1 : wb) * cus);
         a->wf_blocks_fast = (uint32_t)((wbf < 1 ? 1 : wbf) * cus);
         int qb = 0;
-        HIP_TRY(queue_occupancy(a->stack_depth, &qb));
+        HIP_TRY(queue_occupancy(a->stack_depth, extra_lds, &qb));
         a->queue_blocks = (uint32_t)((qb < 1 ? 1 : qb) * cus);
         a->cus = (uint32_t)cus;
         // LDS-resident scene: the REFERENCE tree's nodes (56 of 64 bytes, padded to 80 when that fits),
@@ -1072,6 +1095,19 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                 a->ldss_blocks = (uint32_t)cus;
             }
             a->accels.upload(fm.accels); // again, now with the compact bases
+            if (a->accel_image_n16) { // the accel records alone, global bases in unit [6] (the LDS-resident image carries compact ones)
+                std::vector<uint32_t> img((size_t)a->accel_image_n16 * 4, 0u);
+                for (size_t i = 0; i < fm.accels.size(); ++i) {
+                    const DAccel &A = fm.accels[i];
+                    uint32_t *rec = &img[i * LDS_ACCEL_UNITS * 4];
+                    std::memcpy(rec, &A.minv, 96);
+                    rec[24] = A.node_base; rec[25] = A.prim_base; rec[26] = 0u; rec[27] = A.flags;
+                    rec[28] = (uint32_t)A.parent; rec[29] = A.nchain;
+                    for (int k = 0; k < MAX_CHAIN; ++k) rec[32 + k] = A.chain[k];
+                    std::memcpy(rec + 40, A.prune, sizeof A.prune);
+                }
+                a->accel_image.upload(img);
+            }
         }
         // Which organisation is the default (measured, tools/threshold_sweep.py): the megakernel unless the scene has
         // so many spheres / boxes that BVH-node and sphere tests dominate a ray (>= 512: with the scene tables in LDS
@@ -1088,9 +1124,18 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
             // (100k-triangle glass torus: 226 against 136 ms): those stay in the megakernel, where other tiles fill the gaps.
             a->prune_default = big_mesh >= 256; // the reference's mesh leaves hold up to 254 triangles (bvh.rs:187,289): skipping one pays for many node steps
             a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512 && !(f.has_specular && big_mesh >= 4096);
-            // glass / mirror over a big mesh: the queue organisation (round 4; config 4: 38.0 against the megakernel's 42.6 ms, and
-            // the level-by-level pipeline's 80; 4m: 15.8 / 15.9; launches of 2^16 pixels and more)
-            a->queue_default = f.has_specular && big_mesh >= 4096;
+            // a big mesh of glass / mirror: the queue organisation (round 4; config 4: 38.7 against the megakernel's 40.8 ms and the
+            // level-by-level pipeline's 80; a metal mesh beside a small mirror -- config 4m -- stays in the megakernel: 14.7 / 16.4)
+            bool specular_mesh = false; // a mesh of >= 4096 triangles that is itself glass / mirror: every hit on it spawns secondary rays
+            for (const DAccel &A : f.accels)
+                if ((A.flags & AF_MESH) && A.material >= 0) {
+                    const int kind = f.materials[(size_t)A.material].kind;
+                    size_t tris = 0;
+                    for (const auto &m : a->scene->meshes) if (m && m->tri.size() / 3 > tris) tris = m->tri.size() / 3; // (an upper bound: the largest mesh)
+                    specular_mesh = specular_mesh || ((kind == MAT_GLASS || kind == MAT_MIRROR) && tris >= 4096);
+                }
+            a->queue_default = f.has_specular && big_mesh >= 4096 && specular_mesh;
+            a->mega_waves3 = big_mesh >= 4096;
             a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 20);
         }
 }
@@ -1107,7 +1152,7 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.vpos, y.vpos); swap(x.vnorm, y.vnorm); swap(x.vtex, y.vtex); swap(x.leaf_soup, y.leaf_soup); swap(x.chunks, y.chunks); swap(x.leaf_soup2, y.leaf_soup2);
     swap(x.sphere_ref_leaf, y.sphere_ref_leaf); swap(x.cuboid_ref_leaf, y.cuboid_ref_leaf); swap(x.tri_ref_leaf, y.tri_ref_leaf); swap(x.accel_ref_leaf, y.accel_ref_leaf);
     swap(x.accels, y.accels); swap(x.materials, y.materials); swap(x.lights, y.lights);
-    swap(x.lds_image, y.lds_image);
+    swap(x.lds_image, y.lds_image); swap(x.accel_image, y.accel_image); swap(x.accel_image_n16, y.accel_image_n16);
     swap(x.lds_image_n16, y.lds_image_n16); swap(x.lds_node_off, y.lds_node_off); swap(x.lds_prim_off, y.lds_prim_off);
     swap(x.lds_soup_off, y.lds_soup_off); swap(x.lds_accel_off, y.lds_accel_off);
     swap(x.ldss_blocks, y.ldss_blocks); swap(x.cus, y.cus);

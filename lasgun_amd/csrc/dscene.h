@@ -289,8 +289,13 @@ struct DParams {
     uint32_t lds_prim_off;                  // primref[] as dwords from here
     uint32_t lds_soup_off;                  // one 3-unit (48-byte) leaf record per primref slot
     uint32_t lds_accel_off;                 // LDS_ACCEL_UNITS units per accel: what the walk needs of a DAccel (see LDS_ACCEL_UNITS)
+    // scenes whose tables stay in L2: just the accel records in their LDS layout (LDS_ACCEL_UNITS units each, unit [6] with global
+    // node / primref bases), copied behind the stacks by the 256-lane kernels (walk.h, lvl_set); nullptr: too many accels
+    const void *accel_image;
+    uint32_t accel_image_n16;
     unsigned long long *stamp_counts; // diagnostic build (-DLG_STAMPS) only
     uint32_t stats_filter;      // counting variant: 0 = all traversals, 1 = closest-hit (primary/secondary) only, 2 = shadow only
+    uint32_t mega_waves;        // megakernel, 256-lane form: 3 = the instantiation allocated for three waves per SIMD (scenes with a big mesh)
     uint32_t audit;             // counting variant: also audit what the pruned walk skips (walk.h, audit_prim)
 };
 

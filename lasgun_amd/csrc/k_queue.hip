@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
         __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling work
         scn = dst;
     }
+    const uint4 *const arec = LDSS ? nullptr : load_accel_image(P, P.stack_depth * LG_BLOCK);
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)cnt;
     uint32_t *const ctl = P.q_ctl;
     const uint32_t levels = P.wf_levels;
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
                 }
                 Best b;
                 b.ref = NO_HIT; b.t = INFINITY; b.accel = 0u;
-                if (shadow ? hit : valid) walk<LDSS, false, PRUNE>(P, tray, shadow, stack, stride, b, scn, cnt);
+                if (shadow ? hit : valid) walk<LDSS, false, PRUNE>(P, tray, shadow, stack, stride, b, scn, cnt, arec);
                 if (!shadow) {
                     hit = valid && b.ref != NO_HIT;
                     if (hit) {
@@ -368,13 +369,13 @@ hipError_t launch_queue(const DParams &P, uint32_t blocks, hipStream_t stream) {
         else hipLaunchKernelGGL((queue_kernel<true, false>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
         return hipGetLastError();
     }
-    const size_t lds = (size_t)P.stack_depth * LG_BLOCK * sizeof(uint32_t);
+    const size_t lds = (size_t)P.stack_depth * LG_BLOCK * sizeof(uint32_t) + (P.accel_image ? (size_t)P.accel_image_n16 * 16u : 0u);
     if (P.prune) hipLaunchKernelGGL((queue_kernel<false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     else hipLaunchKernelGGL((queue_kernel<false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     return hipGetLastError();
 }
-hipError_t queue_occupancy(uint32_t stack_depth, int *blocks_per_cu) {
-    const size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
+hipError_t queue_occupancy(uint32_t stack_depth, size_t extra_lds, int *blocks_per_cu) {
+    const size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t) + extra_lds;
     int a = 0, b = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, queue_kernel<false, false>, LG_BLOCK, lds);
     if (e != hipSuccess) return e;

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
         __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling tiles
         scn = dst;
     }
+    const uint4 *const arec = (LDSS || FAST) ? nullptr : load_accel_image(P, P.stack_depth * LG_BLOCK);
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)cnt;
     // Tiles are claimed XCD by XCD (kcommon.h, claim_tile) where the scene sits in LDS and the claim itself is what waves queue on:
     // headline frame 3.39 + 3.52 -> 3.10 + 3.19 ms for the two traversal passes.  With the tables in L2 (mesh scenes) the bands
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             b.ref = NO_HIT; b.t = INFINITY; b.accel = 0u;
             if (active) {
                 bool tie = false;
-                walk<LDSS, FAST, PRUNE>(P, ray, false, stack, stride, b, scn, cnt);
+                walk<LDSS, FAST, PRUNE>(P, ray, false, stack, stride, b, scn, cnt, arec);
                 (void)tie;
             }
             const bool hit = active && b.ref != NO_HIT;
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
                 Ray sray = ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
                 Best b;
                 bool tie = false;
-                walk<LDSS, FAST, PRUNE>(P, sray, true, stack, stride, b, scn, cnt);
+                walk<LDSS, FAST, PRUNE>(P, sray, true, stack, stride, b, scn, cnt, arec);
                 (void)tie;
                 if (!(b.t < 1.0)) vis |= 1u << l; // point.rs:49
             }
@@ -331,7 +332,7 @@ hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t bl
     const bool l0 = !shadow && P.wf_level == 0u;
     const uint32_t block = ldss ? LG_LDSS_BLOCK : LG_BLOCK;
     const uint32_t depth = fast ? stack_depth : P.stack_depth;
-    size_t lds = (size_t)depth * block * sizeof(uint32_t) + (ldss ? (size_t)P.lds_image_n16 * 16u : 0u);
+    size_t lds = (size_t)depth * block * sizeof(uint32_t) + (ldss ? (size_t)P.lds_image_n16 * 16u : (!fast && P.accel_image ? (size_t)P.accel_image_n16 * 16u : 0u));
 #define LG_LAUNCH(F, S, L, Z) hipLaunchKernelGGL((wf_trace_kernel<F, S, L, Z>), dim3(blocks), dim3(block), lds, stream, P)
 #define LG_LAUNCH_PRUNED(S, L, Z) hipLaunchKernelGGL((wf_trace_kernel<false, S, L, Z, true>), dim3(blocks), dim3(block), lds, stream, P)
     if (P.prune && !fast) {
@@ -357,8 +358,8 @@ hipError_t launch_wf_combine(const DParams &P, uint32_t blocks, hipStream_t stre
     hipLaunchKernelGGL(wf_combine_kernel, dim3(blocks), dim3(LG_BLOCK), 0, stream, P);
     return hipGetLastError();
 }
-hipError_t wf_trace_occupancy(uint32_t stack_depth, bool fast, int *blocks_per_cu) {
-    size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t);
+hipError_t wf_trace_occupancy(uint32_t stack_depth, bool fast, size_t extra_lds, int *blocks_per_cu) {
+    size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t) + (fast ? 0u : extra_lds);
     int a = 0, b = 0;
     hipError_t e;
     if (fast) {

@@ -250,6 +250,17 @@ __device__ __forceinline__ Pixel pixel_of(const DParams &P, uint32_t tile, uint3
 
 extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
 
+// 256-lane kernels (scene tables in L2): the accel records copied in behind the per-lane stacks (walk.h, lvl_set); nullptr when the
+// scene has too many accels for that.  Called by every wave of the workgroup before it pulls work (one barrier).
+__device__ __forceinline__ const uint4 *load_accel_image(const DParams &P, uint32_t stack_words) {
+    if (!P.accel_image) return nullptr;
+    uint4 *dst = reinterpret_cast<uint4 *>(lds_stack + stack_words);
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.accel_image);
+    for (uint32_t i = threadIdx.x; i < P.accel_image_n16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return dst;
+}
+
 // Shading frame of a hit from the ray that found it (resolve_hit + SurfaceInteraction::from,
 // surface.rs:158-183).  Pure function of (ray, best): recomputed after each shadow traversal
 // instead of being kept in registers across it, which is what lets 4-5 waves share a SIMD.

@@ -578,11 +578,15 @@ struct Lvl { // the accel level a lane is walking
 constexpr uint32_t LDS_NODE_BYTES = LDS_NODE_STRIDE * 16u;
 constexpr uint32_t LDS_NODE_WALK_OFF = 64u; // words 16..19 of the 80-byte record
 // What the walk needs of a DAccel: from the LDS image (LDS_ACCEL_UNITS) or from the table in HBM / L2
+// `arec`: the accel records in LDS (LDS_ACCEL_UNITS units each) -- part of the LDS-resident scene image (LDSS), or, for a scene whose
+// tables stay in L2, the small image of just these records that the 256-lane kernels copy in behind their stacks (DParams::
+// accel_image; its unit [6] carries global node / primref bases); nullptr: the DAccel table in HBM / L2.  Entering and leaving
+// nested accels is a chain of DEPENDENT fetches of these fields: from L2 that was 37 % of the walk's cycles on config 4m.
 template <bool LDSS, bool FAST = false>
-__device__ __forceinline__ void lvl_set(const DParams &P, const uint4 *scn, Lvl &L, uint32_t accel) {
+__device__ __forceinline__ void lvl_set(const DParams &P, const uint4 *arec, Lvl &L, uint32_t accel) {
     L.accel = accel;
-    if (LDSS) {
-        const uint4 info = scn[P.lds_accel_off + accel * LDS_ACCEL_UNITS + 6u];
+    if (LDSS || (!FAST && arec)) {
+        const uint4 info = arec[accel * LDS_ACCEL_UNITS + 6u];
         L.node_base = info.x; L.prim_base = info.y; L.soup_delta = info.z; L.flags = info.w;
     } else {
         const DAccel *A = P.accels + accel;
@@ -590,9 +594,9 @@ __device__ __forceinline__ void lvl_set(const DParams &P, const uint4 *scn, Lvl 
     }
 }
 template <bool LDSS>
-__device__ __forceinline__ Ray accel_local_ray(const DParams &P, const uint4 *scn, uint32_t accel, const Ray &r) { // inverse_transform_ray (bvh.rs:462)
-    if (LDSS) {
-        const double2 *q = reinterpret_cast<const double2 *>(scn + (P.lds_accel_off + accel * LDS_ACCEL_UNITS));
+__device__ __forceinline__ Ray accel_local_ray(const DParams &P, const uint4 *arec, uint32_t accel, const Ray &r) { // inverse_transform_ray (bvh.rs:462)
+    if (LDSS || arec) {
+        const double2 *q = reinterpret_cast<const double2 *>(arec + accel * LDS_ACCEL_UNITS);
         const double2 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
         Affine m;
         m.c[0][0] = a.x; m.c[0][1] = a.y; m.c[0][2] = b.x; m.c[1][0] = b.y; m.c[1][1] = c.x; m.c[1][2] = c.y;
@@ -847,9 +851,15 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
         // rate this loop is otherwise bound by.
         bool in_run = false, done = false;
         uint32_t off = 0;
+#ifdef LG_STAMPS
+        unsigned long long ml_cnt[6] = {0, 0, 0, 0, 1ull, (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true))};
+#endif
         for (;;) {
             bool seeking = wave_any(!in_run && rec < rec_end);
             while (seeking) {
+#ifdef LG_STAMPS
+                ml_cnt[0] += 1; ml_cnt[1] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(!in_run && rec < rec_end));
+#endif
                 if (!in_run && rec < rec_end) {
                     if (COUNT) cnt.nodes++; // (a record test is counted with the node tests)
                     uint32_t start, count;
@@ -877,6 +887,9 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
             bool testing = wave_any(in_run);
             if (!testing) break;
             while (testing) {
+#ifdef LG_STAMPS
+                ml_cnt[2] += 1; ml_cnt[3] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_run));
+#endif
                 if (in_run) {
                     const bool two = s + 1u < run_end;
                     const uint32_t off0 = __builtin_amdgcn_readfirstlane(off);
@@ -897,6 +910,10 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
                 testing = wave_any(in_run);
             }
         }
+#ifdef LG_STAMPS
+        if (P.stamp_counts && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+            for (int i = 0; i < 6; ++i) atomicAdd(P.stamp_counts + 9 + i, ml_cnt[i]);
+#endif
         return done;
 #undef LG_TRI2
         return false;
@@ -945,8 +962,9 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 // 4 accel entered, 5 returned to the parent, 6 triangle accepted.
 template <bool LDSS, bool FAST = false, bool PRUNE = false, bool COUNT = false>
 __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
-                                             Best &best, const uint4 *scn, bool &tie, Counters &cnt) {
+                                             Best &best, const uint4 *scn, bool &tie, Counters &cnt, const uint4 *arec_in = nullptr) {
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
+    const uint4 *const arec = LDSS ? scn + P.lds_accel_off : (FAST ? nullptr : arec_in); // the accel records in LDS, if they are there (lvl_set)
     static_assert(!(FAST && PRUNE), "the fast mode prunes its own trees by its own rule");
 #ifdef LG_STAMPS
     unsigned long long stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_readcyclecounter();
@@ -956,13 +974,13 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     if (COUNT) cnt.entries++; // the root accel
     uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
     Lvl L;
-    lvl_set<LDSS, FAST>(P, scn, L, 0u);
+    lvl_set<LDSS, FAST>(P, arec, L, 0u);
     double limit = prune_limit(INFINITY, anyhit); // FAST: nodes whose tnear lies beyond this are skipped
     TriSetup tri;                                  // FAST: per mesh level (its leaves hold one triangle: per leaf the three divides would dominate)
     tri.kz = 0; tri.sx = 0.0; tri.sy = 0.0; tri.sz = 0.0;
     // ---- the root accel's local ray (bvh.rs:462), kept for the returns
     Ray root = wray;
-    if (!((L.flags & AF_IDENTITY) && ray_plain(wray))) root = accel_local_ray<LDSS>(P, scn, 0u, wray);
+    if (!((L.flags & AF_IDENTITY) && ray_plain(wray))) root = accel_local_ray<LDSS>(P, arec, 0u, wray);
     Ray ray = root;
     double dd = dot(ray.d, ray.d);      // a of every sphere's quadratic at this level
     double four_a = 4.0 * dd;           // 4.0 * a of its discriminant b*b - 4.0*a*c (core/math.rs:16: (4.0 * a) * c)
@@ -988,8 +1006,8 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     };
     auto prune_level = [&]() { // after L and ray have changed
         double c[6];
-        if (LDSS) {
-            const double2 *q = reinterpret_cast<const double2 *>(scn + (P.lds_accel_off + L.accel * LDS_ACCEL_UNITS + 10u));
+        if (LDSS || arec) {
+            const double2 *q = reinterpret_cast<const double2 *>(arec + (L.accel * LDS_ACCEL_UNITS + 10u));
             const double2 a = q[0], b = q[1], e = q[2];
             c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
         } else {
@@ -1218,12 +1236,12 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         if (wave_any(state == ST_LEVEL_DONE)) stamp_cnt[4] += 1;
 #endif
         if (state == ST_ENTER) {
-            lvl_set<LDSS, FAST>(P, scn, L, enter);
+            lvl_set<LDSS, FAST>(P, arec, L, enter);
             const bool same = (L.flags & AF_IDENTITY) != 0u && ray_plain(ray);
             stk[sp * stride] = li; stk[(sp + 1u) * stride] = le; stk[(sp + 2u) * stride] = base | (same ? FRAME_SAME_RAY : 0u);
             sp += 3u; base = sp;
             if (!same) {
-                ray = accel_local_ray<LDSS>(P, scn, enter, ray);
+                ray = accel_local_ray<LDSS>(P, arec, enter, ray);
                 dd = dot(ray.d, ray.d);
                 four_a = 4.0 * dd;
                 negmask = neg_mask_x(ray);
@@ -1244,22 +1262,22 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 if (COUNT) dbg_event(P, 5.0, (double)L.accel, (double)li, (double)le);
                 uint32_t parent, nchain;
                 const uint32_t *chain;
-                if (LDSS) {
-                    const uint4 *rec = scn + (P.lds_accel_off + L.accel * LDS_ACCEL_UNITS);
+                if (LDSS || arec) {
+                    const uint4 *rec = arec + L.accel * LDS_ACCEL_UNITS;
                     parent = rec[7].x;
-                    const uint4 *prec = scn + (P.lds_accel_off + parent * LDS_ACCEL_UNITS);
+                    const uint4 *prec = arec + parent * LDS_ACCEL_UNITS;
                     nchain = prec[7].y; chain = reinterpret_cast<const uint32_t *>(prec + 8);
                 } else {
                     parent = (uint32_t)P.accels[L.accel].parent;
                     nchain = P.accels[parent].nchain; chain = P.accels[parent].chain;
                 }
-                lvl_set<LDSS, FAST>(P, scn, L, parent);
+                lvl_set<LDSS, FAST>(P, arec, L, parent);
                 if (!(w2 & FRAME_SAME_RAY)) { // the parent's ray again: from the root's, through the same transforms
                     ray = root;
                     for (uint32_t i = 1; i < nchain; ++i) {
                         const uint32_t c = chain[i];
-                        const uint32_t cflags = LDSS ? scn[P.lds_accel_off + c * LDS_ACCEL_UNITS + 6u].w : P.accels[c].flags;
-                        if (!((cflags & AF_IDENTITY) && ray_plain(ray))) ray = accel_local_ray<LDSS>(P, scn, c, ray);
+                        const uint32_t cflags = (LDSS || arec) ? arec[c * LDS_ACCEL_UNITS + 6u].w : P.accels[c].flags;
+                        if (!((cflags & AF_IDENTITY) && ray_plain(ray))) ray = accel_local_ray<LDSS>(P, arec, c, ray);
                     }
                     dd = dot(ray.d, ray.d);
                     four_a = 4.0 * dd;
@@ -1501,7 +1519,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
                 uint32_t parent, nchain;
                 const uint32_t *chain;
                 if (LDSS) {
-                    const uint4 *rec = scn + (P.lds_accel_off + L.accel * LDS_ACCEL_UNITS);
+                    const uint4 *rec = scn + (P.lds_accel_off + L.accel * LDS_ACCEL_UNITS); // (never taken: LDSS is false here)
                     parent = rec[7].x;
                     const uint4 *prec = scn + (P.lds_accel_off + parent * LDS_ACCEL_UNITS);
                     nchain = prec[7].y; chain = reinterpret_cast<const uint32_t *>(prec + 8);
@@ -1538,13 +1556,13 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
 // otherwise the ray is traced again with the reference walk over the tables in HBM / L2.
 template <bool LDSS, bool FAST, bool PRUNE = false, bool COUNT = false>
 __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const bool anyhit, uint32_t *stack, const uint32_t stride, Best &best,
-                                     const uint4 *scn, Counters &cnt) {
+                                     const uint4 *scn, Counters &cnt, const uint4 *arec = nullptr) {
     bool tie = false;
 #ifndef LG_FAST_ONE_NODE
     if (FAST) traverse_fast<COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt);
     else
 #endif
-    traverse_ref<LDSS, FAST, PRUNE, COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt);
+    traverse_ref<LDSS, FAST, PRUNE, COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt, arec);
     if (!FAST) return;
     if (COUNT) dbg_event(P, 9.0, tie ? 1.0 : 0.0, best.t, (double)best.ref);
     bool redo;
@@ -1555,7 +1573,7 @@ __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const boo
         if (!redo && best.ref != NO_HIT) redo = !ref_candidate(P, ray, best);
 #endif
     }
-    if (redo) traverse_ref<false, false, false, COUNT>(P, ray, anyhit, stack, stride, best, nullptr, tie, cnt);
+    if (redo) traverse_ref<false, false, false, COUNT>(P, ray, anyhit, stack, stride, best, nullptr, tie, cnt, arec);
 }
 
 // ------------------------------------------------------------------------------------------
