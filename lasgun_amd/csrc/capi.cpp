@@ -21,7 +21,7 @@
 namespace lg {
 // k_mega.hip, k_wavefront.hip, k_queue.hip, k_probe.hip
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
-hipError_t trace_occupancy(uint32_t stack_depth, bool fast, bool waves3, size_t extra_lds, int *blocks_per_cu);
+hipError_t trace_occupancy(uint32_t stack_depth, bool fast, size_t extra_lds, int *blocks_per_cu);
 hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
 hipError_t launch_wf_shade(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t launch_wf_combine(const DParams &P, uint32_t blocks, hipStream_t stream);
@@ -250,8 +250,6 @@ struct lg_accel {
     uint32_t stack_depth = 1;      // reference traversal
     uint32_t stack_depth_fast1 = 1; // fast traversal (one word per pending child; also deep enough for its reference re-trace)
     uint32_t max_blocks = 1;
-    uint32_t max_blocks3 = 1;      // grid of the megakernel's three-waves-per-SIMD instantiation
-    bool mega_waves3 = false;      // the scene carries a big mesh: the megakernel's 256-lane form runs at three waves per SIMD
     uint32_t max_blocks_fast = 1;
     uint64_t device_bytes = 0;
     mutable bool profiling = false;
@@ -700,10 +698,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         enqueue_wavefront(a, P, c, stream);
         return;
     }
-    static const int waves_env = [] { const char *e = std::getenv("LASGUN_MEGA_WAVES"); return e ? std::atoi(e) : 0; }(); // (3 / 4: A/B)
-    const bool waves3 = !stats && !a.fast && !(a.lds_scene && a.ldss_blocks) && (waves_env == 3 || (waves_env == 0 && a.mega_waves3));
-    P.mega_waves = waves3 ? 3u : 4u;
-    uint32_t cap = a.fast ? a.max_blocks_fast : waves3 ? a.max_blocks3 : a.max_blocks;
+    uint32_t cap = a.fast ? a.max_blocks_fast : a.max_blocks;
     uint32_t blocks = (P.ntiles + 3u) / 4u;
     if (blocks > cap) blocks = cap;
     uint32_t maxb = a.max_blocks > a.max_blocks_fast ? a.max_blocks : a.max_blocks_fast;
@@ -994,17 +989,14 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         size_t lds = (size_t)std::max(a->stack_depth, a->stack_depth_fast1) * 256 * 4 + extra_lds;
         if (lds > 64 * 1024) { HIP_TRY(mega_set_lds_limit(lds, false)); HIP_TRY(wf_set_lds_limit(lds, false)); HIP_TRY(queue_set_lds_limit(lds, false)); }
         int per_cu = 0, cus = 0;
-        HIP_TRY(trace_occupancy(a->stack_depth, false, false, extra_lds, &per_cu));
-        int per_cu3 = 0;
-        HIP_TRY(trace_occupancy(a->stack_depth, false, true, extra_lds, &per_cu3));
+        HIP_TRY(trace_occupancy(a->stack_depth, false, extra_lds, &per_cu));
         int per_cu_fast = 0;
-        HIP_TRY(trace_occupancy(a->stack_depth_fast1, true, false, 0, &per_cu_fast));
+        HIP_TRY(trace_occupancy(a->stack_depth_fast1, true, 0, &per_cu_fast));
         if (per_cu_fast < 1) per_cu_fast = 1;
         a->max_blocks_fast = (uint32_t)per_cu_fast;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device));
         if (per_cu < 1) per_cu = 1;
         a->max_blocks = (uint32_t)(per_cu * cus);
-        a->max_blocks3 = (uint32_t)((per_cu3 < 1 ? 1 : per_cu3) * cus);
         a->max_blocks_fast *= (uint32_t)cus;
         int wb = 0, wbf = 0;
         HIP_TRY(wf_trace_occupancy(a->stack_depth, false, extra_lds, &wb));
@@ -1135,7 +1127,6 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                     specular_mesh = specular_mesh || ((kind == MAT_GLASS || kind == MAT_MIRROR) && tris >= 4096);
                 }
             a->queue_default = f.has_specular && big_mesh >= 4096 && specular_mesh;
-            a->mega_waves3 = big_mesh >= 4096;
             a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 20);
         }
 }

@@ -295,7 +295,6 @@ struct DParams {
     uint32_t accel_image_n16;
     unsigned long long *stamp_counts; // diagnostic build (-DLG_STAMPS) only
     uint32_t stats_filter;      // counting variant: 0 = all traversals, 1 = closest-hit (primary/secondary) only, 2 = shadow only
-    uint32_t mega_waves;        // megakernel, 256-lane form: 3 = the instantiation allocated for three waves per SIMD (scenes with a big mesh)
     uint32_t audit;             // counting variant: also audit what the pruned walk skips (walk.h, audit_prim)
 };
 

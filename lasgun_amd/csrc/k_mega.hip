@@ -5,11 +5,8 @@ namespace lg {
 
 // LDSS (reference traversal only): one 1024-lane workgroup per CU with the scene's node / primref / sphere /
 // cuboid tables copied into LDS behind the stacks (see load_node); otherwise 256-lane workgroups and L1/L2.
-// WAVES: waves per SIMD the register allocation is made for (4: 128 VGPRs; 3: 168).  Scenes with a big mesh run the 256-lane form
-// at 3: the state machine's spills shrink and the fat-leaf loops gain more than the fourth wave hid (config 4 44.0 -> 40.3 ms,
-// 4m 16.2 -> 15.1; the small LDS-resident scenes lose with it: Cornell glass 0.83 -> 0.84, so they keep 4).
-template <bool STATS, bool FAST, bool LDSS, bool PRUNE = false, int WAVES = LG_WAVES_PER_SIMD>
-__global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, WAVES) trace_kernel(const DParams P) {
+template <bool STATS, bool FAST, bool LDSS, bool PRUNE = false>
+__global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(const DParams P) {
     static_assert(!(PRUNE && FAST), "the fast mode prunes its own trees by its own rule");
     static_assert(!(FAST && LDSS) && !(STATS && LDSS), "LDS-resident scene: plain reference traversal only");
     const uint32_t tid = threadIdx.x;
@@ -295,7 +292,6 @@ hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks
     size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t) + (!fast && P.accel_image ? (size_t)P.accel_image_n16 * 16u : 0u);
     if (prune) {
         if (stats) hipLaunchKernelGGL((trace_kernel<true, false, false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-        else if (P.mega_waves == 3u) hipLaunchKernelGGL((trace_kernel<false, false, false, true, 3>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
         else hipLaunchKernelGGL((trace_kernel<false, false, false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
         return hipGetLastError();
     }
@@ -304,15 +300,13 @@ hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks
         else hipLaunchKernelGGL((trace_kernel<false, true, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     } else {
         if (stats) hipLaunchKernelGGL((trace_kernel<true, false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-        else if (P.mega_waves == 3u) hipLaunchKernelGGL((trace_kernel<false, false, false, false, 3>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
         else hipLaunchKernelGGL((trace_kernel<false, false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     }
     return hipGetLastError();
 }
-hipError_t trace_occupancy(uint32_t stack_depth, bool fast, bool waves3, size_t extra_lds, int *blocks_per_cu) {
+hipError_t trace_occupancy(uint32_t stack_depth, bool fast, size_t extra_lds, int *blocks_per_cu) {
     size_t lds = (size_t)stack_depth * LG_BLOCK * sizeof(uint32_t) + (fast ? 0u : extra_lds);
     if (fast) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, true, false>, LG_BLOCK, lds);
-    if (waves3) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, false, false, true, 3>, LG_BLOCK, lds);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_kernel<false, false, false>, LG_BLOCK, lds);
 }
 hipError_t launch_trace_pixel(const DParams &P, bool fast, uint32_t stack_depth, uint32_t x, uint32_t y, double *out, hipStream_t stream) {
@@ -332,9 +326,7 @@ hipError_t mega_set_lds_limit(size_t bytes, bool ldss) {
         reinterpret_cast<const void *>(trace_kernel<false, true, false>),
         reinterpret_cast<const void *>(trace_kernel<true, true, false>),
         reinterpret_cast<const void *>(trace_kernel<false, false, false, true>),
-        reinterpret_cast<const void *>(trace_kernel<true, false, false, true>),
-        reinterpret_cast<const void *>(trace_kernel<false, false, false, false, 3>),
-        reinterpret_cast<const void *>(trace_kernel<false, false, false, true, 3>)};
+        reinterpret_cast<const void *>(trace_kernel<true, false, false, true>)};
     const void *const *fns = ldss ? ldss_fns : plain_fns;
     const size_t n = ldss ? sizeof ldss_fns / sizeof ldss_fns[0] : sizeof plain_fns / sizeof plain_fns[0];
     for (size_t i = 0; i < n; ++i) {
