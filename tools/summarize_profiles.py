@@ -7,9 +7,9 @@ import os
 import statistics
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final3"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final4"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
 
 
 def newest(pattern):
