@@ -1172,7 +1172,9 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 const uint32_t kind = ref >> 30, idx = ref & PRIM_INDEX_MASK;
                 bool accepted = false;
                 double t = 0.0;
-                if (kind == PK_SPHERE) { // Sphere::intersect_t + quad_roots (sphere.rs:30-69, core/math.rs) == sphere_t_a
+                // (the slots of a non-mesh accel are spheres, boxes and nested accels -- triangles live in mesh accels, whose leaves
+                // mesh_leaf2 walks; the sphere is asked for first, with one compare on the primref: the common case passes one branch)
+                if (ref < (1u << 30)) { // PK_SPHERE: Sphere::intersect_t + quad_roots (sphere.rs:30-69, core/math.rs) == sphere_t_a
                     const V3 cen{rec_f64(g.a.x, g.a.y), rec_f64(g.a.z, g.a.w), rec_f64(g.b.x, g.b.y)};
                     const V3 l = ray.o - cen;
                     const double b = 2.0 * dot(ray.d, l);
@@ -1192,20 +1194,16 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                         }
                     }
                     accepted = has && !(t < 0.0) && !(t >= best.t);
-                } else if (kind == PK_CUBOID) {
-                    double mn[3] = {rec_f64(g.a.x, g.a.y), rec_f64(g.a.z, g.a.w), rec_f64(g.b.x, g.b.y)};
-                    double mx[3] = {rec_f64(g.b.z, g.b.w), rec_f64(g.c.x, g.c.y), rec_f64(g.c.z, g.c.w)};
-                    V3 d0, d1;
-                    if (cuboid_hit<false>(mn, mx, ray, t, d0, d1)) accepted = !(t >= best.t);
-                } else if (kind == PK_ACCEL) {
+                } else if (ref >= (3u << 30)) { // PK_ACCEL
                     // nested BVHAccel (Group / Mesh): entered below, outside this loop -- the ray and the level are
                     // loop-invariant here, which keeps them out of the loop's register shuffles
                     enter = idx;
                     state = ST_ENTER;
-                } else { // a triangle outside a mesh accel cannot be built by the scene API; kept for completeness
-                    const uint32_t *vi = P.tri_v + 3ull * idx;
-                    TriHit h;
-                    if (triangle_t(load_f3(P.vpos, vi[0]), load_f3(P.vpos, vi[1]), load_f3(P.vpos, vi[2]), ray, h)) { t = h.t; accepted = !(t >= best.t); }
+                } else { // PK_CUBOID (a triangle slot outside a mesh accel cannot be built: host.cpp, Flattener::aggregate)
+                    double mn[3] = {rec_f64(g.a.x, g.a.y), rec_f64(g.a.z, g.a.w), rec_f64(g.b.x, g.b.y)};
+                    double mx[3] = {rec_f64(g.b.z, g.b.w), rec_f64(g.c.x, g.c.y), rec_f64(g.c.z, g.c.w)};
+                    V3 d0, d1;
+                    if (cuboid_hit<false>(mn, mx, ray, t, d0, d1)) accepted = !(t >= best.t);
                 }
                 if (COUNT) {
                     if (kind == PK_SPHERE) cnt.spheres++; else if (kind == PK_CUBOID) cnt.cuboids++; else if (kind == PK_ACCEL) cnt.entries++; else cnt.triangles++;
