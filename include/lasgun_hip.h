@@ -188,12 +188,14 @@ int lg_capture_stats(const lg_accel *, uint32_t width, uint32_t height, uint32_t
  * box test passes) is also walked the reference's way.  A primitive found there that the reference would have ACCEPTED at that
  * moment -- `t < isect.t` for a closest-hit ray (sphere.rs:86, cuboid.rs:95, triangle.rs:251), t < 1 for a shadow ray
  * (point.rs:49) -- is a violation of the property the walk's exactness rests on: `violations` must be 0.  For the others,
- * (t - limit) / margin is sampled (margin: the skipping rule's own, eps' * |1/d_axis|): min_slack_* = how much of the shipped
- * margin the scene actually needed (+inf: no sample).  Reference traversal only (not the fast mode); the pruned walk is forced
+ * (t - limit) / margin is sampled (margin: the skipping rule's own, eps' * |1/d_axis|): min_slack_* = how far beyond the limit the
+ * nearest skipped primitive was (+inf: no sample; a box whose own plane parameter IS the slab entry sits at 1 + a rounding).  Reference traversal only (not the fast mode); the pruned walk is forced
  * on for this render whatever the accel's setting. */
 typedef struct lg_prune_audit {
     uint64_t skipped_nodes, skipped_runs, primitives, violations;
     double min_slack_nodes, min_slack_runs;
+    double max_margin_used_nodes; /* largest (slab entry parameter - t) / margin over the primitives under skipped nodes: the share of the
+                                   * shipped margin that property (P) actually needed on this scene (1 would be the edge of a violation) */
 } lg_prune_audit;
 int lg_audit_prune(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, lg_prune_audit *out);
 

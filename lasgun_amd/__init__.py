@@ -204,7 +204,7 @@ class HipApi(Api):
         is also walked the reference's way; `violations` (skipped primitives the reference would have accepted) must be 0."""
         class _A(_C.Structure):
             _fields_ = [("skipped_nodes", _C.c_uint64), ("skipped_runs", _C.c_uint64), ("primitives", _C.c_uint64), ("violations", _C.c_uint64),
-                        ("min_slack_nodes", _C.c_double), ("min_slack_runs", _C.c_double)]
+                        ("min_slack_nodes", _C.c_double), ("min_slack_runs", _C.c_double), ("max_margin_used_nodes", _C.c_double)]
         r = _A()
         if self.call("audit_prune", accel.h, w, h, y0, h if y1 is None else y1, _C.byref(r)):
             raise LasgunError(self.last_error())

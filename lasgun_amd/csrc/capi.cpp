@@ -1483,7 +1483,9 @@ int lg_audit_prune(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint3
             double v; std::memcpy(&v, &bits, sizeof v);
             return v;
         };
-        *out = lg_prune_audit{s.audit_nodes, s.audit_runs, s.audit_prims, s.audit_violations, slack(s.audit_slack_nodes), slack(s.audit_slack_runs)};
+        double used = 0.0;
+        std::memcpy(&used, &s.audit_used_nodes, sizeof used);
+        *out = lg_prune_audit{s.audit_nodes, s.audit_runs, s.audit_prims, s.audit_violations, slack(s.audit_slack_nodes), slack(s.audit_slack_runs), used};
     });
 }
 int lg_accel_set_lds_scene(const lg_accel *a, int enabled) {

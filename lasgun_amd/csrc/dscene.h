@@ -172,6 +172,7 @@ struct DStats { // per-launch counters (stats kernel variant only)
     // audit of the pruned walk (DParams::audit): skipped nodes / runs, primitives below them that yield a t, those the reference
     // would have accepted (must be 0), smallest (t - limit) / margin among the rest (complemented f64 bits, kept with atomicMax; 0 = no sample)
     unsigned long long audit_nodes, audit_runs, audit_prims, audit_violations, audit_slack_nodes, audit_slack_runs;
+    unsigned long long audit_used_nodes; // largest share of a node's margin a skipped primitive needed (f64 bits of a value >= 0, kept with atomicMax)
 };
 
 // Per-frame record of the explicit Whitted recursion stack (integrate.rs:69-79), in doubles.

@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
             // zeroed, so the MINIMUM is kept as the maximum of the complemented bits: 0 = no sample)
             atomicMax(&P.stats->audit_slack_nodes, ~(unsigned long long)__double_as_longlong(fmax_(cnt.a_slack_n, 0.0)));
             atomicMax(&P.stats->audit_slack_runs, ~(unsigned long long)__double_as_longlong(fmax_(cnt.a_slack_r, 0.0)));
+            atomicMax(&P.stats->audit_used_nodes, (unsigned long long)__double_as_longlong(fmax_(cnt.a_used_n, 0.0)));
         }
     }
 }

@@ -357,6 +357,7 @@ struct Counters {
     // (violations of property (P), DESIGN.md 3.4: must be 0), and the smallest (t - limit) / margin over the others
     uint32_t a_nodes = 0u, a_runs = 0u, a_prims = 0u, a_viol = 0u;
     double a_slack_n = INFINITY, a_slack_r = INFINITY;
+    double a_used_n = 0.0; // nodes: the largest (slab entry parameter - t) / margin over the skipped primitives: the share of the margin (P) needed
 };
 
 __device__ __forceinline__ Affine load_affine(const Affine *p) { return *p; }
@@ -724,8 +725,11 @@ __device__ __forceinline__ void audit_prim(bool valid, double t, double limit, d
 }
 // every primitive the reference reaches below node `top` of level L (its own box has passed the reference's test): no nested
 // accel can be among them (NODE_NOPRUNE keeps such nodes from being skipped)
+// `entry` / `emargin`: the skipped node's slab entry parameter and margin on each axis that said "beyond" (margin +inf elsewhere): the
+// rule relies on t >= entry_i - emargin_i for every primitive below the node; (entry_i - t) / emargin_i is the share of the margin a
+// primitive actually needed (<= 0: none; >= 1 would be a violation of (P))
 __device__ __noinline__ void audit_subtree(const DParams &P, uint32_t node_base, uint32_t prim_base, uint32_t top, const Ray &ray, double dd, double four_a,
-                                           double limit, double margin, bool anyhit, Counters &cnt) {
+                                           double limit, double margin, bool anyhit, Counters &cnt, V3 entry, V3 emargin) {
     uint32_t st[64];
     int sp = 0;
     uint32_t n = top;
@@ -771,6 +775,10 @@ __device__ __noinline__ void audit_subtree(const DParams &P, uint32_t node_base,
                         t = hh.t;
                     } else { cnt.a_viol++; } // a nested accel below a skipped node: the host's NODE_NOPRUNE marking failed
                     audit_prim(valid, t, limit, margin, anyhit, false, cnt, cnt.a_slack_n);
+                    if (valid) {
+                        const double used = fmax_(fmax_((entry.x - t) / emargin.x, (entry.y - t) / emargin.y), (entry.z - t) / emargin.z); // (x / inf = 0)
+                        if (used > cnt.a_used_n) cnt.a_used_n = used;
+                    }
                 }
             } else {
                 st[sp++] = node_base + nd->link; // second child
@@ -1078,10 +1086,11 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     const bool beyond = tx > plim.x || ty > plim.y || tz > plim.z; // (a NaN entry parameter compares false)
                     if (COUNT && !LDSS && P.audit && hit && beyond && (w_meta & NODE_NOPRUNE) == 0u) { // skipped although the reference would walk it
                         double margin = INFINITY; // the smallest margin among the axes that said "beyond"
-                        if (tx > plim.x) margin = fmin_(margin, peps * fabs(ray.dinv.x));
-                        if (ty > plim.y) margin = fmin_(margin, peps * fabs(ray.dinv.y));
-                        if (tz > plim.z) margin = fmin_(margin, peps * fabs(ray.dinv.z));
-                        audit_subtree(P, L.node_base, L.prim_base, cur, ray, dd, four_a, anyhit ? 1.0 : best.t, margin, anyhit, cnt);
+                        V3 em{INFINITY, INFINITY, INFINITY};
+                        if (tx > plim.x) { em.x = peps * fabs(ray.dinv.x); margin = fmin_(margin, em.x); }
+                        if (ty > plim.y) { em.y = peps * fabs(ray.dinv.y); margin = fmin_(margin, em.y); }
+                        if (tz > plim.z) { em.z = peps * fabs(ray.dinv.z); margin = fmin_(margin, em.z); }
+                        audit_subtree(P, L.node_base, L.prim_base, cur, ray, dd, four_a, anyhit ? 1.0 : best.t, margin, anyhit, cnt, V3{tx, ty, tz}, em);
                     }
                     hit = hit && !(beyond && (w_meta & NODE_NOPRUNE) == 0u);
                 } else if (SG < 8) {
