@@ -38,11 +38,16 @@ GENERATORS = {
     "adversarial_prune": (S.adversarial_prune_scene, (64, 48)),
     "progression_soup": (S.progression_soup_scene, (64, 48)),
 }
-# Generators that build knife-edge scenes on purpose (spheres touching in a point, rays through the tangent points): there one ulp
-# of atan2 / acos -- glibc's against the portable algorithm the device and the oracle's second mode share -- can turn into another
-# pixel value.  Everywhere else the device film must equal the GLIBC oracle's film byte for byte.
+# The oracle is rendered twice: with glibc's trigonometry (what the Rust binary calls) and with the portable algorithm the device
+# shares.  Where the two films agree -- all but a handful of pixels per campaign -- the device must equal the GLIBC film byte for
+# byte.  They can disagree in two ways: a knife-edge scene (spheres touching in a point, rays through the
+# tangent points: the generator adversarial_prune_scene builds them on purpose) turns one ulp of atan2 / acos into another pixel
+# value; and, anywhere, a channel whose value before quantisation sits within that ulp of a k + 0.5 boundary rounds the other way
+# (measured, round 4: 1 pixel in 46 M outside the knife-edge generator).  Both are properties of the two libms, not of the device:
+# budgeted per scene, counted, and the device may differ from the glibc film ONLY on those pixels.
 KNIFE_EDGE = {"adversarial_prune"}
-LIBM_PIXELS_PER_SCENE = 8  # budget of libm-sensitive pixels in one knife-edge scene (measured: 31 pixels in 49,600 scenes, at most 2 in one)
+LIBM_PIXELS_PER_SCENE = 8        # knife-edge generator (measured: 31 pixels in 49,600 scenes, at most 2 in one)
+LIBM_PIXELS_PER_SCENE_ELSEWHERE = 2
 # (streaming, fast, -, prune): megakernel and wavefront pipeline in either traversal mode, the pruned form of the reference walk in megakernel and wavefront pipeline, and the queue organisation (3) with either walk
 ORGANISATIONS = ((0, False, False, False), (0, True, False, False), (2, False, False, False), (2, True, False, False),
                  (0, False, False, True), (2, False, False, True), (3, False, False, False), (3, False, False, True))
@@ -79,10 +84,8 @@ def test_fuzz_campaign(gen):
             o.set_trig_mode(0)
         libm_sensitive = (ofilm_libm.pixels() != ofilm.pixels()).any(axis=-1)  # pixels on which the two oracle modes disagree
         done["libm_sensitive_pixels"] += int(libm_sensitive.sum())
-        if gen in KNIFE_EDGE:
-            assert int(libm_sensitive.sum()) <= LIBM_PIXELS_PER_SCENE, (gen, seed, int(libm_sensitive.sum()))
-        else:
-            assert not libm_sensitive.any(), ("the portable-trig oracle left the glibc oracle's bytes", gen, seed, int(libm_sensitive.sum()))
+        budget = LIBM_PIXELS_PER_SCENE if gen in KNIFE_EDGE else LIBM_PIXELS_PER_SCENE_ELSEWHERE
+        assert int(libm_sensitive.sum()) <= budget, ("the oracle's two trig modes differ on more pixels than one ulp explains", gen, seed, int(libm_sensitive.sum()))
         acc = G.Accel(build(G, seed))
         done["scenes"] += 1
         done["nan_pixels"] += int(np.isnan(np.asarray(orad)).any(axis=-1).sum())
