@@ -278,6 +278,10 @@ int lg_host_build_dump(const lg_scene *, const double **f, size_t *nf, const int
  * depth the flattening reserved, 0, 0 }.  Violations: a child box not containing its node's box, a leaf reached twice or
  * never, a dangling link. */
 int lg_host_check_wide_records(const lg_scene *, uint64_t out[8]);
+/* Host-only self-check of the triangle strips the pruned walk's leaf loop streams (no device): out = { mesh leaves with culling
+ * records, runs, triangles, strip entries, violations, 0, 0, 0 }.  Violations: a triangle of such a leaf that is not exactly one
+ * strip triangle, a strip triangle whose three vertices are not its slot's three vertices, a run whose counts disagree. */
+int lg_host_check_strips(const lg_scene *, uint64_t out[8]);
 
 /* One pixel traced by a single lane (sample 0): out = { t, primref, accel instance, number of lights, then per light
  * the shadow ray's { t, primref }, then the shadow rays' origin (3) } -- primref is 4294967295 for "no hit"; out_len >=

@@ -65,6 +65,7 @@ _EXTRA = {
     "host_build_dump": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.POINTER(_C.c_double)), _C.POINTER(_C.c_size_t),
                                    _C.POINTER(_C.POINTER(_C.c_int64)), _C.POINTER(_C.c_size_t), _C.c_uint64 * 8]),
     "host_check_wide_records": (_C.c_int, [_C.c_void_p, _C.c_uint64 * 8]),
+    "host_check_strips": (_C.c_int, [_C.c_void_p, _C.c_uint64 * 8]),
 }
 
 
@@ -244,6 +245,13 @@ class HipApi(Api):
         i = _np.ctypeslib.as_array(pi, shape=(ni.value,)).copy()
         keys = ("nodes", "primrefs", "spheres", "cuboids", "triangles", "accels", "max_stack", "has_specular")
         return f, i, dict(zip(keys, [int(v) for v in info]))
+
+    def host_check_strips(self, scene):
+        """Host-only self-check of the triangle strips of the mesh leaves (include/lasgun_hip.h, lg_host_check_strips)."""
+        out = (_C.c_uint64 * 8)()
+        if self.call("host_check_strips", scene.h, out):
+            raise LasgunError(self.last_error())
+        return dict(zip(("leaves", "runs", "triangles", "entries", "violations"), [int(v) for v in out]))
 
     def host_check_wide_records(self, scene):
         """Host-only self-check of the fast mode's wide node records (no GPU needed): dict of counts; `violations` must be 0."""

@@ -195,7 +195,7 @@ struct lg_accel {
     DevBuf<float> vpos, vnorm, vtex;
     DevBuf<DLeafRec> leaf_soup;
     DevBuf<DChunk> chunks;
-    DevBuf<DLeafRec> leaf_soup2;
+    DevBuf<DStrip> strips;
     DevBuf<uint32_t> sphere_ref_leaf, cuboid_ref_leaf, tri_ref_leaf, accel_ref_leaf;
     DevBuf<DAccel> accels;
     DevBuf<DMaterial> materials;
@@ -312,7 +312,7 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     DParams P{};
     P.nodes = a.nodes.p; P.nodes4 = a.nodes4.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
     P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
-    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.chunks = a.chunks.p; P.leaf_soup2 = a.leaf_soup2.n ? a.leaf_soup2.p : a.leaf_soup.p; /* (a scene without a mesh has no second soup) */ P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
+    P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.chunks = a.chunks.p; P.strips = a.strips.p; P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
     P.tri_ref_leaf = a.tri_ref_leaf.p; P.accel_ref_leaf = a.accel_ref_leaf.p; P.accels = a.accels.p; P.materials = a.materials.p;
     P.lights = a.lights.p;
     P.nlights = (uint32_t)a.flat.lights.size();
@@ -940,13 +940,13 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         const FlatScene &f = a->flat;
         a->nodes.upload(f.nodes); a->nodes4.upload(f.nodes4); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
         a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
-        a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->chunks.upload(f.chunks); a->leaf_soup2.upload(f.leaf_soup2); a->sphere_ref_leaf.upload(f.sphere_ref_leaf); a->cuboid_ref_leaf.upload(f.cuboid_ref_leaf);
+        a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->chunks.upload(f.chunks); a->strips.upload(f.strips); a->sphere_ref_leaf.upload(f.sphere_ref_leaf); a->cuboid_ref_leaf.upload(f.cuboid_ref_leaf);
         a->tri_ref_leaf.upload(f.tri_ref_leaf); a->accel_ref_leaf.upload(f.accel_ref_leaf); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
         a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
         a->stats.alloc(2); // (the second record: iteration counters of the diagnostic build)
         a->device_bytes = f.nodes.size() * sizeof(DNode) + f.nodes4.size() * sizeof(DNode4) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
                           f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 + f.leaf_soup.size() * sizeof(DLeafRec) +
-                          f.leaf_soup2.size() * sizeof(DLeafRec) + f.chunks.size() * sizeof(DChunk) +
+                          f.strips.size() * sizeof(DStrip) + f.chunks.size() * sizeof(DChunk) +
                           f.accels.size() * sizeof(DAccel) + f.materials.size() * sizeof(DMaterial);
         if (!a->stream) HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
         // per-lane LDS stack: worst case of this scene graph, +2 guard entries
@@ -974,6 +974,30 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
             if (!(worst <= 1e-11)) { // two orders below the 1e-9 the fast tree's boxes are pushed out by
                 a->fast_available = false;
                 a->fast_refusal = "fast mode unavailable: an aggregate's transform and inverse do not match (rotate() about a non-unit axis?)";
+            }
+        }
+        // The fast mode cannot be made exact for meshes in principle: a ray that lies within rounding of a FAR triangle's
+        // plane is accepted by the reference wherever it passes (its fat leaves test every triangle), and a tight tree never visits that
+        // triangle.  The band in which that happens is ~ 64 u R^2 / edge wide: negligible for a tessellated surface seen from nearby,
+        // not for a mesh whose coordinates dwarf its small triangles (round 4's progression_soup_scene: triangles at 1e9 beside
+        // triangles of 0.05 -- 5 wrong pixels in 4,100 scenes).  Such a mesh is refused, like a transform that does not invert.
+        for (const auto &m : a->scene->meshes) {
+            if (!m) continue;
+            double max_abs = 0.0, min_edge = INFINITY;
+            for (float v : m->position) if (std::isfinite(v)) max_abs = std::fmax(max_abs, std::fabs((double)v));
+            for (size_t t = 0; t + 2 < m->tri.size(); t += 3) {
+                double longest = 0.0;
+                for (int e = 0; e < 3; ++e) {
+                    const size_t i = (size_t)m->tri[t + e].v, j = (size_t)m->tri[t + (e + 1) % 3].v;
+                    double d2 = 0.0;
+                    for (int c = 0; c < 3; ++c) { const double d = (double)m->position[3 * i + c] - (double)m->position[3 * j + c]; d2 += d * d; }
+                    longest = std::fmax(longest, std::sqrt(d2));
+                }
+                if (longest > 0.0 && std::isfinite(longest)) min_edge = std::fmin(min_edge, longest);
+            }
+            if (std::isfinite(min_edge) && max_abs > min_edge * 0x1p20) {
+                a->fast_available = false;
+                a->fast_refusal = "fast mode unavailable: a mesh whose coordinates exceed 2^20 times its smallest triangle (a ray in a far triangle's plane is accepted by the reference wherever it passes)";
             }
         }
         if (!a->fast_available) a->stack_depth_fast1 = a->stack_depth;
@@ -1140,7 +1164,7 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.flat, y.flat);
     swap(x.nodes, y.nodes); swap(x.nodes4, y.nodes4); swap(x.primref, y.primref); swap(x.spheres, y.spheres); swap(x.sphere_mat, y.sphere_mat);
     swap(x.cuboids, y.cuboids); swap(x.cuboid_mat, y.cuboid_mat); swap(x.tri_v, y.tri_v); swap(x.tri_n, y.tri_n); swap(x.tri_t, y.tri_t);
-    swap(x.vpos, y.vpos); swap(x.vnorm, y.vnorm); swap(x.vtex, y.vtex); swap(x.leaf_soup, y.leaf_soup); swap(x.chunks, y.chunks); swap(x.leaf_soup2, y.leaf_soup2);
+    swap(x.vpos, y.vpos); swap(x.vnorm, y.vnorm); swap(x.vtex, y.vtex); swap(x.leaf_soup, y.leaf_soup); swap(x.chunks, y.chunks); swap(x.strips, y.strips);
     swap(x.sphere_ref_leaf, y.sphere_ref_leaf); swap(x.cuboid_ref_leaf, y.cuboid_ref_leaf); swap(x.tri_ref_leaf, y.tri_ref_leaf); swap(x.accel_ref_leaf, y.accel_ref_leaf);
     swap(x.accels, y.accels); swap(x.materials, y.materials); swap(x.lights, y.lights);
     swap(x.lds_image, y.lds_image); swap(x.accel_image, y.accel_image); swap(x.accel_image_n16, y.accel_image_n16);
@@ -1588,6 +1612,61 @@ int lg_host_build_dump(const lg_scene *s, const double **f, size_t *nf, const in
 // out[0] records, out[1] children, out[2] leaves reached, out[3] the deepest stack a walk that pushes every child but one would need
 // (frames of nested accels not counted), out[4] violations (a child box that does not contain its node's f64 box, a leaf reached
 // twice or never, a link that is not a node of the tree), out[5] = FlatScene::max_stack_fast1.
+// Host-only self-check of the triangle strips (DStrip) against the leaves they are made from: out = { mesh leaves with records, runs,
+// triangles, strip entries, violations, 0, 0, 0 }.  Every triangle slot of a mesh leaf with records must come up in exactly one
+// run, exactly once, as a STRIP_TRI entry whose three vertices (the two entries before it and its own) are the slot's three
+// vertices in some order; the entry counts must match the run records.
+int lg_host_check_strips(const lg_scene *s, uint64_t out[8]) {
+    return guarded([&] {
+        FlatScene flat;
+        flatten_scene(s->s, flat, false);
+        for (int k = 0; k < 8; ++k) out[k] = 0;
+        std::vector<char> seen_node(flat.nodes.size(), 0);
+        for (const DAccel &A : flat.accels) {
+            if (!(A.flags & AF_MESH)) continue;
+            std::vector<uint32_t> todo{0};
+            while (!todo.empty()) {
+                const uint32_t nidx = todo.back(); todo.pop_back();
+                if (seen_node[A.node_base + nidx]) continue;
+                seen_node[A.node_base + nidx] = 1;
+                const DNode &nd = flat.nodes[A.node_base + nidx];
+                if (!(nd.meta & NODE_LEAF)) { todo.push_back(nidx + 1); todo.push_back(nd.link); continue; }
+                const uint32_t nrec = nd.pad >> 24, rec0 = nd.pad & 0x00FFFFFFu;
+                if (nrec == 0) continue; // (a leaf without records: walked in the reference's order)
+                out[0]++;
+                const size_t first = (size_t)A.prim_base + nd.link, count = nd.meta & 0xFFFFu;
+                std::vector<int> hits(count, 0);
+                for (uint32_t r = rec0; r < rec0 + nrec; ++r) {
+                    const DChunk &k = flat.chunks[r];
+                    if (k.start == CHUNK_IS_GROUP) continue;
+                    out[1]++;
+                    const uint32_t ntri = k.count & 0xFFu, nent = k.count >> 8;
+                    uint32_t tris = 0;
+                    for (uint32_t e = k.pad; e < k.pad + nent; ++e) {
+                        out[3]++;
+                        const DStrip &E = flat.strips[e];
+                        if (!(E.code & STRIP_TRI)) continue;
+                        ++tris; out[2]++;
+                        const uint32_t slot = E.code & STRIP_SLOT_MASK;
+                        if (slot < first || slot >= first + count || e < k.pad + 2) { out[4]++; continue; }
+                        hits[slot - first]++;
+                        uint32_t want[3][3], got[3][3];
+                        std::memcpy(want, flat.leaf_soup[slot].w, 36);
+                        std::memcpy(got[0], &flat.strips[e - 2].x, 12); std::memcpy(got[1], &flat.strips[e - 1].x, 12); std::memcpy(got[2], &E.x, 12);
+                        bool used[3] = {false, false, false};
+                        int matched = 0;
+                        for (int i = 0; i < 3; ++i)
+                            for (int j = 0; j < 3; ++j)
+                                if (!used[j] && std::memcmp(got[i], want[j], 12) == 0) { used[j] = true; ++matched; break; }
+                        if (matched != 3) out[4]++;
+                    }
+                    if (tris != ntri) out[4]++;
+                }
+                for (size_t i = 0; i < count; ++i) if (hits[i] != 1) out[4]++;
+            }
+        }
+    });
+}
 int lg_host_check_wide_records(const lg_scene *s, uint64_t out[8]) {
     return guarded([&] {
         FlatScene flat;

@@ -103,11 +103,26 @@ struct alignas(64) DChunk {
     float cos_t;            // cos(theta), rounded down; -1 = no lateral culling for this record (wide cone, degenerate triangle)
     float g2;               // max over the triangles of (longest edge)^2 / (smallest altitude)^3, rounded up
     float hmin;             // smallest altitude of any triangle of the record, rounded down
-    uint32_t start, count;  // its run of leaf_soup2 slots
+    uint32_t start, count;  // run record: first slot of the run in the host's run-ordered soup, triangles | strip entries << 8; group record: CHUNK_IS_GROUP, runs behind it
     float sin_t;            // sin(theta), rounded up
-    uint32_t pad;
+    uint32_t pad;           // run record: its first strip entry (DParams::strips)
 };
 static_assert(sizeof(DChunk) == 64, "DChunk is one 64-byte line");
+// The triangles of a run again, as TRIANGLE STRIPS (round 4): one 16-byte entry per NEW vertex.  A strip is a sequence of triangles
+// in which each shares the last two vertices of the one before, so an entry carries one vertex (f32 position, as in the soup) and
+// a code word: STRIP_TRI = this vertex completes a triangle with the two before it (low 28 bits: the triangle's slot in leaf_soup);
+// otherwise it only (re)starts a strip.  What the walk does with them (walk.h, mesh_leaf2): the reference transforms the three
+// vertices of every triangle and forms three edge functions (triangle.rs:186-222) -- per vertex and per edge the SAME doubles for
+// every triangle that shares them, and an edge function seen from the neighbouring triangle is the same value negated -- and its
+// first test is "all three of one sign" (triangle.rs:224-230), which does not change when all three are negated or permuted.  Along
+// a strip one vertex transform and two products-and-a-difference per triangle answer that test exactly; only a triangle that
+// passes it (about one in thirty) is put to the reference's whole formula, from its own record.
+struct alignas(16) DStrip {
+    float x, y, z;
+    uint32_t code;
+};
+constexpr uint32_t STRIP_TRI = 0x80000000u, STRIP_SLOT_MASK = 0x0FFFFFFFu;
+// a run record's `count` word: triangles of the run | strip entries of the run << 8; its `pad` word: first strip entry
 constexpr uint32_t CHUNK_SHIFT = 5u;            // at most 32 slots per run (measured, config 4 / 4m / 5 in ms: 16 slots in groups of 4: 44.2 / 16.1 / 62.7;
                                                 // 32 in groups of 2: 42.0 / 15.6 / 61.7; 8 in 4: 48.7 / 17.6 / 64.8; a binary hierarchy of groups: no change)
 constexpr uint32_t CHUNK_GROUP = 2u;            // runs per group record
@@ -195,9 +210,8 @@ struct DParams {
     const float *vnorm;
     const float *vtex;
     const DLeafRec *leaf_soup; // slot j <-> primref[j]
-    const DLeafRec *leaf_soup2; // the triangle slots again, permuted WITHIN every leaf of a mesh's reference tree into a spatially
-                               // coherent order (word 9 = the slot it came from): what the pruned walk's leaf loop reads
-    const DChunk *chunks;      // culling records of the mesh leaves (DNode::pad), each with its run of leaf_soup2 slots
+    const DChunk *chunks;      // culling records of the mesh leaves (DNode::pad), each with its run of strip entries
+    const DStrip *strips;      // the runs' triangles as strips (DChunk::pad = a run's first entry)
     // fast mode's candidate check (host.h): reference leaf of every sphere / cuboid / triangle / accel (parents: DNode::parent)
     const uint32_t *sphere_ref_leaf, *cuboid_ref_leaf, *tri_ref_leaf, *accel_ref_leaf;
     const DAccel *accels;

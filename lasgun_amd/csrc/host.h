@@ -118,6 +118,7 @@ struct FlatScene {
     std::vector<DLeafRec> leaf_soup; // one per primref slot (+2 spare)
     std::vector<DLeafRec> leaf_soup2; // leaf_soup with every mesh leaf's triangles in k-d order (word 9: original slot)
     std::vector<DChunk> chunks;      // culling records (runs and groups of runs) of leaf_soup2: of the pruned walk's fat mesh leaves
+    std::vector<DStrip> strips;      // the runs' triangles as triangle strips: what the pruned walk's leaf loop streams (dscene.h, DStrip)
     // fast mode's candidate check: a hit found through the fast tree counts only if the REFERENCE tree would have tested
     // that primitive for this ray, i.e. if every box on its root-to-leaf path in the reference tree passes the slab test
     std::vector<uint32_t> sphere_ref_leaf, cuboid_ref_leaf, tri_ref_leaf; // per primitive: the leaf of ITS accel's reference tree holding it

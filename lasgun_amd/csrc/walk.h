@@ -659,10 +659,6 @@ struct LeafCull {
 // and the triangles are not degenerate at its distance: the accepted hit point lies within m = CHUNK_K0 * R^2 * g2 / sigma^3 of the
 // triangle (the edge functions' rounding, 48 u R^2, moves the projected origin by at most that over an altitude), so t lies in
 // every axis's [tmin_i - m |1/d_i|, tmax_i + m |1/d_i|]: an empty intersection, one beyond the limit or one before 0 accepts nothing.
-#ifdef LG_CHUNK_DEBUG
-static __device__ int g_dbg_gate_dummy;
-#define g_dbg_gate lc_dbg_gate
-#endif
 struct ChunkRec { uint4 a, b, c, d; }; // one DChunk as loaded: four 16-byte words of one line
 __device__ __forceinline__ ChunkRec load_chunk(const DChunk *rec) {
     const uint4 *q = reinterpret_cast<const uint4 *>(rec);
@@ -673,11 +669,7 @@ __device__ __forceinline__ ChunkRec load_chunk_uniform(const DChunk *rec) { // (
     return ChunkRec{load_const_u4(q, 0), load_const_u4(q, 1), load_const_u4(q, 2), load_const_u4(q, 3)};
 }
 template <int KZ>
-__device__ __forceinline__ bool chunk_culled(const ChunkRec &k, const Ray &ray, const LeafCull &lc, uint32_t &run_start, uint32_t &run_count
-#ifdef LG_CHUNK_DEBUG
-                                             , int &lc_dbg_gate
-#endif
-) {
+__device__ __forceinline__ bool chunk_culled(const ChunkRec &k, const Ray &ray, const LeafCull &lc, uint32_t &run_start, uint32_t &run_count ) {
     const uint4 a = k.a, b = k.b, c = k.c;
     run_start = k.d.x; run_count = k.d.y;
     const double bmin[3] = {rec_f32(a.x), rec_f32(a.y), rec_f32(a.z)}, bmax[3] = {rec_f32(a.w), rec_f32(b.x), rec_f32(b.y)};
@@ -698,9 +690,6 @@ __device__ __forceinline__ bool chunk_culled(const ChunkRec &k, const Ray &ray, 
     const float sa = sqrtf(fmaxf(1.0f - ca * ca, 0.0f)) * (1.0f + 4e-6f) + 1e-6f;
     const float sigma = (ca * cos_t - sa * sin_t) - 1e-5f;
     const float Rf = (float)((fmax_(fabs(ox), fabs(px)) + fmax_(fabs(oy), fabs(py))) + fmax_(fabs(oz), fabs(pz))) * (1.0f + 1e-6f); // >= the 1-norm distance to any vertex
-#ifdef LG_CHUNK_DEBUG
-    lc_dbg_gate = sigma >= CHUNK_SIGMA_MIN ? 1 : 0;
-#endif
     if (sigma >= CHUNK_SIGMA_MIN && hmin * hmin * sigma >= CHUNK_HGATE * Rf * Rf) {
         const float inv = __frcp_rn(sigma) * (1.0f + 1e-6f);
         const double m = (double)(((CHUNK_K0 * g2) * (inv * inv * inv)) * (Rf * Rf) * (1.0f + 1e-5f));
@@ -790,17 +779,21 @@ __device__ __noinline__ void audit_subtree(const DParams &P, uint32_t node_base,
         n = st[--sp];
     }
 }
-// the triangles of the leaf_soup2 slots [s0, s1) (a culled run, or the runs of a culled group) against the ray, the reference's way
+// the triangles of the strip entries [e0, e1) (a culled run, or the runs of a culled group) against the ray, the reference's way: each
+// from its own record in leaf_soup
 template <int KZ>
-__device__ __noinline__ void audit_run(const DParams &P, uint32_t s0, uint32_t s1, V3 o, TriSetup tri, double best_t, uint32_t best_ref, uint32_t leaf_slot,
+__device__ __noinline__ void audit_run(const DParams &P, uint32_t e0, uint32_t e1, V3 o, TriSetup tri, double best_t, uint32_t best_ref, uint32_t leaf_slot,
                                        double ekz, bool anyhit, Counters &cnt) {
     cnt.a_runs++;
-    for (uint32_t s = s0; s < s1; ++s) {
-        const uint4 *q = reinterpret_cast<const uint4 *>(P.leaf_soup2 + s);
+    for (uint32_t e = e0; e < e1; ++e) {
+        const uint32_t code = P.strips[e].code;
+        if (!(code & STRIP_TRI)) continue;
+        const uint32_t slot = code & STRIP_SLOT_MASK;
+        const uint4 *q = reinterpret_cast<const uint4 *>(P.leaf_soup + slot);
         const LeafRec r{q[0], q[1], q[2]};
         TriHit hh;
         const bool valid = tri_rec_t<KZ>(r, o, tri.sx, tri.sy, tri.sz, hh);
-        const bool tie_wins = valid && hh.t == best_t && best_ref != NO_HIT && leaf_slot != NO_HIT && r.c.y < leaf_slot;
+        const bool tie_wins = valid && hh.t == best_t && best_ref != NO_HIT && leaf_slot != NO_HIT && slot < leaf_slot;
         audit_prim(valid, hh.t, anyhit ? 1.0 : best_t, ekz, anyhit, tie_wins, cnt, cnt.a_slack_r);
     }
 }
@@ -826,22 +819,35 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
         }                                                                                                                \
     } while (0)
     if (PRUNE && lc.ekz < INFINITY && (lc.records >> 24) != 0u) { // (a level or ray outside the stated ranges, or a leaf the host gave no records: the plain loop below, in the reference's order)
-        // The leaf in runs of <= 32 slots of leaf_soup2 counted from its first slot (one culling record per run), where the
-        // leaf's triangles stand in a k-d order: a run whose record is culled is stepped over.  The reference scans the leaf in
-        // order[] sequence and keeps the FIRST of several triangles with exactly the same t (triangle.rs:251: `t >= isect.t`
-        // rejects); scanning in another order gives the same winner when a tie goes to the lower original slot -- the final hit
-        // is the lexicographic minimum of (t, slot) either way.  (No t is NaN inside the stated ranges.)
-        const char *base2 = reinterpret_cast<const char *>(P.leaf_soup2);
+        // The leaf in runs of <= 32 triangles that are neighbours in space (one culling record per run; host.cpp, build_chunks): a run
+        // whose record is culled is stepped over.  The reference scans the leaf in order[] sequence and keeps the FIRST of several
+        // triangles with exactly the same t (triangle.rs:251: `t >= isect.t` rejects); scanning in another order gives the same
+        // winner when a tie goes to the lower original slot -- the final hit is the lexicographic minimum of (t, slot) either way.
+        // (No t is NaN inside the stated ranges.)
+        //
+        // A kept run is read as TRIANGLE STRIPS (dscene.h, DStrip): one entry per new vertex.  Per entry the vertex is transformed as
+        // triangle.rs:186-201 transforms it (translate, permute, shear in x and y) and the edge function across it and its predecessor
+        // formed (triangle.rs:204-206: a.x * b.y - a.y * b.x); a triangle entry forms the third edge function and asks the reference's
+        // first question -- are the three of mixed sign (triangle.rs:224-230)?  The three values are the doubles the reference would
+        // compute for that triangle, or all three negated (cross(b, a) = 0 - cross(a, b) bit for bit, zeros staying zeros), in
+        // some rotation: the answer is the same.  Only a triangle that passes (about one in thirty) is put to the reference's whole
+        // formula, from its own 48-byte record, after the run (at most one is parked per lane; a second one flushes the first).
+        const char *sbase = reinterpret_cast<const char *>(P.strips);
+        const char *rbase = reinterpret_cast<const char *>(P.leaf_soup);
+        constexpr uint32_t SREC = (uint32_t)sizeof(DStrip);
         uint32_t rec = lc.records & 0x00FFFFFFu;                 // the next record to look at
         const uint32_t rec_end = rec + (lc.records >> 24);
-        uint32_t s = 0, run_end = 0;                              // the run being tested: leaf_soup2 slots [s, run_end)
+        uint32_t s = 0, run_end = 0;                              // the run being tested: strip entries [s, run_end)
         uint32_t leaf_slot = NO_HIT; // original slot of the hit this leaf has given so far
-#define LG_TRI2(R)                                                                                                       \
+        uint32_t pend = NO_HIT;      // a triangle that passed the sign test and waits for the reference's whole formula
+        double ax = 0.0, ay = 0.0, bx = 0.0, by = 0.0, cab = 0.0; // the last two transformed vertices of the strip, the edge function across them
+        bool done = false;
+#define LG_TRI_FULL(SLOT)                                                                                                \
     do {                                                                                                                 \
+        const uint32_t from_ = (SLOT);                                                                                   \
+        const LeafRec r_ = load_rec_at(rbase, from_ * REC);                                                              \
         TriHit h_;                                                                                                       \
-        if (COUNT) cnt.triangles++;                                                                                      \
-        if (tri_rec_t<KZ>(R, o, tri.sx, tri.sy, tri.sz, h_)) {                                                           \
-            const uint32_t from_ = (R).c.y;                                                                              \
+        if (tri_rec_t<KZ>(r_, o, tri.sx, tri.sy, tri.sz, h_)) {                                                          \
             if (h_.t < best.t || (h_.t == best.t && leaf_slot != NO_HIT && from_ < leaf_slot)) {                         \
                 best.t = h_.t; best.ref = load_primref<LDSS>(P, scn, from_ - soup_delta); best.accel = accel;            \
                 leaf_slot = from_;                                                                                       \
@@ -851,13 +857,27 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
+#define LG_STRIP(E)                                                                                                      \
+    do {                                                                                                                 \
+        const V3 pt_ = permute_kz<KZ>(V3{rec_f32((E).x), rec_f32((E).y), rec_f32((E).z)} - o);                           \
+        const double vx_ = pt_.x + tri.sx * pt_.z, vy_ = pt_.y + tri.sy * pt_.z;                                         \
+        const double cbc_ = bx * vy_ - by * vx_;                                                                         \
+        if ((E).w & STRIP_TRI) {                                                                                         \
+            const double cca_ = vx_ * ay - vy_ * ax;                                                                     \
+            if (COUNT) cnt.triangles++;                                                                                  \
+            if (!((f64_neg(cab) || f64_neg(cbc_) || f64_neg(cca_)) && (f64_pos(cab) || f64_pos(cbc_) || f64_pos(cca_)))) { \
+                if (pend != NO_HIT) LG_TRI_FULL(pend);                                                                   \
+                pend = (E).w & STRIP_SLOT_MASK;                                                                          \
+            }                                                                                                            \
+        }                                                                                                                \
+        ax = bx; ay = by; bx = vx_; by = vy_; cab = cbc_;                                                                \
+    } while (0)
         // Two wave-uniform phases, like the walk itself: every lane first steps over culled runs until it stands in one that
-        // survives (or its leaf ends), then the lanes that stand in a run test it, two triangles per trip with the next record in
-        // flight.  A lane's own loop nest would make the whole wave pay for every run that ANY lane keeps.
+        // survives (or its leaf ends), then the lanes that stand in a run test it, two entries per trip.  A lane's own loop nest
+        // would make the whole wave pay for every run that ANY lane keeps.
         // When every lane that takes a step stands at the same record (the lanes of a coherent wave in the same leaf mostly do),
-        // the record comes through the scalar cache (load_*_uniform) instead of 64 times through the vector L1, whose request
-        // rate this loop is otherwise bound by.
-        bool in_run = false, done = false;
+        // the record comes through the scalar cache (load_*_uniform) instead of 64 times through the vector L1.
+        bool in_run = false;
         uint32_t off = 0;
 #ifdef LG_STAMPS
         unsigned long long ml_cnt[6] = {0, 0, 0, 0, 1ull, (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true))};
@@ -871,24 +891,19 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
                 if (!in_run && rec < rec_end) {
                     if (COUNT) cnt.nodes++; // (a record test is counted with the node tests)
                     uint32_t start, count;
-                    bool culled_;
                     const uint32_t rec0 = __builtin_amdgcn_readfirstlane(rec);
-#ifdef LG_CHUNK_DEBUG
-                    int gate_ = 0;
-                    culled_ = chunk_culled<KZ>(load_chunk(P.chunks + rec), ray, lc, start, count, gate_);
-                    if (COUNT) { cnt.cuboids++; if (LG_CHUNK_DEBUG == 1 ? gate_ != 0 : LG_CHUNK_DEBUG == 2 ? !culled_ : (!culled_ && gate_)) cnt.spheres++; }
-#else
-                    if (__builtin_amdgcn_ballot_w64(rec != rec0) == 0ull) culled_ = chunk_culled<KZ>(load_chunk_uniform(P.chunks + rec0), ray, lc, start, count);
-                    else culled_ = chunk_culled<KZ>(load_chunk(P.chunks + rec), ray, lc, start, count);
-#endif
+                    ChunkRec ck;
+                    if (__builtin_amdgcn_ballot_w64(rec != rec0) == 0ull) ck = load_chunk_uniform(P.chunks + rec0);
+                    else ck = load_chunk(P.chunks + rec);
+                    const bool culled_ = chunk_culled<KZ>(ck, ray, lc, start, count);
                     if (COUNT && P.audit && culled_) { // what the skipped run (or the runs of the skipped group) would have given the reference
-                        uint32_t s0 = start, s1 = start + count;
-                        if (start == CHUNK_IS_GROUP) { s0 = P.chunks[rec + 1u].start; s1 = P.chunks[rec + count].start + P.chunks[rec + count].count; }
-                        audit_run<KZ>(P, s0, s1, o, tri, best.t, best.ref, leaf_slot, lc.ekz, anyhit, cnt);
+                        uint32_t e0 = ck.d.w, e1 = ck.d.w + (count >> 8);
+                        if (start == CHUNK_IS_GROUP) { e0 = P.chunks[rec + 1u].pad; e1 = P.chunks[rec + count].pad + (P.chunks[rec + count].count >> 8); }
+                        audit_run<KZ>(P, e0, e1, o, tri, best.t, best.ref, leaf_slot, lc.ekz, anyhit, cnt);
                     }
                     ++rec;
                     if (start == CHUNK_IS_GROUP) { if (culled_) rec += count; } // a group record: culled, its runs are stepped over; kept, they come next
-                    else if (!culled_) { in_run = true; s = start; run_end = start + count; off = s * REC; } // (the array holds < 2^32 / 48 slots: checked by the host)
+                    else if (!culled_) { in_run = true; s = ck.d.w; run_end = s + (count >> 8); off = s * SREC; } // (< 2^32 / 16 entries: checked by the host)
                 }
                 seeking = wave_any(!in_run && rec < rec_end);
             }
@@ -901,29 +916,35 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
                 if (in_run) {
                     const bool two = s + 1u < run_end;
                     const uint32_t off0 = __builtin_amdgcn_readfirstlane(off);
-                    if (__builtin_amdgcn_ballot_w64(off != off0) == 0ull) { // two triangles per trip (two spare records behind the last slot: always readable)
-                        const LeafRec ra = load_rec_uniform(base2, off0), rb = load_rec_uniform(base2, off0 + REC);
-                        LG_TRI2(ra);
-                        if (two && !done) LG_TRI2(rb);
+                    uint4 ea, eb; // two entries per trip (two spare entries behind the last: always readable)
+                    if (__builtin_amdgcn_ballot_w64(off != off0) == 0ull) {
+                        lg_const_u4 q = (lg_const_u4)(uintptr_t)(sbase + off0);
+                        ea = load_const_u4(q, 0); eb = load_const_u4(q, 1);
                     } else {
-                        const LeafRec ra = load_rec_at(base2, off), rb = load_rec_at(base2, off + REC);
-                        LG_TRI2(ra);
-                        if (two && !done) LG_TRI2(rb);
+                        const uint4 *q = reinterpret_cast<const uint4 *>(sbase + off);
+                        ea = q[0]; eb = q[1];
                     }
+                    LG_STRIP(ea);
+                    if (two) LG_STRIP(eb);
                     s += two ? 2u : 1u;
-                    off += 2u * REC;
-                    if (done) { rec = rec_end; in_run = false; } // an occluded any-hit ray: nothing more to find
-                    else if (s >= run_end) in_run = false;
+                    off += 2u * SREC;
+                    if (s >= run_end) in_run = false;
                 }
                 testing = wave_any(in_run);
             }
+            // the triangles that passed the sign test: the reference's whole formula, once per lane and round
+            if (wave_any(pend != NO_HIT)) {
+                if (pend != NO_HIT) { LG_TRI_FULL(pend); pend = NO_HIT; }
+            }
+            if (done) rec = rec_end; // an occluded any-hit ray: nothing more to find
         }
 #ifdef LG_STAMPS
         if (P.stamp_counts && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
             for (int i = 0; i < 6; ++i) atomicAdd(P.stamp_counts + 9 + i, ml_cnt[i]);
 #endif
         return done;
-#undef LG_TRI2
+#undef LG_STRIP
+#undef LG_TRI_FULL
         return false;
     }
     uint32_t off = (li + soup_delta) * REC; // (the array holds < 2^32 / 48 slots: checked by the host)

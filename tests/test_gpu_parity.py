@@ -412,7 +412,8 @@ def test_fast_mode_adversarial_scenes():
         try:
             G.set_mode(acc2, True)
         except la.LasgunError as e:
-            assert "inverse" in str(e)
+            # ... and for a mesh whose smallest triangle is far below its coordinates' precision (round 4)
+            assert "inverse" in str(e) or "smallest triangle" in str(e)
             refused += 1
             continue
         outs = []

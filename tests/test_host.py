@@ -78,6 +78,20 @@ def test_incoherent_fat_leaves_build(seed):
     assert np.array_equal(i, oi) and np.array_equal(f.view(np.uint64), of.view(np.uint64))
 
 
+@pytest.mark.parametrize("name", ["mesh_100k", "mixed_small", "tie_mesh", "exotic", "soup0", "soup3", "slabs"])
+def test_triangle_strips_cover_their_leaves(name):
+    """The strips the pruned walk's leaf loop streams (DStrip): every triangle of every mesh leaf with culling records is exactly one
+    strip triangle, made of its own three vertices; on a tessellated surface a strip entry serves most of a triangle."""
+    builders = {"mesh_100k": lambda: S.mesh_scene(la.api), "mixed_small": lambda: S.mixed_scene(la.api, 300, 40, 40), "tie_mesh": lambda: S.tie_mesh_scene(la.api),
+                "exotic": lambda: S.exotic_obj_scene(la.api), "soup0": lambda: S.progression_soup_scene(la.api, 0), "soup3": lambda: S.progression_soup_scene(la.api, 3),
+                "slabs": lambda: S.adversarial_prune_scene(la.api, 5)}
+    r = la.api.host_check_strips(builders[name]())
+    assert r["violations"] == 0, r
+    assert r["entries"] >= r["triangles"] and r["entries"] <= 3 * r["triangles"], r
+    if name == "mesh_100k":
+        assert r["triangles"] >= 100352 and r["entries"] < 1.5 * r["triangles"], r  # (three entries per triangle without strips)
+
+
 def test_transform_concat_matches_oracle():
     o = oracle()
     outs = []
