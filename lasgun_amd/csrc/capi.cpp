@@ -227,6 +227,7 @@ struct lg_accel {
     // ray's cost (tools/threshold_sweep.py): set from the scene by lg_accel_from
     bool streaming_pays = false;
     unsigned long long streaming_min_items = 1ull << 20;
+    unsigned long long specular_small_items = 1ull << 19; // a glass / mirror scene resident in LDS: frames up to this many pixels go level by level
     uint32_t wf_blocks = 1, wf_blocks_fast = 1;   // grids of the wavefront pipeline's 256-lane traversal kernels
     uint32_t queue_blocks = 1;                    // grid of the queue organisation's persistent kernel (256-lane form)
     mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
@@ -693,8 +694,13 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         if (can && want) { enqueue_queue(a, P, c, stream); return; }
     }
     // ---- wavefront pipeline: li() level by level (any scene with <= 32 lights; not the counting variant)
+    // (also a SMALL frame of a small glass / mirror scene: in the megakernel one wave then walks a tile's whole recursion tree -- up to
+    // 2^(depth + 1) closest-hit and shadow walks one after the other -- while most of the chip has nothing to do; level by level every
+    // ray of a level has a lane of its own.  Cornell glass, 512^2: 0.61 against 0.81 ms; the megakernel is ahead again from ~750^2.)
+    const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
+    const bool small_specular = a.flat.has_specular && P.recursion > 0 && !a.fast && a.lds_scene && a.ldss_blocks && items <= a.specular_small_items;
     if (a.streaming && !stats && P.nlights <= 32 && P.recursion < 20 &&
-        (a.streaming_forced || (a.streaming_pays && (unsigned long long)P.ntiles * 64ull >= a.streaming_min_items))) {
+        (a.streaming_forced || small_specular || (a.streaming_pays && items >= a.streaming_min_items))) {
         enqueue_wavefront(a, P, c, stream);
         return;
     }

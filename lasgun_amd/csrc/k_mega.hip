@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
     }
     const uint4 *const arec = (LDSS || FAST) ? nullptr : load_accel_image(P, P.stack_depth * LG_BLOCK);
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (!wave_has_work(P.ntiles)) return; // (after the workgroup's barrier: a small film leaves most of the grid nothing to claim)
 
     for (;;) {
         // ---- fetch the next 64-pixel tile for this wavefront.  (One head word for the whole chip here: the per-XCD bands of

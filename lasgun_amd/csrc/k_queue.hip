@@ -158,6 +158,9 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)cnt;
     uint32_t *const ctl = P.q_ctl;
     const uint32_t levels = P.wf_levels;
+    // (a small film: level 0 has q_units units and a unit's family has at most 2^d packets in flight at level d -- more waves than
+    // that find nothing to do, yet would take tickets and poll until the launch ends; they leave before touching a control word)
+    if (!wave_has_work((unsigned long long)P.q_units << (levels - 1u))) return;
     uint32_t backoff = 1u, idle = 0u;
     uint32_t band = xcc_id(), bands_left = TILE_HEADS; // level 0 still has units while bands_left != 0 (as far as this wave knows)
     uint32_t done0 = 0u;     // level-0 units this wave has taken through and not yet counted

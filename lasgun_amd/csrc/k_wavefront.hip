@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
     }
     const uint4 *const arec = (LDSS || FAST) ? nullptr : load_accel_image(P, P.stack_depth * LG_BLOCK);
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)cnt;
+    if (!wave_has_work(ntiles)) return; // (after the workgroup's barrier; a deep level or a small film leaves most of the grid nothing to claim)
     // Tiles are claimed XCD by XCD (kcommon.h, claim_tile) where the scene sits in LDS and the claim itself is what waves queue on:
     // headline frame 3.39 + 3.52 -> 3.10 + 3.19 ms for the two traversal passes.  With the tables in L2 (mesh scenes) the bands
     // measured no better than one head word (config 5: 68.4 vs 69.4 ms), so those forms keep the single word.

@@ -28,6 +28,8 @@ namespace lg {
 // (TILE_HEADS, TILE_HEAD_STRIDE, TILE_COUNTER_WORDS, NO_TILE: dscene.h, shared with the host)
 __device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; } // XCC_ID[3:0], register 20 (gfx942 / gfx950)
 // `band` is the wave's state (start it at xcc_id(), `left` at TILE_HEADS); called by every lane of the wave, the same tile comes back in all
+// (Measured and dropped, round 4: a wave that has found one band exhausted LOOKING at the next heads -- a plain load -- before it queues on
+// them.  The headline's traversal passes went from 3.10 to 3.40 ms with it.)
 __device__ __forceinline__ uint32_t claim_tile(uint32_t *counter, uint32_t ntiles, uint32_t &band, uint32_t &left) {
     uint32_t tile = NO_TILE;
     if ((threadIdx.x & 63u) == 0u) {
@@ -42,5 +44,13 @@ __device__ __forceinline__ uint32_t claim_tile(uint32_t *counter, uint32_t ntile
     band = (uint32_t)__builtin_amdgcn_readfirstlane((int)band);
     left = (uint32_t)__builtin_amdgcn_readfirstlane((int)left);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+}
+// The persistent grids hold as many waves as the chip runs at once (4,096 for the LDS-resident kernels); a launch with fewer work
+// items than that has nothing for the surplus, and each surplus wave would still queue once on every head word before it leaves --
+// for a 64 x 64 film that queueing was the whole frame (75-90 microseconds a launch, measured round 4).  Waves are numbered
+// wave-in-workgroup major, so the first n of them sit on n different CUs (and SIMDs): those claim, the others leave at once.  Which
+// wave renders a tile never matters; that the claiming waves are all resident does -- the grid is sized so that every wave is.
+__device__ __forceinline__ bool wave_has_work(unsigned long long items) {
+    return (unsigned long long)((threadIdx.x >> 6) * gridDim.x + blockIdx.x) < items;
 }
 } // namespace lg
