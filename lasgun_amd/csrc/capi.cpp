@@ -227,7 +227,7 @@ struct lg_accel {
     // ray's cost (tools/threshold_sweep.py): set from the scene by lg_accel_from
     bool streaming_pays = false;
     unsigned long long streaming_min_items = 1ull << 20;
-    unsigned long long specular_small_items = 1ull << 19; // a glass / mirror scene resident in LDS: frames up to this many pixels go level by level
+    unsigned long long specular_small_items = 1ull << 20; // a glass / mirror scene resident in LDS: frames up to this many pixels go level by level
     uint32_t wf_blocks = 1, wf_blocks_fast = 1;   // grids of the wavefront pipeline's 256-lane traversal kernels
     uint32_t queue_blocks = 1;                    // grid of the queue organisation's persistent kernel (256-lane form)
     mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
@@ -694,13 +694,19 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         if (can && want) { enqueue_queue(a, P, c, stream); return; }
     }
     // ---- wavefront pipeline: li() level by level (any scene with <= 32 lights; not the counting variant)
-    // (also a SMALL frame of a small glass / mirror scene: in the megakernel one wave then walks a tile's whole recursion tree -- up to
-    // 2^(depth + 1) closest-hit and shadow walks one after the other -- while most of the chip has nothing to do; level by level every
-    // ray of a level has a lane of its own.  Cornell glass, 512^2: 0.61 against 0.81 ms; the megakernel is ahead again from ~750^2.)
+    // Also (round 4, once a launch no longer ended in 75-90 us of failed tile claims -- kcommon.h -- and the level-by-level passes of a small
+    // frame became cheap), for a scene resident in LDS:
+    //   * glass / mirror, frames up to 2^20 pixels: in the megakernel one wave walks a tile's whole recursion tree -- up to 2^(depth + 1)
+    //     closest-hit and shadow walks one after the other -- while most of the chip has nothing to do; level by level every ray of a level
+    //     has a lane of its own.  Cornell glass: 0.41 against 0.81 ms at 512^2, 0.99 / 1.18 at 1024^2, 1.81 / 1.64 at 1536^2.
+    //   * no glass / mirror and few primitives, frames from 2^18 pixels (2^20 when supersampled): README sphere 0.07 / 0.12 ms at 512^2,
+    //     2.2 / 3.5 at 4096^2; Cornell plastic 0.10 / 0.15 and 3.4 / 4.6; below, the two are within a few microseconds of each other.
     const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
-    const bool small_specular = a.flat.has_specular && P.recursion > 0 && !a.fast && a.lds_scene && a.ldss_blocks && items <= a.specular_small_items;
+    const bool lds_resident = !a.fast && a.lds_scene && a.ldss_blocks, specular = a.flat.has_specular && P.recursion > 0;
+    const bool small_specular = lds_resident && specular && items <= a.specular_small_items;
+    const bool light_scene = lds_resident && !specular && !a.streaming_pays && items >= (P.ss_root > 1u ? 1ull << 20 : 1ull << 18);
     if (a.streaming && !stats && P.nlights <= 32 && P.recursion < 20 &&
-        (a.streaming_forced || small_specular || (a.streaming_pays && items >= a.streaming_min_items))) {
+        (a.streaming_forced || small_specular || light_scene || (a.streaming_pays && items >= a.streaming_min_items))) {
         enqueue_wavefront(a, P, c, stream);
         return;
     }
@@ -1157,7 +1163,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                     specular_mesh = specular_mesh || ((kind == MAT_GLASS || kind == MAT_MIRROR) && tris >= 4096);
                 }
             a->queue_default = f.has_specular && big_mesh >= 4096 && specular_mesh;
-            a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 20);
+            a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 21); // (config 3's scene at 1024^2: 0.84 ms in the megakernel, 0.99 level by level; at 2048^2: 2.20 / 2.11)
         }
 }
 

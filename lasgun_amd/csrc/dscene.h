@@ -30,9 +30,11 @@ constexpr uint32_t PRIM_INDEX_MASK = 0x3FFFFFFFu;
 constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
 constexpr uint32_t WF_NONE = 0xFFFFFFFFu, WF_MISS = 0xFFFFFFFEu; // wavefront pipeline: no such child / the ray hit nothing
 constexpr int MAX_CHAIN = 8;      // scene-graph nesting levels (root = 1)
-// tile counters of a persistent kernel (kcommon.h, claim_tile): [0..15] plain words ([0]: the single-head forms' next tile), then one head word per XCD, 64 bytes apart
-constexpr uint32_t TILE_HEADS = 8u, TILE_HEAD_STRIDE = 16u;
-constexpr uint32_t TILE_COUNTER_WORDS = 16u + TILE_HEADS * TILE_HEAD_STRIDE;
+// tile counters of a persistent kernel (kcommon.h, claim_tile): word [0] the single-head forms' next tile, word [TILE_GONE] one bit per XCD band
+// that is known to be exhausted (a line no claim touches), then one head word per XCD band from [TILE_HEAD0] on, 128 bytes -- one L2 line -- apart
+constexpr uint32_t TILE_HEADS = 8u, TILE_HEAD_STRIDE = 32u;
+constexpr uint32_t TILE_HEAD0 = 32u, TILE_GONE = 16u;
+constexpr uint32_t TILE_COUNTER_WORDS = TILE_HEAD0 + TILE_HEADS * TILE_HEAD_STRIDE;
 constexpr uint32_t NO_TILE = 0xFFFFFFFFu;
 constexpr uint32_t NODE_LEAF = 0x80000000u;
 // reference trees: a leaf below this node holds a nested BVHAccel -- the pruned walk never skips such a
@@ -91,10 +93,11 @@ struct alignas(16) DLeafRec { // 48-byte leaf-ordered geometry record (see heade
     uint32_t w[12];
 };
 // Pruned walk, inside the reference's fat mesh leaves (up to 254 triangles, bvh.rs:187,289): one record per run of <= 32
-// consecutive leaf_soup2 slots, made by the host from the triangles in those slots -- their bounds, a cone around their
-// normals and two shape numbers.  (The reference orders a leaf's triangles by a Morton code that ignores x, bvh.rs:575-579:
-// sixteen consecutive ones are no neighbours.  leaf_soup2 holds each leaf's triangles in spatial runs instead; the leaf loop
-// then decides exact ties in t by the ORIGINAL slot number, which is what the reference's first-come rule amounts to.)  The walk skips the 16 triangle tests when NONE of them could be accepted:
+// triangles of the leaf, made by the host from those triangles -- their bounds, a cone around their normals and two shape numbers.
+// (The reference orders a leaf's triangles by a Morton code that ignores x, bvh.rs:575-579: sixteen consecutive ones are no
+// neighbours.  The host regroups each leaf's triangles into spatial runs -- host.h, leaf_soup2, never uploaded -- and the device reads a run
+// as triangle strips, DStrip below; the leaf loop decides exact ties in t by the ORIGINAL slot number, which is what the reference's
+// first-come rule amounts to.)  The walk skips a run's triangle tests when NONE of them could be accepted:
 // always by the ray's dominant axis; on all three axes with a margin that grows with 1 / sigma^3, sigma a lower bound (from the
 // cone) of the sine of the angle at which the ray crosses the record's triangles -- never for a ray that may lie in a triangle's plane.
 struct alignas(64) DChunk {

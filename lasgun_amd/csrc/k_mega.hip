@@ -26,13 +26,12 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!wave_has_work(P.ntiles)) return; // (after the workgroup's barrier: a small film leaves most of the grid nothing to claim)
 
-    for (;;) {
+    for (bool final = false; !final;) {
         // ---- fetch the next 64-pixel tile for this wavefront.  (One head word for the whole chip here: the per-XCD bands of
-        // claim_tile, which buy the traversal-only kernels 9 %, cost this kernel 5-12 % on every config it runs -- measured.)
-        uint32_t tile = 0;
-        if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
-        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-        if (tile >= P.ntiles) break; // every wave reaches this exit
+        // claim_tile, which buy the traversal-only kernels 9 %, cost this kernel 5-12 % on every config it runs -- measured, and again
+        // in round 4 with the cheap launch end of kcommon.h: 1b 0.71 -> 0.78 ms, Cornell glass 0.80 -> 0.88, only one-sphere scenes gain.)
+        const uint32_t tile = claim_tile_single(P.tile_counter, P.ntiles, final);
+        if (tile == NO_TILE) break; // (a wave leaves here, or after one of the launch's last tiles: kcommon.h)
 
         const Pixel px = pixel_of(P, tile, lane);
         const uint32_t x = px.x, y = px.y;

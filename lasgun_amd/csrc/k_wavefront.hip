@@ -118,16 +118,11 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
     // headline frame 3.39 + 3.52 -> 3.10 + 3.19 ms for the two traversal passes.  With the tables in L2 (mesh scenes) the bands
     // measured no better than one head word (config 5: 68.4 vs 69.4 ms), so those forms keep the single word.
     uint32_t band = LDSS ? xcc_id() : 0u, bands_left = TILE_HEADS;
-    for (;;) {
+    for (bool final = false; !final;) {
         uint32_t tile;
-        if (LDSS) tile = claim_tile(P.tile_counter, ntiles, band, bands_left);
-        else {
-            tile = 0u;
-            if (lane == 0) tile = atomicAdd(P.tile_counter, 1u);
-            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-            if (tile >= ntiles) tile = NO_TILE;
-        }
-        if (tile == NO_TILE) break; // every wave reaches this exit
+        if (LDSS) tile = claim_tile(P.tile_counter, ntiles, band, bands_left, final);
+        else tile = claim_tile_single(P.tile_counter, ntiles, final);
+        if (tile == NO_TILE) break; // (a wave leaves here, or after one of the launch's last tiles: kcommon.h)
         if (!SHADOW) {
             const unsigned long long i = (unsigned long long)tile * lpt + lane;
             Pixel px;

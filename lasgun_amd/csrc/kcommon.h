@@ -25,32 +25,58 @@ namespace lg {
 // instead of being dealt over all eight, and 256 CUs no longer queue on one atomic (MI355X_MICROARCH.md: 0.3 us against 2.8 us a
 // claim).  A wave whose band is exhausted moves on to the next band for good, so the launch still drains evenly.  Which XCD a
 // wave runs on is read from the hardware (HW_REG_XCC_ID); it only decides where a tile is rendered, never what is rendered.
-// (TILE_HEADS, TILE_HEAD_STRIDE, TILE_COUNTER_WORDS, NO_TILE: dscene.h, shared with the host)
+// (TILE_HEADS, TILE_HEAD_STRIDE, TILE_HEAD0, TILE_GONE, TILE_COUNTER_WORDS, NO_TILE: dscene.h, shared with the host)
+//
+// How a launch ENDS (round 4).  A persistent grid holds W waves (4,096 for the LDS-resident kernels), and a wave used to learn that nothing
+// was left by failing on every head: W x 8 failed fetch-adds on eight words, 75-90 microseconds -- the whole cost of a 64 x 64 film, half of a
+// 512 x 512 one.  Three rules remove them, none of which changes what is rendered (which wave renders a tile never matters):
+//   * a launch of n < W items is claimed by the first n waves only (numbered wave-in-workgroup major: n different CUs and SIMDs);
+//   * in a SMALL launch (n <= TILE_SMALL_LAUNCH x W) the last floor(W / 8) tiles of every band -- W tiles at most -- are "final": a wave that
+//     has rendered one leaves without asking again.  Each wave takes at most one final tile, there are no more final tiles than waves, and a
+//     wave that has not had one keeps claiming: every tile is taken, and a claim only fails for a wave that moves from an exhausted band to
+//     the next.  (Not for big launches: waves that leave after their own band's last tiles no longer help a slower band out -- the headline's
+//     shadow pass went from 3.2 to 4.5 ms.  And not from ONE head word instead of eight: 16 k claims on one word are 0.3 ms by themselves.)
+//   * the first wave to find a band exhausted sets its bit in the TILE_GONE word, and a wave that has just failed on one head reads that word
+//     and steps over the bands whose bit is set.  (LOOKING at the next HEAD words instead -- plain loads of the contended lines -- was
+//     measured too: the headline's traversal passes went from 3.10 to 3.40 ms.)
+// Cornell glass at 512^2, level by level: 0.92 -> 0.42 ms; the 1-sphere README scene at 640^2: 0.25 -> 0.10 ms; headline unchanged.
+constexpr uint32_t TILE_SMALL_LAUNCH = 2u; // (8: one rank's share of the headline frame at 8 GPUs -- 32,768 tiles -- went from 0.98 to 1.18 ms: its bands are not equally heavy)
 __device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; } // XCC_ID[3:0], register 20 (gfx942 / gfx950)
-// `band` is the wave's state (start it at xcc_id(), `left` at TILE_HEADS); called by every lane of the wave, the same tile comes back in all
-// (Measured and dropped, round 4: a wave that has found one band exhausted LOOKING at the next heads -- a plain load -- before it queues on
-// them.  The headline's traversal passes went from 3.10 to 3.40 ms with it.)
-__device__ __forceinline__ uint32_t claim_tile(uint32_t *counter, uint32_t ntiles, uint32_t &band, uint32_t &left) {
-    uint32_t tile = NO_TILE;
+__device__ __forceinline__ uint32_t grid_waves() { return gridDim.x * (blockDim.x >> 6); }
+__device__ __forceinline__ bool wave_has_work(unsigned long long items) {
+    return (unsigned long long)((threadIdx.x >> 6) * gridDim.x + blockIdx.x) < items;
+}
+// the single-head form (word [0]; kernels whose tiles are long: the claim is not what they wait for)
+__device__ __forceinline__ uint32_t claim_tile_single(uint32_t *counter, uint32_t ntiles, bool &final) {
+    uint32_t tile = 0u;
+    if ((threadIdx.x & 63u) == 0u) tile = atomicAdd(counter, 1u);
+    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+    const uint32_t w = grid_waves();
+    final = ntiles <= TILE_SMALL_LAUNCH * w && (unsigned long long)tile + w >= ntiles;
+    return tile < ntiles ? tile : NO_TILE;
+}
+// the banded form: `band` is the wave's state (start it at xcc_id(), `left` at TILE_HEADS); called by every lane of the wave, the same tile
+// comes back in all; `final` comes back true for a final tile of a small launch
+__device__ __forceinline__ uint32_t claim_tile(uint32_t *counter, uint32_t ntiles, uint32_t &band, uint32_t &left, bool &final) {
+    uint32_t tile = NO_TILE, fin = 0u;
     if ((threadIdx.x & 63u) == 0u) {
+        const uint32_t w = grid_waves(), tail = ntiles <= TILE_SMALL_LAUNCH * w ? w / TILE_HEADS : 0u;
+        uint32_t gone = 0u;
         while (left != 0u) {
             const uint32_t lo = (uint32_t)(((unsigned long long)band * ntiles) / TILE_HEADS), hi = (uint32_t)(((unsigned long long)(band + 1u) * ntiles) / TILE_HEADS);
-            const uint32_t t = atomicAdd(counter + 16u + band * TILE_HEAD_STRIDE, 1u);
-            if (t < hi - lo) { tile = lo + t; break; }
+            if (!((gone >> band) & 1u)) {
+                const uint32_t t = atomicAdd(counter + TILE_HEAD0 + band * TILE_HEAD_STRIDE, 1u);
+                if (t < hi - lo) { tile = lo + t; fin = (t + tail >= hi - lo) ? 1u : 0u; break; }
+                if (t == hi - lo) atomicOr(counter + TILE_GONE, 1u << band);
+                gone = __hip_atomic_load(counter + TILE_GONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             band = (band + 1u) & (TILE_HEADS - 1u); // this band is done (for every wave: its head only grows)
             --left;
         }
     }
     band = (uint32_t)__builtin_amdgcn_readfirstlane((int)band);
     left = (uint32_t)__builtin_amdgcn_readfirstlane((int)left);
+    final = __builtin_amdgcn_readfirstlane((int)fin) != 0;
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-}
-// The persistent grids hold as many waves as the chip runs at once (4,096 for the LDS-resident kernels); a launch with fewer work
-// items than that has nothing for the surplus, and each surplus wave would still queue once on every head word before it leaves --
-// for a 64 x 64 film that queueing was the whole frame (75-90 microseconds a launch, measured round 4).  Waves are numbered
-// wave-in-workgroup major, so the first n of them sit on n different CUs (and SIMDs): those claim, the others leave at once.  Which
-// wave renders a tile never matters; that the claiming waves are all resident does -- the grid is sized so that every wave is.
-__device__ __forceinline__ bool wave_has_work(unsigned long long items) {
-    return (unsigned long long)((threadIdx.x >> 6) * gridDim.x + blockIdx.x) < items;
 }
 } // namespace lg
