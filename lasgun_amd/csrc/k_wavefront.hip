@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
     if (LDSS) {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_stack + P.stack_depth * stride);
         const uint4 *src = reinterpret_cast<const uint4 *>(P.lds_image);
-        for (uint32_t i = tid; i < P.lds_image_n16; i += stride) dst[i] = src[i];
+        copy_to_lds(dst, src, P.lds_image_n16, tid, stride);
         __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling tiles
         scn = dst;
     }

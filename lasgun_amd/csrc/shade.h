@@ -256,7 +256,7 @@ __device__ __forceinline__ const uint4 *load_accel_image(const DParams &P, uint3
     if (!P.accel_image) return nullptr;
     uint4 *dst = reinterpret_cast<uint4 *>(lds_stack + stack_words);
     const uint4 *src = reinterpret_cast<const uint4 *>(P.accel_image);
-    for (uint32_t i = threadIdx.x; i < P.accel_image_n16; i += blockDim.x) dst[i] = src[i];
+    copy_to_lds(dst, src, P.accel_image_n16, threadIdx.x, blockDim.x);
     __syncthreads();
     return dst;
 }
