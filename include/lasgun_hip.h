@@ -204,8 +204,11 @@ int lg_audit_prune(const lg_accel *, uint32_t width, uint32_t height, uint32_t y
  * over the same primitives, front-to-back with pruning beyond the best hit; same primitive tests
  * and arithmetic.  Its winner is put to the reference tree's own box tests (leaf to root, through every
  * nested accel); a winner that fails them, or an exact tie in t, re-traces the ray with the reference
- * traversal.  Verified byte-identical to mode 0 on every test, benchmark config, fuzz and adversarial
- * scene; its two rounding margins are argued, not PROVEN.  The fast trees cost 5-10x the
+ * traversal.  Verified byte-identical to mode 0 on every test and benchmark config; its two rounding margins are argued, not
+ * PROVEN, and it CAN differ from the reference where a ray lies within rounding of a far triangle's plane (DESIGN.md section 3.3:
+ * 5 pixels in 4,100 fuzz scenes whose meshes span ten orders of magnitude).  Refused -- non-zero return, lg_last_error -- for a scene with a
+ * transform that does not invert (rotate() about a non-unit axis) or a mesh whose largest |coordinate| exceeds 2^20 times the longest
+ * edge of its smallest triangle.  The fast trees cost 5-10x the
  * reference build, so lg_accel_from does not build them: the first lg_accel_set_mode(accel, 1) does (it
  * synchronises the device and uploads the tables again; the Scene must still be alive, as for any use of the accel). */
 int lg_accel_set_mode(const lg_accel *, int mode);
@@ -219,10 +222,12 @@ int lg_accel_set_mode(const lg_accel *, int mode);
 int lg_accel_set_prune(const lg_accel *, int enabled);
 int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel default, LASGUN_PRUNE, lg_accel_set_prune, fast mode): 0 / 1 */
 
-/* Kernel organisation (same arithmetic, same bytes either way).  1 (default): scenes with <= 32 lights and at least 512
- * spheres / boxes (where node and sphere tests dominate a ray; glass / mirror over a big mesh excepted) run level by level in
- * the WAVEFRONT pipeline (below) with per-ray state in HBM when the launch covers at least 2^20 pixels (2^23 when the scene
- * carries a big mesh); everything else -- and everything when 0 -- runs in the single persistent megakernel.
+/* Kernel organisation (same arithmetic, same bytes either way).  1 (default): the organisation is chosen per launch from what was
+ * measured (tools/size_sweep.py, tools/bench_configs.py --org=...).  Level by level in the WAVEFRONT pipeline (below), with per-ray
+ * state in HBM: scenes with <= 32 lights and at least 512 spheres / boxes (node and sphere tests dominate a ray) from 2^21 pixels
+ * a launch (2^23 when the scene carries a big mesh; glass / mirror over a big mesh excepted); and, for a scene small enough to live
+ * in LDS, glass / mirror frames of up to 2^20 pixels (a tile's recursion tree is otherwise one wave's serial work) and plain frames
+ * from 2^18 pixels (2^20 when supersampled).  Everything else -- and everything when 0 -- runs in the single persistent megakernel.
  * 2 = use the pipeline wherever it is possible (tests).
  * 3 = the QUEUE organisation wherever it is possible (reference traversal, <= 32 lights, recursion depth <= 7): ONE persistent
  * launch per chunk of the film whose waves pull 64-ray packets from per-level ray queues -- level 0's packets are the 8x8 pixel
