@@ -218,7 +218,8 @@ def mesh_roofline(G, la, stream):
             "reference_work_rate_frac": flops_ref / (ms * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS,
             "note": "byte-identical to the oracle in tests/test_gpu_configs.py.  `frac` prices the tests the pruned walk still makes against the unfused f64 rate "
                     "(profiles/r04_config4_pmc.txt: the kernel issues VALU instructions ~70 % of the time at ~59 % lane use -- it is bound by the instruction stream "
-                    "of its node, culling-record and triangle tests, not by L2); `plain_walk` is the same frame with every test the reference makes, "
+                    "of its node, culling-record and triangle tests, not by L2; a triangle reached through the strips of a kept run is priced at the reference's 36 operations "
+                    "although the strip answers its sign test with ~20); `plain_walk` is the same frame with every test the reference makes, "
                     "`reference_work_rate_frac` that work over the pruned walk's time (what skipping buys, not a roofline fraction)"}
 
 

@@ -883,12 +883,13 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
         unsigned long long ml_cnt[6] = {0, 0, 0, 0, 1ull, (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true))};
 #endif
         for (;;) {
-            bool seeking = wave_any(!in_run && rec < rec_end);
+            bool seeks = !in_run && rec < rec_end; // (carried like at_node_l in traverse_ref)
+            bool seeking = wave_any(seeks);
             while (seeking) {
 #ifdef LG_STAMPS
                 ml_cnt[0] += 1; ml_cnt[1] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(!in_run && rec < rec_end));
 #endif
-                if (!in_run && rec < rec_end) {
+                if (seeks) {
                     if (COUNT) cnt.nodes++; // (a record test is counted with the node tests)
                     uint32_t start, count;
                     const uint32_t rec0 = __builtin_amdgcn_readfirstlane(rec);
@@ -905,7 +906,8 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
                     if (start == CHUNK_IS_GROUP) { if (culled_) rec += count; } // a group record: culled, its runs are stepped over; kept, they come next
                     else if (!culled_) { in_run = true; s = ck.d.w; run_end = s + (count >> 8); off = s * SREC; } // (< 2^32 / 16 entries: checked by the host)
                 }
-                seeking = wave_any(!in_run && rec < rec_end);
+                seeks = !in_run && rec < rec_end;
+                seeking = wave_any(seeks);
             }
             bool testing = wave_any(in_run);
             if (!testing) break;
@@ -1061,12 +1063,15 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         // with it its signs, only changes between phases.
         auto node_phase = [&](auto sgc) __attribute__((always_inline)) {
         constexpr int SG = decltype(sgc)::value;
+        // (the lane's "at a node" predicate is carried from the bottom of one trip to the top of the next: written as two tests of `state`,
+        // hipcc compares twice per trip -- one vector instruction of ~35)
         bool more_nodes = true;
+        bool at_node_l = state == ST_NODE;
         while (more_nodes) {
 #ifdef LG_STAMPS
             stamp_cnt[5] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_NODE));
 #endif
-            if (state == ST_NODE) {
+            if (at_node_l) {
                 // the record's walk words: interior -> (second child's cursor, 1 << split axis, -), leaf -> (first slot, NODE_LEAF, last slot + 1)
                 double bmin[3], bmax[3];
                 uint32_t w_link, w_meta, w_end, w_chunk;
@@ -1136,7 +1141,8 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
             stamp_cnt[0] += 1; // (lanes that took this step: those whose state was ST_NODE when it began -- counted after it as "not idle")
             stamp_cnt[6] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_DONE));
 #endif
-            more_nodes = wave_any(state == ST_NODE);
+            at_node_l = state == ST_NODE;
+            more_nodes = wave_any(at_node_l);
         }
         };
         {
@@ -1185,13 +1191,14 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
             else state = ST_LEVEL_DONE;
         }
         LG_STAMP(2);
-        bool more_prims = wave_any(state == ST_LEAF);
+        bool at_slot_l = state == ST_LEAF; // (carried like at_node_l above)
+        bool more_prims = wave_any(at_slot_l);
         while (more_prims) {
 #ifdef LG_STAMPS
             stamp_cnt[7] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_LEAF));
             stamp_cnt[8] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_DONE));
 #endif
-            if (state == ST_LEAF) {
+            if (at_slot_l) {
                 const uint32_t slot = li;
                 const uint32_t ref = load_primref<LDSS>(P, scn, slot);
                 LeafRec g;
@@ -1252,7 +1259,8 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     else state = ST_LEVEL_DONE;
                 }
             }
-            more_prims = wave_any(state == ST_LEAF);
+            at_slot_l = state == ST_LEAF;
+            more_prims = wave_any(at_slot_l);
 #ifdef LG_STAMPS
             stamp_cnt[2] += 1;
 #endif
