@@ -389,6 +389,24 @@ def test_extreme_film_shapes(w, h):
         assert np.array_equal(film.pixels(), ofilm.pixels()), streaming
 
 
+# films whose 8x8 tiles number just below, at and just above the sizes at which a persistent launch changes how it ends (kcommon.h: fewer
+# tiles than the grid has waves -- 4,096 on an MI355X with the scene in LDS --, at most twice as many: "final" tiles; more: plain bands)
+@pytest.mark.parametrize("w, h", [(8, 8), (360, 728), (512, 512), (136, 1928), (8, 65528), (1024, 512), (24, 21848), (1000, 600)])
+@pytest.mark.parametrize("kind", ["glass", "plastic"])
+def test_launches_end_without_losing_tiles(w, h, kind):
+    """1, 4095, 4096, 4097, 8191, 8192, 8193 and 9375 tiles: every pixel of the film against the oracle, in each organisation and by default
+    (a tile nobody claimed would keep the bytes the film was created with)."""
+    o = oracle()
+    ofilm = o.Film(w, h)
+    o.capture_subset_mt(0, 1, o.Accel(S.cornell_scene(o, kind)), ofilm, 16)
+    acc = G.Accel(S.cornell_scene(G, kind))
+    for streaming in (1, 0, 2, 3):
+        G.set_streaming(acc, streaming)
+        film = G.Film.new_with_output(w, h, np.full((h, w, 4), 99, np.uint8))
+        G.capture_subset(0, 1, acc, film)
+        assert np.array_equal(film.pixels(), ofilm.pixels()), streaming
+
+
 def test_fast_mode_adversarial_scenes():
     """Scenes built against fast mode's margins (wall-sized spheres, lights a hair from a surface, needle boxes, twin
     spheres); seeds 75 and 375 differed by one pixel each before the fast walk's winner was put to the reference tree's

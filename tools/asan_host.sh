@@ -26,6 +26,8 @@ for seed in range(150):
             G.host_build_dump(gen(G, seed)); n += 1
             r = G.host_check_wide_records(gen(G, seed))  # the fast trees and their wide records too
             assert r["violations"] == 0 and r["deepest_stack"] <= r["reserved_stack"], (gen.__name__, seed, r)
+            r = G.host_check_strips(gen(G, seed))  # the pruned walk's runs and triangle strips
+            assert r["violations"] == 0, (gen.__name__, seed, r)
         except la.LasgunError:
             pass
 for b in (lambda: S.mesh_scene(G), lambda: S.mixed_scene(G), lambda: S.spheres_scene(G), lambda: S.kitchen_sink_scene(G), lambda: S.instanced_scene(G), lambda: S.tie_mesh_scene(G), lambda: S.exotic_obj_scene(G)):
