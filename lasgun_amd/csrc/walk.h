@@ -1000,6 +1000,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
 #ifdef LG_STAMPS
     unsigned long long stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_readcyclecounter();
     unsigned long long stamp_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ret_acc[7] = {0, 0, 0, 0, 0, 0, 0}; // inside phase C: loop entry, frame + parent fetch, level record, ray, prune constants, next state; iterations
 #endif
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
     if (COUNT) cnt.entries++; // the root accel
@@ -1289,7 +1290,14 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         }
         LG_STAMP(4);
         // ---- phase C: this nested BVHAccel is exhausted: resume the parent's leaf loop (bvh.rs:483-488)
+#ifdef LG_STAMPS
+        unsigned long long rt_t = __builtin_readcyclecounter();
+#define LG_RSTAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); ret_acc[i] += now_ - rt_t; rt_t = now_; } while (0)
+#else
+#define LG_RSTAMP(i) do { } while (0)
+#endif
         while (state == ST_LEVEL_DONE) { // (a lane comes back through every level that is exhausted with it)
+            LG_RSTAMP(0);
             if (L.accel == 0u) state = ST_DONE;
             else {
                 const uint32_t w2 = stk[(sp - 1u) * stride];
@@ -1307,7 +1315,9 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     parent = (uint32_t)P.accels[L.accel].parent;
                     nchain = P.accels[parent].nchain; chain = P.accels[parent].chain;
                 }
+                LG_RSTAMP(1);
                 lvl_set<LDSS, FAST>(P, arec, L, parent);
+                LG_RSTAMP(2);
                 if (!(w2 & FRAME_SAME_RAY)) { // the parent's ray again: from the root's, through the same transforms
                     ray = root;
                     for (uint32_t i = 1; i < nchain; ++i) {
@@ -1319,12 +1329,19 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     four_a = 4.0 * dd;
                     negmask = neg_mask_x(ray);
                 }
+                LG_RSTAMP(3);
                 if (PRUNE) prune_level();
+                LG_RSTAMP(4);
                 if (li < le) state = ST_LEAF;
                 else if (sp != base) { --sp; cur = stk[sp * stride]; state = ST_NODE; }
                 else state = ST_LEVEL_DONE; // the parent level is exhausted as well
+                LG_RSTAMP(5);
+#ifdef LG_STAMPS
+                ret_acc[6] += 1;
+#endif
             }
         }
+#undef LG_RSTAMP
         LG_STAMP(5);
 #ifdef LG_STAMPS
         stamp_acc[6] += 1;
@@ -1332,12 +1349,15 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         if (!wave_any(state != ST_DONE)) break;
     }
 #ifdef LG_STAMPS
+    for (int i = 0; i < 7; ++i) // phase C runs lane by lane: the wave's figure is its busiest lane's
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o_ = __shfl_xor(ret_acc[i], off); ret_acc[i] = o_ > ret_acc[i] ? o_ : ret_acc[i]; }
     if ((threadIdx.x & 63u) == 0u && P.stats) {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(P.stats);
         for (int i = 0; i < 7; ++i) atomicAdd(dst + i, stamp_acc[i]);
         atomicAdd(dst + 7, 1ull);
         unsigned long long *cnt = P.stamp_counts;
         if (cnt) for (int i = 0; i < 9; ++i) atomicAdd(cnt + i, stamp_cnt[i]);
+        for (int i = 0; i < 7; ++i) atomicAdd(dst + 8 + i, ret_acc[i]); // (words 8..14 of the first record; the lane that has seen most)
     }
 #endif
 }

@@ -26,6 +26,8 @@ tot = sum(out[i] for i in range(6))
 for i, n in enumerate(names):
     print("%-14s %16d cycles  %5.1f %%" % (n, out[i], 100.0 * out[i] / tot))
 walks = out[7]
+r = out[8:15]
+print("phase C inside (cycles per walk): loop entry %.0f, frame + parent fetch %.0f, level record %.0f, ray %.0f, prune constants %.0f, next state %.0f; iterations per walk %.1f" % tuple([v / walks for v in r[:6]] + [r[6] / walks]))
 c = out[16:32]
 print("walks (wave level) %d, outer trips per walk %.1f" % (walks, out[6] / walks))
 print("node trips per walk %.1f: %.1f lanes stepping, %.1f done" % (c[0] / walks, c[5] / max(c[0], 1), c[6] / max(c[0], 1)))
