@@ -4,12 +4,16 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
+#include <mutex>
+#include <thread>
 
 namespace lg {
 
@@ -1147,7 +1151,7 @@ static DChunk make_record(const FlatScene &out, size_t a, size_t b) {
 // strips an unused triangle could start (three rotations each; a strip keeps taking the unused triangle that contains the last two
 // vertices emitted) the longest is emitted, until none is left.  Vertices are identified by their f32 bits (what the reference's transforms see); winding plays no
 // part (the sign test the strips serve is indifferent to it).  Returns the number of entries.
-static uint32_t make_strips(FlatScene &out, size_t a, size_t b) {
+static uint32_t make_strips(const FlatScene &out, size_t a, size_t b, std::vector<DStrip> &strips) {
     const size_t n = b - a;
     struct T { uint32_t raw[3][3]; int v[3]; uint32_t slot; bool used; };
     std::vector<T> t(n);
@@ -1172,9 +1176,9 @@ static uint32_t make_strips(FlatScene &out, size_t a, size_t b) {
         DStrip e;
         std::memcpy(&e.x, p, 12);
         e.code = code;
-        out.strips.push_back(e);
+        strips.push_back(e);
     };
-    const size_t before = out.strips.size();
+    const size_t before = strips.size();
     std::vector<char> taken(n, 0);
     // the triangles a strip started at triangle i0 in rotation rot would take, in order (nothing is marked for good)
     auto follow = [&](size_t i0, int rot, std::vector<std::pair<int, int>> &path) {
@@ -1249,7 +1253,7 @@ static uint32_t make_strips(FlatScene &out, size_t a, size_t b) {
             --left;
         }
     }
-    return (uint32_t)(out.strips.size() - before);
+    return (uint32_t)(strips.size() - before);
 }
 // leaf_soup2 (the triangles of every mesh leaf again, run after run; word 9 of a record = the slot it came from), the runs'
 // records, and in DNode::pad of every mesh leaf: index of its first record | number of its records << 24.
@@ -1261,71 +1265,107 @@ static void build_chunks(FlatScene &out) {
     for (const DAccel &A : out.accels) any_mesh = any_mesh || (A.flags & AF_MESH) != 0u;
     if (!any_mesh) return; // (the pruned walk reads leaf_soup2 / chunks in mesh leaves only; capi.cpp points them at leaf_soup then)
     out.leaf_soup2 = out.leaf_soup;
-    std::vector<char> done(out.nodes.size(), 0);
-    for (const DAccel &A : out.accels) {
-        if (!(A.flags & AF_MESH) || done[A.node_base]) continue;
-        std::vector<uint32_t> todo{0};
-        while (!todo.empty()) {
-            const uint32_t nidx = todo.back(); todo.pop_back();
-            done[A.node_base + nidx] = 1;
-            DNode &nd = out.nodes[A.node_base + nidx];
-            if (!(nd.meta & NODE_LEAF)) { todo.push_back(nidx + 1); todo.push_back(nd.link); continue; }
-            const size_t first = (size_t)A.prim_base + nd.link, count = nd.meta & 0xFFFFu;
-            std::vector<LeafTri> tris(count);
-            for (size_t i = 0; i < count; ++i) {
-                float p[9];
-                std::memcpy(p, out.leaf_soup[first + i].w, sizeof p);
-                const V3 v0{p[0], p[1], p[2]}, v1{p[3], p[4], p[5]}, v2{p[6], p[7], p[8]};
-                V3 n = cross(v1 - v0, v2 - v0);
-                const double l = std::sqrt(dot(n, n));
-                n = l > 0.0 && std::isfinite(l) ? n * (1.0 / l) : V3{0, 0, 0};
-                tris[i] = LeafTri{(uint32_t)(first + i), (v0 + v1 + v2) * (1.0 / 3.0), n};
+    // every mesh leaf once (instances share their trees), in the order the records are laid out in
+    struct LeafJob { uint32_t node; size_t first, count; std::vector<DChunk> chunks; std::vector<DStrip> strips; };
+    std::vector<LeafJob> jobs;
+    {
+        std::vector<char> done(out.nodes.size(), 0);
+        for (const DAccel &A : out.accels) {
+            if (!(A.flags & AF_MESH) || done[A.node_base]) continue;
+            std::vector<uint32_t> todo{0};
+            while (!todo.empty()) {
+                const uint32_t nidx = todo.back(); todo.pop_back();
+                done[A.node_base + nidx] = 1;
+                const DNode &nd = out.nodes[A.node_base + nidx];
+                if (!(nd.meta & NODE_LEAF)) { todo.push_back(nidx + 1); todo.push_back(nd.link); continue; }
+                jobs.push_back(LeafJob{A.node_base + nidx, (size_t)A.prim_base + nd.link, (size_t)(nd.meta & 0xFFFFu), {}, {}});
             }
-            std::vector<std::pair<size_t, size_t>> runs;
-            cut_runs(tris, 0, count, runs);
-            // The records are an optimisation: a leaf whose cut does not fit the 8-bit record count of DNode::pad (a soup of
-            // incoherent triangles, a geometric progression of centroids: the gap rule peels one triangle per cut) is cut into
-            // plain runs of <= 32 consecutive triangles of the sorted set instead (<= 8 runs + 4 group records), and a mesh
-            // beyond the 24-bit record index leaves its remaining leaves without records: pad = 0, and the leaf loop walks
-            // such a leaf in the reference's order over the reference's soup (walk.h, mesh_leaf2).
-            auto records_of = [](size_t nruns) { return nruns + nruns / CHUNK_GROUP; }; // one record per run, one per group of CHUNK_GROUP (= 2) runs
-            if (records_of(runs.size()) > 255) {
-                runs.clear();
-                for (size_t r0 = 0; r0 < count; r0 += (size_t)1 << CHUNK_SHIFT) runs.emplace_back(r0, std::min(count, r0 + ((size_t)1 << CHUNK_SHIFT)));
-            }
-            if (out.chunks.size() + records_of(runs.size()) + 2 >= (1u << 24)) { nd.pad = 0u; continue; }
-            nd.pad = (uint32_t)out.chunks.size();
-            for (size_t i = 0; i < count; ++i) {
-                DLeafRec r = out.leaf_soup[tris[i].slot];
-                r.w[9] = tris[i].slot;
-                out.leaf_soup2[first + i] = r;
-            }
-            // the leaf's record stream: runs in groups of <= CHUNK_GROUP, every group of two or more behind a GROUP record over the
-            // triangles of all its runs (start = CHUNK_IS_GROUP, count = how many run records follow it: a culled group is
-            // stepped over whole)
-            size_t nrec = 0;
-            for (size_t g = 0; g < runs.size(); g += CHUNK_GROUP) {
-                const size_t ge = std::min(runs.size(), g + CHUNK_GROUP);
-                if (ge - g >= 2) {
-                    DChunk gk = make_record(out, first + runs[g].first, first + runs[ge - 1].second);
-                    gk.start = CHUNK_IS_GROUP;
-                    gk.count = (uint32_t)(ge - g);
-                    out.chunks.push_back(gk);
-                    ++nrec;
-                }
-                for (size_t r = g; r < ge; ++r) {
-                    DChunk k = make_record(out, first + runs[r].first, first + runs[r].second);
-                    if (out.strips.size() >= 0xFFFFFF00u) throw Error("too many strip entries"); // (cannot happen: < 3 entries per slot, < 80M slots)
-                    k.pad = (uint32_t)out.strips.size();
-                    const uint32_t entries = make_strips(out, first + runs[r].first, first + runs[r].second); // <= 3 * 32
-                    k.count |= entries << 8;
-                    out.chunks.push_back(k);
-                    ++nrec;
-                }
-            }
-            if (nrec > 255) throw Error("internal: a leaf's culling records exceed their 8-bit count"); // (cannot happen: see records_of above)
-            nd.pad |= (uint32_t)nrec << 24;
         }
+    }
+    // A leaf's runs, records and strips depend on that leaf alone (its own slots of leaf_soup / leaf_soup2): the leaves are worked on by
+    // several host threads, each into vectors of the leaf's own (record `pad` words relative to the leaf's first strip entry), and laid
+    // out one after the other below -- the tables are what one thread makes, whatever the thread count.  (The strips doubled the
+    // time of this function; lg_capture rebuilds the accel on every call, as the reference does.)
+    auto one_leaf = [&out](LeafJob &J) {
+        const size_t first = J.first, count = J.count;
+        std::vector<LeafTri> tris(count);
+        for (size_t i = 0; i < count; ++i) {
+            float p[9];
+            std::memcpy(p, out.leaf_soup[first + i].w, sizeof p);
+            const V3 v0{p[0], p[1], p[2]}, v1{p[3], p[4], p[5]}, v2{p[6], p[7], p[8]};
+            V3 n = cross(v1 - v0, v2 - v0);
+            const double l = std::sqrt(dot(n, n));
+            n = l > 0.0 && std::isfinite(l) ? n * (1.0 / l) : V3{0, 0, 0};
+            tris[i] = LeafTri{(uint32_t)(first + i), (v0 + v1 + v2) * (1.0 / 3.0), n};
+        }
+        std::vector<std::pair<size_t, size_t>> runs;
+        cut_runs(tris, 0, count, runs);
+        // The records are an optimisation: a leaf whose cut does not fit the 8-bit record count of DNode::pad (a soup of
+        // incoherent triangles, a geometric progression of centroids: the gap rule peels one triangle per cut) is cut into
+        // plain runs of <= 32 consecutive triangles of the sorted set instead (<= 8 runs + 4 group records), and a mesh
+        // beyond the 24-bit record index leaves its remaining leaves without records: pad = 0, and the leaf loop walks
+        // such a leaf in the reference's order over the reference's soup (walk.h, mesh_leaf2).
+        auto records_of = [](size_t nruns) { return nruns + nruns / CHUNK_GROUP; }; // one record per run, one per group of CHUNK_GROUP (= 2) runs
+        if (records_of(runs.size()) > 255) {
+            runs.clear();
+            for (size_t r0 = 0; r0 < count; r0 += (size_t)1 << CHUNK_SHIFT) runs.emplace_back(r0, std::min(count, r0 + ((size_t)1 << CHUNK_SHIFT)));
+        }
+        for (size_t i = 0; i < count; ++i) { // (this leaf's slots of leaf_soup2: no other leaf reads or writes them)
+            DLeafRec r = out.leaf_soup[tris[i].slot];
+            r.w[9] = tris[i].slot;
+            out.leaf_soup2[first + i] = r;
+        }
+        // the leaf's record stream: runs in groups of <= CHUNK_GROUP, every group of two or more behind a GROUP record over the
+        // triangles of all its runs (start = CHUNK_IS_GROUP, count = how many run records follow it: a culled group is
+        // stepped over whole)
+        for (size_t g = 0; g < runs.size(); g += CHUNK_GROUP) {
+            const size_t ge = std::min(runs.size(), g + CHUNK_GROUP);
+            if (ge - g >= 2) {
+                DChunk gk = make_record(out, first + runs[g].first, first + runs[ge - 1].second);
+                gk.start = CHUNK_IS_GROUP;
+                gk.count = (uint32_t)(ge - g);
+                J.chunks.push_back(gk);
+            }
+            for (size_t r = g; r < ge; ++r) {
+                DChunk k = make_record(out, first + runs[r].first, first + runs[r].second);
+                k.pad = (uint32_t)J.strips.size(); // (relative to the leaf's first entry until the tables are laid out)
+                const uint32_t entries = make_strips(out, first + runs[r].first, first + runs[r].second, J.strips); // <= 3 * 32
+                k.count |= entries << 8;
+                J.chunks.push_back(k);
+            }
+        }
+    };
+    {
+        size_t tris_total = 0;
+        for (const LeafJob &J : jobs) tris_total += J.count;
+        unsigned nthreads = std::thread::hardware_concurrency();
+        if (const char *e = std::getenv("LASGUN_HOST_THREADS")) nthreads = (unsigned)std::max(1, std::atoi(e));
+        nthreads = std::min({nthreads ? nthreads : 1u, 16u, (unsigned)(tris_total / 4096 + 1)}); // (a small mesh is not worth a thread's start)
+        if (nthreads <= 1) { for (LeafJob &J : jobs) one_leaf(J); }
+        else {
+            std::atomic<size_t> next{0};
+            std::exception_ptr failed;
+            std::mutex failed_mtx;
+            std::vector<std::thread> pool;
+            for (unsigned w = 0; w < nthreads; ++w)
+                pool.emplace_back([&] {
+                    try { for (size_t j; (j = next.fetch_add(1)) < jobs.size();) one_leaf(jobs[j]); }
+                    catch (...) { std::lock_guard<std::mutex> lk(failed_mtx); if (!failed) failed = std::current_exception(); }
+                });
+            for (std::thread &th : pool) th.join();
+            if (failed) std::rethrow_exception(failed);
+        }
+    }
+    for (LeafJob &J : jobs) {
+        DNode &nd = out.nodes[J.node];
+        if (J.chunks.size() > 255) throw Error("internal: a leaf's culling records exceed their 8-bit count"); // (cannot happen: see records_of above)
+        if (out.chunks.size() + J.chunks.size() + 2 >= (1u << 24)) { nd.pad = 0u; continue; }
+        if (out.strips.size() + J.strips.size() >= 0xFFFFFF00u) throw Error("too many strip entries"); // (cannot happen: < 3 entries per slot, < 80M slots)
+        nd.pad = (uint32_t)out.chunks.size() | (uint32_t)J.chunks.size() << 24;
+        const uint32_t strip_base = (uint32_t)out.strips.size();
+        for (DChunk &k : J.chunks) { if (k.start != CHUNK_IS_GROUP) k.pad += strip_base; out.chunks.push_back(k); }
+        out.strips.insert(out.strips.end(), J.strips.begin(), J.strips.end());
+        std::vector<DChunk>().swap(J.chunks); std::vector<DStrip>().swap(J.strips);
     }
     if (std::getenv("LASGUN_DEBUG_CHUNKS")) { // what the runs look like: sizes, and how much room their cones leave
         size_t n = out.chunks.size(), never = 0, tris = 0, hist[6] = {0, 0, 0, 0, 0, 0};
