@@ -284,7 +284,8 @@ int lg_host_build_dump(const lg_scene *, const double **f, size_t *nf, const int
  * never, a dangling link. */
 int lg_host_check_wide_records(const lg_scene *, uint64_t out[8]);
 /* Host-only self-check of the triangle strips the pruned walk's leaf loop streams (no device): out = { mesh leaves with culling
- * records, runs, triangles, strip entries, violations, 0, 0, 0 }.  Violations: a triangle of such a leaf that is not exactly one
+ * records, runs, triangles, strip entries, violations, FNV-1a of the culling records and the leaves' record words, FNV-1a of the strip
+ * entries, 0 } (the hashes: the tables must not depend on how many host threads made them, LASGUN_HOST_THREADS).  Violations: a triangle of such a leaf that is not exactly one
  * strip triangle, a strip triangle whose three vertices are not its slot's three vertices, a run whose counts disagree. */
 int lg_host_check_strips(const lg_scene *, uint64_t out[8]);
 

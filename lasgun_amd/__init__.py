@@ -251,7 +251,7 @@ class HipApi(Api):
         out = (_C.c_uint64 * 8)()
         if self.call("host_check_strips", scene.h, out):
             raise LasgunError(self.last_error())
-        return dict(zip(("leaves", "runs", "triangles", "entries", "violations"), [int(v) for v in out]))
+        return dict(zip(("leaves", "runs", "triangles", "entries", "violations", "records_hash", "strips_hash"), [int(v) for v in out]))
 
     def host_check_wide_records(self, scene):
         """Host-only self-check of the fast mode's wide node records (no GPU needed): dict of counts; `violations` must be 0."""

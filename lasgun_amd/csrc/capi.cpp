@@ -1625,7 +1625,7 @@ int lg_host_build_dump(const lg_scene *s, const double **f, size_t *nf, const in
 // (frames of nested accels not counted), out[4] violations (a child box that does not contain its node's f64 box, a leaf reached
 // twice or never, a link that is not a node of the tree), out[5] = FlatScene::max_stack_fast1.
 // Host-only self-check of the triangle strips (DStrip) against the leaves they are made from: out = { mesh leaves with records, runs,
-// triangles, strip entries, violations, 0, 0, 0 }.  Every triangle slot of a mesh leaf with records must come up in exactly one
+// triangles, strip entries, violations, hash of the records and the leaves' pad words, hash of the strips, 0 }.  Every triangle slot of a mesh leaf with records must come up in exactly one
 // run, exactly once, as a STRIP_TRI entry whose three vertices (the two entries before it and its own) are the slot's three
 // vertices in some order; the entry counts must match the run records.
 int lg_host_check_strips(const lg_scene *s, uint64_t out[8]) {
@@ -1677,6 +1677,13 @@ int lg_host_check_strips(const lg_scene *s, uint64_t out[8]) {
                 for (size_t i = 0; i < count; ++i) if (hits[i] != 1) out[4]++;
             }
         }
+        // FNV-1a over the tables as they would be uploaded (the threaded build must give what one thread gives) and over the leaves' pad words
+        auto fnv = [](uint64_t h, const void *p, size_t n) { const unsigned char *b = static_cast<const unsigned char *>(p); for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; };
+        uint64_t h = 14695981039346656037ull;
+        h = fnv(h, flat.chunks.data(), flat.chunks.size() * sizeof(DChunk));
+        for (const DNode &nd : flat.nodes) h = fnv(h, &nd.pad, sizeof nd.pad);
+        out[5] = h;
+        out[6] = fnv(14695981039346656037ull, flat.strips.data(), flat.strips.size() * sizeof(DStrip));
     });
 }
 int lg_host_check_wide_records(const lg_scene *s, uint64_t out[8]) {

@@ -78,6 +78,19 @@ def test_incoherent_fat_leaves_build(seed):
     assert np.array_equal(i, oi) and np.array_equal(f.view(np.uint64), of.view(np.uint64))
 
 
+def test_leaf_records_do_not_depend_on_the_thread_count(monkeypatch):
+    """The fat leaves' runs, culling records and strips are made by several host threads, one leaf per task (host.cpp, build_chunks), and
+    laid out in leaf order: the tables -- hashed as they would be uploaded -- are what one thread makes."""
+    for build in (lambda: S.mesh_scene(la.api), lambda: S.mixed_scene(la.api, 300, 40, 40), lambda: S.adversarial_prune_scene(la.api, 5)):
+        seen = set()
+        for threads in ("1", "3", "8"):
+            monkeypatch.setenv("LASGUN_HOST_THREADS", threads)
+            r = la.api.host_check_strips(build())
+            assert r["violations"] == 0
+            seen.add((r["records_hash"], r["strips_hash"], r["runs"], r["entries"]))
+        assert len(seen) == 1, seen
+
+
 @pytest.mark.parametrize("name", ["mesh_100k", "mixed_small", "tie_mesh", "exotic", "soup0", "soup3", "slabs"])
 def test_triangle_strips_cover_their_leaves(name):
     """The strips the pruned walk's leaf loop streams (DStrip): every triangle of every mesh leaf with culling records is exactly one
