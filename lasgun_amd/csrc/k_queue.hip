@@ -1,4 +1,5 @@
 // lasgun_amd/csrc/k_queue.hip -- the queue organisation: li() for every recursion level of a chunk of the film in ONE persistent launch.
+#define LG_DIR_PER_RECORD 1 // (walk.h, chunk_culled: this kernel keeps the per-record form)
 #include "shade.h"
 
 namespace lg {

@@ -651,6 +651,7 @@ __device__ __forceinline__ bool tri_rec_t(const LeafRec &r, V3 o, double sx, dou
 struct LeafCull {
     double lb, ekz, dd;
     uint32_t records;      // DNode::pad of the leaf: first record | number of records << 24
+    float dhx, dhy, dhz;   // the ray's direction over its length, in f32, every rounding towards a shorter vector (per leaf, not per record)
 };
 // One culling record (DChunk) against the ray: true = none of its triangles (<= 32 for a run) can be accepted, the tests are skipped.
 // (t1, t2) per axis are the slab test's own expressions on the record's box.  Dominant axis: an accepted t is a convex
@@ -673,7 +674,6 @@ __device__ __forceinline__ bool chunk_culled(const ChunkRec &k, const Ray &ray, 
     const uint4 a = k.a, b = k.b, c = k.c;
     run_start = k.d.x; run_count = k.d.y;
     const double bmin[3] = {rec_f32(a.x), rec_f32(a.y), rec_f32(a.z)}, bmax[3] = {rec_f32(a.w), rec_f32(b.x), rec_f32(b.y)};
-    const V3 ax{rec_f32(b.z), rec_f32(b.w), rec_f32(c.x)};
     const float cos_t = __uint_as_float(c.y), g2 = __uint_as_float(c.z), hmin = __uint_as_float(c.w), sin_t = __uint_as_float(k.d.z);
     const double ox = bmin[0] - ray.o.x, px = bmax[0] - ray.o.x, oy = bmin[1] - ray.o.y, py = bmax[1] - ray.o.y, oz = bmin[2] - ray.o.z, pz = bmax[2] - ray.o.z;
     double t1 = ox * ray.dinv.x, t2 = px * ray.dinv.x;
@@ -686,7 +686,15 @@ __device__ __forceinline__ bool chunk_culled(const ChunkRec &k, const Ray &ray, 
     bool skip = nk > lc.lb + lc.ekz || fk < -lc.ekz; // (NaN parameters compare false)
     // sigma: a lower bound of |n . d| / |d| over the record's triangles -- cos(alpha + theta) with cos(alpha) = |axis . d| / |d|, in
     // f32 with every rounding pushed towards a smaller sigma (a larger margin)
+    // (round 4: the unit direction is the leaf's -- LeafCull -- not the record's: three conversions and an f64 dot product less per record;
+    // the f32 dot product's own rounding, ~2e-7, sits inside the 4e-6: config 4m 14.7 -> 14.2 ms, 5 54.2 -> 53.8.  The level's S in place of
+    // the record's own R was measured too: 5 % more triangle tests -- the margin grows with R^2 -- and no time gained.)
+#ifdef LG_DIR_PER_RECORD // (k_queue.hip: three more registers live across the leaf loop cost that kernel more than the conversions -- config 4 36.9 -> 37.5 ms)
+    const V3 ax{rec_f32(b.z), rec_f32(b.w), rec_f32(c.x)};
     const float ca = fminf(fabsf((float)dot(ax, ray.d)) * __frsqrt_rn((float)lc.dd) * (1.0f - 4e-6f), 1.0f);
+#else
+    const float ca = fminf(fabsf((__uint_as_float(b.z) * lc.dhx + __uint_as_float(b.w) * lc.dhy) + __uint_as_float(c.x) * lc.dhz), 1.0f);
+#endif
     const float sa = sqrtf(fmaxf(1.0f - ca * ca, 0.0f)) * (1.0f + 4e-6f) + 1e-6f;
     const float sigma = (ca * cos_t - sa * sin_t) - 1e-5f;
     const float Rf = (float)((fmax_(fabs(ox), fabs(px)) + fmax_(fabs(oy), fabs(py))) + fmax_(fabs(oz), fabs(pz))) * (1.0f + 1e-6f); // >= the 1-norm distance to any vertex
@@ -1176,11 +1184,15 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
             if (!FAST) tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
             bool done;
-            LeafCull lc{INFINITY, INFINITY, dd, lcb};
+            LeafCull lc{INFINITY, INFINITY, dd, lcb, 0.0f, 0.0f, 0.0f};
             if (PRUNE) { // the level's limits, as prune_limits made them: the dominant axis carries lb + eps * |1/d_kz|
                 const double lim = anyhit ? 1.0 : best.t;
                 lc.lb = lim + lim * PRUNE_LIMIT_REL;
                 lc.ekz = peps * fabs(tri.kz == 0 ? ray.dinv.x : tri.kz == 1 ? ray.dinv.y : ray.dinv.z);
+#ifndef LG_DIR_PER_RECORD
+                const float inv_len = __frsqrt_rn((float)dd) * (1.0f - 4e-6f);
+                lc.dhx = (float)ray.d.x * inv_len; lc.dhy = (float)ray.d.y * inv_len; lc.dhz = (float)ray.d.z * inv_len;
+#endif
             }
             if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
             else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
@@ -1474,7 +1486,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
         if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
             if (!FAST) tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
             bool done;
-            const LeafCull lc{INFINITY, INFINITY, dd, 0u};
+            const LeafCull lc{INFINITY, INFINITY, dd, 0u, 0.0f, 0.0f, 0.0f};
             if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST, COUNT>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
             else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST, COUNT>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
             else done = mesh_leaf2<2, LDSS, FAST, COUNT>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
