@@ -381,6 +381,22 @@ __device__ __forceinline__ uint4 load_const_u4(lg_const_u4 q, int i) {
     const lg_u32x4 v = q[i];
     return uint4{v.x, v.y, v.z, v.w};
 }
+// The accel records in LDS (`arec` below), read through a pointer that SAYS it is LDS.  A kernel that may find them in LDS or in the DAccel
+// table (the 256-lane forms: `arec` is a run-time value) otherwise gets both alternatives merged into one generic pointer and read with
+// flat_load -- which waits on the vector-memory AND the LDS counters and takes the long way round (round 4, read in the ISA: every
+// field of an accel record on entering and leaving a nested accel went that way).
+typedef const __attribute__((address_space(3))) lg_u32x4 *lg_lds_u4;
+typedef double lg_f64x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) lg_f64x2 *lg_lds_d2;
+typedef const __attribute__((address_space(3))) uint32_t *lg_lds_u32;
+__device__ __forceinline__ uint4 lds_u4(const uint4 *p) {
+    const lg_u32x4 v = *(lg_lds_u4)p;
+    return uint4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ double2 lds_d2(const void *p) {
+    const lg_f64x2 v = *(lg_lds_d2)p;
+    return double2{v.x, v.y};
+}
 // ---- scene table access: HBM/L2 tables, or (LDSS) the copy a 1024-lane workgroup holds in LDS.
 // Lanes of a wave read DIFFERENT records, 56 bytes per node visit: through the vector L1 that is
 // 64 B/clk per CU and the traversal kernels were bound by it as much as by VALU issue; the LDS
@@ -587,7 +603,7 @@ template <bool LDSS, bool FAST = false>
 __device__ __forceinline__ void lvl_set(const DParams &P, const uint4 *arec, Lvl &L, uint32_t accel) {
     L.accel = accel;
     if (LDSS || (!FAST && arec)) {
-        const uint4 info = arec[accel * LDS_ACCEL_UNITS + 6u];
+        const uint4 info = lds_u4(arec + (accel * LDS_ACCEL_UNITS + 6u));
         L.node_base = info.x; L.prim_base = info.y; L.soup_delta = info.z; L.flags = info.w;
     } else {
         const DAccel *A = P.accels + accel;
@@ -597,8 +613,8 @@ __device__ __forceinline__ void lvl_set(const DParams &P, const uint4 *arec, Lvl
 template <bool LDSS>
 __device__ __forceinline__ Ray accel_local_ray(const DParams &P, const uint4 *arec, uint32_t accel, const Ray &r) { // inverse_transform_ray (bvh.rs:462)
     if (LDSS || arec) {
-        const double2 *q = reinterpret_cast<const double2 *>(arec + accel * LDS_ACCEL_UNITS);
-        const double2 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
+        const uint4 *q = arec + accel * LDS_ACCEL_UNITS;
+        const double2 a = lds_d2(q), b = lds_d2(q + 1), c = lds_d2(q + 2), d = lds_d2(q + 3), e = lds_d2(q + 4), f = lds_d2(q + 5);
         Affine m;
         m.c[0][0] = a.x; m.c[0][1] = a.y; m.c[0][2] = b.x; m.c[1][0] = b.y; m.c[1][1] = c.x; m.c[1][2] = c.y;
         m.c[2][0] = d.x; m.c[2][1] = d.y; m.c[2][2] = e.x; m.c[3][0] = e.y; m.c[3][1] = f.x; m.c[3][2] = f.y;
@@ -1047,8 +1063,8 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     auto prune_level = [&]() { // after L and ray have changed
         double c[6];
         if (LDSS || arec) {
-            const double2 *q = reinterpret_cast<const double2 *>(arec + (L.accel * LDS_ACCEL_UNITS + 10u));
-            const double2 a = q[0], b = q[1], e = q[2];
+            const uint4 *q = arec + (L.accel * LDS_ACCEL_UNITS + 10u);
+            const double2 a = lds_d2(q), b = lds_d2(q + 1), e = lds_d2(q + 2);
             c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
         } else {
             const double *q = P.accels[L.accel].prune;
@@ -1317,15 +1333,12 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 sp -= 3u; base = w2 & ~FRAME_SAME_RAY;
                 if (COUNT) dbg_event(P, 5.0, (double)L.accel, (double)li, (double)le);
                 uint32_t parent, nchain;
-                const uint32_t *chain;
                 if (LDSS || arec) {
-                    const uint4 *rec = arec + L.accel * LDS_ACCEL_UNITS;
-                    parent = rec[7].x;
-                    const uint4 *prec = arec + parent * LDS_ACCEL_UNITS;
-                    nchain = prec[7].y; chain = reinterpret_cast<const uint32_t *>(prec + 8);
+                    parent = lds_u4(arec + (L.accel * LDS_ACCEL_UNITS + 7u)).x;
+                    nchain = lds_u4(arec + (parent * LDS_ACCEL_UNITS + 7u)).y;
                 } else {
                     parent = (uint32_t)P.accels[L.accel].parent;
-                    nchain = P.accels[parent].nchain; chain = P.accels[parent].chain;
+                    nchain = P.accels[parent].nchain;
                 }
                 LG_RSTAMP(1);
                 lvl_set<LDSS, FAST>(P, arec, L, parent);
@@ -1333,8 +1346,14 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 if (!(w2 & FRAME_SAME_RAY)) { // the parent's ray again: from the root's, through the same transforms
                     ray = root;
                     for (uint32_t i = 1; i < nchain; ++i) {
-                        const uint32_t c = chain[i];
-                        const uint32_t cflags = (LDSS || arec) ? arec[c * LDS_ACCEL_UNITS + 6u].w : P.accels[c].flags;
+                        uint32_t c, cflags; // the parent's root -> self chain, one accel at a time
+                        if (LDSS || arec) {
+                            c = ((lg_lds_u32)(arec + (parent * LDS_ACCEL_UNITS + 8u)))[i];
+                            cflags = lds_u4(arec + (c * LDS_ACCEL_UNITS + 6u)).w;
+                        } else {
+                            c = P.accels[parent].chain[i];
+                            cflags = P.accels[c].flags;
+                        }
                         if (!((cflags & AF_IDENTITY) && ray_plain(ray))) ray = accel_local_ray<LDSS>(P, arec, c, ray);
                     }
                     dd = dot(ray.d, ray.d);
