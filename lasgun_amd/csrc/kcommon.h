@@ -16,7 +16,9 @@
 #endif
 // LDSS (reference traversal only): one 1024-lane workgroup per CU with the scene's node / primref / sphere / cuboid tables
 // copied into LDS behind the stacks (walk.h, load_node); otherwise 256-lane workgroups and L1 / L2.
-#define LG_LDSS_BLOCK 1024
+#ifndef LG_LDSS_BLOCK
+#define LG_LDSS_BLOCK 1024 // (768 lanes -- three waves per SIMD, 168 registers, no spills -- measured: headline passes 3.08 + 3.14 -> 3.48 + 3.75 ms)
+#endif
 
 namespace lg {
 // Work tiles of a persistent kernel, claimed XCD by XCD.  The tile sequence of a launch (8x8 pixel tiles in row order, or 64
