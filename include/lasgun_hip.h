@@ -227,7 +227,7 @@ int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel defaul
  * state in HBM: scenes with <= 32 lights and at least 512 spheres / boxes (node and sphere tests dominate a ray) from 2^21 pixels
  * a launch (2^23 when the scene carries a big mesh; glass / mirror over a big mesh excepted); and, for a scene small enough to live
  * in LDS, glass / mirror frames of up to 2^20 pixels (a tile's recursion tree is otherwise one wave's serial work) and plain frames
- * from 2^18 pixels (2^20 when supersampled).  Everything else -- and everything when 0 -- runs in the single persistent megakernel.
+ * of one sample per pixel from 2^18 pixels.  Everything else -- and everything when 0 -- runs in the single persistent megakernel.
  * 2 = use the pipeline wherever it is possible (tests).
  * 3 = the QUEUE organisation wherever it is possible (reference traversal, <= 32 lights, recursion depth <= 7): ONE persistent
  * launch per chunk of the film whose waves pull 64-ray packets from per-level ray queues -- level 0's packets are the 8x8 pixel

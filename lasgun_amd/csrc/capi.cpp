@@ -228,6 +228,7 @@ struct lg_accel {
     bool streaming_pays = false;
     unsigned long long streaming_min_items = 1ull << 20;
     unsigned long long specular_small_items = 1ull << 20; // a glass / mirror scene resident in LDS: frames up to this many pixels go level by level
+    bool mega_narrow = false;        // the LDS-resident megakernel in 768-lane workgroups: scenes of fewer than 512 spheres / boxes (measured, k_mega.hip)
     uint32_t wf_blocks = 1, wf_blocks_fast = 1;   // grids of the wavefront pipeline's 256-lane traversal kernels
     uint32_t queue_blocks = 1;                    // grid of the queue organisation's persistent kernel (256-lane form)
     mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
@@ -699,12 +700,14 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     //   * glass / mirror, frames up to 2^20 pixels: in the megakernel one wave walks a tile's whole recursion tree -- up to 2^(depth + 1)
     //     closest-hit and shadow walks one after the other -- while most of the chip has nothing to do; level by level every ray of a level
     //     has a lane of its own.  Cornell glass: 0.41 against 0.81 ms at 512^2, 0.99 / 1.18 at 1024^2, 1.81 / 1.64 at 1536^2.
-    //   * no glass / mirror and few primitives, frames from 2^18 pixels (2^20 when supersampled): README sphere 0.07 / 0.12 ms at 512^2,
-    //     2.2 / 3.5 at 4096^2; Cornell plastic 0.10 / 0.15 and 3.4 / 4.6; below, the two are within a few microseconds of each other.
+    //   * no glass / mirror, few primitives and one sample per pixel, frames from 2^18 pixels: README sphere 0.07 / 0.10 ms at 512^2,
+    //     2.2 / 3.5 at 4096^2; Cornell plastic 0.11 / 0.15 and 3.4 / 4.6; below, the two are within a few microseconds of each other.
+    //     (Supersampled frames stay in the megakernel -- in its 768-lane form, k_mega.hip, it is ahead at every size: simple.rs at 9 spp
+    //     0.61 / 0.73 ms at 512^2, 4.7 / 5.5 at 2048^2.)
     const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
     const bool lds_resident = !a.fast && a.lds_scene && a.ldss_blocks, specular = a.flat.has_specular && P.recursion > 0;
     const bool small_specular = lds_resident && specular && items <= a.specular_small_items;
-    const bool light_scene = lds_resident && !specular && !a.streaming_pays && items >= (P.ss_root > 1u ? 1ull << 20 : 1ull << 18);
+    const bool light_scene = lds_resident && !specular && !a.streaming_pays && P.ss_root == 1u && items >= (1ull << 18);
     if (a.streaming && !stats && P.nlights <= 32 && P.recursion < 20 &&
         (a.streaming_forced || small_specular || light_scene || (a.streaming_pays && items >= a.streaming_min_items))) {
         enqueue_wavefront(a, P, c, stream);
@@ -717,6 +720,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     if (!stats && !a.fast && a.lds_scene && a.ldss_blocks) { // scene tables resident in LDS: one 1024-lane workgroup per CU
         P.lds_image = a.lds_image.p; P.lds_image_n16 = a.lds_image_n16;
         P.lds_node_off = a.lds_node_off; P.lds_prim_off = a.lds_prim_off; P.lds_soup_off = a.lds_soup_off; P.lds_accel_off = a.lds_accel_off;
+        P.mega_lanes = a.mega_narrow ? 768u : 1024u; // (k_mega.hip: three waves per SIMD and 168 registers where shading weighs more than walking)
         blocks = a.ldss_blocks;
     }
     if (maxb < a.ldss_blocks * 4u) maxb = a.ldss_blocks * 4u; // per-lane slots below: 1024 lanes per LDS-scene workgroup
@@ -1152,6 +1156,8 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
             // (100k-triangle glass torus: 226 against 136 ms): those stay in the megakernel, where other tiles fill the gaps.
             a->prune_default = big_mesh >= 256; // the reference's mesh leaves hold up to 254 triangles (bvh.rs:187,289): skipping one pays for many node steps
             a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512 && !(f.has_specular && big_mesh >= 4096);
+            a->mega_narrow = f.spheres.size() + f.cuboids.size() < 512;
+            if (const char *e = std::getenv("LASGUN_MEGA_LANES")) a->mega_narrow = std::atoi(e) == 768; // (A/B)
             // a big mesh of glass / mirror: the queue organisation (round 4; config 4: 38.7 against the megakernel's 40.8 ms and the
             // level-by-level pipeline's 80; a metal mesh beside a small mirror -- config 4m -- stays in the megakernel: 14.7 / 16.4)
             bool specular_mesh = false; // a mesh of >= 4096 triangles that is itself glass / mirror: every hit on it spawns secondary rays
@@ -1186,7 +1192,7 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.stack_depth, y.stack_depth); swap(x.stack_depth_fast1, y.stack_depth_fast1); swap(x.max_blocks, y.max_blocks); swap(x.max_blocks_fast, y.max_blocks_fast);
     swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast);
     swap(x.device_bytes, y.device_bytes); swap(x.fast_available, y.fast_available); swap(x.fast_refusal, y.fast_refusal);
-    swap(x.streaming_pays, y.streaming_pays); swap(x.streaming_min_items, y.streaming_min_items);
+    swap(x.streaming_pays, y.streaming_pays); swap(x.streaming_min_items, y.streaming_min_items); swap(x.mega_narrow, y.mega_narrow);
 }
 static void ensure_fast_trees(const lg_accel *ca) {
     if (ca->flat.has_fast) return;

@@ -303,6 +303,7 @@ struct DParams {
     // strides are in 16-byte units from the start of the image
     const void *lds_image;
     uint32_t lds_image_n16;
+    uint32_t mega_lanes;        // the LDS-resident megakernel's workgroup: 0 / 1024 lanes (four waves per SIMD, 128 registers), or 768 (three, 168: k_mega.hip)
     uint32_t lds_node_off;                  // DNode without its pad, LDS_NODE_STRIDE units per node
     uint32_t lds_prim_off;                  // primref[] as dwords from here
     uint32_t lds_soup_off;                  // one 3-unit (48-byte) leaf record per primref slot

@@ -5,15 +5,20 @@ namespace lg {
 
 // LDSS (reference traversal only): one 1024-lane workgroup per CU with the scene's node / primref / sphere /
 // cuboid tables copied into LDS behind the stacks (see load_node); otherwise 256-lane workgroups and L1/L2.
-template <bool STATS, bool FAST, bool LDSS, bool PRUNE = false>
-__global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_SIMD) trace_kernel(const DParams P) {
+// LB: lanes of the LDS-resident form's workgroup.  1024 = four waves per SIMD under 128 registers, what the traversal-only kernels want; 768 =
+// three waves under 168 registers and hardly a spill, which this kernel -- the walk AND the shading code in one register allocation -- prefers
+// on scenes of few primitives (simple.rs at 9 spp 512^2: 0.67 -> 0.61 ms, 1024^2: 1.84 -> 1.33; Cornell glass 1024^2: 1.14 -> 1.00; the
+// 1024-sphere scene loses 8 %: more walk than shading, and the walk wants the fourth wave).  The host chooses (DParams::mega_lanes).
+constexpr int LG_MEGA_NARROW = 768;
+template <bool STATS, bool FAST, bool LDSS, bool PRUNE = false, int LB = LG_LDSS_BLOCK>
+__global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_NARROW) ? 3 : LG_WAVES_PER_SIMD) trace_kernel(const DParams P) {
     static_assert(!(PRUNE && FAST), "the fast mode prunes its own trees by its own rule");
     static_assert(!(FAST && LDSS) && !(STATS && LDSS), "LDS-resident scene: plain reference traversal only");
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + tid;
     uint32_t *stack = lds_stack + tid; // entry i at stack[i * stride]: bank = tid % 32 for every i
-    constexpr uint32_t stride = LDSS ? LG_LDSS_BLOCK : LG_BLOCK;
+    constexpr uint32_t stride = LDSS ? (uint32_t)LB : LG_BLOCK;
     const uint4 *scn = nullptr;
     if (LDSS) {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_stack + P.stack_depth * stride);
@@ -284,9 +289,13 @@ __global__ void trace_pixel_kernel(const DParams P, uint32_t x, uint32_t y, doub
 // ------------------------------------------------------------------------------------------
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
     const bool prune = P.prune && !fast;
-    if (P.lds_image && !stats && !fast) { // LDS-resident scene: `blocks` = one 1024-lane workgroup per CU
-        size_t lds = (size_t)P.stack_depth * LG_LDSS_BLOCK * sizeof(uint32_t) + (size_t)P.lds_image_n16 * 16u;
-        if (prune) hipLaunchKernelGGL((trace_kernel<false, false, true, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
+    if (P.lds_image && !stats && !fast) { // LDS-resident scene: `blocks` = one workgroup per CU, of 1024 or of 768 lanes
+        const bool narrow = P.mega_lanes == (uint32_t)LG_MEGA_NARROW;
+        const size_t lds = (size_t)P.stack_depth * (narrow ? LG_MEGA_NARROW : LG_LDSS_BLOCK) * sizeof(uint32_t) + (size_t)P.lds_image_n16 * 16u;
+        if (narrow) {
+            if (prune) hipLaunchKernelGGL((trace_kernel<false, false, true, true, LG_MEGA_NARROW>), dim3(blocks), dim3(LG_MEGA_NARROW), lds, stream, P);
+            else hipLaunchKernelGGL((trace_kernel<false, false, true, false, LG_MEGA_NARROW>), dim3(blocks), dim3(LG_MEGA_NARROW), lds, stream, P);
+        } else if (prune) hipLaunchKernelGGL((trace_kernel<false, false, true, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
         else hipLaunchKernelGGL((trace_kernel<false, false, true>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
         return hipGetLastError();
     }
@@ -320,7 +329,9 @@ hipError_t launch_trace_pixel(const DParams &P, bool fast, uint32_t stack_depth,
 hipError_t mega_set_lds_limit(size_t bytes, bool ldss) {
     const void *ldss_fns[] = {
         reinterpret_cast<const void *>(trace_kernel<false, false, true>),
-        reinterpret_cast<const void *>(trace_kernel<false, false, true, true>)};
+        reinterpret_cast<const void *>(trace_kernel<false, false, true, true>),
+        reinterpret_cast<const void *>(trace_kernel<false, false, true, false, LG_MEGA_NARROW>),
+        reinterpret_cast<const void *>(trace_kernel<false, false, true, true, LG_MEGA_NARROW>)};
     const void *plain_fns[] = {
         reinterpret_cast<const void *>(trace_kernel<false, false, false>),
         reinterpret_cast<const void *>(trace_kernel<true, false, false>),
