@@ -69,6 +69,16 @@ BLOCK_ROWS = 64
 # stream, ms per frame at N = 1 / one rank's share at N = 8: 1 stream 7.80 / 1.17, 2 streams 7.56 / 1.07, 4 streams 7.22 / 0.96
 FRAMES_IN_FLIGHT = int(os.environ.get("LASGUN_BENCH_FRAMES", "4"))  # (the variable: A/B only)
 
+# --workload: which BASELINE.json config a step renders.  The default is the one the metric is quoted on (configs[2], 4096^2); configs[4] is
+# BASELINE's sharded case -- "8192x8192, mixed mesh+sphere scene, row-tile sharded across 8 GPUs with RCCL gather" -- through the SAME
+# harness: same partition, same single gather per frame, same in-run verification (gathered film == rank 0's own film == oracle sample).
+WORKLOADS = {
+    "configs2": {"size": 4096, "build": lambda scenes, api: scenes.spheres_scene(api),
+                 "desc": "configs[2]: %dx%d, Cornell shell + 1024 random plastic spheres (SplitMix64 0x1A560001), 1 spp, 1 point light"},
+    "configs4": {"size": 8192, "build": lambda scenes, api: scenes.mixed_scene(api),
+                 "desc": "configs[4]: %dx%d, mixed: config 3's 1024 spheres + the 100,352-triangle torus (plastic) in the Cornell shell, 1 spp, 1 point light"},
+}
+
 
 def algorithmic_bytes(st):
     return (BYTES_NODE * st["nodes_tested"] + BYTES_SPHERE * st["spheres_tested"] + BYTES_CUBOID * st["cuboids_tested"]
@@ -91,7 +101,20 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(width, height, gpu_film=None, target_seconds=15.0):
+def physical_cores():
+    """Distinct (package, core) pairs among the CPUs this process may run on (`cores` / `threads` count hardware THREADS: SMT siblings)."""
+    try:
+        allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else range(os.cpu_count() or 1)
+        seen = set()
+        for c in allowed:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline(width, height, gpu_film=None, target_seconds=15.0, build=None):
     """Time the CPU oracle on a bounded strided sample {k + i*n} of the same frame (all host cores); with `gpu_film`
     (the timed frame, (h, w, 4) uint8 on the host) also compare every pixel of that sample byte for byte."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -99,7 +122,7 @@ def cpu_baseline(width, height, gpu_film=None, target_seconds=15.0):
     from lasgun_amd import scenes
     o = oracle()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    acc = o.Accel(scenes.spheres_scene(o))
+    acc = o.Accel((build or WORKLOADS["configs2"]["build"])(scenes, o))
     film = o.Film(width, height)
     area = width * height
 
@@ -116,7 +139,7 @@ def cpu_baseline(width, height, gpu_film=None, target_seconds=15.0):
     want_pixels = min(area, max(65536, int(rate * target_seconds / 2.0)))
     n = max(1, area // want_pixels)
     dt, rays, pixels = run(n)
-    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
+    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "threads": cores, "physical_cores": physical_cores(), "cpu": cpu_model(), "kind": "port",
            "sample": "capture_subset(0, n=%d) of the same %dx%d frame: %d pixels, %d rays in %.2f s on %d threads"
                      % (n, width, height, pixels, rays, dt, cores)}
     check = None
@@ -129,7 +152,7 @@ def cpu_baseline(width, height, gpu_film=None, target_seconds=15.0):
     return out, check
 
 
-def oracle_sample_check(width, height, gpu_film, n):
+def oracle_sample_check(width, height, gpu_film, n, build=None):
     """Pixels {0, n, 2n, ...} of `gpu_film` ((h, w, 4) uint8 on the host) against the CPU oracle, byte for byte (untimed)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import oracle
@@ -137,7 +160,7 @@ def oracle_sample_check(width, height, gpu_film, n):
     o = oracle()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     film = o.Film(width, height)
-    o.capture_subset_mt(0, n, o.Accel(scenes.spheres_scene(o)), film, cores)
+    o.capture_subset_mt(0, n, o.Accel((build or WORKLOADS["configs2"]["build"])(scenes, o)), film, cores)
     want = film.pixels().reshape(-1, 4)[::n]
     got = gpu_film.reshape(-1, 4)[::n]
     bad = int((want != got).sum())
@@ -228,7 +251,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--workload", default="configs2", choices=sorted(WORKLOADS),
+                    help="BASELINE.json config a step renders: configs2 = the headline (4096^2, 1024 spheres; default), configs4 = 8192^2 mixed mesh + spheres")
+    ap.add_argument("--size", type=int, default=None, help="film side in pixels (default: the workload's own, 4096 / 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fast-mode / host-film / rate-probe extras (profiling runs)")
     ap.add_argument("--sequential", action="store_true", help="A/B: frames one after the other on one stream (no overlap)")
@@ -271,8 +296,12 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     from lasgun_amd.distributed import InterleavedGather, gather_tiles, interleave_ok, row_tile
 
+    wl = WORKLOADS[args.workload]
+    if args.size is None:
+        args.size = wl["size"]
+    headline = args.workload == "configs2"
     w = h = args.size
-    scene = la.scenes.spheres_scene(G)  # replicated on every GPU
+    scene = wl["build"](la.scenes, G)  # replicated on every GPU
     t0 = time.perf_counter()
     acc = G.Accel(scene)  # host HLBVH build + flatten + upload (outside the timed region, reported below)
     accel_build_s = time.perf_counter() - t0
@@ -397,8 +426,8 @@ def main():
     total = {k: int(v) for k, v in zip(keys, vec.tolist())}
     elapsed, latency_ms = float(tmax[0]), float(tmax[2])
     repeats = [float(x) for x in tmax[3:]]
-    # the metric counts primary + shadow rays; config 3 has no specular material, so there are no secondary rays
-    assert total["secondary_rays"] == 0, "the headline workload must not cast secondary rays"
+    # the metric counts primary + shadow rays; neither workload has a specular material, so there are no secondary rays
+    assert total["secondary_rays"] == 0, "the bench workloads must not cast secondary rays"
     rays = total["primary_rays"] + total["shadow_rays"]
 
     # N > 1 (always, no switch): the TIMED frame as gathered on rank 0 against the same frame rendered by rank 0's GPU alone --
@@ -446,7 +475,7 @@ def main():
         del ref_film
         torch.cuda.empty_cache()
         probes = {"hbm_copy_GBps": G.probe_rate("hbm_copy"), "lds_read_GBps": G.probe_rate("lds_read")}
-        mesh_info = mesh_roofline(G, la, cur_stream) if args.size == 4096 else None
+        mesh_info = mesh_roofline(G, la, cur_stream) if (args.size == 4096 and headline) else None
 
     if rank == 0:
         value = rays * args.steps / elapsed / 1e6
@@ -468,7 +497,7 @@ def main():
             per_kernel = {"trace_kernel": frame_ms}
         dom_bytes, dom_flops = algorithmic_bytes(dst), algorithmic_flops(dst)
         secs = dom_ms * 1e-3
-        traffic, traffic_src = profiled_traffic(kernel_name, world, args.size)
+        traffic, traffic_src = profiled_traffic(kernel_name, world, args.size) if headline else (None, None)
         tops = dom_flops / secs / 1e12
         gbs = dom_bytes / secs / 1e9
         hbm_measured = probes["hbm_copy_GBps"] if probes else None
@@ -481,7 +510,7 @@ def main():
             "latency_ms": latency_ms,
             "value_repeats": [rays * args.steps / r / 1e6 for r in repeats],  # [0] is `value`; the other two: the same K steps again
             "value_single_frame": rays / latency_ms / 1e3,  # Mrays/s of ONE frame issued alone (render + gather), nothing else in flight
-            "config": {"workload": "configs[2]: %dx%d, Cornell shell + 1024 random plastic spheres (SplitMix64 0x1A560001), 1 spp, 1 point light" % (w, h),
+            "config": {"workload": wl["desc"] % (w, h), "workload_key": args.workload,
                        "rays_per_frame": rays, "primary": total["primary_rays"], "shadow": total["shadow_rays"],
                        "parallelism": ("64-row blocks dealt round-robin over %d rank(s)%s; consecutive frames %s"
                                        % (world, " + 1 RCCL gather per frame" if multi else "",
@@ -511,11 +540,11 @@ def main():
             out["roofline_mesh"] = mesh_info
         check = None
         if world == 1 and not args.no_cpu_baseline and not args.force_dist and not args.no_extras:
-            out["cpu_baseline"], check = cpu_baseline(w, h, timed_film)
+            out["cpu_baseline"], check = cpu_baseline(w, h, timed_film, build=wl["build"])
         elif multi and not args.no_cpu_baseline:
             # N > 1: no CPU baseline figure (rank 0 at N = 1 only), but the gathered frame still meets the oracle on a bounded
             # sample (every 64th pixel: a fraction of a second of host time)
-            check = oracle_sample_check(w, h, timed_film, 64)
+            check = oracle_sample_check(w, h, timed_film, 64 if headline else 1024, build=wl["build"])
         if multi:
             out["gathered_equals_single_gpu"] = gathered_ok
             out["rccl_ranks"] = dist.get_world_size()

@@ -168,6 +168,40 @@ template <class T> struct DevBuf {
     ~DevBuf() { release(); }
 };
 
+// Sticky error words of the queue organisation (k_queue.hip: a wave that gave up waiting for work).  They live in PINNED HOST memory
+// that every device writes straight into (system-scope store), one word per accel, handed out from pages of 1024: the host reads
+// a word without a HIP call -- after any synchronise, at the head of every enqueue, in lg_accel_synchronize -- and only the host
+// ever clears it, after it has reported it.  (Round 4 kept the word among the per-launch control words: the memset before the
+// next chunk or supersample erased it, and a launch on a caller's stream was looked at before it had finished -- ADVICE r4.)
+namespace {
+struct ErrWords {
+    std::mutex mtx;
+    std::vector<uint32_t *> pages;
+    std::vector<uint32_t *> spare;
+    uint32_t *take() {
+        std::lock_guard<std::mutex> g(mtx);
+        if (spare.empty()) {
+            void *q = nullptr;
+            hipError_t e = hipHostMalloc(&q, 4096, hipHostMallocPortable | hipHostMallocMapped);
+            if (e != hipSuccess) throw Error(std::string("hipHostMalloc(error words): ") + hipGetErrorString(e));
+            std::memset(q, 0, 4096);
+            pages.push_back((uint32_t *)q);
+            for (int i = 1023; i >= 0; --i) spare.push_back((uint32_t *)q + i);
+        }
+        uint32_t *w = spare.back();
+        spare.pop_back();
+        *(volatile uint32_t *)w = 0u;
+        return w;
+    }
+    void give(uint32_t *w) {
+        if (!w) return;
+        std::lock_guard<std::mutex> g(mtx);
+        spare.push_back(w);
+    }
+};
+ErrWords &g_err_words = *new ErrWords(); // never destroyed (see g_pool)
+} // namespace
+
 struct lg_scene {
     Scene s;
 };
@@ -210,7 +244,6 @@ struct lg_accel {
         DevBuf<double> frames, stash;                          // megakernel: Whitted frame stack, parked shading frame
         DevBuf<uint8_t> wf_mem;                                // wavefront pipeline: every per-level array of a chunk, carved from one allocation
         DevBuf<uint32_t> wf_counters;                          // its queue counts and per-launch tile counters
-        bool queue_used = false;                               // the queue organisation ran on it: wf_counters holds its control words (QC_ERROR is checked after a synchronise)
     };
     mutable std::vector<std::unique_ptr<LaunchCtx>> ctxs;
     // wavefront pipeline, big launches: the frame is cut into bands rendered on internal streams (each with a launch context
@@ -231,6 +264,7 @@ struct lg_accel {
     bool mega_narrow = false;        // the LDS-resident megakernel in 768-lane workgroups: scenes of fewer than 512 spheres / boxes (measured, k_mega.hip)
     uint32_t wf_blocks = 1, wf_blocks_fast = 1;   // grids of the wavefront pipeline's 256-lane traversal kernels
     uint32_t queue_blocks = 1;                    // grid of the queue organisation's persistent kernel (256-lane form)
+    mutable uint32_t *q_err = nullptr;            // the queue organisation's sticky error word (pinned host memory, g_err_words): taken at its first launch
     mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
     bool queue_default = false;                   // glass / mirror over a big mesh: long uneven walks, sparse deep levels (k_queue.hip)
     mutable size_t queue_budget = 0;              // bytes one launch context may hold for it (0 = from the free memory at first use)
@@ -270,6 +304,7 @@ struct lg_accel {
         if (aux_fork) (void)hipEventDestroy(aux_fork);
         for (auto st : aux_streams) (void)hipStreamDestroy(st);
         if (stream) (void)hipStreamDestroy(stream);
+        g_err_words.give(q_err);
     }
 };
 
@@ -296,16 +331,20 @@ static lg_accel::LaunchCtx &ctx_for(const lg_accel &a, hipStream_t stream) {
     return *c;
 }
 
-// Wait for the accel's stream; then, if the queue organisation ran, look at its error word: a wave that gave up waiting for
-// work that never came (a scheduler bug) must fail the call, not leave a half-rendered film behind.  Caller holds a.mtx.
+// The queue organisation's error word: a wave that gave up waiting for work that never came (a scheduler bug) must fail a call, not
+// leave a half-rendered film behind.  The word is sticky -- the device only ever sets it -- and is cleared here, once reported.
+// Looked at after every synchronise of the accel's stream, at the head of every enqueue and in lg_accel_synchronize: a launch on a
+// CALLER's stream that stalled is reported by the first of those that follows its end.  Caller holds a.mtx.
+static void check_queue_error(const lg_accel &a) {
+    if (!a.q_err) return;
+    volatile uint32_t *w = a.q_err;
+    if (*w == 0u) return;
+    *w = 0u;
+    throw Error("queue organisation: a wave gave up waiting for work (scheduler stalled); the film is incomplete");
+}
 static void sync_checked(const lg_accel &a) {
     HIP_TRY(hipStreamSynchronize(a.stream));
-    for (auto &c : a.ctxs) {
-        if (!c->queue_used || !c->wf_counters.p) continue;
-        uint32_t w = 0u;
-        HIP_TRY(hipMemcpy(&w, c->wf_counters.p + QC_ERROR, sizeof w, hipMemcpyDeviceToHost));
-        if (w != 0u) throw Error("queue organisation: a wave gave up waiting for work (scheduler stalled); the film is incomplete");
-    }
+    check_queue_error(a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -628,7 +667,7 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
         }
         K.accum = nsamples > 1 ? (double *)take((size_t)n0 * 3 * 8) : nullptr;
     }
-    c.queue_used = true;
+    if (!a.q_err) a.q_err = g_err_words.take();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (a.profiling) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
     auto timed = [&](int kind, auto &&launch) { // HIP events around ONE kernel on its launch stream
@@ -648,7 +687,7 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
         P.n_items = n0; // SoA stride of level 0's arrays and of the sample accumulator
         P.accum = K.accum;
         P.wf_levels = levels;
-        P.q_ctl = c.wf_counters.p; P.q_ready = c.wf_counters.p + QC_WORDS;
+        P.q_ctl = c.wf_counters.p; P.q_ready = c.wf_counters.p + QC_WORDS; P.q_err = a.q_err;
         P.q_unit_tiles = levels > 1 ? unit_tiles : 1u;
         // the tile sequence: rectangles whose chunk is whole tile rows go block by block, XCD by XCD (k_queue.hip, q_seq_tile)
         P.q_order = (order_blocks && !ldss && P.mode == 0u && P.tiles_x != 0u && t0 % P.tiles_x == 0u && P.ntiles % P.tiles_x == 0u) ? 1u : 0u;
@@ -683,6 +722,7 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
 // Enqueue one render on `stream`.  Caller holds a.mtx.
 static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t stream) {
     if (P.ntiles == 0) return;
+    check_queue_error(a); // (an earlier launch on a caller's stream that stalled: reported here at the latest)
     lg_accel::LaunchCtx &c = ctx_for(a, stream);
     P.tile_counter = c.tile_counter.p;
     // ---- queue organisation: every recursion level in one persistent launch (reference traversal, <= 32 lights, <= 7 levels of
@@ -1190,7 +1230,8 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.lds_soup_off, y.lds_soup_off); swap(x.lds_accel_off, y.lds_accel_off);
     swap(x.ldss_blocks, y.ldss_blocks); swap(x.cus, y.cus);
     swap(x.stack_depth, y.stack_depth); swap(x.stack_depth_fast1, y.stack_depth_fast1); swap(x.max_blocks, y.max_blocks); swap(x.max_blocks_fast, y.max_blocks_fast);
-    swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast);
+    swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast); swap(x.queue_blocks, y.queue_blocks);
+    swap(x.queue_default, y.queue_default); swap(x.prune_default, y.prune_default); swap(x.queue_min_items, y.queue_min_items); swap(x.specular_small_items, y.specular_small_items);
     swap(x.device_bytes, y.device_bytes); swap(x.fast_available, y.fast_available); swap(x.fast_refusal, y.fast_refusal);
     swap(x.streaming_pays, y.streaming_pays); swap(x.streaming_min_items, y.streaming_min_items); swap(x.mega_narrow, y.mega_narrow);
 }

@@ -172,7 +172,7 @@ struct alignas(16) DAccel {
 
 // Control words of the queue organisation (DParams::q_ctl).  Every word that many waves hammer sits on a 128-byte line of its own
 // (agent-scope atomics and sc1 polls are served per line, ~88 per microsecond: MI355X_MICROARCH.md): header [QC_FINISHED] every
-// level is done, [QC_ERROR] a wave gave up waiting (a scheduler bug: reported by the host, never silent); then QC_LEVEL_WORDS
+// level is done ([QC_ERROR]: unused since round 5 -- the error word is DParams::q_err, outside everything a launch clears); then QC_LEVEL_WORDS
 // words per level d at QC_LEVEL0 + QC_LEVEL_WORDS * d: [QC_COUNT] packets reserved so far (level 0: unused), [QC_CLAIMED] tickets handed out (level 0: units),
 // [QC_STATE, +1] one 64-bit word (packets of the level + 1) << 32 | packets done -- the high half is added when the count is final.
 // Ready words (DParams::q_ready), one per 64-ray packet of the levels >= 1: QR_LAST | its ray count once the wave that filled it has
@@ -290,6 +290,7 @@ struct DParams {
     // of every level >= 1: how many of its rays have been written
     uint32_t *q_ctl;
     uint32_t *q_ready;
+    uint32_t *q_err; // sticky error word in pinned HOST memory (capi.cpp, g_err_words): set by a wave that gave up waiting, cleared by the host alone
     uint32_t q_units, q_unit_tiles; // level 0's work items: units of q_unit_tiles consecutive 8x8 tiles of the tile SEQUENCE
     // the tile sequence: q_order 0 = the tiles in row order (any addressing mode); 1 (rectangles) = blocks of 32 x 32 tiles in row
     // order, Morton order inside a block, the sequence cut into 8 contiguous bands claimed XCD by XCD (k_queue.hip, q_seq_tile)

@@ -1398,7 +1398,8 @@ void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     build_chunks(out);
     out.boxes_finite = true;
     for (const DNode &nd : out.nodes)
-        for (int k = 0; k < 3; ++k) out.boxes_finite = out.boxes_finite && std::isfinite(nd.bmin[k]) && std::isfinite(nd.bmax[k]);
+        for (int k = 0; k < 3; ++k) // finite AND ordered: slab_intersects_sg takes the near / far plane from the ray's sign, which is the reference's min / max only for bmin <= bmax
+            out.boxes_finite = out.boxes_finite && std::isfinite(nd.bmin[k]) && std::isfinite(nd.bmax[k]) && nd.bmin[k] <= nd.bmax[k];
     out.sphere_ref_leaf.resize(out.spheres.size(), NO_HIT);
     out.cuboid_ref_leaf.resize(out.cuboids.size(), NO_HIT);
     out.tri_ref_leaf.resize(out.tri_v.size() / 3, NO_HIT);

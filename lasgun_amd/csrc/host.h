@@ -131,7 +131,7 @@ struct FlatScene {
     uint32_t max_stack_fast1 = 0; // the fast trees under the wide walk (one word per pending child, 3-word level frames)
     bool has_specular = false;   // any glass / mirror material present
     bool has_fast = false;       // the fast mode's trees are part of the tables
-    bool boxes_finite = false;   // every node box is finite (DParams::boxes_finite: the sign-specialised slab test is exact then)
+    bool boxes_finite = false;   // every node box is finite with bmin <= bmax on every axis (DParams::boxes_finite: the sign-specialised slab test is exact then)
     // structure dump in the same format as the oracle's orc_accel_dump (build-parity tests)
     std::vector<double> dump_f;
     std::vector<int64_t> dump_i;

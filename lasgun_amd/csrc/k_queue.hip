@@ -31,7 +31,7 @@ namespace lg {
 // agent-scope acquire and reads the rays.  Exactly one atomic operation on a level's 64-bit word observes "count final and every
 // packet done"; that wave publishes the next level's packet count.  Level 0's units are counted per wave and flushed when the
 // wave turns to a deeper level or finds the units exhausted: one atomic per unit (the claim).  Every wave leaves through
-// QC_FINISHED (or, should the protocol ever stall, through the poll limit with QC_ERROR set -- reported by the host, never silent).
+// QC_FINISHED (or, should the protocol ever stall, through the poll limit with DParams::q_err set -- reported by the host, never silent).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t q_lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
             for (uint32_t s = 0; s < backoff; ++s) __builtin_amdgcn_s_sleep(127);
             backoff = backoff < 8u ? backoff * 2u : 8u;
             if (++idle > Q_POLL_LIMIT) {
-                if (lane == 0u) __hip_atomic_store(ctl + QC_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0u && P.q_err) __hip_atomic_store(P.q_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // sticky, in host memory: no later launch clears it
                 break;
             }
             continue;

@@ -108,7 +108,7 @@ __device__ __forceinline__ bool slab_intersects_nc_axes(const double bmin[3], co
 }
 
 // slab_intersects_nc for a ray whose sign triple is known at compile time (SG: bit a set <=> dinv[a] < 0) -- the "plain" case:
-// every box coordinate finite (the host checks the scene: DParams::boxes_finite), the ray's origin finite, dinv finite and not
+// every box coordinate finite and every box ordered, bmin <= bmax (the host checks the scene: DParams::boxes_finite), the ray's origin finite, dinv finite and not
 // zero on every axis (ray_signs_plain).  Then fl(bmin - o) <= fl(bmax - o) (rounding is monotone; both may overflow to the same
 // infinity, neither is NaN), and multiplying by a finite non-zero dinv keeps (dinv > 0) or reverses (dinv < 0) that order, again
 // without a NaN (inf * 0 needs dinv = 0): min(t1, t2) and max(t1, t2) of cuboid.rs:113-117 ARE (t1, t2) or (t2, t1), up to the
@@ -794,6 +794,7 @@ __device__ __noinline__ void audit_subtree(const DParams &P, uint32_t node_base,
                     }
                 }
             } else {
+                if (sp == 64) { cnt.a_viol++; break; } // deeper than the audit's own stack: reported as a violation, never an overrun (the walk's depth is data-dependent)
                 st[sp++] = node_base + nd->link; // second child
                 n = n + 1u;                      // first child
                 continue;

@@ -212,6 +212,25 @@ def test_multi_device_capture_through_rccl_on_one_gpu():
     assert p.returncode == 0 and "rccl gather ok" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
 
 
+@pytest.mark.parametrize("block_rows, force_rccl", [(64, False), (0, False), (64, True), (0, True)])
+def test_config5_as_eight_shares(block_rows, force_rccl):
+    """BASELINE configs[4] -- "8192x8192 mixed mesh + spheres, row-tile sharded across 8 GPUs with RCCL gather" -- through the library's
+    own sharded path on a 1-GPU box: lg_multi_* over devices [0] * 8, as 8 shares of interleaved 64-row blocks and as 8 contiguous row
+    tiles, gathered by device-local copies and (LASGUN_MULTI_FORCE_RCCL=1) by ncclSend / ncclRecv inside one group.  The gathered
+    8192^2 film == the single-device film, every byte, == the CPU oracle on a 16384-pixel strided sample.  In a child process with a
+    time limit (tests/multi_child.py).  The same scenario over DISTINCT devices: tests/test_gpu_multi_device.py.
+    Reference: src/lib.rs:55-104 (fan-out), :152 (the partition never changes a pixel)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "multi_child.py"), "--scene", "config5", "--devices", ",".join(["0"] * 8),
+           "--block-rows", str(block_rows), "--w", "8192", "--h", "8192", "--sample", "16384", "--repeats", "1"]
+    if force_rccl:
+        cmd.append("--force-rccl")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "MULTI_CHILD_OK ranks=8" in p.stdout, (p.stdout[-800:], p.stderr[-3000:])
+
+
 def test_wavefront_bands_on_internal_streams_leave_the_film_unchanged():
     """lg_accel_set_wf_split: a 2048^2 launch cut into 1 / 2 / 4 / 8 bands rendered on internal streams (fork from and join
     into the caller's stream), glass scene included: byte-identical films, and identical to the megakernel's."""

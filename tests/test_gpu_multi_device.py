@@ -9,11 +9,9 @@ import os
 import subprocess
 import sys
 
-import numpy as np
 import pytest
 
 import lasgun_amd as la
-from oracle_lib import oracle
 
 pytestmark = pytest.mark.gpu
 G = la.api
@@ -33,14 +31,18 @@ def need(n):
         pytest.skip("needs %d distinct HIP devices, this box has %d" % (n, ndev()))
 
 
-def oracle_film(builder, w, h):
-    o = oracle()
-    f = o.Film(w, h)
-    o.capture_subset_mt(0, 1, o.Accel(builder(o)), f, max(1, min(32, len(os.sched_getaffinity(0)))))
-    return f.pixels()
-
-
 SCENES = {"kitchen_sink": lambda api: S.kitchen_sink_scene(api), "cornell_glass": lambda api: S.cornell_scene(api, "glass")}
+
+
+def run_multi_child(args, env_extra=None, timeout=600):
+    """One lg_multi_* scenario in a FRESH process with a time limit (tests/multi_child.py): every test that initialises RCCL goes
+    through here -- a hung ncclCommInitAll / exchange is one failed test, never a hung pytest."""
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_child.py")] + [str(a) for a in args],
+                       capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0 and "MULTI_CHILD_OK" in p.stdout, (args, p.stdout[-800:], p.stderr[-3000:])
+    return p.stdout
 
 
 @pytest.mark.parametrize("n", [2, 4, 8])
@@ -48,37 +50,22 @@ SCENES = {"kitchen_sink": lambda api: S.kitchen_sink_scene(api), "cornell_glass"
 @pytest.mark.parametrize("scene", sorted(SCENES))
 def test_multi_capture_over_distinct_devices(scene, block_rows, w, h, n):
     """Every rank renders its share on ITS device, one grouped RCCL exchange (or device-to-device copies) puts the shares into the
-    root's film: device film, host film and -- for the interleaved blocks' case too -- the all-gather form, against the
-    single-device film and the oracle."""
+    root's film: device film, host film and the all-gather form, against the single-device film and the oracle -- in a child
+    process with a time limit (tests/multi_child.py)."""
     need(n)
-    import torch
-    devices = list(range(n))
-    want = oracle_film(SCENES[scene], w, h)
-    G.set_devices([0])
-    try:
-        one = G.Film(w, h)
-        G.capture(SCENES[scene](G), one)
-        assert np.array_equal(one.pixels(), want)
-        m = G.Multi(SCENES[scene](G), devices, block_rows)
-        assert m.ranks == n
-        dev = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda:0")
-        torch.cuda.synchronize(0)
-        for _ in range(2):  # tiles and communicators are reused
-            m.capture_device(w, h, dev.data_ptr())
-            assert np.array_equal(dev.cpu().numpy(), want)
-        host = G.Film.new_with_output(w, h, np.full((h, w, 4), 9, np.uint8))
-        m.capture(host)
-        assert np.array_equal(host.pixels(), want)
-        if m.uses_rccl:  # the all-gather form needs a communicator with one rank per device
-            bufs = [torch.full((h, w, 4), 7, dtype=torch.uint8, device="cuda:%d" % d) for d in devices]
-            for d in devices:
-                torch.cuda.synchronize(d)
-            m.capture_device_all(w, h, [b.data_ptr() for b in bufs])
-            for d, b in zip(devices, bufs):
-                assert np.array_equal(b.cpu().numpy(), want), d
-        m.close()
-    finally:
-        G.set_devices([0])
+    run_multi_child(["--scene", scene, "--devices", ",".join(str(d) for d in range(n)), "--block-rows", block_rows, "--w", w, "--h", h,
+                     "--host-film", "--all-gather"])
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+@pytest.mark.parametrize("block_rows", [64, 0])
+def test_config5_sharded_over_distinct_devices(block_rows, n):
+    """BASELINE configs[4] -- 8192^2, mesh + 1024 spheres -- as n shares on n DISTINCT devices with one RCCL gather: the gathered
+    film equals the single-device film, which equals the oracle on a 16384-pixel sample (the 1-GPU rehearsal of the same thing
+    with a repeated device: tests/test_gpu_configs.py::test_config5_as_eight_shares)."""
+    need(n)
+    run_multi_child(["--scene", "config5", "--devices", ",".join(str(d) for d in range(n)), "--block-rows", block_rows, "--w", 8192, "--h", 8192,
+                     "--sample", 16384, "--repeats", 1], timeout=900)
 
 
 def run_child(code, env_extra=None, timeout=600):

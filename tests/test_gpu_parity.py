@@ -767,6 +767,28 @@ def test_bench_two_ranks_end_to_end_under_torchrun(collective):
     assert line["gathered_equals_single_gpu"] is True and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo"
 
 
+def test_bench_configs4_workload_two_ranks_under_torchrun():
+    """`bench.py --workload configs4` (BASELINE configs[4]: mixed mesh + spheres, 8192^2 by default; 1024^2 here) under the driver's
+    N > 1 launch line, two ranks sharing this box's GPU over gloo: the same partition, one gather per frame, the gathered film verified
+    against rank 0's own render (every byte) and the oracle sample; `config.workload` names the config."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    port = str(30300 + (os.getpid() % 300))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "configs4", "--size", "1024", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "verify: gathered 2-rank film == single-GPU film" in p.stderr, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["workload_key"] == "configs4" and line["config"]["workload"].startswith("configs[4]: 1024x1024")
+    assert line["config"]["work_per_frame"]["triangles_tested"] > 0 and line["config"]["work_per_frame"]["spheres_tested"] > 0
+    assert line["bit_exact"] is True and line["gathered_equals_single_gpu"] is True and line["rccl_ranks"] == 2
+
+
 def test_exact_ties_inside_fat_leaves_go_to_the_reference_winner():
     """Rays through edges and corners shared by two to six triangles of a mesh with per-corner shading normals: the winner of an
     exact tie in t shows in the picture.  The pruned walk scans a fat leaf run by run instead of in the reference's order and gives
