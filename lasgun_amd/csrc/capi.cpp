@@ -1085,6 +1085,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         a->wf_blocks_fast = (uint32_t)((wbf < 1 ? 1 : wbf) * cus);
         int qb = 0;
         HIP_TRY(queue_occupancy(a->stack_depth, extra_lds, &qb));
+        if (const char *e = std::getenv("LASGUN_QUEUE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v < qb) qb = v; } // (diagnostic: how much the kernel gains from each resident workgroup)
         a->queue_blocks = (uint32_t)((qb < 1 ? 1 : qb) * cus);
         a->cus = (uint32_t)cus;
         // LDS-resident scene: the REFERENCE tree's nodes (56 of 64 bytes, padded to 80 when that fits),

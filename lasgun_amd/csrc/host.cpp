@@ -1368,15 +1368,15 @@ static void build_chunks(FlatScene &out) {
         std::vector<DChunk>().swap(J.chunks); std::vector<DStrip>().swap(J.strips);
     }
     if (std::getenv("LASGUN_DEBUG_CHUNKS")) { // what the runs look like: sizes, and how much room their cones leave
-        size_t n = out.chunks.size(), never = 0, tris = 0, hist[6] = {0, 0, 0, 0, 0, 0};
+        size_t n = out.chunks.size(), never = 0, tris = 0, hist[6] = {0, 0, 0, 0, 0, 0}, sizes[5] = {0, 0, 0, 0, 0}, nruns = 0;
         for (const DChunk &k : out.chunks) {
-            tris += k.count;
+            if (k.start != CHUNK_IS_GROUP) { const size_t c = k.count & 0xFFu; tris += c; ++nruns; ++sizes[c <= 4 ? 0 : c <= 8 ? 1 : c <= 16 ? 2 : c <= 24 ? 3 : 4]; }
             if (k.cos_t < 0.0f) { ++never; continue; }
             const double room = 90.0 - std::acos((double)k.cos_t) * 57.29578; // how far from the axis a ray may point before it is edge-on to some triangle
             ++hist[room < 30 ? 0 : room < 45 ? 1 : room < 60 ? 2 : room < 70 ? 3 : room < 80 ? 4 : 5];
         }
-        std::fprintf(stderr, "[lasgun] culling records: %zu over %zu triangles (%.1f per record); no lateral culling: %zu; room <30: %zu, <45: %zu, <60: %zu, <70: %zu, <80: %zu, >=80: %zu\n",
-                     n, tris, n ? (double)tris / (double)n : 0.0, never, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+        std::fprintf(stderr, "[lasgun] culling records: %zu (%zu runs) over %zu triangles (%.1f per run; runs of <=4: %zu, <=8: %zu, <=16: %zu, <=24: %zu, <=32: %zu); no lateral culling: %zu; room <30: %zu, <45: %zu, <60: %zu, <70: %zu, <80: %zu, >=80: %zu\n",
+                     n, nruns, tris, nruns ? (double)tris / (double)nruns : 0.0, sizes[0], sizes[1], sizes[2], sizes[3], sizes[4], never, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
     }
     out.chunks.resize(out.chunks.size() + 2, DChunk{});
     out.strips.resize(out.strips.size() + 2, DStrip{0.f, 0.f, 0.f, 0u}); // two spare entries: the leaf loop keeps the next entry in flight

@@ -711,11 +711,22 @@ __device__ __forceinline__ bool chunk_culled(const ChunkRec &k, const Ray &ray, 
 #else
     const float ca = fminf(fabsf((__uint_as_float(b.z) * lc.dhx + __uint_as_float(b.w) * lc.dhy) + __uint_as_float(c.x) * lc.dhz), 1.0f);
 #endif
+    // (v_sqrt_f32 and v_rcp_f32 as the hardware has them -- 1 ulp, 1.2e-7 -- instead of the correctly rounded library forms, ~18 and ~12
+    // instructions each: both results are padded by 1e-6 and more towards a smaller sigma; a denormal argument of the root comes back as
+    // 0 or as itself, and the + 1e-6 covers sqrt(1.2e-38))
+#ifdef LG_LIB_SQRT // (A/B: the library forms)
     const float sa = sqrtf(fmaxf(1.0f - ca * ca, 0.0f)) * (1.0f + 4e-6f) + 1e-6f;
+#else
+    const float sa = __builtin_amdgcn_sqrtf(fmaxf(1.0f - ca * ca, 0.0f)) * (1.0f + 4e-6f) + 1e-6f;
+#endif
     const float sigma = (ca * cos_t - sa * sin_t) - 1e-5f;
     const float Rf = (float)((fmax_(fabs(ox), fabs(px)) + fmax_(fabs(oy), fabs(py))) + fmax_(fabs(oz), fabs(pz))) * (1.0f + 1e-6f); // >= the 1-norm distance to any vertex
     if (sigma >= CHUNK_SIGMA_MIN && hmin * hmin * sigma >= CHUNK_HGATE * Rf * Rf) {
+#ifdef LG_LIB_SQRT
         const float inv = __frcp_rn(sigma) * (1.0f + 1e-6f);
+#else
+        const float inv = __builtin_amdgcn_rcpf(sigma) * (1.0f + 1e-6f);
+#endif
         const double m = (double)(((CHUNK_K0 * g2) * (inv * inv * inv)) * (Rf * Rf) * (1.0f + 1e-5f));
         const double ex = m * fabs(ray.dinv.x), ey = m * fabs(ray.dinv.y), ez = m * fabs(ray.dinv.z);
         const double tn = fmax_(fmax_(nx - ex, ny - ey), nz - ez), tf = fmin_(fmin_(fx + ex, fy + ey), fz + ez); // (inf - inf = NaN: ignored)
@@ -919,9 +930,17 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
                     uint32_t start, count;
                     const uint32_t rec0 = __builtin_amdgcn_readfirstlane(rec);
                     ChunkRec ck;
+                    bool culled_;
+#ifdef LG_NO_UNIFORM_DUP
                     if (__builtin_amdgcn_ballot_w64(rec != rec0) == 0ull) ck = load_chunk_uniform(P.chunks + rec0);
                     else ck = load_chunk(P.chunks + rec);
-                    const bool culled_ = chunk_culled<KZ>(ck, ray, lc, start, count);
+                    culled_ = chunk_culled<KZ>(ck, ray, lc, start, count);
+#else
+                    // (the test is written out once per load path: merged behind the two loads, the scalar path's sixteen words are first
+                    // copied into vector registers -- 16 of the trip's ~125 vector instructions; here its arithmetic reads them as they are)
+                    if (__builtin_amdgcn_ballot_w64(rec != rec0) == 0ull) { ck = load_chunk_uniform(P.chunks + rec0); culled_ = chunk_culled<KZ>(ck, ray, lc, start, count); }
+                    else { ck = load_chunk(P.chunks + rec); culled_ = chunk_culled<KZ>(ck, ray, lc, start, count); }
+#endif
                     if (COUNT && P.audit && culled_) { // what the skipped run (or the runs of the skipped group) would have given the reference
                         uint32_t e0 = ck.d.w, e1 = ck.d.w + (count >> 8);
                         if (start == CHUNK_IS_GROUP) { e0 = P.chunks[rec + 1u].pad; e1 = P.chunks[rec + count].pad + (P.chunks[rec + count].count >> 8); }
@@ -944,6 +963,19 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
                     const bool two = s + 1u < run_end;
                     const uint32_t off0 = __builtin_amdgcn_readfirstlane(off);
                     uint4 ea, eb; // two entries per trip (two spare entries behind the last: always readable)
+#ifdef LG_STRIP_DUP
+                    if (__builtin_amdgcn_ballot_w64(off != off0) == 0ull) {
+                        lg_const_u4 q = (lg_const_u4)(uintptr_t)(sbase + off0);
+                        ea = load_const_u4(q, 0); eb = load_const_u4(q, 1);
+                        LG_STRIP(ea);
+                        if (two) LG_STRIP(eb);
+                    } else {
+                        const uint4 *q = reinterpret_cast<const uint4 *>(sbase + off);
+                        ea = q[0]; eb = q[1];
+                        LG_STRIP(ea);
+                        if (two) LG_STRIP(eb);
+                    }
+#else
                     if (__builtin_amdgcn_ballot_w64(off != off0) == 0ull) {
                         lg_const_u4 q = (lg_const_u4)(uintptr_t)(sbase + off0);
                         ea = load_const_u4(q, 0); eb = load_const_u4(q, 1);
@@ -953,6 +985,7 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
                     }
                     LG_STRIP(ea);
                     if (two) LG_STRIP(eb);
+#endif
                     s += two ? 2u : 1u;
                     off += 2u * SREC;
                     if (s >= run_end) in_run = false;
