@@ -1,7 +1,8 @@
-// Progressive rendering with `capture_subset`: the film is refined in PASSES interleaved pixel subsets {k, k + n, ...}
-// (nfrasser/lasgun src/lib.rs:110-162 is the entry point the reference's wasm front end drives the same way).  Each
-// subset is one GPU launch over a pixel list; a preview is written after every quarter of the passes.
-use ::lasgun::{ scene::Scene, Accel, Material, capture_subset, output };
+// Progressive rendering: the film is refined in PASSES interleaved pixel subsets {k, k + n, ...} (nfrasser/lasgun
+// src/lib.rs:110-162 is the entry point the reference's wasm front end drives the same way, one `capture_subset` per
+// pass).  Here the passes between two previews go out as ONE batch (`capture_subsets`: one render, one copy home), which
+// writes exactly the pixels the single calls would; a preview is written after every quarter of the passes.
+use ::lasgun::{ scene::Scene, Accel, Material, capture_subsets, output };
 
 mod common;
 
@@ -16,9 +17,9 @@ fn main() {
     let accel = Accel::from(&scene); // built once, shared by every pass
     let mut film = output::film([1024, 1024]);
     // a fixed permutation of the passes (5 is coprime to 16): early previews cover the image evenly
-    for step in 0..PASSES {
-        let pass = (step * 5 + 3) % PASSES;
-        capture_subset(pass, PASSES, &accel, &mut film);
-        if (step + 1) % (PASSES / 4) == 0 { film.save(&format!("progressive_{:02}.png", step + 1)) }
+    let order: Vec<usize> = (0..PASSES).map(|step| (step * 5 + 3) % PASSES).collect();
+    for (quarter, batch) in order.chunks(PASSES / 4).enumerate() {
+        capture_subsets(batch, PASSES, &accel, &mut film);
+        film.save(&format!("progressive_{:02}.png", (quarter + 1) * (PASSES / 4)))
     }
 }

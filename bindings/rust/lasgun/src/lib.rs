@@ -294,6 +294,28 @@ pub fn capture_subset(k: usize, n: usize, root: &Accel, img: &mut impl Img) {
     }
 }
 
+/// Several subsets of one `n` in ONE render: writes what the calls `capture_subset(k, n, ..)` for `k` in `ks` write, and nothing else.
+/// No counterpart in the reference, whose progressive front end calls `capture_subset` a hundred times in a row
+/// (www/renderer.ts:103-120); on a GPU a batch costs `ks.len() / n` of a frame instead of a launch chain per subset.
+pub fn capture_subsets(ks: &[usize], n: usize, root: &Accel, img: &mut impl Img) {
+    assert!(n > 0);
+    let (w, h) = (img.w(), img.h());
+    let area = (w as usize) * (h as usize);
+    let staging = unsafe { sys::lg_film_new(w, h) };
+    let rc = unsafe { sys::lg_capture_subsets(ks.as_ptr(), ks.len(), n, root.ptr, staging) };
+    if rc != 0 {
+        unsafe { sys::lg_film_free(staging) };
+        panic!("lasgun: {}", last_error())
+    }
+    let px = unsafe { std::slice::from_raw_parts(sys::lg_film_pixels(staging), area * 4) };
+    for &k in ks {
+        for o in (k..area).step_by(n) {
+            img.set((o % w as usize) as u32, (o / w as usize) as u32, &[px[4 * o], px[4 * o + 1], px[4 * o + 2], px[4 * o + 3]])
+        }
+    }
+    unsafe { sys::lg_film_free(staging) }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // output::render (src/output.rs:5-18): render to a PNG file
 // ---------------------------------------------------------------------------------------------------------------

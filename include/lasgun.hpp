@@ -174,6 +174,10 @@ inline void capture(const Scene &scene, Film &film) { // lib.rs:55
 inline void capture_subset(size_t k, size_t n, const Accel &root, Film &film) { // lib.rs:110
     if (lg_capture_subset(k, n, root.handle(), film.handle())) throw Error(lg_last_error());
 }
+// several subsets of one n as ONE render: the pixels of the calls capture_subset(k, n, ...) for k in ks (lasgun_hip.h, lg_capture_subsets)
+inline void capture_subsets(const std::vector<size_t> &ks, size_t n, const Accel &root, Film &film) {
+    if (lg_capture_subsets(ks.data(), ks.size(), n, root.handle(), film.handle())) throw Error(lg_last_error());
+}
 inline Film render(const Scene &scene, std::pair<uint32_t, uint32_t> resolution) { // lib.rs:46
     lg_film *f = lg_render(scene.handle(), resolution.first, resolution.second);
     if (!f) throw Error(lg_last_error());

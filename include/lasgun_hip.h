@@ -166,6 +166,14 @@ int lg_capture_interleaved_device(const lg_accel *, uint32_t width, uint32_t hei
 /* capture_subset into a full width*height device film (pixels outside the subset untouched). */
 int lg_capture_subset_device(size_t k, size_t n, const lg_accel *, uint32_t width, uint32_t height, void *dev_rgba,
                              void *hip_stream);
+/* SEVERAL subsets {ks[j] + i*n} of one n as ONE render: the pixels written are exactly those of the `count` calls
+ * lg_capture_subset(ks[j], n, ...) and no others (repeated k values count once, a k behind the film is an empty subset, as at
+ * lib.rs:152).  No counterpart in the reference: its progressive caller (www/renderer.ts:103-120) calls capture_subset a hundred times
+ * in a row, and a launch chain per call fills a fraction of a GPU; a batch costs count/n of a frame, and the batch of every k of
+ * 0 .. n-1 IS the frame.  Host film: one D2H copy per batch; device film: only enqueues on `hip_stream`, like the calls above. */
+int lg_capture_subsets(const size_t *ks, size_t count, size_t n, const lg_accel *, lg_film *);
+int lg_capture_subsets_device(const size_t *ks, size_t count, size_t n, const lg_accel *, uint32_t width, uint32_t height,
+                              void *dev_rgba, void *hip_stream);
 void *lg_accel_stream(const lg_accel *);      /* the accel's own hipStream_t */
 int lg_accel_synchronize(const lg_accel *);    /* hipStreamSynchronize(lg_accel_stream()) */
 
@@ -222,12 +230,14 @@ int lg_accel_set_mode(const lg_accel *, int mode);
 int lg_accel_set_prune(const lg_accel *, int enabled);
 int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel default, LASGUN_PRUNE, lg_accel_set_prune, fast mode): 0 / 1 */
 
-/* Kernel organisation (same arithmetic, same bytes either way).  1 (default): the organisation is chosen per launch from what was
- * measured (tools/size_sweep.py, tools/bench_configs.py --org=...).  Level by level in the WAVEFRONT pipeline (below), with per-ray
- * state in HBM: scenes with <= 32 lights and at least 512 spheres / boxes (node and sphere tests dominate a ray) from 2^21 pixels
- * a launch (2^23 when the scene carries a big mesh; glass / mirror over a big mesh excepted); and, for a scene small enough to live
- * in LDS, glass / mirror frames of up to 2^20 pixels (a tile's recursion tree is otherwise one wave's serial work) and plain frames
- * of one sample per pixel from 2^18 pixels.  Everything else -- and everything when 0 -- runs in the single persistent megakernel.
+/* Kernel organisation (same arithmetic, same bytes either way).  1 (default): the organisation of a launch is MEASURED -- the first
+ * launch of a kind (the scene's shape, the device, the launch's size class and addressing mode) renders with every organisation
+ * that can take it, on the caller's stream with the host waiting, and the fastest is kept for the process (capture() rebuilds its
+ * accel per frame, so the memory is keyed by the scene's shape); later launches of the kind only enqueue.  LASGUN_AUTOTUNE=0 keeps
+ * the fitted rule of rounds 2-4 instead: level by level in the WAVEFRONT pipeline (below) for scenes with <= 32 lights and at least
+ * 512 spheres / boxes from 2^21 pixels a launch, and for a scene small enough to live in LDS glass / mirror frames of up to 2^20
+ * pixels and plain frames of one sample per pixel from 2^18; the queue organisation for glass / mirror over a big mesh; the single
+ * persistent megakernel for everything else.  0 = the megakernel only.
  * 2 = use the pipeline wherever it is possible (tests).
  * 3 = the QUEUE organisation wherever it is possible (reference traversal, <= 32 lights, recursion depth <= 7): ONE persistent
  * launch per chunk of the film whose waves pull 64-ray packets from per-level ray queues -- level 0's packets are the 8x8 pixel
@@ -237,6 +247,7 @@ int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel defaul
  * runs deep levels with a few lanes per wave and the level-by-level pipeline ends every launch with its slowest wave's tail.
  * Returns non-zero (lg_last_error) for any other value. */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
+int lg_accel_last_organisation(const lg_accel *); /* what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue; -1: none yet */
 
 /* The WAVEFRONT pipeline is li() level by level: per recursion level a closest-hit pass (hits compacted into a queue, misses
  * finished on the spot), an any-hit shadow pass and a shade pass that appends the specular children to the next level's ray

@@ -31,6 +31,9 @@ _EXTRA = {
                                        _C.c_void_p, _C.c_void_p]),
     "capture_subset_device": (_C.c_int, [_C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p,
                                          _C.c_void_p]),
+    "capture_subsets": (_C.c_int, [_C.POINTER(_C.c_size_t), _C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_void_p]),
+    "capture_subsets_device": (_C.c_int, [_C.POINTER(_C.c_size_t), _C.c_size_t, _C.c_size_t, _C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p,
+                                          _C.c_void_p]),
     "capture_interleaved_device": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32,
                                               _C.c_void_p, _C.c_void_p]),
     "accel_stream": (_C.c_void_p, [_C.c_void_p]),
@@ -38,6 +41,7 @@ _EXTRA = {
     "accel_set_prune": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_streaming": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_get_prune": (_C.c_int, [_C.c_void_p]),
+    "accel_last_organisation": (_C.c_int, [_C.c_void_p]),
     "accel_set_lds_scene": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_wf_split": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
@@ -89,6 +93,10 @@ class HipApi(Api):
         triangles), False / True = off / on (include/lasgun_hip.h, lg_accel_set_prune)."""
         if self.call("accel_set_prune", accel.h, -1 if enabled is None or enabled == -1 else (1 if enabled else 0)):
             raise LasgunError(self.last_error())
+
+    def last_organisation(self, accel):
+        """What the accel's last launch ran as: "megakernel", "wavefront" (level by level), "queue"; None before the first."""
+        return {0: "megakernel", 1: "wavefront", 2: "queue"}.get(self.call("accel_last_organisation", accel.h))
 
     def get_prune(self, accel):
         """Whether a render of this accel uses the pruned reference walk right now (accel default, LASGUN_PRUNE, set_prune, fast mode)."""
@@ -164,6 +172,22 @@ class HipApi(Api):
 
     def capture_subset_device(self, k, n, accel, width, height, dev_ptr, stream=None):
         if self.call("capture_subset_device", k, n, accel.h, width, height, _C.c_void_p(int(dev_ptr)),
+                     self._stream(accel, stream)):
+            raise LasgunError(self.last_error())
+
+    def capture_subsets(self, ks, n, accel, film):
+        """Several subsets of one n as ONE render: writes exactly the pixels of the calls capture_subset(k, n, ...) for k in ks (no
+        counterpart in the reference, whose progressive caller makes those calls one by one: www/renderer.ts:103-120)."""
+        ks = [int(k) for k in ks]
+        arr = (_C.c_size_t * max(len(ks), 1))(*ks)
+        if self.call("capture_subsets", arr, len(ks), int(n), accel.h, film.h):
+            raise LasgunError(self.last_error())
+
+    def capture_subsets_device(self, ks, n, accel, width, height, dev_ptr, stream=None):
+        """Enqueue the subsets {k + i*n}, k in ks, as one render into a full width*height device film."""
+        ks = [int(k) for k in ks]
+        arr = (_C.c_size_t * max(len(ks), 1))(*ks)
+        if self.call("capture_subsets_device", arr, len(ks), int(n), accel.h, width, height, _C.c_void_p(int(dev_ptr)),
                      self._stream(accel, stream)):
             raise LasgunError(self.last_error())
 

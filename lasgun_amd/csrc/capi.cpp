@@ -3,10 +3,12 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -68,7 +70,7 @@ static void use_device(int dev) {
 }
 static void use_device() { use_device(g_device); }
 
-// Device allocations of 1 MiB and more are recycled through a small per-process pool (at most 4 GiB parked per
+// Device allocations of 1 KiB and more are recycled through a small per-process pool (at most 4 GiB parked per
 // device): capture() builds and drops an accel -- film staging, per-pixel state -- for every frame, like the
 // reference, and hipMalloc / hipFree of those buffers would otherwise cost about a millisecond of each frame.
 // Nothing relies on the contents of a fresh buffer: every buffer is written (kernel, memset or copy) before it is read.
@@ -78,7 +80,7 @@ struct DevPool {
     struct Block { int device; size_t bytes; void *p; };
     std::vector<Block> parked;
     size_t parked_bytes[64] = {0};
-    static constexpr size_t MIN_BYTES = 1u << 20, CAP = 4ull << 30;
+    static constexpr size_t MIN_BYTES = 1u << 10, CAP = 4ull << 30, MAX_BLOCKS = 256; // (from 1 KiB: the table arena, tile counters and queue counts of a frame are recycled too)
     // a parked block of at least `bytes` (and at most 1.25x that); *capacity receives its real size
     void *take(int device, size_t bytes, size_t *capacity) {
         std::lock_guard<std::mutex> g(mtx);
@@ -95,7 +97,7 @@ struct DevPool {
     }
     bool park(int device, size_t bytes, void *p) {
         std::lock_guard<std::mutex> g(mtx);
-        if (bytes < MIN_BYTES || parked_bytes[device & 63] + bytes > CAP || parked.size() >= 64) return false;
+        if (bytes < MIN_BYTES || parked_bytes[device & 63] + bytes > CAP || parked.size() >= MAX_BLOCKS) return false;
         parked.push_back(Block{device, bytes, p});
         parked_bytes[device & 63] += bytes;
         return true;
@@ -132,10 +134,12 @@ template <class T> struct DevBuf {
     size_t n = 0;
     size_t bytes_ = 0; // capacity in bytes (what the pool is told)
     int device_ = 0;
+    bool borrowed_ = false; // a view into another DevBuf's allocation (TableStage): nothing to free
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    friend void swap(DevBuf &a, DevBuf &b) { std::swap(a.p, b.p); std::swap(a.n, b.n); std::swap(a.bytes_, b.bytes_); std::swap(a.device_, b.device_); }
+    friend void swap(DevBuf &a, DevBuf &b) { std::swap(a.p, b.p); std::swap(a.n, b.n); std::swap(a.bytes_, b.bytes_); std::swap(a.device_, b.device_); std::swap(a.borrowed_, b.borrowed_); }
+    void view(T *ptr, size_t count) { release(); p = ptr; n = count; borrowed_ = true; }
     void obtain(size_t bytes) {
         release();
         HIP_TRY(hipGetDevice(&device_));
@@ -162,11 +166,64 @@ template <class T> struct DevBuf {
         n = count;
     }
     void release() {
-        if (p && !g_pool.park(device_, bytes_, p)) (void)hipFree(p);
-        p = nullptr; n = 0; bytes_ = 0;
+        if (p && !borrowed_ && !g_pool.park(device_, bytes_, p)) (void)hipFree(p);
+        p = nullptr; n = 0; bytes_ = 0; borrowed_ = false;
     }
     ~DevBuf() { release(); }
 };
+
+// The scene tables of an accel go to the device in ONE allocation and ONE copy: capture() builds an accel for every frame like the
+// reference (lib.rs:64), and two dozen hipMalloc + hipMemcpy pairs of a few kilobytes each were a third of lg_accel_from's millisecond
+// on the headline scene.  Tables of 256 KiB and more keep an allocation and a copy of their own (staging them would cost a host
+// memcpy of megabytes); the rest are staged here, 256-byte aligned, and become views into `arena` at commit().
+struct TableStage {
+    std::vector<uint8_t> host;
+    std::vector<std::function<void(uint8_t *)>> fix;
+    template <class T> void add(DevBuf<T> &buf, const std::vector<T> &v) {
+        const size_t bytes = v.size() * sizeof(T);
+        if (bytes >= (256u << 10)) { buf.upload(v); return; }
+        const size_t off = (host.size() + 255) & ~(size_t)255;
+        host.resize(off + (bytes ? bytes : 1));
+        if (bytes) std::memcpy(host.data() + off, v.data(), bytes);
+        const size_t count = v.size();
+        DevBuf<T> *b = &buf;
+        fix.push_back([b, off, count](uint8_t *base) { b->view(reinterpret_cast<T *>(base + off), count); });
+    }
+    void commit(DevBuf<uint8_t> &arena) {
+        arena.alloc(host.size() ? host.size() : 1);
+        if (!host.empty()) HIP_TRY(hipMemcpy(arena.p, host.data(), host.size(), hipMemcpyHostToDevice));
+        for (auto &f : fix) f(arena.p);
+    }
+};
+
+// Streams are recycled per device as well: capture() makes an accel per frame, and creating its stream (and the copy stream of a
+// banded capture) cost a tenth of a millisecond each.  A stream goes back when its accel dies; whatever it may still hold is ahead
+// of the next owner's work in stream order.
+namespace {
+struct StreamPool {
+    std::mutex mtx;
+    std::vector<std::pair<int, hipStream_t>> spare;
+    hipStream_t take(int device) {
+        {
+            std::lock_guard<std::mutex> g(mtx);
+            for (size_t i = 0; i < spare.size(); ++i)
+                if (spare[i].first == device) { hipStream_t s = spare[i].second; spare.erase(spare.begin() + (long)i); return s; }
+        }
+        hipStream_t s = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        return s;
+    }
+    void give(int device, hipStream_t s) {
+        if (!s) return;
+        {
+            std::lock_guard<std::mutex> g(mtx);
+            if (spare.size() < 64) { spare.emplace_back(device, s); return; }
+        }
+        (void)hipStreamDestroy(s);
+    }
+};
+StreamPool &g_streams = *new StreamPool(); // never destroyed (see g_pool)
+} // namespace
 
 // Sticky error words of the queue organisation (k_queue.hip: a wave that gave up waiting for work).  They live in PINNED HOST memory
 // that every device writes straight into (system-scope store), one word per accel, handed out from pages of 1024: the host reads
@@ -218,8 +275,10 @@ struct lg_accel {
     const Scene *scene = nullptr;
     int device = 0; // the HIP device this accel's tables and launches live on
     FlatScene flat;
+    DevBuf<uint8_t> arena; // the small tables live here (TableStage); the DevBufs below are views into it or allocations of their own
     DevBuf<DNode> nodes;
     DevBuf<DNode4> nodes4;
+    DevBuf<DNode32> nodes32;
     DevBuf<uint32_t> primref;
     DevBuf<DSphere> spheres;
     DevBuf<int32_t> sphere_mat;
@@ -244,6 +303,7 @@ struct lg_accel {
         DevBuf<double> frames, stash;                          // megakernel: Whitted frame stack, parked shading frame
         DevBuf<uint8_t> wf_mem;                                // wavefront pipeline: every per-level array of a chunk, carved from one allocation
         DevBuf<uint32_t> wf_counters;                          // its queue counts and per-launch tile counters
+        DevBuf<unsigned long long> ks;                         // lg_capture_subsets: the batch's k values (addressing mode 3)
     };
     mutable std::vector<std::unique_ptr<LaunchCtx>> ctxs;
     // wavefront pipeline, big launches: the frame is cut into bands rendered on internal streams (each with a launch context
@@ -264,8 +324,10 @@ struct lg_accel {
     bool mega_narrow = false;        // the LDS-resident megakernel in 768-lane workgroups: scenes of fewer than 512 spheres / boxes (measured, k_mega.hip)
     uint32_t wf_blocks = 1, wf_blocks_fast = 1;   // grids of the wavefront pipeline's 256-lane traversal kernels
     uint32_t queue_blocks = 1;                    // grid of the queue organisation's persistent kernel (256-lane form)
+    bool queue_root_lds = false;                  // ... with the root accel's ray parked in LDS above the stacks (walk.h, RLDS)
     mutable uint32_t *q_err = nullptr;            // the queue organisation's sticky error word (pinned host memory, g_err_words): taken at its first launch
     mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
+    mutable int last_org = -1;                    // what the last launch ran as: 0 megakernel, 1 level by level, 2 queue (lg_accel_last_organisation)
     bool queue_default = false;                   // glass / mirror over a big mesh: long uneven walks, sparse deep levels (k_queue.hip)
     mutable size_t queue_budget = 0;              // bytes one launch context may hold for it (0 = from the free memory at first use)
     unsigned long long queue_min_items = 1ull << 16; // launches below this many pixels stay with the megakernel
@@ -302,8 +364,8 @@ struct lg_accel {
         for (auto &v : kind_events) for (auto &e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto e : aux_done) (void)hipEventDestroy(e);
         if (aux_fork) (void)hipEventDestroy(aux_fork);
-        for (auto st : aux_streams) (void)hipStreamDestroy(st);
-        if (stream) (void)hipStreamDestroy(stream);
+        for (auto st : aux_streams) g_streams.give(device, st);
+        g_streams.give(device, stream);
         g_err_words.give(q_err);
     }
 };
@@ -351,6 +413,10 @@ static void sync_checked(const lg_accel &a) {
 static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     const Scene &s = *a.scene;
     DParams P{};
+    {   // LASGUN_NODES32=0 (A/B): the 64-byte node records for every accel
+        static const bool n32 = [] { const char *e = std::getenv("LASGUN_NODES32"); return !(e && e[0] == '0'); }();
+        P.nodes32 = n32 && a.nodes32.n ? a.nodes32.p : nullptr;
+    }
     P.nodes = a.nodes.p; P.nodes4 = a.nodes4.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
     P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
     P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.chunks = a.chunks.p; P.strips = a.strips.p; P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
@@ -383,6 +449,16 @@ static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     P.w = w; P.h = h;
     P.winv = 1. / (double)w; P.hinv = 1. / (double)h; P.aspect = (double)w / (double)h; // film.rs:40-42
     return P;
+}
+
+// the accel's internal streams (bands of a big wavefront launch, bands of a whole-film capture).  Caller holds a.mtx.
+static void ensure_aux_streams(const lg_accel &a, unsigned n) {
+    while (a.aux_streams.size() < n) {
+        hipStream_t st = g_streams.take(a.device); hipEvent_t ev = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        a.aux_streams.push_back(st); a.aux_done.push_back(ev);
+    }
+    if (!a.aux_fork) HIP_TRY(hipEventCreateWithFlags(&a.aux_fork, hipEventDisableTiming));
 }
 
 // The wavefront pipeline (k_wavefront.hip): per chunk of the film and per supersample, levels 0 .. L-1 top-down (closest,
@@ -431,15 +507,7 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
     if (split > 1) chunk_tiles = std::min<unsigned long long>(chunk_tiles, (P0.ntiles + split - 1) / split);
     unsigned long long nchunks = (P0.ntiles + chunk_tiles - 1) / chunk_tiles;
     const unsigned nstreams = split > 1 && nchunks > 1 ? (unsigned)std::min<unsigned long long>(split, nchunks) : 0u; // 0: everything on the caller's stream
-    if (nstreams && a.aux_streams.size() < nstreams) {
-        while (a.aux_streams.size() < nstreams) {
-            hipStream_t st = nullptr; hipEvent_t ev = nullptr;
-            HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            a.aux_streams.push_back(st); a.aux_done.push_back(ev);
-        }
-        if (!a.aux_fork) HIP_TRY(hipEventCreateWithFlags(&a.aux_fork, hipEventDisableTiming));
-    }
+    if (nstreams) ensure_aux_streams(a, nstreams);
     unsigned long long n0 = 0;
     size_t need = 0, hit_cap = 0, hit_len = 0;
     const uint32_t nlaunch = 4 * levels;
@@ -689,6 +757,7 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
         P.wf_levels = levels;
         P.q_ctl = c.wf_counters.p; P.q_ready = c.wf_counters.p + QC_WORDS; P.q_err = a.q_err;
         P.q_unit_tiles = levels > 1 ? unit_tiles : 1u;
+        P.q_root_lds = !ldss && a.queue_root_lds ? 1u : 0u;
         // the tile sequence: rectangles whose chunk is whole tile rows go block by block, XCD by XCD (k_queue.hip, q_seq_tile)
         P.q_order = (order_blocks && !ldss && P.mode == 0u && P.tiles_x != 0u && t0 % P.tiles_x == 0u && P.ntiles % P.tiles_x == 0u) ? 1u : 0u;
         P.q_tiles_y = P.q_order ? P.ntiles / P.tiles_x : 0u;
@@ -719,40 +788,37 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
     if (a.profiling) { HIP_TRY(hipEventRecord(e1, stream)); a.events.emplace_back(e0, e1); }
 }
 
-// Enqueue one render on `stream`.  Caller holds a.mtx.
-static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t stream) {
-    if (P.ntiles == 0) return;
-    check_queue_error(a); // (an earlier launch on a caller's stream that stalled: reported here at the latest)
-    lg_accel::LaunchCtx &c = ctx_for(a, stream);
-    P.tile_counter = c.tile_counter.p;
-    // ---- queue organisation: every recursion level in one persistent launch (reference traversal, <= 32 lights, <= 7 levels of
-    // recursion; not the counting variant).  Forced by lg_accel_set_streaming(3); the default for glass / mirror over a big mesh.
-    {
-        const uint32_t levels = (a.flat.has_specular && P.recursion > 0) ? P.recursion + 1u : 1u;
-        const bool can = !stats && !a.fast && P.nlights <= 32 && levels <= QC_MAX_LEVELS;
-        const bool want = a.queue == 1 || (a.queue < 0 && a.streaming && !a.streaming_forced && a.queue_default &&
-                                           (unsigned long long)P.ntiles * 64ull >= a.queue_min_items);
-        if (can && want) { enqueue_queue(a, P, c, stream); return; }
-    }
-    // ---- wavefront pipeline: li() level by level (any scene with <= 32 lights; not the counting variant)
-    // Also (round 4, once a launch no longer ended in 75-90 us of failed tile claims -- kcommon.h -- and the level-by-level passes of a small
-    // frame became cheap), for a scene resident in LDS:
-    //   * glass / mirror, frames up to 2^20 pixels: in the megakernel one wave walks a tile's whole recursion tree -- up to 2^(depth + 1)
-    //     closest-hit and shadow walks one after the other -- while most of the chip has nothing to do; level by level every ray of a level
-    //     has a lane of its own.  Cornell glass: 0.41 against 0.81 ms at 512^2, 0.99 / 1.18 at 1024^2, 1.81 / 1.64 at 1536^2.
-    //   * no glass / mirror, few primitives and one sample per pixel, frames from 2^18 pixels: README sphere 0.07 / 0.10 ms at 512^2,
-    //     2.2 / 3.5 at 4096^2; Cornell plastic 0.11 / 0.15 and 3.4 / 4.6; below, the two are within a few microseconds of each other.
-    //     (Supersampled frames stay in the megakernel -- in its 768-lane form, k_mega.hip, it is ahead at every size: simple.rs at 9 spp
-    //     0.61 / 0.73 ms at 512^2, 4.7 / 5.5 at 2048^2.)
+// ---- which organisation renders a launch -----------------------------------------------------------------
+enum Org : int { ORG_MEGA = 0, ORG_WAVEFRONT = 1, ORG_QUEUE = 2 };
+static uint32_t levels_of(const lg_accel &a, const DParams &P) { return (a.flat.has_specular && P.recursion > 0) ? P.recursion + 1u : 1u; }
+// what each organisation can take: the queue organisation the reference traversal with <= 32 lights and <= 8 recursion levels, the
+// level-by-level pipeline any scene with <= 32 lights; neither the counting variant
+static bool org_possible(const lg_accel &a, const DParams &P, bool stats, Org org) {
+    if (org == ORG_QUEUE) return !stats && !a.fast && P.nlights <= 32 && levels_of(a, P) <= QC_MAX_LEVELS;
+    if (org == ORG_WAVEFRONT) return !stats && P.nlights <= 32 && P.recursion < 20;
+    return true;
+}
+// The FITTED rule of rounds 2-4 (primitive count, glass / mirror, pixels per launch, samples per pixel): what a launch gets when
+// nothing has been measured for its kind -- LASGUN_AUTOTUNE=0, or the first candidate the measurement below starts from.
+//   * queue organisation: glass / mirror over a big mesh (long uneven walks, sparse deep levels), launches of 2^16 pixels and more;
+//   * level by level, for a scene resident in LDS (round 4, once a launch no longer ended in 75-90 us of failed tile claims): glass /
+//     mirror frames up to 2^20 pixels (Cornell glass 0.41 against 0.81 ms at 512^2, 0.99 / 1.18 at 1024^2, 1.81 / 1.64 at 1536^2), and
+//     frames from 2^18 pixels of few primitives at one sample per pixel (README sphere 2.2 / 3.5 ms at 4096^2); and wherever node and
+//     sphere tests dominate (>= 512 spheres / boxes) from 2^21 pixels;
+//   * the megakernel otherwise (supersampled frames of small scenes: its 768-lane form is ahead at every size).
+static Org org_by_rule(const lg_accel &a, const DParams &P, bool stats) {
     const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
+    if (org_possible(a, P, stats, ORG_QUEUE) && a.streaming && a.queue_default && items >= a.queue_min_items) return ORG_QUEUE;
     const bool lds_resident = !a.fast && a.lds_scene && a.ldss_blocks, specular = a.flat.has_specular && P.recursion > 0;
     const bool small_specular = lds_resident && specular && items <= a.specular_small_items;
     const bool light_scene = lds_resident && !specular && !a.streaming_pays && P.ss_root == 1u && items >= (1ull << 18);
-    if (a.streaming && !stats && P.nlights <= 32 && P.recursion < 20 &&
-        (a.streaming_forced || small_specular || light_scene || (a.streaming_pays && items >= a.streaming_min_items))) {
-        enqueue_wavefront(a, P, c, stream);
-        return;
-    }
+    if (a.streaming && org_possible(a, P, stats, ORG_WAVEFRONT) && (small_specular || light_scene || (a.streaming_pays && items >= a.streaming_min_items)))
+        return ORG_WAVEFRONT;
+    return ORG_MEGA;
+}
+
+// the megakernel (k_mega.hip): the whole of li() per lane
+static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, bool stats, hipStream_t stream) {
     uint32_t cap = a.fast ? a.max_blocks_fast : a.max_blocks;
     uint32_t blocks = (P.ntiles + 3u) / 4u;
     if (blocks > cap) blocks = cap;
@@ -801,6 +867,137 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         a.events.emplace_back(e0, e1);
     }
 }
+static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Org org, bool stats, hipStream_t stream) { // (P by value: an organisation fills in its own fields)
+    P.tile_counter = c.tile_counter.p;
+    if (org == ORG_QUEUE) enqueue_queue(a, P, c, stream);
+    else if (org == ORG_WAVEFRONT) enqueue_wavefront(a, P, c, stream);
+    else enqueue_mega(a, P, c, stats, stream);
+}
+
+// The MEASURED choice (round 5; the rule above was a fit to eight scenes and wrong by 6-22 % on the first scene that was not among
+// them).  Every organisation renders the same bytes, so which one runs is a question of time alone, and the answer is taken from
+// the clock: the first launch of a KIND -- the scene's shape (table sizes, lights, recursion, samples per pixel, traversal mode,
+// LDS residency), the device, the launch's size class (log2 of its pixels) and addressing mode -- renders the launch with every
+// organisation that can take it (a warm-up pass, then three timed passes over the candidates in turn, HIP events on the caller's stream, the host
+// waiting; the best of each), keeps the
+// fastest (the rule's own choice unless another beats it by 2 %) and remembers it for the process: capture() rebuilds its accel for
+// every frame (lib.rs:64), so the memory is keyed by the scene's shape, not by the accel.  The launch itself is then enqueued as
+// usual; what the measurement rendered into the caller's film are the same pixels.  Overridden by lg_accel_set_streaming(0 / 2 / 3)
+// (lg_accel_last_organisation says what a launch ran as); LASGUN_AUTOTUNE=0 keeps the rule.
+namespace {
+struct TuneKey {
+    uint64_t v[12];
+    bool operator<(const TuneKey &o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
+};
+std::mutex g_tune_mtx;
+std::map<TuneKey, int> &g_tuned = *new std::map<TuneKey, int>(); // never destroyed (see g_pool)
+bool autotune_enabled() {
+    static const bool on = [] { const char *e = std::getenv("LASGUN_AUTOTUNE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+} // namespace
+static TuneKey tune_key(const lg_accel &a, const DParams &P) {
+    const FlatScene &f = a.flat;
+    const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
+    uint64_t cls = 0;
+    while ((items >> cls) > 1ull) ++cls;
+    TuneKey k{};
+    k.v[0] = f.nodes.size(); k.v[1] = f.primref.size(); k.v[2] = f.spheres.size(); k.v[3] = f.cuboids.size(); k.v[4] = f.tri_v.size();
+    k.v[5] = f.accels.size(); k.v[6] = ((uint64_t)f.max_stack << 32) | (uint64_t)f.lights.size();
+    k.v[7] = ((uint64_t)P.recursion << 32) | ((uint64_t)P.ss_root << 8) | (f.has_specular ? 1u : 0u);
+    k.v[8] = ((uint64_t)P.prune << 2) | (a.fast ? 2u : 0u) | (a.lds_scene && a.ldss_blocks ? 1u : 0u);
+    {   // what the primitives are made of decides how many rays have children: two scenes of one shape (config 4's glass torus, 4m's metal one) are two kinds
+        uint64_t hsh = 1469598103934665603ull;
+        auto mix = [&hsh](const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; ++i) { hsh ^= b[i]; hsh *= 1099511628211ull; } };
+        for (const DMaterial &m : f.materials) mix(&m.kind, sizeof m.kind);
+        for (const DAccel &A : f.accels) { mix(&A.material, sizeof A.material); mix(&A.flags, sizeof A.flags); }
+        if (!f.sphere_mat.empty()) mix(f.sphere_mat.data(), f.sphere_mat.size() * sizeof f.sphere_mat[0]);
+        if (!f.cuboid_mat.empty()) mix(f.cuboid_mat.data(), f.cuboid_mat.size() * sizeof f.cuboid_mat[0]);
+        k.v[9] = hsh ^ ((uint64_t)a.device << 56);
+    }
+    k.v[10] = cls;
+    k.v[11] = P.mode == 0u ? 0u : 1u;
+    return k;
+}
+static Org tuned_org(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx &c, hipStream_t stream) {
+    const Org rule = org_by_rule(a, P, false);
+    const TuneKey key = tune_key(a, P);
+    {
+        std::lock_guard<std::mutex> g(g_tune_mtx);
+        auto it = g_tuned.find(key);
+        if (it != g_tuned.end()) return (Org)it->second;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const bool was_profiling = a.profiling;
+    a.profiling = false; // (the measurement's launches are not the caller's: lg_profile_read must not count them)
+    float best_ms[3] = {INFINITY, INFINITY, INFINITY};
+    bool in_race[3];
+    for (int org = 0; org < 3; ++org)
+        in_race[org] = org_possible(a, P, false, (Org)org) &&
+                       !(org == ORG_QUEUE && (unsigned long long)P.ntiles * 64ull < 4096ull && rule != ORG_QUEUE); // (a persistent scheduler for a handful of tiles: never ahead)
+    try {
+        // pass 0 warms every candidate up (buffers, code, clocks); passes 1-3 time them IN TURN, so that a drift of the clocks or a
+        // neighbour's launch hits all alike, and the best of the three counts (the persistent kernels' own run-to-run spread is ~5 %:
+        // config 4m's megakernel / queue pair, 6 % apart, was called wrongly by one warm-up + best of two in a row); a candidate that
+        // is 1.3 x behind after a pass is out, and launches of a quarter second measure themselves in one pass
+        for (int pass = 0; pass < 4; ++pass) {
+            float fastest = INFINITY;
+            for (int org = 0; org < 3; ++org) {
+                if (!in_race[org]) continue;
+                HIP_TRY(hipEventRecord(e0, stream));
+                enqueue_org(a, P, c, (Org)org, false, stream);
+                HIP_TRY(hipEventRecord(e1, stream));
+                HIP_TRY(hipEventSynchronize(e1));
+                float ms = 0.0f;
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                if ((pass > 0 || ms > 250.0f) && ms < best_ms[org]) best_ms[org] = ms;
+                fastest = std::min(fastest, pass > 0 || ms > 250.0f ? best_ms[org] : ms);
+            }
+            int left = 0;
+            for (int org = 0; org < 3; ++org) {
+                if (in_race[org] && pass > 0 && best_ms[org] > 1.3f * fastest) in_race[org] = false;
+                left += in_race[org] ? 1 : 0;
+            }
+            if (left <= 1 && pass > 0) break;
+            if (fastest > 250.0f) break;
+        }
+    } catch (...) {
+        a.profiling = was_profiling;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        throw;
+    }
+    a.profiling = was_profiling;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    check_queue_error(a);
+    int best = (int)rule;
+    for (int org = 0; org < 3; ++org)
+        if (best_ms[org] < best_ms[best] * 0.98f) best = org;
+    if (std::getenv("LASGUN_DEBUG"))
+        std::fprintf(stderr, "[lasgun] organisation measured for %llu pixels: megakernel %.3f ms, level by level %.3f ms, queue %.3f ms -> %d (rule: %d)\n",
+                     (unsigned long long)P.ntiles * 64ull, best_ms[0], best_ms[1], best_ms[2], best, (int)rule);
+    std::lock_guard<std::mutex> g(g_tune_mtx);
+    g_tuned[key] = best;
+    return (Org)best;
+}
+
+// Enqueue one render on `stream`.  Caller holds a.mtx.
+static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t stream) {
+    if (P.ntiles == 0) return;
+    check_queue_error(a); // (an earlier launch on a caller's stream that stalled: reported here at the latest)
+    lg_accel::LaunchCtx &c = ctx_for(a, stream);
+    Org org;
+    if (stats) org = ORG_MEGA;                                                                   // the counting variant
+    else if (a.queue == 1) org = org_possible(a, P, stats, ORG_QUEUE) ? ORG_QUEUE : org_by_rule(a, P, stats); // lg_accel_set_streaming(3)
+    else if (!a.streaming) org = ORG_MEGA;                                                       // lg_accel_set_streaming(0)
+    else if (a.streaming_forced) org = org_possible(a, P, stats, ORG_WAVEFRONT) ? ORG_WAVEFRONT : ORG_MEGA; // lg_accel_set_streaming(2)
+    else if (a.queue == 0 || !autotune_enabled()) {                                              // the fitted rule (queue ruled out by set_streaming(0 .. 2))
+        org = org_by_rule(a, P, stats);
+        if (a.queue == 0 && org == ORG_QUEUE) org = ORG_MEGA;
+    } else org = tuned_org(a, P, c, stream);
+    a.last_org = (int)org;
+    enqueue_org(a, P, c, org, stats, stream);
+}
 
 static void set_rect(DParams &P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
     P.mode = 0; P.x0 = x0; P.y0 = y0; P.x1 = x1; P.y1 = y1;
@@ -815,6 +1012,38 @@ static void set_subset(DParams &P, size_t k, size_t n, uint32_t w, uint32_t h) {
     P.mode = 1; P.sub_k = k; P.sub_n = n;
     P.sub_count = k < area ? (area - k + n - 1) / n : 0;
     P.ntiles = (uint32_t)((P.sub_count + 63ull) / 64ull);
+}
+
+// Several subsets {k_j + i*n} of one n as ONE render (lg_capture_subsets): the k values sorted and without repeats or empty subsets,
+// the periods the longest subset has, and whether the batch is every pixel of the film (every k of 0 .. n-1: the frame itself).
+struct SubsetBatch {
+    std::vector<unsigned long long> ks;
+    unsigned long long n = 1, periods = 0, items = 0;
+    bool whole = false;
+};
+static SubsetBatch make_batch(const size_t *ks, size_t count, size_t n, uint32_t w, uint32_t h) {
+    if (n == 0) throw Error("n must be > 0");
+    if (count != 0 && !ks) throw Error("ks is NULL");
+    const unsigned long long area = (unsigned long long)w * h;
+    SubsetBatch b;
+    b.n = n;
+    for (size_t j = 0; j < count; ++j) if (ks[j] < area) b.ks.push_back(ks[j]); // (a subset that starts behind the film has no pixel: lib.rs:152)
+    std::sort(b.ks.begin(), b.ks.end());
+    b.ks.erase(std::unique(b.ks.begin(), b.ks.end()), b.ks.end());
+    for (unsigned long long k : b.ks) b.periods = std::max(b.periods, (area - k + n - 1) / n);
+    b.items = (unsigned long long)b.ks.size() * b.periods;
+    if (b.items >= 0xFFFFFFFFull) throw Error("too many pixels for one batch of subsets (2^32 work items)");
+    b.whole = b.ks.size() == n;
+    for (size_t j = 0; b.whole && j < b.ks.size(); ++j) b.whole = b.ks[j] == j;
+    return b;
+}
+// the batch as addressing mode 3 on `stream` (its k table lives in the stream's launch context).  Caller holds a.mtx.
+static void set_subsets(const lg_accel &a, DParams &P, const SubsetBatch &b, hipStream_t stream) {
+    lg_accel::LaunchCtx &c = ctx_for(a, stream);
+    if (c.ks.n < b.ks.size()) { HIP_TRY(hipDeviceSynchronize()); c.ks.alloc(std::max<size_t>(b.ks.size(), 256)); } // (an earlier launch may still read the old table)
+    HIP_TRY(hipMemcpyAsync(c.ks.p, b.ks.data(), b.ks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream)); // (pageable source: staged before the call returns)
+    P.mode = 3; P.pixel_list = c.ks.p; P.sub_m = (uint32_t)b.ks.size(); P.sub_n = b.n; P.sub_k = 0; P.sub_count = b.items;
+    P.ntiles = (uint32_t)((b.items + 63ull) / 64ull);
 }
 
 template <class F> static int guarded(F f) {
@@ -991,20 +1220,28 @@ int lg_device_count(void) {
 // once more, with them, by the first lg_accel_set_mode(accel, 1).
 static void build_and_upload(lg_accel *a, bool with_fast) {
     a->ldss_blocks = 0; a->lds_image_n16 = 0; a->fast_available = true;
+        static const bool times = std::getenv("LASGUN_DEBUG_TIMES") != nullptr; // (where lg_accel_from's time goes: flatten / upload / derived)
+        const auto t_begin = std::chrono::steady_clock::now();
         flatten_scene(*a->scene, a->flat, with_fast); // host HLBVH build + flatten (throws on what the reference would panic on)
+        const auto t_flat = std::chrono::steady_clock::now();
         use_device(a->device);
         const FlatScene &f = a->flat;
-        a->nodes.upload(f.nodes); a->nodes4.upload(f.nodes4); a->primref.upload(f.primref); a->spheres.upload(f.spheres); a->sphere_mat.upload(f.sphere_mat);
-        a->cuboids.upload(f.cuboids); a->cuboid_mat.upload(f.cuboid_mat); a->tri_v.upload(f.tri_v); a->tri_n.upload(f.tri_n);
-        a->tri_t.upload(f.tri_t); a->leaf_soup.upload(f.leaf_soup); a->chunks.upload(f.chunks); a->strips.upload(f.strips); a->sphere_ref_leaf.upload(f.sphere_ref_leaf); a->cuboid_ref_leaf.upload(f.cuboid_ref_leaf);
-        a->tri_ref_leaf.upload(f.tri_ref_leaf); a->accel_ref_leaf.upload(f.accel_ref_leaf); a->vpos.upload(f.vpos); a->vnorm.upload(f.vnorm); a->vtex.upload(f.vtex);
-        a->accels.upload(f.accels); a->materials.upload(f.materials); a->lights.upload(f.lights);
-        a->stats.alloc(2); // (the second record: iteration counters of the diagnostic build)
+        TableStage stage; // (committed at the end: one allocation, one copy)
+        stage.add(a->nodes, f.nodes); stage.add(a->nodes4, f.nodes4); stage.add(a->nodes32, f.nodes32); stage.add(a->primref, f.primref); stage.add(a->spheres, f.spheres); stage.add(a->sphere_mat, f.sphere_mat);
+        stage.add(a->cuboids, f.cuboids); stage.add(a->cuboid_mat, f.cuboid_mat); stage.add(a->tri_v, f.tri_v); stage.add(a->tri_n, f.tri_n);
+        stage.add(a->tri_t, f.tri_t); stage.add(a->leaf_soup, f.leaf_soup); stage.add(a->chunks, f.chunks); stage.add(a->strips, f.strips); stage.add(a->sphere_ref_leaf, f.sphere_ref_leaf); stage.add(a->cuboid_ref_leaf, f.cuboid_ref_leaf);
+        stage.add(a->tri_ref_leaf, f.tri_ref_leaf); stage.add(a->accel_ref_leaf, f.accel_ref_leaf); stage.add(a->vpos, f.vpos); stage.add(a->vnorm, f.vnorm); stage.add(a->vtex, f.vtex);
+        stage.add(a->materials, f.materials); stage.add(a->lights, f.lights); // (the accel records: below, once their compact bases are known)
+        {   // the counters' two records, zeroed (the second: iteration counters of the diagnostic build)
+            static const std::vector<DStats> zero(2);
+            stage.add(a->stats, zero);
+        }
+        const auto t_up = std::chrono::steady_clock::now();
         a->device_bytes = f.nodes.size() * sizeof(DNode) + f.nodes4.size() * sizeof(DNode4) + f.primref.size() * 4 + f.spheres.size() * sizeof(DSphere) +
                           f.cuboids.size() * sizeof(DCuboid) + f.tri_v.size() * 12 + f.vpos.size() * 4 + f.vnorm.size() * 4 + f.leaf_soup.size() * sizeof(DLeafRec) +
                           f.strips.size() * sizeof(DStrip) + f.chunks.size() * sizeof(DChunk) +
                           f.accels.size() * sizeof(DAccel) + f.materials.size() * sizeof(DMaterial);
-        if (!a->stream) HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+        if (!a->stream) a->stream = g_streams.take(a->device);
         // per-lane LDS stack: worst case of this scene graph, +2 guard entries
         a->stack_depth = f.max_stack + 2;
         // the fast kernel falls back to the reference traversal on exact ties, so its stack must hold either
@@ -1087,6 +1324,14 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         HIP_TRY(queue_occupancy(a->stack_depth, extra_lds, &qb));
         if (const char *e = std::getenv("LASGUN_QUEUE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v < qb) qb = v; } // (diagnostic: how much the kernel gains from each resident workgroup)
         a->queue_blocks = (uint32_t)((qb < 1 ? 1 : qb) * cus);
+        {   // the root ray in LDS (walk.h, RLDS): when twelve more words per lane leave as many workgroups on a CU; LASGUN_QUEUE_ROOT_LDS=0|1: A/B
+            int qb2 = 0;
+            HIP_TRY(queue_occupancy(a->stack_depth + 12u, extra_lds, &qb2));
+            a->queue_root_lds = qb2 >= qb && qb >= 1;
+            if (const char *e = std::getenv("LASGUN_QUEUE_ROOT_LDS")) a->queue_root_lds = a->queue_root_lds && e[0] != '0';
+            const size_t lds2 = (size_t)(a->stack_depth + 12u) * 256 * 4 + extra_lds;
+            if (a->queue_root_lds && lds2 > 64 * 1024) HIP_TRY(queue_set_lds_limit(lds2, false));
+        }
         a->cus = (uint32_t)cus;
         // LDS-resident scene: the REFERENCE tree's nodes (56 of 64 bytes, padded to 80 when that fits),
         // its primrefs, the spheres (padded to 48 when that fits) and cuboids, behind 1024 per-lane
@@ -1162,12 +1407,12 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                     for (int k = 0; k < MAX_CHAIN; ++k) rec[32 + k] = A.chain[k];
                     std::memcpy(rec + 40, A.prune, sizeof A.prune);
                 }
-                a->lds_image.upload(img);
+                stage.add(a->lds_image, img);
                 a->lds_image_n16 = (uint32_t)n16;
                 HIP_TRY(mega_set_lds_limit(LDS_MAX, true)); HIP_TRY(wf_set_lds_limit(LDS_MAX, true)); HIP_TRY(queue_set_lds_limit(LDS_MAX, true));
                 a->ldss_blocks = (uint32_t)cus;
             }
-            a->accels.upload(fm.accels); // again, now with the compact bases
+            stage.add(a->accels, fm.accels); // with the compact bases
             if (a->accel_image_n16) { // the accel records alone, global bases in unit [6] (the LDS-resident image carries compact ones)
                 std::vector<uint32_t> img((size_t)a->accel_image_n16 * 4, 0u);
                 for (size_t i = 0; i < fm.accels.size(); ++i) {
@@ -1179,9 +1424,10 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                     for (int k = 0; k < MAX_CHAIN; ++k) rec[32 + k] = A.chain[k];
                     std::memcpy(rec + 40, A.prune, sizeof A.prune);
                 }
-                a->accel_image.upload(img);
+                stage.add(a->accel_image, img);
             }
         }
+        stage.commit(a->arena);
         // Which organisation is the default (measured, tools/threshold_sweep.py): the megakernel unless the scene has
         // so many spheres / boxes that BVH-node and sphere tests dominate a ray (>= 512: with the scene tables in LDS
         // the megakernel keeps up to ~50 node + primitive tests per ray; beyond that the traversal kernels' lower
@@ -1212,6 +1458,11 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
             a->queue_default = f.has_specular && big_mesh >= 4096 && specular_mesh;
             a->streaming_min_items = big_mesh >= 4096 ? (1ull << 23) : (1ull << 21); // (config 3's scene at 1024^2: 0.84 ms in the megakernel, 0.99 level by level; at 2048^2: 2.20 / 2.11)
         }
+        if (times) {
+            const auto t_end = std::chrono::steady_clock::now();
+            auto ms = [](auto a0, auto a1) { return std::chrono::duration<double, std::milli>(a1 - a0).count(); };
+            std::fprintf(stderr, "[lasgun] accel build: flatten %.3f ms, table uploads %.3f ms, streams / occupancy / LDS images %.3f ms\n", ms(t_begin, t_flat), ms(t_flat, t_up), ms(t_up, t_end));
+        }
 }
 
 // First request for the fast mode: its trees are built and every table is uploaded into a SECOND accel; only when all of
@@ -1221,7 +1472,8 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
 static void swap_tables(lg_accel &x, lg_accel &y) {
     using std::swap;
     swap(x.flat, y.flat);
-    swap(x.nodes, y.nodes); swap(x.nodes4, y.nodes4); swap(x.primref, y.primref); swap(x.spheres, y.spheres); swap(x.sphere_mat, y.sphere_mat);
+    swap(x.arena, y.arena); swap(x.stats, y.stats); // (the counters' record is a view into the arena like the small tables)
+    swap(x.nodes, y.nodes); swap(x.nodes4, y.nodes4); swap(x.nodes32, y.nodes32); swap(x.primref, y.primref); swap(x.spheres, y.spheres); swap(x.sphere_mat, y.sphere_mat);
     swap(x.cuboids, y.cuboids); swap(x.cuboid_mat, y.cuboid_mat); swap(x.tri_v, y.tri_v); swap(x.tri_n, y.tri_n); swap(x.tri_t, y.tri_t);
     swap(x.vpos, y.vpos); swap(x.vnorm, y.vnorm); swap(x.vtex, y.vtex); swap(x.leaf_soup, y.leaf_soup); swap(x.chunks, y.chunks); swap(x.strips, y.strips);
     swap(x.sphere_ref_leaf, y.sphere_ref_leaf); swap(x.cuboid_ref_leaf, y.cuboid_ref_leaf); swap(x.tri_ref_leaf, y.tri_ref_leaf); swap(x.accel_ref_leaf, y.accel_ref_leaf);
@@ -1231,7 +1483,7 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.lds_soup_off, y.lds_soup_off); swap(x.lds_accel_off, y.lds_accel_off);
     swap(x.ldss_blocks, y.ldss_blocks); swap(x.cus, y.cus);
     swap(x.stack_depth, y.stack_depth); swap(x.stack_depth_fast1, y.stack_depth_fast1); swap(x.max_blocks, y.max_blocks); swap(x.max_blocks_fast, y.max_blocks_fast);
-    swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast); swap(x.queue_blocks, y.queue_blocks);
+    swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast); swap(x.queue_blocks, y.queue_blocks); swap(x.queue_root_lds, y.queue_root_lds);
     swap(x.queue_default, y.queue_default); swap(x.prune_default, y.prune_default); swap(x.queue_min_items, y.queue_min_items); swap(x.specular_small_items, y.specular_small_items);
     swap(x.device_bytes, y.device_bytes); swap(x.fast_available, y.fast_available); swap(x.fast_refusal, y.fast_refusal);
     swap(x.streaming_pays, y.streaming_pays); swap(x.streaming_min_items, y.streaming_min_items); swap(x.mega_narrow, y.mega_narrow);
@@ -1334,17 +1586,68 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) {
         const unsigned long long count = whole ? area : (k < area ? (area - k + n - 1) / n : 0);
         if (count == 0) return;
         DevBuf<uint32_t> buf; // this call's own output (returned to the pool when the call ends)
+        // A whole film of 2^22 pixels and more goes out in ROW BANDS: the bands are rendered one after the other on the accel's stream, and
+        // each is copied home on a second stream as soon as it is done -- band j's 16 MiB cross PCIe while band j + 1 renders; round 4
+        // issued ONE copy of the whole film after the last kernel (config 3: 1.2 of capture()'s 9.96 ms).  Same pixels, same bytes: a
+        // pixel's value does not depend on the launch it is rendered in.  (Bands side by side on four streams were measured first: their
+        // persistent grids share the chip, all four finish together and the copies still come last -- 8.57 against 8.29 ms.)
+        static const unsigned bands_env = [] { const char *e = std::getenv("LASGUN_CAPTURE_BANDS"); return e ? (unsigned)std::atoi(e) : 4u; }();
+        const unsigned nbands = whole && area >= (1ull << 22) && bands_env >= 2 && h >= 64 ? std::min(bands_env, 16u) : 1u;
+        const uint32_t rows8 = (h + 7u) / 8u; // bands are whole rows of 8x8 tiles
+        auto band_rows = [&](unsigned j, uint32_t &y0, uint32_t &y1) {
+            y0 = (uint32_t)((unsigned long long)rows8 * j / nbands) * 8u;
+            y1 = std::min(h, (uint32_t)((unsigned long long)rows8 * (j + 1) / nbands) * 8u);
+        };
+        hipStream_t copy_stream = nullptr;
+        std::vector<hipEvent_t> rendered;
         {
             std::lock_guard<std::mutex> g(a->mtx);
             use_device(a->device);
             buf.alloc((size_t)count);
             DParams P = base_params(*a, w, h);
-            if (whole) set_rect(P, 0, 0, w, h);
-            else { set_subset(P, k, n, w, h); P.out_compact = 1; }
             P.out_row0 = 0;
             P.out_rgba = (uint8_t *)buf.p;
-            enqueue(*a, P, false, a->stream);
-            if (whole) HIP_TRY(hipMemcpyAsync(film->px, buf.p, (size_t)area * 4, hipMemcpyDeviceToHost, a->stream));
+            if (nbands > 1) {
+                ensure_aux_streams(*a, 1);
+                copy_stream = a->aux_streams[0];
+                for (unsigned j = 0; j < nbands; ++j) {
+                    uint32_t y0, y1;
+                    band_rows(j, y0, y1);
+                    hipEvent_t ev = nullptr;
+                    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    rendered.push_back(ev);
+                    if (y1 > y0) {
+                        DParams B = P;
+                        set_rect(B, 0, y0, w, y1);
+                        enqueue(*a, B, false, a->stream);
+                    }
+                    HIP_TRY(hipEventRecord(ev, a->stream));
+                }
+            } else {
+                if (whole) set_rect(P, 0, 0, w, h);
+                else { set_subset(P, k, n, w, h); P.out_compact = 1; }
+                enqueue(*a, P, false, a->stream);
+                if (whole) HIP_TRY(hipMemcpyAsync(film->px, buf.p, (size_t)area * 4, hipMemcpyDeviceToHost, a->stream));
+            }
+        }
+        if (nbands > 1) { // the copies, in band order, every render already enqueued (a copy into pageable memory holds this thread until its band is home)
+            use_device(a->device);
+            hipError_t err = hipSuccess;
+            for (unsigned j = 0; j < nbands && err == hipSuccess; ++j) {
+                uint32_t y0, y1;
+                band_rows(j, y0, y1);
+                if (y1 <= y0) continue;
+                const size_t off = (size_t)y0 * w * 4, bytes = (size_t)(y1 - y0) * w * 4;
+                err = hipStreamWaitEvent(copy_stream, rendered[j], 0);
+                if (err == hipSuccess) err = hipMemcpyAsync(film->px + off, (const uint8_t *)buf.p + off, bytes, hipMemcpyDeviceToHost, copy_stream);
+            }
+            if (err == hipSuccess) err = hipStreamSynchronize(copy_stream);
+            const hipError_t err2 = hipStreamSynchronize(a->stream); // (nothing may still write `buf` when it goes back to the pool)
+            for (hipEvent_t ev : rendered) (void)hipEventDestroy(ev);
+            if (err != hipSuccess || err2 != hipSuccess) throw Error(std::string("banded capture: ") + hipGetErrorString(err != hipSuccess ? err : err2));
+            std::lock_guard<std::mutex> g(a->mtx);
+            check_queue_error(*a);
+            return;
         }
         if (whole) { use_device(a->device); sync_checked(*a); return; }
         std::vector<uint32_t> host((size_t)count);
@@ -1353,6 +1656,66 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) {
         sync_checked(*a);
         uint8_t *px = film->px;
         for (unsigned long long i = 0; i < count; ++i) std::memcpy(px + 4 * (k + i * n), &host[(size_t)i], 4);
+    });
+}
+// Several subsets of one n in ONE render (no counterpart in the reference, whose progressive caller -- www/renderer.ts:103-120 -- makes a
+// hundred capture_subset calls one after the other; each is then a launch chain that fills a fraction of the GPU).  The pixels written
+// are exactly those of the `count` calls lg_capture_subset(ks[j], n, ...), every other pixel is left alone; a batch that lists every
+// k of 0 .. n-1 is the frame and is rendered as one (8x8 tiles).
+int lg_capture_subsets_device(const size_t *ks, size_t count, size_t n, const lg_accel *a, uint32_t w, uint32_t h, void *dev_rgba, void *hip_stream) {
+    return guarded([&] {
+        const SubsetBatch b = make_batch(ks, count, n, w, h);
+        if (b.items == 0) return;
+        std::lock_guard<std::mutex> g(a->mtx);
+        use_device(a->device);
+        DParams P = base_params(*a, w, h);
+        if (b.whole) set_rect(P, 0, 0, w, h);
+        else set_subsets(*a, P, b, (hipStream_t)hip_stream);
+        P.out_row0 = 0;
+        P.out_rgba = (uint8_t *)dev_rgba;
+        enqueue(*a, P, false, (hipStream_t)hip_stream);
+    });
+}
+int lg_capture_subsets(const size_t *ks, size_t count, size_t n, const lg_accel *a, lg_film *film) {
+    return guarded([&] {
+        const uint32_t w = film->w, h = film->h;
+        const SubsetBatch b = make_batch(ks, count, n, w, h);
+        if (b.items == 0) return;
+        if (b.whole) { if (lg_capture_subset(0, 1, a, film)) throw Error(tl_error); return; }
+        // as lg_capture_subset: a compact buffer of this call's own (work item i -> word i), one D2H copy for the batch, and only
+        // the owned pixels of the host film are written (concurrent callers on one film own disjoint pixels)
+        DevBuf<uint32_t> buf;
+        std::vector<uint32_t> host((size_t)b.items);
+        {
+            std::lock_guard<std::mutex> g(a->mtx);
+            use_device(a->device);
+            buf.alloc((size_t)b.items);
+            DParams P = base_params(*a, w, h);
+            set_subsets(*a, P, b, a->stream);
+            P.out_compact = 1;
+            P.out_row0 = 0;
+            P.out_rgba = (uint8_t *)buf.p;
+            enqueue(*a, P, false, a->stream);
+            HIP_TRY(hipMemcpyAsync(host.data(), buf.p, (size_t)b.items * 4, hipMemcpyDeviceToHost, a->stream));
+        }
+        use_device(a->device);
+        sync_checked(*a);
+        const unsigned long long area = (unsigned long long)w * h, m = b.ks.size();
+        uint8_t *px = film->px;
+        auto scatter = [&](unsigned long long q0, unsigned long long q1) { // periods [q0, q1): ascending addresses
+            for (unsigned long long q = q0; q < q1; ++q)
+                for (unsigned long long j = 0; j < m; ++j) {
+                    const unsigned long long off = b.ks[(size_t)j] + q * b.n;
+                    if (off < area) std::memcpy(px + 4 * off, &host[(size_t)(q * m + j)], 4);
+                }
+        };
+        const unsigned nthreads = b.items >= (1ull << 21) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        if (nthreads <= 1) scatter(0, b.periods);
+        else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(scatter, b.periods * t / nthreads, b.periods * (t + 1) / nthreads);
+            for (auto &th : pool) th.join();
+        }
     });
 }
 // Any list of pixels of a width x height film (offset = y * width + x), results compact and in list order:
@@ -1590,6 +1953,10 @@ int lg_accel_set_streaming(const lg_accel *a, int enabled) {
     a->streaming_forced = enabled == 2; // 2 = use it whatever the scene and the launch size (tests)
     a->queue = enabled == 3 ? 1 : enabled == 1 ? -1 : 0; // 3 = the queue organisation whatever the scene; 1 = the accel's defaults
     return 0;
+}
+int lg_accel_last_organisation(const lg_accel *a) { // what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue; -1 before the first
+    std::lock_guard<std::mutex> g(a->mtx);
+    return a->last_org;
 }
 int lg_accel_get_prune(const lg_accel *a) { // the EFFECTIVE setting of the pruned walk: what a render of this accel uses right now
     std::lock_guard<std::mutex> g(a->mtx);

@@ -239,8 +239,17 @@ __device__ __forceinline__ Pixel pixel_of(const DParams &P, uint32_t tile, uint3
     } else {
         unsigned long long i = (unsigned long long)tile * 64ull + lane;
         px.active = i < P.sub_count;
-        // mode 1: the strided subset {k + i*n} (lib.rs:152); mode 2: an explicit list of pixel offsets
-        unsigned long long off = P.mode == 1 ? P.sub_k + i * P.sub_n : (px.active ? P.pixel_list[i] : 0ull);
+        // mode 1: the strided subset {k + i*n} (lib.rs:152); mode 2: an explicit list of pixel offsets; mode 3: SEVERAL strided subsets of one
+        // n in one launch (lg_capture_subsets) -- work item i = q * m + j is pixel ks[j] + q*n, ks = pixel_list[0 .. m) ascending: with every
+        // k of 0 .. n-1 listed that is pixel i itself, the row-major film (the host keeps sub_count below 2^32 for this mode)
+        unsigned long long off;
+        if (P.mode == 1) off = P.sub_k + i * P.sub_n;
+        else if (P.mode == 3) {
+            const uint32_t q = (uint32_t)i / P.sub_m, j = (uint32_t)i - q * P.sub_m;
+            off = P.pixel_list[j] + (unsigned long long)q * P.sub_n;
+            px.active = px.active && off < (unsigned long long)P.w * P.h; // (the last period of a subset may end before the others')
+            if (!px.active) off = 0ull;
+        } else off = px.active ? P.pixel_list[i] : 0ull;
         px.x = (uint32_t)(off % P.w);
         px.y = (uint32_t)(off / P.w);
         px.pix = P.out_compact ? i : off;

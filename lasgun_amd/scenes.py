@@ -237,6 +237,201 @@ def mixed_scene(api, nspheres=1024, nu=224, nv=224, supersampling=0):
     return scene
 
 
+def blob_obj(nu, nv, centre, radii, lumps, seed, normals=False, name="blob"):
+    """OBJ text of a closed, lumpy UV surface (stand-in for the reference's bunny / skull meshes, which are Git-LFS stubs): a sphere whose
+    radius is modulated by `lumps` low-frequency cosine lobes, poles closed by triangle fans; 2 * nu * (nv - 1) triangles.  Coordinates
+    are printed with %.6f and parsed back as f32 by the OBJ reader."""
+    rng = SplitMix64(seed)
+    lobes = [(rng.uniform(0.05, 0.22), 1 + int(rng.uniform(0, 4)), 1 + int(rng.uniform(0, 3)), rng.uniform(0, 6.28), rng.uniform(0, 6.28)) for _ in range(lumps)]
+
+    def point(u, v):
+        rho = 1.0 + sum(a * math.cos(ku * u + pu) * math.cos(kv * v + pv) * math.sin(v) for a, ku, kv, pu, pv in lobes)
+        d = (math.sin(v) * math.cos(u), math.cos(v), math.sin(v) * math.sin(u))
+        return (centre[0] + radii[0] * rho * d[0], centre[1] + radii[1] * rho * d[1], centre[2] + radii[2] * rho * d[2]), d
+
+    lines = ["o " + name]
+    verts, norms = [], []
+    p, d = point(0.0, 0.0)
+    verts.append(p); norms.append(d)
+    for j in range(1, nv):
+        for i in range(nu):
+            p, d = point(2.0 * math.pi * i / nu, math.pi * j / nv)
+            verts.append(p); norms.append(d)
+    p, d = point(0.0, math.pi)
+    verts.append(p); norms.append(d)
+    for x, y, z in verts:
+        lines.append("v %.6f %.6f %.6f" % (x, y, z))
+    if normals:
+        for x, y, z in norms:
+            lines.append("vn %.6f %.6f %.6f" % (x, y, z))
+    ring = lambda j, i: 2 + (j - 1) * nu + (i % nu)
+    south = len(verts)
+    f = (lambda a, b, c: "f %d//%d %d//%d %d//%d" % (a, a, b, b, c, c)) if normals else (lambda a, b, c: "f %d %d %d" % (a, b, c))
+    for i in range(nu):
+        lines.append(f(1, ring(1, i + 1), ring(1, i)))
+    for j in range(1, nv - 1):
+        for i in range(nu):
+            a, b, c, e = ring(j, i), ring(j, i + 1), ring(j + 1, i + 1), ring(j + 1, i)
+            lines.append(f(a, b, c))
+            lines.append(f(a, c, e))
+    for i in range(nu):
+        lines.append(f(south, ring(nv - 1, i), ring(nv - 1, i + 1)))
+    return "\n".join(lines) + "\n"
+
+
+def buckyball_obj():
+    """OBJ text of a truncated icosahedron -- 60 vertices, 12 pentagons and 20 hexagons AS POLYGONS, the way a modelling tool writes a
+    buckyball: the reference's TriangleIterator takes the FIRST THREE vertices of every polygon (src/shape/triangle.rs:52-53,315-371),
+    so the rendered solid is the 32 corner triangles -- a stand-in for the reference's buckyball.obj (a Git-LFS stub), with unit circumradius."""
+    phi = (1.0 + math.sqrt(5.0)) / 2.0
+    ico = []
+    for a in (-1.0, 1.0):
+        for b in (-phi, phi):
+            ico += [(0.0, a, b), (a, b, 0.0), (b, 0.0, a)]
+    def near(p):  # an icosahedron vertex's five neighbours
+        ds = sorted((sum((x - y) ** 2 for x, y in zip(p, q)), k) for k, q in enumerate(ico) if q != p)
+        return [k for _, k in ds[:5]]
+    verts, index = [], {}
+    for k, p in enumerate(ico):  # every edge cut at a third from each end
+        for m in near(p):
+            q = ico[m]
+            index[(k, m)] = len(verts)
+            verts.append(tuple(p[i] + (q[i] - p[i]) / 3.0 for i in range(3)))
+    scale = 1.0 / math.sqrt(sum(c * c for c in verts[0]))
+    lines = ["o buckyball"] + ["v %.6f %.6f %.6f" % tuple(c * scale for c in v) for v in verts]
+    def ordered(face_pts, centre):  # vertices of a planar convex face in order around its centre, counter-clockwise seen from outside
+        n = centre
+        ref = tuple(verts[face_pts[0]][i] - n[i] * sum(verts[face_pts[0]][j] * n[j] for j in range(3)) / sum(c * c for c in n) for i in range(3))
+        def angle(idx):
+            v = verts[idx]
+            w = tuple(v[i] - n[i] * sum(v[j] * n[j] for j in range(3)) / sum(c * c for c in n) for i in range(3))
+            cr = (ref[1] * w[2] - ref[2] * w[1], ref[2] * w[0] - ref[0] * w[2], ref[0] * w[1] - ref[1] * w[0])
+            return math.atan2(sum(cr[i] * n[i] for i in range(3)) / math.sqrt(sum(c * c for c in n)), sum(ref[i] * w[i] for i in range(3)))
+        return sorted(face_pts, key=angle)
+    for k, p in enumerate(ico):  # pentagons: around every icosahedron vertex
+        lines.append("f " + " ".join(str(i + 1) for i in ordered([index[(k, m)] for m in near(p)], p)))
+    seen = set()
+    for a in range(12):  # hexagons: one per icosahedron face
+        for b in near(ico[a]):
+            for c in near(ico[b]):
+                if c in near(ico[a]) and len({a, b, c}) == 3 and frozenset((a, b, c)) not in seen:
+                    seen.add(frozenset((a, b, c)))
+                    pts = [index[(a, b)], index[(b, a)], index[(b, c)], index[(c, b)], index[(c, a)], index[(a, c)]]
+                    centre = tuple(ico[a][i] + ico[b][i] + ico[c][i] for i in range(3))
+                    lines.append("f " + " ".join(str(i + 1) for i in ordered(pts, centre)))
+    return "\n".join(lines) + "\n"
+
+
+def playground_scene(api, nu=40, nv=24, supersampling=2):
+    """src/examples/playground.rs:5-27: one metal mesh added straight to `scene.root` (`add_obj_of`), radial background, one light,
+    3x3 supersampling.  The bunny is a Git-LFS stub in the reference: a lumpy closed stand-in mesh (no normals, like the Stanford
+    bunny's OBJ) sits where the camera looks."""
+    scene = api.Scene.new()
+    scene.set_ambient_light([0.1, 0.1, 0.1])
+    scene.set_radial_background([0.93, 0.87, 0.36], [0.94, 0.6, 0.1], 0.8)
+    camera = scene.set_perspective_camera(60.0)
+    camera.look_at([0.0, 1.0, 4.0], [-0.1, 1.0, 3.0], [0.0, 1.0, 0.0])
+    camera.set_supersampling(supersampling)
+    mat0 = api.Material.metal([0.9, 0.1, 0.9], [0.7, 1.0, 0.7], 0.25, 0.25)
+    bunny = scene.parse_obj(blob_obj(nu, nv, (-0.35, 0.95, 0.2), (0.9, 0.75, 0.7), 5, 0xB0771, normals=False, name="bunny"))
+    scene.add_point_light([0.0, 2.0, 3.0], [0.9, 0.9, 0.9], [1.0, 0.0, 0.0])
+    scene.root.add_obj_of(bunny, mat0)
+    return scene
+
+
+def spooky_scene(api, nu=36, nv=22, supersampling=2):
+    """src/examples/spooky.rs:6-52 at its own 768 x 768: white ambient light, two lights, a mesh under scale / rotate_y / translate inside
+    a group inside the rotated root, glass cube and spheres beside a plastic one, a plane scaled by 100, `scene.root.rotate_y` applied to
+    the root in place BEFORE the groups are added.  The skull is a Git-LFS stub: a lumpy stand-in with vertex normals."""
+    scene = api.Scene.new()
+    scene.set_ambient_light([1.0, 1.0, 1.0])
+    scene.set_radial_background([0.39, 0.29, 0.29], [0.1, 0.0, 0.0], 1.0)
+    camera = scene.set_perspective_camera(50.0)
+    camera.look_at([-5.0, 2.0, 6.0], [-3.0, 2.2, 1.0], [0.0, 1.0, 0.0])
+    camera.set_supersampling(supersampling)
+    skull = scene.parse_obj(blob_obj(nu, nv, (0.0, 2.2, 0.0), (2.2, 2.6, 2.9), 6, 0x5C011, normals=True, name="skull"))
+    plane = scene.parse_obj(PLANE_OBJ)
+    M, A = api.Material, api.Aggregate
+    floor = M.plastic([0.8, 0.7, 0.7], [0.0, 0.0, 0.0], 0.0)
+    bone = M.plastic([0.7, 0.7, 0.5], [0.3, 0.3, 0.3], 0.20)
+    purple = M.plastic([0.7, 0.6, 1.0], [0.8, 0.8, 0.8], 0.25)
+    glass = M.glass([0.7, 0.6, 1.0], [0.8, 0.8, 0.8], 1.333)
+    scene.add_point_light([-20.0, 15.0, 0.0], [0.9, 0.9, 0.9], [1.0, 0.0, 0.0])
+    scene.add_point_light([40.0, 10.0, 15.0], [1.0, 0.5, 0.0], [1.0, 0.0, 0.0])
+    skull_group = A.new()
+    skull_group.scale(0.5, 0.5, 0.5)
+    skull_group.rotate_y(-60.0)
+    skull_group.translate([4.0, 0.5, -4.0])
+    skull_group.add_obj_of(skull, bone)
+    item_group = A.new()
+    item_group.add_group(skull_group)
+    item_group.add_sphere([4.0, 4.0, -11.0], 4.0, purple)
+    item_group.add_cube([-2.5, 0.001, -3.0], 1.75, glass)
+    item_group.add_sphere([0.0, 2.0, -15.0], 2.0, glass)
+    item_group.add_sphere([2.5, 1.0, -2.0], 1.0, glass)
+    floor_group = A.new()
+    floor_group.scale(100.0, 1.0, 100.0)
+    floor_group.add_obj_of(plane, floor)
+    scene.root.rotate_y(10.0)
+    scene.root.add_group(item_group)
+    scene.root.add_group(floor_group)
+    return scene
+
+
+def simplecows_scene(api, supersampling=2):
+    """src/examples/simplecows.rs:5-104: the plane scaled by 30, a buckyball (here: the polygon OBJ of `buckyball_obj`, of which the
+    reference's reader keeps each face's first three vertices), six arches of two scaled cubes and a scaled sphere each -- groups three
+    deep, built with CHAINED transforms (`p1.scale(..).translate(..)`) --, three cows of seven spheres, and `scene.root.rotate_x(23)`
+    applied to the root in place AFTER its children were added (:90)."""
+    scene = api.Scene.new()
+    scene.set_ambient_light([0.2, 0.2, 0.2])
+    scene.set_radial_background([0.85, 0.82, 0.6], [0.69, 0.85, 0.73], 0.5)
+    camera = scene.set_perspective_camera(50.0)
+    camera.look_at([0.0, 2.0, 30.0], [0.0, 2.0, 29.0], [0.0, 1.0, 0.0])
+    camera.set_supersampling(supersampling)
+    scene.add_point_light([200.0, 202.0, 430.0], [0.8, 0.8, 0.8], [1.0, 0.0, 0.0])
+    M, A = api.Material, api.Aggregate
+    stone = M.metal([0.0, 0.0, 0.0], [0.7, 0.7, 0.7], 0.5, 0.5)
+    grass = M.plastic([0.1, 0.7, 0.1], [0.0, 0.0, 0.0], 0.0)
+    hide = M.plastic([0.84, 0.6, 0.53], [0.3, 0.3, 0.3], 0.2)
+    planemesh = scene.parse_obj(PLANE_OBJ)
+    buckyballmesh = scene.parse_obj(buckyball_obj())
+    plane = A.new()
+    plane.scale(30.0, 30.0, 30.0)
+    plane.add_obj_of(planemesh, grass)
+    scene.root.add_group(plane)
+    buckyball = A.new()
+    buckyball.scale(1.5, 1.5, 1.5)
+    buckyball.add_obj_of(buckyballmesh, stone)
+    scene.root.add_group(buckyball)
+    for i in range(1, 7):
+        p1 = A.new()
+        p1.add_cube([0.0, 0.0, 0.0], 1.0, stone)
+        p1.scale(0.8, 4.0, 0.8).translate([-2.4, 0.0, -0.4])
+        p2 = A.new()
+        p2.add_cube([0.0, 0.0, 0.0], 1.0, stone)
+        p2.scale(0.8, 4.0, 0.8).translate([1.6, 0.0, -0.4])
+        s = A.new()
+        s.add_sphere([0.0, 0.0, 0.0], 1.0, stone)
+        s.scale(4.0, 0.6, 0.6).translate([0.0, 4.0, 0.0])
+        arc = A.new()
+        arc.add_group(p1)
+        arc.add_group(p2)
+        arc.add_group(s)
+        arc.translate([0.0, 0.0, -10.0])
+        arc.rotate_y(float((i - 1) * 60))
+        scene.root.add_group(arc)
+    for translation, rotation in (([1.0, 1.3, 14.0], 20.0), ([5.0, 1.3, -11.0], 180.0), ([-5.5, 1.3, -3.0], -60.0)):
+        cow = A.new()
+        cow.scale(1.4, 1.4, 1.4).rotate_y(rotation).translate(translation)
+        for center, radius in (([0.0, 0.0, 0.0], 1.0), ([0.9, 0.3, 0.0], 0.6), ([-0.94, 0.34, 0.0], 0.2), ([0.7, -0.7, -0.7], 0.3),
+                               ([-0.7, -0.7, -0.7], 0.3), ([0.7, -0.7, 0.7], 0.3), ([-0.7, -0.7, 0.7], 0.3)):
+            cow.add_sphere(center, radius, hide)
+        scene.root.add_group(cow)
+    scene.root.rotate_x(23.0)
+    return scene
+
+
 def instanced_scene(api, nu=24, nv=16, supersampling=0):
     """No glass / mirror (so every kernel organisation applies): one torus mesh instanced three times under
     different transforms and materials (the instances share BVH nodes and primrefs on the device), nested two

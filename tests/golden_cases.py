@@ -11,6 +11,10 @@ CASES = {
     "mesh_glass": (lambda api: S.mesh_scene(api, 24, 24, "glass"), 48, 48),
     "mesh_metal_flat": (lambda api: S.mesh_scene(api, 24, 24, "metal", smoothing=False), 48, 40),
     "mesh_default": (lambda api: S.mesh_scene(api, 16, 16, "default"), 40, 48),
+    # the reference's remaining example programs (src/examples/playground.rs, spooky.rs, simplecows.rs) with generated stand-in meshes
+    "playground": (lambda api: S.playground_scene(api, 24, 14), 48, 48),
+    "spooky": (lambda api: S.spooky_scene(api, 20, 12), 48, 48),
+    "simplecows": (S.simplecows_scene, 48, 48),
 }
 
 # 64x64 crops of the FULL-SIZE films of BASELINE.json's configs[3] (100k-triangle mesh, glass / metal, mirror sphere:

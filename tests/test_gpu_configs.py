@@ -254,6 +254,33 @@ def test_wavefront_bands_on_internal_streams_leave_the_film_unchanged():
             assert torch.equal(film, ref), bands
 
 
+def test_capture_into_a_host_film_in_row_bands_is_the_same_film():
+    """capture() / capture_subset(0, 1) of a film of 2^22 pixels and more renders in row bands on the accel's internal streams, each
+    band followed by its own copy home (lg_capture_subset): the host film equals the device film of one launch, for a film whose height
+    is not a multiple of the band size, in the megakernel, level by level and in the queue organisation; and equals the oracle's on a sample."""
+    import torch
+    w, h = 2048, 2056 + 8 * 3  # 260 rows of tiles: bands of 65 rows of tiles
+    for build, orgs in ((lambda api: S.cornell_scene(api, "glass"), (0, 2, 3)), (lambda api: S.spheres_scene(api), (1,))):
+        scene = build(G)
+        acc = G.Accel(scene)
+        ref = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        G.capture_rows_device(acc, w, h, 0, h, ref.data_ptr(), row0=0)
+        G.synchronize(acc)
+        want = ref.cpu().numpy()
+        for org in orgs:
+            G.set_streaming(acc, org)
+            buf = np.full((h, w, 4), 9, np.uint8)
+            G.capture_subset(0, 1, acc, G.Film.new_with_output(w, h, buf))
+            assert np.array_equal(buf, want), org
+        film = G.Film(w, h)
+        G.capture(scene, film)  # lib.rs:55-104: rebuilds the accel, then the same path
+        assert np.array_equal(film.pixels(), want)
+        o = oracle()
+        idx = np.arange(977, w * h, 4099, dtype=np.uint64)
+        want_s, _ = o.capture_pixels(o.Accel(build(o)), w, h, idx, radiance=False, nthreads=max(1, min(64, len(os.sched_getaffinity(0)))))
+        assert np.array_equal(want.reshape(-1, 4)[idx.astype(np.int64)], want_s.reshape(-1, 4))
+
+
 @pytest.mark.parametrize("w, h, block_rows", [(128, 256, 64), (96, 80, 0)])
 def test_multi_device_all_gather_form_single_rank(w, h, block_rows):
     """lg_multi_capture_device_all, the all-gather form (every rank's device ends with the whole film), at the one size a 1-GPU

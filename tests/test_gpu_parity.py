@@ -140,6 +140,12 @@ MID = {
     # OBJ forms beyond `f a b c`: negative indices, v//vn, a 4- and a 5-vertex polygon (first three vertices), o / g groups
     "exotic_obj_smooth": (lambda api: S.exotic_obj_scene(api, True), 160, 120),
     "exotic_obj_flat": (lambda api: S.exotic_obj_scene(api, False), 96, 72),
+    # the reference's other example programs: a mesh added straight to the root; white ambient light, glass beside a mesh three groups deep,
+    # the root rotated in place before its groups are added (spooky.rs renders 768 x 768: a third of it here); a polygon OBJ, arches of
+    # scaled cubes and spheres three groups deep, the root rotated in place AFTER its children were added (simplecows.rs:90)
+    "playground_ss2": (S.playground_scene, 128, 128),
+    "spooky_ss2_256": (S.spooky_scene, 256, 256),
+    "simplecows_ss2": (S.simplecows_scene, 160, 160),
     # ragged / tiny films: tiles cut by the right and bottom edges, and a single pixel
     "ragged_67x13": (lambda api: S.cornell_scene(api, "glass"), 67, 13),
     "ragged_5x131": (lambda api: S.spheres_scene(api, 64, seed=11), 5, 131),
@@ -501,6 +507,69 @@ def test_capture_subset_partitions_and_preserves_other_pixels():
     # k beyond the area writes nothing; ragged last tile
     G.capture_subset(w * h + 5, 3, acc, film)
     assert np.array_equal(buf, want)
+
+
+def test_capture_subsets_batch_equals_the_single_calls_and_the_oracle():
+    """lg_capture_subsets: several subsets of one n as ONE render (the progressive caller's batch, www/renderer.ts:103-120) writes
+    exactly what the single capture_subset calls write -- which the oracle's capture_subset (lib.rs:110-162) pins -- and nothing else."""
+    import torch
+    w, h = 97, 61  # (not a multiple of 8 or of n: ragged tiles, a ragged last period)
+    for scene_of, n, ks in ((lambda api: S.cornell_scene(api, "glass"), 7, (3, 0, 5)), (lambda api: S.simple_scene(api, 1), 100, (17, 99, 0, 42, 41, 63))):
+        acc = G.Accel(scene_of(G))
+        o = oracle()
+        oacc = o.Accel(scene_of(o))
+        want = np.full((h, w, 4), 9, np.uint8)
+        ofilm = o.Film.new_with_output(w, h, want)
+        for k in ks:
+            o.capture_subset(k, n, oacc, ofilm)
+        buf = np.full((h, w, 4), 9, np.uint8)
+        film = G.Film.new_with_output(w, h, buf)
+        G.capture_subsets(list(ks) + [ks[0], w * h + 3], n, acc, film)  # a repeated k counts once, a k behind the film is an empty subset
+        assert np.array_equal(buf, want)
+        done = np.zeros(w * h, bool)
+        for k in ks:
+            done[k::n] = True
+        assert np.all(buf.reshape(-1, 4)[~done] == 9)
+        # the device-film form; then the rest of the subsets: the whole frame
+        dev = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda")
+        G.capture_subsets_device(ks, n, acc, w, h, dev.data_ptr())
+        G.synchronize(acc)
+        assert np.array_equal(dev.cpu().numpy(), want)
+        G.capture_subsets_device([k for k in range(n) if k not in ks], n, acc, w, h, dev.data_ptr())
+        G.synchronize(acc)
+        full = G.Film(w, h)
+        G.capture_subset(0, 1, acc, full)
+        assert np.array_equal(dev.cpu().numpy(), full.pixels())
+        # every k of 0 .. n-1 in one batch IS the frame (rendered as one); an empty batch and n larger than the film are fine
+        buf2 = np.full((h, w, 4), 9, np.uint8)
+        film2 = G.Film.new_with_output(w, h, buf2)
+        G.capture_subsets(list(range(n))[::-1], n, acc, film2)
+        assert np.array_equal(buf2, full.pixels())
+        G.capture_subsets([], n, acc, film2)
+        big = np.full((h, w, 4), 9, np.uint8)
+        G.capture_subsets([5, w * h - 1], w * h + 10, acc, G.Film.new_with_output(w, h, big))
+        flat = big.reshape(-1, 4)
+        assert np.array_equal(flat[5], full.pixels().reshape(-1, 4)[5]) and np.array_equal(flat[-1], full.pixels().reshape(-1, 4)[-1])
+        assert np.all(flat[6:-1] == 9) and np.all(flat[:5] == 9)
+    with pytest.raises(la.LasgunError):
+        G.capture_subsets([0], 0, acc, film)
+
+
+def test_capture_subsets_in_every_organisation():
+    """the batched addressing mode through the megakernel, the level-by-level pipeline and the queue organisation: same film"""
+    w, h, n, ks = 120, 72, 10, (9, 2, 4, 7)
+    scene = S.cornell_scene(G, "glass")
+    acc = G.Accel(scene)
+    full = G.Film(w, h)
+    G.capture_subset(0, 1, acc, full)
+    want = np.full((h * w, 4), 9, np.uint8)
+    for k in ks:
+        want[k::n] = full.pixels().reshape(-1, 4)[k::n]
+    for org in (0, 2, 3):
+        G.set_streaming(acc, org)
+        buf = np.full((h, w, 4), 9, np.uint8)
+        G.capture_subsets(ks, n, acc, G.Film.new_with_output(w, h, buf))
+        assert np.array_equal(buf.reshape(-1, 4), want), org
 
 
 def test_capture_rebuilds_and_render_matches():

@@ -126,11 +126,18 @@ def mesh_witness_scene(api, smoothing):
 
 @pytest.mark.parametrize("name, w, h", [("readme", 40, 40), ("base", 44, 33), ("ortho", 36, 27), ("ss", 24, 18), ("shallow", 36, 27), ("deep", 36, 27),
                                         ("simplereflect", 40, 30), ("grouped", 48, 36), ("grouped_ortho", 40, 30),
-                                        ("mesh_smooth", 48, 36), ("mesh_flat", 48, 36)])
+                                        ("mesh_smooth", 48, 36), ("mesh_flat", 48, 36),
+                                        ("playground", 20, 20), ("spooky", 28, 28), ("simplecows", 28, 28)])
 def test_oracle_matches_the_python_witness(name, w, h):
     def build(api):
         if name == "readme":
             return S.readme_scene(api)
+        if name == "playground":  # src/examples/playground.rs, spooky.rs, simplecows.rs with small stand-in meshes
+            return S.playground_scene(api, 10, 6, 1)
+        if name == "spooky":
+            return S.spooky_scene(api, 9, 6, 0)
+        if name == "simplecows":
+            return S.simplecows_scene(api, 0)
         if name.startswith("mesh"):
             return mesh_witness_scene(api, name == "mesh_smooth")
         if name.startswith("grouped"):
@@ -308,7 +315,8 @@ def _bvh_dump(scene):
     return np.asarray(f, dtype=np.float64), np.asarray(i, dtype=np.int64)
 
 
-@pytest.mark.parametrize("name", ["readme", "grouped", "mesh_smooth", "spheres1024", "mesh_torus", "kitchen_sink", "random3", "random7", "random19"])
+@pytest.mark.parametrize("name", ["readme", "grouped", "mesh_smooth", "spheres1024", "mesh_torus", "kitchen_sink", "random3", "random7", "random19",
+                                  "playground", "spooky", "simplecows"])
 def test_bvh_build_matches_the_python_witness(name):
     """Nodes (bounds to the bit, leaf / interior words), order[] and transforms of every nested accel: the oracle's
     orc_accel_dump against the Python restatement of bvh.rs:164-453."""
@@ -325,6 +333,8 @@ def test_bvh_build_matches_the_python_witness(name):
             return torus_only(api)
         if name == "kitchen_sink":
             return kitchen_like(api)
+        if name in ("playground", "spooky", "simplecows"):  # the reference's other example programs, full-size stand-in meshes
+            return getattr(S, name + "_scene")(api)
         return random_witness_scene(api, int(name[6:]))
 
     o = oracle()
