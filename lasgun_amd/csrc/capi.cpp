@@ -2107,6 +2107,28 @@ int lg_host_check_wide_records(const lg_scene *s, uint64_t out[8]) {
         flatten_scene(s->s, flat, true);
         for (int k = 0; k < 8; ++k) out[k] = 0;
         out[5] = flat.max_stack_fast1;
+        // the 32-byte records of the reference trees (DNode32, AF_NODES32), with the fast trees interleaved in the node table: every node the
+        // reference walk can reach from the accel's root must be there with the DNode's own values -- out[6] checked, out[7] wrong
+        for (const DAccel &A : flat.accels) {
+            if (!(A.flags & AF_NODES32)) continue;
+            std::vector<uint32_t> todo{0u};
+            while (!todo.empty()) {
+                const uint32_t i = todo.back(); todo.pop_back();
+                const DNode &d = flat.nodes[A.node_base + i];
+                bool ok = A.node_base + i < flat.nodes32.size();
+                if (ok) {
+                    const DNode32 &q = flat.nodes32[A.node_base + i];
+                    for (int k = 0; k < 3; ++k) ok = ok && (double)q.bmin[k] == d.bmin[k] && (double)q.bmax[k] == d.bmax[k];
+                    ok = ok && q.link == d.link && q.meta == d.meta;
+                }
+                out[6]++;
+                if (!ok) {
+                    out[7]++;
+                    if (std::getenv("LASGUN_DEBUG")) std::fprintf(stderr, "[lasgun] nodes32 mismatch: accel node_base %u fnode_base %u node %u (table sizes %zu / %zu), meta %x link %u\n", A.node_base, A.fnode_base, i, flat.nodes.size(), flat.nodes32.size(), d.meta, d.link);
+                }
+                if (!(d.meta & NODE_LEAF)) { todo.push_back(i + 1u); todo.push_back(d.link); }
+            }
+        }
         std::vector<uint32_t> seen_tree;
         for (const DAccel &A : flat.accels) {
             if (std::find(seen_tree.begin(), seen_tree.end(), A.fnode_base) != seen_tree.end()) continue; // (mesh instances share a tree)
