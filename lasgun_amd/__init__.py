@@ -282,7 +282,7 @@ class HipApi(Api):
         out = (_C.c_uint64 * 8)()
         if self.call("host_check_wide_records", scene.h, out):
             raise LasgunError(self.last_error())
-        keys = ("records", "children", "leaves", "deepest_stack", "violations", "reserved_stack", "nodes32_checked", "nodes32_wrong")
+        keys = ("records", "children", "leaves", "deepest_stack", "violations", "reserved_stack")
         return dict(zip(keys, [int(v) for v in out]))
 
     def Multi(self, scene, devices, block_rows=64):

@@ -278,7 +278,6 @@ struct lg_accel {
     DevBuf<uint8_t> arena; // the small tables live here (TableStage); the DevBufs below are views into it or allocations of their own
     DevBuf<DNode> nodes;
     DevBuf<DNode4> nodes4;
-    DevBuf<DNode32> nodes32;
     DevBuf<uint32_t> primref;
     DevBuf<DSphere> spheres;
     DevBuf<int32_t> sphere_mat;
@@ -324,7 +323,6 @@ struct lg_accel {
     bool mega_narrow = false;        // the LDS-resident megakernel in 768-lane workgroups: scenes of fewer than 512 spheres / boxes (measured, k_mega.hip)
     uint32_t wf_blocks = 1, wf_blocks_fast = 1;   // grids of the wavefront pipeline's 256-lane traversal kernels
     uint32_t queue_blocks = 1;                    // grid of the queue organisation's persistent kernel (256-lane form)
-    bool queue_root_lds = false;                  // ... with the root accel's ray parked in LDS above the stacks (walk.h, RLDS)
     mutable uint32_t *q_err = nullptr;            // the queue organisation's sticky error word (pinned host memory, g_err_words): taken at its first launch
     mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
     mutable int last_org = -1;                    // what the last launch ran as: 0 megakernel, 1 level by level, 2 queue (lg_accel_last_organisation)
@@ -413,10 +411,6 @@ static void sync_checked(const lg_accel &a) {
 static DParams base_params(const lg_accel &a, uint32_t w, uint32_t h) {
     const Scene &s = *a.scene;
     DParams P{};
-    {   // LASGUN_NODES32=0 (A/B): the 64-byte node records for every accel
-        static const bool n32 = [] { const char *e = std::getenv("LASGUN_NODES32"); return !(e && e[0] == '0'); }();
-        P.nodes32 = n32 && a.nodes32.n ? a.nodes32.p : nullptr;
-    }
     P.nodes = a.nodes.p; P.nodes4 = a.nodes4.p; P.primref = a.primref.p; P.spheres = a.spheres.p; P.sphere_mat = a.sphere_mat.p;
     P.cuboids = a.cuboids.p; P.cuboid_mat = a.cuboid_mat.p; P.tri_v = a.tri_v.p; P.tri_n = a.tri_n.p; P.tri_t = a.tri_t.p;
     P.vpos = a.vpos.p; P.vnorm = a.vnorm.p; P.vtex = a.vtex.p; P.leaf_soup = a.leaf_soup.p; P.chunks = a.chunks.p; P.strips = a.strips.p; P.sphere_ref_leaf = a.sphere_ref_leaf.p; P.cuboid_ref_leaf = a.cuboid_ref_leaf.p;
@@ -757,7 +751,6 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
         P.wf_levels = levels;
         P.q_ctl = c.wf_counters.p; P.q_ready = c.wf_counters.p + QC_WORDS; P.q_err = a.q_err;
         P.q_unit_tiles = levels > 1 ? unit_tiles : 1u;
-        P.q_root_lds = !ldss && a.queue_root_lds ? 1u : 0u;
         // the tile sequence: rectangles whose chunk is whole tile rows go block by block, XCD by XCD (k_queue.hip, q_seq_tile)
         P.q_order = (order_blocks && !ldss && P.mode == 0u && P.tiles_x != 0u && t0 % P.tiles_x == 0u && P.ntiles % P.tiles_x == 0u) ? 1u : 0u;
         P.q_tiles_y = P.q_order ? P.ntiles / P.tiles_x : 0u;
@@ -1227,7 +1220,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         use_device(a->device);
         const FlatScene &f = a->flat;
         TableStage stage; // (committed at the end: one allocation, one copy)
-        stage.add(a->nodes, f.nodes); stage.add(a->nodes4, f.nodes4); stage.add(a->nodes32, f.nodes32); stage.add(a->primref, f.primref); stage.add(a->spheres, f.spheres); stage.add(a->sphere_mat, f.sphere_mat);
+        stage.add(a->nodes, f.nodes); stage.add(a->nodes4, f.nodes4); stage.add(a->primref, f.primref); stage.add(a->spheres, f.spheres); stage.add(a->sphere_mat, f.sphere_mat);
         stage.add(a->cuboids, f.cuboids); stage.add(a->cuboid_mat, f.cuboid_mat); stage.add(a->tri_v, f.tri_v); stage.add(a->tri_n, f.tri_n);
         stage.add(a->tri_t, f.tri_t); stage.add(a->leaf_soup, f.leaf_soup); stage.add(a->chunks, f.chunks); stage.add(a->strips, f.strips); stage.add(a->sphere_ref_leaf, f.sphere_ref_leaf); stage.add(a->cuboid_ref_leaf, f.cuboid_ref_leaf);
         stage.add(a->tri_ref_leaf, f.tri_ref_leaf); stage.add(a->accel_ref_leaf, f.accel_ref_leaf); stage.add(a->vpos, f.vpos); stage.add(a->vnorm, f.vnorm); stage.add(a->vtex, f.vtex);
@@ -1324,14 +1317,6 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         HIP_TRY(queue_occupancy(a->stack_depth, extra_lds, &qb));
         if (const char *e = std::getenv("LASGUN_QUEUE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v < qb) qb = v; } // (diagnostic: how much the kernel gains from each resident workgroup)
         a->queue_blocks = (uint32_t)((qb < 1 ? 1 : qb) * cus);
-        {   // the root ray in LDS (walk.h, RLDS): when twelve more words per lane leave as many workgroups on a CU; LASGUN_QUEUE_ROOT_LDS=0|1: A/B
-            int qb2 = 0;
-            HIP_TRY(queue_occupancy(a->stack_depth + 12u, extra_lds, &qb2));
-            a->queue_root_lds = qb2 >= qb && qb >= 1;
-            if (const char *e = std::getenv("LASGUN_QUEUE_ROOT_LDS")) a->queue_root_lds = a->queue_root_lds && e[0] != '0';
-            const size_t lds2 = (size_t)(a->stack_depth + 12u) * 256 * 4 + extra_lds;
-            if (a->queue_root_lds && lds2 > 64 * 1024) HIP_TRY(queue_set_lds_limit(lds2, false));
-        }
         a->cus = (uint32_t)cus;
         // LDS-resident scene: the REFERENCE tree's nodes (56 of 64 bytes, padded to 80 when that fits),
         // its primrefs, the spheres (padded to 48 when that fits) and cuboids, behind 1024 per-lane
@@ -1473,7 +1458,7 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     using std::swap;
     swap(x.flat, y.flat);
     swap(x.arena, y.arena); swap(x.stats, y.stats); // (the counters' record is a view into the arena like the small tables)
-    swap(x.nodes, y.nodes); swap(x.nodes4, y.nodes4); swap(x.nodes32, y.nodes32); swap(x.primref, y.primref); swap(x.spheres, y.spheres); swap(x.sphere_mat, y.sphere_mat);
+    swap(x.nodes, y.nodes); swap(x.nodes4, y.nodes4); swap(x.primref, y.primref); swap(x.spheres, y.spheres); swap(x.sphere_mat, y.sphere_mat);
     swap(x.cuboids, y.cuboids); swap(x.cuboid_mat, y.cuboid_mat); swap(x.tri_v, y.tri_v); swap(x.tri_n, y.tri_n); swap(x.tri_t, y.tri_t);
     swap(x.vpos, y.vpos); swap(x.vnorm, y.vnorm); swap(x.vtex, y.vtex); swap(x.leaf_soup, y.leaf_soup); swap(x.chunks, y.chunks); swap(x.strips, y.strips);
     swap(x.sphere_ref_leaf, y.sphere_ref_leaf); swap(x.cuboid_ref_leaf, y.cuboid_ref_leaf); swap(x.tri_ref_leaf, y.tri_ref_leaf); swap(x.accel_ref_leaf, y.accel_ref_leaf);
@@ -1483,7 +1468,7 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.lds_soup_off, y.lds_soup_off); swap(x.lds_accel_off, y.lds_accel_off);
     swap(x.ldss_blocks, y.ldss_blocks); swap(x.cus, y.cus);
     swap(x.stack_depth, y.stack_depth); swap(x.stack_depth_fast1, y.stack_depth_fast1); swap(x.max_blocks, y.max_blocks); swap(x.max_blocks_fast, y.max_blocks_fast);
-    swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast); swap(x.queue_blocks, y.queue_blocks); swap(x.queue_root_lds, y.queue_root_lds);
+    swap(x.wf_blocks, y.wf_blocks); swap(x.wf_blocks_fast, y.wf_blocks_fast); swap(x.queue_blocks, y.queue_blocks);
     swap(x.queue_default, y.queue_default); swap(x.prune_default, y.prune_default); swap(x.queue_min_items, y.queue_min_items); swap(x.specular_small_items, y.specular_small_items);
     swap(x.device_bytes, y.device_bytes); swap(x.fast_available, y.fast_available); swap(x.fast_refusal, y.fast_refusal);
     swap(x.streaming_pays, y.streaming_pays); swap(x.streaming_min_items, y.streaming_min_items); swap(x.mega_narrow, y.mega_narrow);
@@ -2107,28 +2092,6 @@ int lg_host_check_wide_records(const lg_scene *s, uint64_t out[8]) {
         flatten_scene(s->s, flat, true);
         for (int k = 0; k < 8; ++k) out[k] = 0;
         out[5] = flat.max_stack_fast1;
-        // the 32-byte records of the reference trees (DNode32, AF_NODES32), with the fast trees interleaved in the node table: every node the
-        // reference walk can reach from the accel's root must be there with the DNode's own values -- out[6] checked, out[7] wrong
-        for (const DAccel &A : flat.accels) {
-            if (!(A.flags & AF_NODES32)) continue;
-            std::vector<uint32_t> todo{0u};
-            while (!todo.empty()) {
-                const uint32_t i = todo.back(); todo.pop_back();
-                const DNode &d = flat.nodes[A.node_base + i];
-                bool ok = A.node_base + i < flat.nodes32.size();
-                if (ok) {
-                    const DNode32 &q = flat.nodes32[A.node_base + i];
-                    for (int k = 0; k < 3; ++k) ok = ok && (double)q.bmin[k] == d.bmin[k] && (double)q.bmax[k] == d.bmax[k];
-                    ok = ok && q.link == d.link && q.meta == d.meta;
-                }
-                out[6]++;
-                if (!ok) {
-                    out[7]++;
-                    if (std::getenv("LASGUN_DEBUG")) std::fprintf(stderr, "[lasgun] nodes32 mismatch: accel node_base %u fnode_base %u node %u (table sizes %zu / %zu), meta %x link %u\n", A.node_base, A.fnode_base, i, flat.nodes.size(), flat.nodes32.size(), d.meta, d.link);
-                }
-                if (!(d.meta & NODE_LEAF)) { todo.push_back(i + 1u); todo.push_back(d.link); }
-            }
-        }
         std::vector<uint32_t> seen_tree;
         for (const DAccel &A : flat.accels) {
             if (std::find(seen_tree.begin(), seen_tree.end(), A.fnode_base) != seen_tree.end()) continue; // (mesh instances share a tree)
@@ -2301,6 +2264,23 @@ int lg_math_eval(int op, size_t n, const double *a, const double *b, double *out
 }
 
 } // extern "C"
+
+// Diagnostic (tools/queue_levels.py): the packets each recursion level of the queue organisation's LAST launch on `hip_stream` held
+// (QC_COUNT of its control block) -- with the rays per level this says how full the 64-ray packets of the deeper levels are.
+extern "C" int lg_debug_queue_packets(const lg_accel *a, void *hip_stream, unsigned long long out[8]) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> g(a->mtx);
+        use_device(a->device);
+        HIP_TRY(hipDeviceSynchronize());
+        for (int d = 0; d < 8; ++d) out[d] = 0;
+        for (auto &c : a->ctxs) {
+            if (c->key != (hipStream_t)hip_stream || c->wf_counters.n < QC_WORDS) continue;
+            std::vector<uint32_t> w(QC_WORDS);
+            HIP_TRY(hipMemcpy(w.data(), c->wf_counters.p, QC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (uint32_t d = 0; d < QC_MAX_LEVELS; ++d) out[d] = w[QC_LEVEL0 + QC_LEVEL_WORDS * d + QC_COUNT];
+        }
+    });
+}
 
 #if defined(LG_PKT_STATS) || defined(LG_STAMPS)
 extern "C" int lg_debug_stats(const lg_accel *a, int clear, unsigned long long *out9) { // analysis builds only

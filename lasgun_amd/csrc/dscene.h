@@ -67,16 +67,6 @@ struct alignas(64) DNode {
     uint32_t pad;    // leaves of a mesh's reference tree: index of the leaf's first culling record (DChunk) | number of its records << 24
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
-// The same node in 32 bytes, for the reference trees whose box coordinates are all f32 VALUES (AF_NODES32): every mesh -- its vertices are
-// f32 (triangle.rs:40-43), a triangle's bounds are min / max of them, a node's the union -- so the widened f32 IS the f64 the reference
-// holds, bit for bit, and the slab test sees the same doubles.  Scenes whose tables stay in L2 read a node with TWO 16-byte loads instead
-// of four: the walk's node phase there waits on the vector-memory pipe (lanes at different nodes: one line each), not on arithmetic.
-// Same index as the DNode; a leaf's culling-record word stays in DNode::pad and is fetched when the leaf is opened.
-struct alignas(32) DNode32 {
-    float bmin[3], bmax[3];
-    uint32_t link, meta;
-};
-static_assert(sizeof(DNode32) == 32, "DNode32 is half a DNode");
 
 // Wide record of an INTERIOR node of a FAST tree (same index as its DNode; only the nodes a wide node was collapsed from are
 // filled in): up to WIDE children -- the node's two children with the larger ones opened in turn (host.cpp, wide_records) --
@@ -160,8 +150,7 @@ struct DLight {
     double pos[3], intensity[3], falloff[3];
 };
 
-enum AccelFlags : uint32_t { AF_SWAP_BACKFACE = 1, AF_MESH = 2, AF_HAS_N = 4, AF_HAS_UV = 8, AF_IDENTITY = 16 /* minv is exactly the identity */,
-                             AF_NODES32 = 32 /* every box coordinate of its reference tree is an f32 value: DNode32 records exist (DParams::nodes32) */ };
+enum AccelFlags : uint32_t { AF_SWAP_BACKFACE = 1, AF_MESH = 2, AF_HAS_N = 4, AF_HAS_UV = 8, AF_IDENTITY = 16 /* minv is exactly the identity */ };
 
 struct alignas(16) DAccel {
     Affine m;    // 96 B
@@ -212,7 +201,6 @@ struct DParams {
     // ---- scene tables
     const DNode *nodes;
     const DNode4 *nodes4; // fast trees: valid at the interior nodes wide records were made for
-    const DNode32 *nodes32; // reference trees of the accels flagged AF_NODES32, same indices as `nodes` (nullptr: none)
     const uint32_t *primref;
     const DSphere *spheres;
     const int32_t *sphere_mat;
@@ -305,7 +293,6 @@ struct DParams {
     uint32_t *q_ctl;
     uint32_t *q_ready;
     uint32_t *q_err; // sticky error word in pinned HOST memory (capi.cpp, g_err_words): set by a wave that gave up waiting, cleared by the host alone
-    uint32_t q_root_lds; // the 256-lane queue kernel parks the root accel's ray in LDS above the stacks (walk.h, RLDS) instead of in scratch
     uint32_t q_units, q_unit_tiles; // level 0's work items: units of q_unit_tiles consecutive 8x8 tiles of the tile SEQUENCE
     // the tile sequence: q_order 0 = the tiles in row order (any addressing mode); 1 (rectangles) = blocks of 32 x 32 tiles in row
     // order, Morton order inside a block, the sequence cut into 8 contiguous bands claimed XCD by XCD (k_queue.hip, q_seq_tile)

@@ -1400,38 +1400,6 @@ void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     for (const DNode &nd : out.nodes)
         for (int k = 0; k < 3; ++k) // finite AND ordered: slab_intersects_sg takes the near / far plane from the ray's sign, which is the reference's min / max only for bmin <= bmax
             out.boxes_finite = out.boxes_finite && std::isfinite(nd.bmin[k]) && std::isfinite(nd.bmax[k]) && nd.bmin[k] <= nd.bmax[k];
-    {   // 32-byte node records for the reference trees whose boxes are f32 values (dscene.h, DNode32): every mesh
-        std::vector<uint32_t> starts;
-        for (const DAccel &A : out.accels) { starts.push_back(A.node_base); starts.push_back(A.fnode_base); }
-        std::sort(starts.begin(), starts.end());
-        bool any = false;
-        for (DAccel &A : out.accels) {
-            auto it = std::upper_bound(starts.begin(), starts.end(), A.node_base);
-            const size_t end = it == starts.end() ? out.nodes.size() : (size_t)*it;
-            bool ok = end > A.node_base;
-            for (size_t i = A.node_base; ok && i < end; ++i)
-                for (int k = 0; k < 3; ++k) {
-                    const double lo = out.nodes[i].bmin[k], hi = out.nodes[i].bmax[k];
-                    ok = ok && std::isfinite(lo) && std::isfinite(hi) && (double)(float)lo == lo && (double)(float)hi == hi &&
-                         std::signbit((float)lo) == std::signbit(lo) && std::signbit((float)hi) == std::signbit(hi);
-                }
-            if (ok) { A.flags |= AF_NODES32; any = true; }
-        }
-        if (any) {
-            out.nodes32.assign(out.nodes.size(), DNode32{});
-            for (const DAccel &A : out.accels) {
-                if (!(A.flags & AF_NODES32)) continue;
-                auto it = std::upper_bound(starts.begin(), starts.end(), A.node_base);
-                const size_t end = it == starts.end() ? out.nodes.size() : (size_t)*it;
-                for (size_t i = A.node_base; i < end; ++i) {
-                    const DNode &nd = out.nodes[i];
-                    DNode32 &q = out.nodes32[i];
-                    for (int k = 0; k < 3; ++k) { q.bmin[k] = (float)nd.bmin[k]; q.bmax[k] = (float)nd.bmax[k]; }
-                    q.link = nd.link; q.meta = nd.meta;
-                }
-            }
-        }
-    }
     out.sphere_ref_leaf.resize(out.spheres.size(), NO_HIT);
     out.cuboid_ref_leaf.resize(out.cuboids.size(), NO_HIT);
     out.tri_ref_leaf.resize(out.tri_v.size() / 3, NO_HIT);

@@ -108,7 +108,6 @@ struct Scene {
 struct FlatScene {
     std::vector<DNode> nodes;
     std::vector<DNode4> nodes4; // wide records of the fast trees' interior nodes (empty without fast trees)
-    std::vector<DNode32> nodes32; // the reference trees of the AF_NODES32 accels in 32-byte records (same indices as `nodes`; empty: no such accel)
     std::vector<uint32_t> primref;
     std::vector<DSphere> spheres;
     std::vector<int32_t> sphere_mat;

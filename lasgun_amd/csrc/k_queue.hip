@@ -141,7 +141,7 @@ __device__ __forceinline__ void q_publish(const DParams &P, uint32_t level, uint
         __hip_atomic_store(q_ready(P, level) + pkt, QR_LAST | rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool LDSS, bool PRUNE, bool RLDS = false>
+template <bool LDSS, bool PRUNE>
 __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_SIMD) queue_kernel(const DParams P) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const unsigned long long gtid = (unsigned long long)blockIdx.x * blockDim.x + tid;
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
         __syncthreads(); // the only workgroup-wide step; every wave reaches it before pulling work
         scn = dst;
     }
-    const uint4 *const arec = LDSS ? nullptr : load_accel_image(P, (P.stack_depth + (RLDS ? ROOT_FRAME_WORDS : 0u)) * LG_BLOCK); // (RLDS: the root ray's words sit between the stacks and the records)
+    const uint4 *const arec = LDSS ? nullptr : load_accel_image(P, P.stack_depth * LG_BLOCK);
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0}; (void)cnt;
     uint32_t *const ctl = P.q_ctl;
     const uint32_t levels = P.wf_levels;
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
                 }
                 Best b;
                 b.ref = NO_HIT; b.t = INFINITY; b.accel = 0u;
-                if (shadow ? hit : valid) walk<LDSS, false, PRUNE, false, RLDS>(P, tray, shadow, stack, stride, b, scn, cnt, arec);
+                if (shadow ? hit : valid) walk<LDSS, false, PRUNE>(P, tray, shadow, stack, stride, b, scn, cnt, arec);
                 if (!shadow) {
                     hit = valid && b.ref != NO_HIT;
                     if (hit) {
@@ -373,11 +373,8 @@ hipError_t launch_queue(const DParams &P, uint32_t blocks, hipStream_t stream) {
         else hipLaunchKernelGGL((queue_kernel<true, false>), dim3(blocks), dim3(LG_LDSS_BLOCK), lds, stream, P);
         return hipGetLastError();
     }
-    const size_t lds = (size_t)(P.stack_depth + (P.q_root_lds ? ROOT_FRAME_WORDS : 0u)) * LG_BLOCK * sizeof(uint32_t) + (P.accel_image ? (size_t)P.accel_image_n16 * 16u : 0u);
-    if (P.q_root_lds) { // the root ray parked in LDS (walk.h, RLDS): where twelve more words per lane keep four workgroups on a CU (capi.cpp)
-        if (P.prune) hipLaunchKernelGGL((queue_kernel<false, true, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-        else hipLaunchKernelGGL((queue_kernel<false, false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
-    } else if (P.prune) hipLaunchKernelGGL((queue_kernel<false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
+    const size_t lds = (size_t)P.stack_depth * LG_BLOCK * sizeof(uint32_t) + (P.accel_image ? (size_t)P.accel_image_n16 * 16u : 0u);
+    if (P.prune) hipLaunchKernelGGL((queue_kernel<false, true>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     else hipLaunchKernelGGL((queue_kernel<false, false>), dim3(blocks), dim3(LG_BLOCK), lds, stream, P);
     return hipGetLastError();
 }
@@ -392,10 +389,9 @@ hipError_t queue_occupancy(uint32_t stack_depth, size_t extra_lds, int *blocks_p
 }
 hipError_t queue_set_lds_limit(size_t bytes, bool ldss) {
     const void *ldss_fns[] = {reinterpret_cast<const void *>(queue_kernel<true, false>), reinterpret_cast<const void *>(queue_kernel<true, true>)};
-    const void *plain_fns[] = {reinterpret_cast<const void *>(queue_kernel<false, false>), reinterpret_cast<const void *>(queue_kernel<false, true>),
-                               reinterpret_cast<const void *>(queue_kernel<false, false, true>), reinterpret_cast<const void *>(queue_kernel<false, true, true>)};
+    const void *plain_fns[] = {reinterpret_cast<const void *>(queue_kernel<false, false>), reinterpret_cast<const void *>(queue_kernel<false, true>)};
     const void *const *fns = ldss ? ldss_fns : plain_fns;
-    for (size_t i = 0; i < (ldss ? 2u : 4u); ++i) {
+    for (size_t i = 0; i < 2; ++i) {
         hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
     }

@@ -438,22 +438,6 @@ __device__ __forceinline__ NodeRec load_node_uniform(const DParams &P, uint32_t 
     n.link = d.x; n.meta = d.y; n.parent = d.z; n.pad = d.w;
     return n;
 }
-// the 32-byte form of a node whose box coordinates are f32 values (dscene.h, DNode32): widened, they are the reference's doubles
-__device__ __forceinline__ NodeRec node32_rec(const uint4 a, const uint4 b) {
-    NodeRec n;
-    n.bmin[0] = (double)__uint_as_float(a.x); n.bmin[1] = (double)__uint_as_float(a.y); n.bmin[2] = (double)__uint_as_float(a.z);
-    n.bmax[0] = (double)__uint_as_float(a.w); n.bmax[1] = (double)__uint_as_float(b.x); n.bmax[2] = (double)__uint_as_float(b.y);
-    n.link = b.z; n.meta = b.w; n.parent = 0u; n.pad = 0u;
-    return n;
-}
-__device__ __forceinline__ NodeRec load_node32(const DParams &P, uint32_t idx) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(P.nodes32 + idx);
-    return node32_rec(q[0], q[1]);
-}
-__device__ __forceinline__ NodeRec load_node32_uniform(const DParams &P, uint32_t idx) { // (idx: the same for every active lane)
-    lg_const_u4 q = (lg_const_u4)(uintptr_t)(P.nodes32 + idx);
-    return node32_rec(load_const_u4(q, 0), load_const_u4(q, 1));
-}
 template <bool LDSS>
 __device__ __forceinline__ uint32_t load_primref(const DParams &P, const uint4 *scn, uint32_t i) {
     if (LDSS) return reinterpret_cast<const uint32_t *>(scn + P.lds_prim_off)[i];
@@ -1065,12 +1049,7 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 // COUNT: the counting instantiation (lg_capture_stats, lg_trace_pixel): the same walk, plus the deterministic work
 // counters and, for lg_trace_pixel, an event log -- 2.x node tested (.1 = taken), 3.x primitive tested (.1 = accepted),
 // 4 accel entered, 5 returned to the parent, 6 triangle accepted.
-// RLDS (round 5; k_queue.hip): the root accel's ray -- live for the whole walk, read only when a lane comes back to the root level, and
-// under the 128-register budget of the 256-lane kernels kept in scratch -- is parked in the lane's LDS column instead (origin and
-// direction: twelve words above the stack, entry i of lane t at dword i * stride + t like every stack entry: conflict-free) and its
-// reciprocal direction is formed again on return by the same IEEE divisions Ray::new made it with (ray.rs:28-33): the same doubles.
-constexpr uint32_t ROOT_FRAME_WORDS = 12u;
-template <bool LDSS, bool FAST = false, bool PRUNE = false, bool COUNT = false, bool RLDS = false>
+template <bool LDSS, bool FAST = false, bool PRUNE = false, bool COUNT = false>
 __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
                                              Best &best, const uint4 *scn, bool &tie, Counters &cnt, const uint4 *arec_in = nullptr) {
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
@@ -1093,15 +1072,6 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     Ray root = wray;
     if (!((L.flags & AF_IDENTITY) && ray_plain(wray))) root = accel_local_ray<LDSS>(P, arec, 0u, wray);
     Ray ray = root;
-    uint32_t *const rootf = stack + P.stack_depth * stride; // RLDS: the root ray's twelve words, above the stack's entries
-    if (RLDS) {
-        const double v[6] = {root.o.x, root.o.y, root.o.z, root.d.x, root.d.y, root.d.z};
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            rootf[(2 * k) * stride] = (uint32_t)__double2loint(v[k]);
-            rootf[(2 * k + 1) * stride] = (uint32_t)__double2hiint(v[k]);
-        }
-    }
     double dd = dot(ray.d, ray.d);      // a of every sphere's quadratic at this level
     double four_a = 4.0 * dd;           // 4.0 * a of its discriminant b*b - 4.0*a*c (core/math.rs:16: (4.0 * a) * c)
     uint32_t negmask = neg_mask_x(ray); // dir_is_neg (bvh.rs:463), + SIGNS_NOT_PLAIN
@@ -1156,8 +1126,6 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         // hipcc compares twice per trip -- one vector instruction of ~35)
         bool more_nodes = true;
         bool at_node_l = state == ST_NODE;
-        // (tables in L2: 32-byte records when every lane at a node walks an accel that has them -- a lane's level does not change inside this phase)
-        const bool n32 = !LDSS && !FAST && P.nodes32 != nullptr && __builtin_amdgcn_ballot_w64(at_node_l && !(L.flags & AF_NODES32)) == 0ull;
         while (more_nodes) {
 #ifdef LG_STAMPS
             stamp_cnt[5] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_NODE));
@@ -1177,16 +1145,14 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                     // (lanes of a coherent wave are mostly at the same node near the root: one scalar fetch then)
                     const uint32_t cur0 = __builtin_amdgcn_readfirstlane(cur);
                     NodeRec nd;
-                    const bool uni = __builtin_amdgcn_ballot_w64(cur != cur0) == 0ull;
-                    if (n32) { if (uni) nd = load_node32_uniform(P, cur0); else nd = load_node32(P, cur); }
-                    else if (uni) nd = load_node_uniform(P, cur0);
+                    if (__builtin_amdgcn_ballot_w64(cur != cur0) == 0ull) nd = load_node_uniform(P, cur0);
                     else nd = load_node<false>(P, scn, cur);
                     bmin[0] = nd.bmin[0]; bmin[1] = nd.bmin[1]; bmin[2] = nd.bmin[2]; bmax[0] = nd.bmax[0]; bmax[1] = nd.bmax[1]; bmax[2] = nd.bmax[2];
                     const bool lf = (nd.meta & NODE_LEAF) != 0u;
                     w_link = (lf ? L.prim_base : L.node_base) + nd.link;
                     w_meta = (lf ? NODE_LEAF : 1u << (nd.meta & 3u)) | (nd.meta & NODE_NOPRUNE);
                     w_end = w_link + (nd.meta & 0xFFFFu);
-                    w_chunk = cur; // (the leaf's culling-record word -- DNode::pad -- is fetched when the leaf is opened: the 32-byte records do not carry it)
+                    w_chunk = nd.pad;
                 }
                 const uint32_t popped = stk[(int)(sp - 1u) * (int)stride];
                 bool hit;
@@ -1273,7 +1239,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
         if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
             if (!FAST) tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
             bool done;
-            LeafCull lc{INFINITY, INFINITY, dd, (LDSS || !PRUNE) ? lcb : P.nodes[lcb].pad, 0.0f, 0.0f, 0.0f};
+            LeafCull lc{INFINITY, INFINITY, dd, lcb, 0.0f, 0.0f, 0.0f};
             if (PRUNE) { // the level's limits, as prune_limits made them: the dominant axis carries lb + eps * |1/d_kz|
                 const double lim = anyhit ? 1.0 : best.t;
                 lc.lb = lim + lim * PRUNE_LIMIT_REL;
@@ -1417,12 +1383,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
                 lvl_set<LDSS, FAST>(P, arec, L, parent);
                 LG_RSTAMP(2);
                 if (!(w2 & FRAME_SAME_RAY)) { // the parent's ray again: from the root's, through the same transforms
-                    if (RLDS) {
-                        double v[6];
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) v[k] = __hiloint2double((int)rootf[(2 * k + 1) * stride], (int)rootf[(2 * k) * stride]);
-                        ray = ray_new(V3{v[0], v[1], v[2]}, V3{v[3], v[4], v[5]}); // (dinv = 1 / d, as every Ray's was made)
-                    } else ray = root;
+                    ray = root;
                     for (uint32_t i = 1; i < nchain; ++i) {
                         uint32_t c, cflags; // the parent's root -> self chain, one accel at a time
                         if (LDSS || arec) {
@@ -1719,7 +1680,7 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
 //   * any-hit: an occluder counts if the reference tree would have tested it (the reference then finds it or one before it);
 //     "not occluded" stands unless a tie / NaN makes the reference's own answer depend on its visit order;
 // otherwise the ray is traced again with the reference walk over the tables in HBM / L2.
-template <bool LDSS, bool FAST, bool PRUNE = false, bool COUNT = false, bool RLDS = false>
+template <bool LDSS, bool FAST, bool PRUNE = false, bool COUNT = false>
 __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const bool anyhit, uint32_t *stack, const uint32_t stride, Best &best,
                                      const uint4 *scn, Counters &cnt, const uint4 *arec = nullptr) {
     bool tie = false;
@@ -1727,7 +1688,7 @@ __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const boo
     if (FAST) traverse_fast<COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt);
     else
 #endif
-    traverse_ref<LDSS, FAST, PRUNE, COUNT, RLDS>(P, ray, anyhit, stack, stride, best, scn, tie, cnt, arec);
+    traverse_ref<LDSS, FAST, PRUNE, COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt, arec);
     if (!FAST) return;
     if (COUNT) dbg_event(P, 9.0, tie ? 1.0 : 0.0, best.t, (double)best.ref);
     bool redo;

@@ -63,11 +63,6 @@ def test_wide_records_of_the_fast_trees_cover_their_binary_trees(name):
     assert r["violations"] == 0, r
     assert r["children"] >= 2 * r["records"] and r["children"] <= 4 * r["records"]
     assert r["deepest_stack"] <= r["reserved_stack"], r
-    # the 32-byte records of the reference trees whose boxes are f32 values (DNode32; every mesh): with the fast trees interleaved in the node
-    # table, every node the reference walk reaches from an accel's root carries the DNode's own box, link and meta words
-    assert r["nodes32_wrong"] == 0, r
-    if "mesh" in name:
-        assert r["nodes32_checked"] > 0, r
     if name == "mesh_100k":
         assert r["leaves"] > 20000 and r["children"] > 2.5 * r["records"], r
 
