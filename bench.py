@@ -24,7 +24,7 @@ Prints ONE JSON line on rank 0.
                 over the kernel's average duration, against 256 CUs x 4 SIMDs x 16 f64 lanes x 2.4 GHz).  The
                 SURVEY 8(d) byte figure is kept beside it (`hbm_algorithmic`: those bytes are served by the LDS-resident
                 scene and never reach HBM) together with the box's measured HBM copy rate and the LDS fraction (`lds`).
-  traffic       HBM bytes per launch of that kernel from rocprofv3 PMC passes of THIS source (profiles/r04_pmc.json
+  traffic       HBM bytes per launch of that kernel from rocprofv3 PMC passes of THIS source (profiles/rNN_pmc.json
                 records the hash of the device sources it was collected on); null when they have changed since.
   cpu_baseline  the CPU oracle (a port: the Rust reference cannot be built here) timed on a bounded strided sample
                 of the same frame on this box's host cores (rank 0, N = 1 only).
@@ -171,13 +171,15 @@ def oracle_sample_check(width, height, gpu_film, n, build=None):
 def profiled_traffic(kernel_name, world, size):
     """HBM bytes per launch of `kernel_name` from the committed PMC passes, only if they were collected on these sources."""
     try:
+        import glob
         import lasgun_amd
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
         sha = lasgun_amd.device_source_sha16()
-        t = pmc["kernels"].get(kernel_name)
-        if t and pmc.get("device_source_sha16") == sha and world == 1 and size == 4096:
-            # FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): doubled; both in KB
-            return (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0, "profiles/r04_pmc.json @ device sources " + sha
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_pmc.json")), reverse=True):  # the newest round's passes first
+            pmc = json.load(open(path))
+            t = pmc["kernels"].get(kernel_name)
+            if t and pmc.get("device_source_sha16") == sha and world == 1 and size == 4096:
+                # FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): doubled; both in KB
+                return (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0, "profiles/%s @ device sources %s" % (os.path.basename(path), sha)
     except (OSError, KeyError, ValueError):
         pass
     return None, None

@@ -7,9 +7,9 @@ import os
 import statistics
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final4"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final5"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r05"
 
 
 def newest(pattern):
@@ -58,4 +58,13 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         for c, vals in cs.items():
             out["kernels"].setdefault(k, {})[c] = statistics.median(vals)
 json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+# the other outputs of tools/final_profile.sh, under the round's tag
+import shutil
+for name in ("bench.json", "configs_parity.jsonl", "configs_fast.jsonl", "configs_megakernel.jsonl", "configs_wavefront.jsonl", "configs_queue.jsonl",
+             "configs_unpruned.jsonl", "configs_pruned.jsonl", "share_time.jsonl", "multi_2x_same_device.json", "multi_2x_same_device_rccl.json",
+             "config4_pmc.txt", "config5_pmc.txt", "progressive.jsonl", "org_choice.jsonl", "host_capture.json", "host_capture_one_band.json",
+             "queue_levels.jsonl", "prune_audit.jsonl"):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copyfile(f, os.path.join(dst, tag + "_" + name))
 print(json.dumps(out, indent=1, sort_keys=True)[:3000])
