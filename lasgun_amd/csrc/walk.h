@@ -762,7 +762,8 @@ __device__ __forceinline__ uint32_t coop_scan(uint32_t x, uint32_t lane, uint32_
 // One pass of the pooled work: lane w takes item g0 + w.  `first` / `n`: this lane's offer (n items starting at pooled index first).
 // Through `heads` -- 64 words of LDS of the wave's own -- every offer that begins (or continues) in the pass marks its first lane; a
 // lane's owner is the last mark at or below it.  Returns false for a lane beyond the pool's end.
-__device__ __forceinline__ bool coop_pass(volatile uint32_t *heads, uint32_t lane, uint32_t g0, uint32_t first, uint32_t n, uint32_t total,
+typedef volatile __attribute__((address_space(3))) uint32_t *lg_lds_vu32; // (LDS by type: a generic volatile pointer is read with flat loads)
+__device__ __forceinline__ bool coop_pass(lg_lds_vu32 heads, uint32_t lane, uint32_t g0, uint32_t first, uint32_t n, uint32_t total,
                                           uint32_t &owner, uint32_t &item) {
     heads[lane] = 0u;
     if (n != 0u && first + n > g0 && first < g0 + 64u) {
@@ -812,7 +813,7 @@ template <bool COUNT>
 __device__ __forceinline__ unsigned long long coop_cull_records(const DParams &P, uint32_t *stack, const bool client, const Ray &ray, const uint32_t kz,
                                                                 const LeafCull &lc, Counters &cnt) {
     const uint32_t lane = threadIdx.x & 63u;
-    volatile uint32_t *heads = stack - lane; // the guard word below every lane's stack (entry -1 of an empty stack: fetched, never used): 64 per wave
+    lg_lds_vu32 heads = (lg_lds_vu32)(stack - lane); // the guard word below every lane's stack (entry -1 of an empty stack: fetched, never used): 64 per wave
     const uint32_t n = client ? lc.records >> 24 : 0u;
     uint32_t total;
     const uint32_t first = coop_scan(n, lane, total);
@@ -1171,9 +1172,17 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 // COUNT: the counting instantiation (lg_capture_stats, lg_trace_pixel): the same walk, plus the deterministic work
 // counters and, for lg_trace_pixel, an event log -- 2.x node tested (.1 = taken), 3.x primitive tested (.1 = accepted),
 // 4 accel entered, 5 returned to the parent, 6 triangle accepted.
-template <bool LDSS, bool FAST = false, bool PRUNE = false, bool COUNT = false>
+// COOP (round 5): the culling records of the fat mesh leaves are tested by the wave's lanes together (coop_cull_records).  Every lane of the
+// wave must then be IN the walk -- a lane without a ray comes along with `live` false and lends itself: the callers that pass COOP call
+// the walk wave-uniformly (queue organisation, level-by-level traversal kernels; the megakernel's per-lane state machine does not).
+#if defined(LG_COOP) && !defined(LG_COOP_OFF) // (LG_COOP_OFF: the host's group-less record layout under the serial leaf loop -- an A/B)
+constexpr bool LG_COOP_ON = true;
+#else
+constexpr bool LG_COOP_ON = false;
+#endif
+template <bool LDSS, bool FAST = false, bool PRUNE = false, bool COUNT = false, bool COOP = false>
 __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
-                                             Best &best, const uint4 *scn, bool &tie, Counters &cnt, const uint4 *arec_in = nullptr) {
+                                             Best &best, const uint4 *scn, bool &tie, Counters &cnt, const uint4 *arec_in = nullptr, const bool live = true) {
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
     const uint4 *const arec = LDSS ? scn + P.lds_accel_off : (FAST ? nullptr : arec_in); // the accel records in LDS, if they are there (lvl_set)
     static_assert(!(FAST && PRUNE), "the fast mode prunes its own trees by its own rule");
@@ -1183,7 +1192,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     unsigned long long ret_acc[7] = {0, 0, 0, 0, 0, 0, 0}; // inside phase C: loop entry, frame + parent fetch, level record, ray, prune constants, next state; iterations
 #endif
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
-    if (COUNT) cnt.entries++; // the root accel
+    if (COUNT && live) cnt.entries++; // the root accel
     uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
     Lvl L;
     lvl_set<LDSS, FAST>(P, arec, L, 0u);
@@ -1198,7 +1207,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     double four_a = 4.0 * dd;           // 4.0 * a of its discriminant b*b - 4.0*a*c (core/math.rs:16: (4.0 * a) * c)
     uint32_t negmask = neg_mask_x(ray); // dir_is_neg (bvh.rs:463), + SIGNS_NOT_PLAIN
     uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0, lcb = 0;
-    uint32_t state = ST_NODE;
+    uint32_t state = live ? ST_NODE : ST_DONE;
     // ---- PRUNE: per-axis limits of the level the lane is in, and the level's margin
     V3 plim{INFINITY, INFINITY, INFINITY};
     double peps = INFINITY;
@@ -1375,7 +1384,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
             }
         }
 #ifdef LG_COOP
-        if (PRUNE && !FAST && !(COUNT && P.audit) && wave_any(mleaf)) { // the leaf's records, tested by the wave together (every lane of the wave lends itself)
+        if (COOP && PRUNE && !FAST && !(COUNT && P.audit) && wave_any(mleaf)) { // the leaf's records, tested by the wave together (every lane of the wave lends itself)
             have_kept = mleaf && lc.ekz < INFINITY && (lcb >> 24) != 0u && (lcb >> 24) <= 64u;
             if (wave_any(have_kept)) kept = coop_cull_records<COUNT>(P, stack, have_kept, ray, (uint32_t)tri.kz, lc, cnt);
         }
@@ -1813,15 +1822,16 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
 //   * any-hit: an occluder counts if the reference tree would have tested it (the reference then finds it or one before it);
 //     "not occluded" stands unless a tie / NaN makes the reference's own answer depend on its visit order;
 // otherwise the ray is traced again with the reference walk over the tables in HBM / L2.
-template <bool LDSS, bool FAST, bool PRUNE = false, bool COUNT = false>
+template <bool LDSS, bool FAST, bool PRUNE = false, bool COUNT = false, bool COOP = false>
 __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const bool anyhit, uint32_t *stack, const uint32_t stride, Best &best,
-                                     const uint4 *scn, Counters &cnt, const uint4 *arec = nullptr) {
+                                     const uint4 *scn, Counters &cnt, const uint4 *arec = nullptr, const bool live = true) {
+    static_assert(!(COOP && FAST), "the cooperative leaf belongs to the pruned reference walk");
     bool tie = false;
 #ifndef LG_FAST_ONE_NODE
     if (FAST) traverse_fast<COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt);
     else
 #endif
-    traverse_ref<LDSS, FAST, PRUNE, COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt, arec);
+    traverse_ref<LDSS, FAST, PRUNE, COUNT, COOP>(P, ray, anyhit, stack, stride, best, scn, tie, cnt, arec, live);
     if (!FAST) return;
     if (COUNT) dbg_event(P, 9.0, tie ? 1.0 : 0.0, best.t, (double)best.ref);
     bool redo;
