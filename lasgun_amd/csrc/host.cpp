@@ -1305,11 +1305,7 @@ static void build_chunks(FlatScene &out) {
         // plain runs of <= 32 consecutive triangles of the sorted set instead (<= 8 runs + 4 group records), and a mesh
         // beyond the 24-bit record index leaves its remaining leaves without records: pad = 0, and the leaf loop walks
         // such a leaf in the reference's order over the reference's soup (walk.h, mesh_leaf2).
-#ifdef LG_COOP // (the cooperative leaf, walk.h: every run record of a leaf is tested in one go by the wave's lanes: no group records)
-        auto records_of = [](size_t nruns) { return nruns; };
-#else
         auto records_of = [](size_t nruns) { return nruns + nruns / CHUNK_GROUP; }; // one record per run, one per group of CHUNK_GROUP (= 2) runs
-#endif
         if (records_of(runs.size()) > 255) {
             runs.clear();
             for (size_t r0 = 0; r0 < count; r0 += (size_t)1 << CHUNK_SHIFT) runs.emplace_back(r0, std::min(count, r0 + ((size_t)1 << CHUNK_SHIFT)));
@@ -1324,12 +1320,7 @@ static void build_chunks(FlatScene &out) {
         // stepped over whole)
         for (size_t g = 0; g < runs.size(); g += CHUNK_GROUP) {
             const size_t ge = std::min(runs.size(), g + CHUNK_GROUP);
-#ifndef LG_COOP
-            if (ge - g >= 2)
-#else
-            if (false)
-#endif
-            {
+            if (ge - g >= 2) {
                 DChunk gk = make_record(out, first + runs[g].first, first + runs[ge - 1].second);
                 gk.start = CHUNK_IS_GROUP;
                 gk.count = (uint32_t)(ge - g);

@@ -274,9 +274,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
                 }
                 Best b;
                 b.ref = NO_HIT; b.t = INFINITY; b.accel = 0u;
-                // (every lane of the wave goes into the walk: one without a ray only lends itself to the cooperative leaf, walk.h)
-                if (LG_COOP_ON && PRUNE) walk<LDSS, false, PRUNE, false, true>(P, tray, shadow, stack, stride, b, scn, cnt, arec, shadow ? hit : valid);
-                else if (shadow ? hit : valid) walk<LDSS, false, PRUNE>(P, tray, shadow, stack, stride, b, scn, cnt, arec);
+                if (shadow ? hit : valid) walk<LDSS, false, PRUNE>(P, tray, shadow, stack, stride, b, scn, cnt, arec);
                 if (!shadow) {
                     hit = valid && b.ref != NO_HIT;
                     if (hit) {

@@ -734,117 +734,6 @@ __device__ __forceinline__ bool chunk_culled(const ChunkRec &k, const Ray &ray, 
     }
     return skip;
 }
-#ifdef LG_COOP
-// ---- the cooperative leaf (round 5) ------------------------------------------------------------------------------------------------
-// Inside a fat mesh leaf a lane used to walk ITS leaf's culling records one after the other while the lanes that were not in a leaf --
-// or had done with theirs -- waited: 25 of 64 lanes took part in an average record trip.  Here the wave pools the work: every lane
-// that stands in a leaf (a "client") offers its leaf's run records, the offers are laid end to end, and the wave's 64 lanes test 64
-// (client, record) pairs per pass, each with the CLIENT's ray (fetched across lanes with ds_bpermute) -- the same test on the same
-// operands, so the same answers; which lane computes them decides nothing.  A client gets back a bit per run: kept or culled.
-// (The limit a record is tested against is the client's limit when it opened the leaf; the serial form tightened it after every hit
-// inside the leaf.  A looser limit culls less, never more: the triangle test itself still compares with the current best.)
-__device__ __forceinline__ uint32_t coop_bperm(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
-__device__ __forceinline__ double coop_bperm(uint32_t src_lane, double v) {
-    return __hiloint2double((int)coop_bperm(src_lane, (uint32_t)__double2hiint(v)), (int)coop_bperm(src_lane, (uint32_t)__double2loint(v)));
-}
-__device__ __forceinline__ float coop_bperm(uint32_t src_lane, float v) { return __uint_as_float(coop_bperm(src_lane, __float_as_uint(v))); }
-// exclusive prefix sum over the wave's lanes (inactive lanes of a divergent caller must not exist: called wave-uniformly); `total` in every lane
-__device__ __forceinline__ uint32_t coop_scan(uint32_t x, uint32_t lane, uint32_t &total) {
-    uint32_t v = x;
-#pragma unroll
-    for (uint32_t d = 1u; d < 64u; d <<= 1) {
-        const uint32_t up = coop_bperm(lane >= d ? lane - d : lane, v);
-        if (lane >= d) v += up;
-    }
-    total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-    return v - x;
-}
-// One pass of the pooled work: lane w takes item g0 + w.  `first` / `n`: this lane's offer (n items starting at pooled index first).
-// Through `heads` -- 64 words of LDS of the wave's own -- every offer that begins (or continues) in the pass marks its first lane; a
-// lane's owner is the last mark at or below it.  Returns false for a lane beyond the pool's end.
-typedef volatile __attribute__((address_space(3))) uint32_t *lg_lds_vu32; // (LDS by type: a generic volatile pointer is read with flat loads)
-__device__ __forceinline__ bool coop_pass(lg_lds_vu32 heads, uint32_t lane, uint32_t g0, uint32_t first, uint32_t n, uint32_t total,
-                                          uint32_t &owner, uint32_t &item) {
-    heads[lane] = 0u;
-    if (n != 0u && first + n > g0 && first < g0 + 64u) {
-        const uint32_t at = first > g0 ? first : g0; // where this offer's share of the pass begins
-        heads[at - g0] = (lane + 1u) | ((at - first) << 8);
-    }
-    const uint32_t mark = heads[lane];
-    const unsigned long long marks = __builtin_amdgcn_ballot_w64(mark != 0u);
-    const unsigned long long below = marks & (~0ull >> (63u - lane)); // marks at lanes <= this one
-    const uint32_t at = below != 0ull ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-    const uint32_t m = coop_bperm(at, mark);
-    owner = (m & 0xFFu) - 1u;
-    item = (m >> 8) + (lane - at);
-    return g0 + lane < total && below != 0ull;
-}
-// chunk_culled with the dominant axis as a value (the pooled test serves clients of all three)
-__device__ __forceinline__ bool chunk_culled_rt(const ChunkRec &k, const V3 o, const V3 dinv, const uint32_t kz, const double lb, const double ekz,
-                                                const float dhx, const float dhy, const float dhz) {
-    const uint4 a = k.a, b = k.b, c = k.c;
-    const double bmin[3] = {rec_f32(a.x), rec_f32(a.y), rec_f32(a.z)}, bmax[3] = {rec_f32(a.w), rec_f32(b.x), rec_f32(b.y)};
-    const float cos_t = __uint_as_float(c.y), g2 = __uint_as_float(c.z), hmin = __uint_as_float(c.w), sin_t = __uint_as_float(k.d.z);
-    const double ox = bmin[0] - o.x, px = bmax[0] - o.x, oy = bmin[1] - o.y, py = bmax[1] - o.y, oz = bmin[2] - o.z, pz = bmax[2] - o.z;
-    double t1 = ox * dinv.x, t2 = px * dinv.x;
-    const double nx = fmin_(t1, t2), fx = fmax_(t1, t2);
-    t1 = oy * dinv.y; t2 = py * dinv.y;
-    const double ny = fmin_(t1, t2), fy = fmax_(t1, t2);
-    t1 = oz * dinv.z; t2 = pz * dinv.z;
-    const double nz = fmin_(t1, t2), fz = fmax_(t1, t2);
-    const double nk = kz == 0u ? nx : kz == 1u ? ny : nz, fk = kz == 0u ? fx : kz == 1u ? fy : fz;
-    bool skip = nk > lb + ekz || fk < -ekz; // (NaN parameters compare false)
-    const float ca = fminf(fabsf((__uint_as_float(b.z) * dhx + __uint_as_float(b.w) * dhy) + __uint_as_float(c.x) * dhz), 1.0f);
-    const float sa = __builtin_amdgcn_sqrtf(fmaxf(1.0f - ca * ca, 0.0f)) * (1.0f + 4e-6f) + 1e-6f;
-    const float sigma = (ca * cos_t - sa * sin_t) - 1e-5f;
-    const float Rf = (float)((fmax_(fabs(ox), fabs(px)) + fmax_(fabs(oy), fabs(py))) + fmax_(fabs(oz), fabs(pz))) * (1.0f + 1e-6f);
-    if (sigma >= CHUNK_SIGMA_MIN && hmin * hmin * sigma >= CHUNK_HGATE * Rf * Rf) {
-        const float inv = __builtin_amdgcn_rcpf(sigma) * (1.0f + 1e-6f);
-        const double m = (double)(((CHUNK_K0 * g2) * (inv * inv * inv)) * (Rf * Rf) * (1.0f + 1e-5f));
-        const double ex = m * fabs(dinv.x), ey = m * fabs(dinv.y), ez = m * fabs(dinv.z);
-        const double tn = fmax_(fmax_(nx - ex, ny - ey), nz - ez), tf = fmin_(fmin_(fx + ex, fy + ey), fz + ez);
-        skip = skip || tn > tf || tf < 0.0 || tn > lb;
-    }
-    return skip;
-}
-// The pooled record stage.  `client`: this lane stands in a fat leaf whose records can be used (at most 64 run records); the others
-// only lend their lanes.  Returns, for a client, the mask of its leaf's runs that are KEPT (bit j: record (records & 0xFFFFFF) + j).
-template <bool COUNT>
-__device__ __forceinline__ unsigned long long coop_cull_records(const DParams &P, uint32_t *stack, const bool client, const Ray &ray, const uint32_t kz,
-                                                                const LeafCull &lc, Counters &cnt) {
-    const uint32_t lane = threadIdx.x & 63u;
-    lg_lds_vu32 heads = (lg_lds_vu32)(stack - lane); // the guard word below every lane's stack (entry -1 of an empty stack: fetched, never used): 64 per wave
-    const uint32_t n = client ? lc.records >> 24 : 0u;
-    uint32_t total;
-    const uint32_t first = coop_scan(n, lane, total);
-    const uint32_t rec0 = lc.records & 0x00FFFFFFu;
-    unsigned long long kept = 0ull;
-    for (uint32_t g0 = 0u; g0 < total; g0 += 64u) {
-        uint32_t owner, item;
-        const bool valid = coop_pass(heads, lane, g0, first, n, total, owner, item);
-        // the client's ray and limits, as the client holds them
-        const V3 o{coop_bperm(owner, ray.o.x), coop_bperm(owner, ray.o.y), coop_bperm(owner, ray.o.z)};
-        const V3 di{coop_bperm(owner, ray.dinv.x), coop_bperm(owner, ray.dinv.y), coop_bperm(owner, ray.dinv.z)};
-        const double lb = coop_bperm(owner, lc.lb), ekz = coop_bperm(owner, lc.ekz);
-        const float dhx = coop_bperm(owner, lc.dhx), dhy = coop_bperm(owner, lc.dhy), dhz = coop_bperm(owner, lc.dhz);
-        const uint32_t meta = coop_bperm(owner, rec0 | (kz << 30));
-        bool keep = false;
-        if (valid) {
-            if (COUNT) cnt.nodes++; // (a record test is counted with the node tests)
-            const ChunkRec ck = load_chunk(P.chunks + ((meta & 0x00FFFFFFu) + item));
-            keep = !chunk_culled_rt(ck, o, di, meta >> 30, lb, ekz, dhx, dhy, dhz);
-        }
-        const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
-        if (n != 0u && first + n > g0 && first < g0 + 64u) { // this client's share of the pass: lanes [at - g0, at - g0 + len)
-            const uint32_t at = first > g0 ? first : g0, end = first + n < g0 + 64u ? first + n : g0 + 64u, len = end - at;
-            const unsigned long long bits = (km >> (at - g0)) & (len >= 64u ? ~0ull : ((1ull << len) - 1ull));
-            kept |= bits << (at - first);
-        }
-    }
-    return kept;
-}
-#endif // LG_COOP
-
 // ---- audit of the pruned walk (diagnostic, counting instantiations only; lg_audit_prune) -----------------------------------------
 // Property (P) of DESIGN.md 3.4 on real data: a primitive under a node or in a run the pruned walk SKIPS must be one the reference
 // would have rejected at that moment -- `t >= isect.t` for a closest-hit ray (an exact tie inside the same fat leaf goes to the
@@ -948,7 +837,7 @@ __device__ __noinline__ void audit_run(const DParams &P, uint32_t e0, uint32_t e
 template <int KZ, bool LDSS, bool FAST = false, bool COUNT = false, bool PRUNE = false>
 __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, const Ray &ray, const TriSetup tri, uint32_t li, const uint32_t le,
                                            const uint32_t soup_delta, const uint32_t accel, const bool anyhit, Best &best, bool &tie, Counters &cnt,
-                                           LeafCull lc, unsigned long long kept = 0ull, const bool have_kept = false) {
+                                           LeafCull lc) {
     const V3 o = ray.o;
     const char *base = reinterpret_cast<const char *>(P.leaf_soup);
     constexpr uint32_t REC = (uint32_t)sizeof(DLeafRec);
@@ -1029,19 +918,7 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 #ifdef LG_STAMPS
         unsigned long long ml_cnt[6] = {0, 0, 0, 0, 1ull, (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true))};
 #endif
-#ifdef LG_COOP
-        if (have_kept) rec = rec_end; // the records were tested by the wave together (coop_cull_records): what is left is the kept runs, one after the other
-#endif
         for (;;) {
-#ifdef LG_COOP
-            if (have_kept && !in_run && kept != 0ull && !done) { // the next kept run: its strip entries from its record
-                const uint32_t j = (uint32_t)__builtin_ctzll(kept);
-                kept &= kept - 1ull;
-                const DChunk *rk = P.chunks + ((lc.records & 0x00FFFFFFu) + j);
-                const uint32_t cnt_w = rk->count, first_e = rk->pad;
-                in_run = true; s = first_e; run_end = s + (cnt_w >> 8); off = s * SREC;
-            }
-#endif
             bool seeks = !in_run && rec < rec_end; // (carried like at_node_l in traverse_ref)
             bool seeking = wave_any(seeks);
             while (seeking) {
@@ -1119,7 +996,7 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
             if (wave_any(pend != NO_HIT)) {
                 if (pend != NO_HIT) { LG_TRI_FULL(pend); pend = NO_HIT; }
             }
-            if (done) { rec = rec_end; kept = 0ull; } // an occluded any-hit ray: nothing more to find
+            if (done) rec = rec_end; // an occluded any-hit ray: nothing more to find
         }
 #ifdef LG_STAMPS
         if (P.stamp_counts && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
@@ -1172,17 +1049,9 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 // COUNT: the counting instantiation (lg_capture_stats, lg_trace_pixel): the same walk, plus the deterministic work
 // counters and, for lg_trace_pixel, an event log -- 2.x node tested (.1 = taken), 3.x primitive tested (.1 = accepted),
 // 4 accel entered, 5 returned to the parent, 6 triangle accepted.
-// COOP (round 5): the culling records of the fat mesh leaves are tested by the wave's lanes together (coop_cull_records).  Every lane of the
-// wave must then be IN the walk -- a lane without a ray comes along with `live` false and lends itself: the callers that pass COOP call
-// the walk wave-uniformly (queue organisation, level-by-level traversal kernels; the megakernel's per-lane state machine does not).
-#if defined(LG_COOP) && !defined(LG_COOP_OFF) // (LG_COOP_OFF: the host's group-less record layout under the serial leaf loop -- an A/B)
-constexpr bool LG_COOP_ON = true;
-#else
-constexpr bool LG_COOP_ON = false;
-#endif
-template <bool LDSS, bool FAST = false, bool PRUNE = false, bool COUNT = false, bool COOP = false>
+template <bool LDSS, bool FAST = false, bool PRUNE = false, bool COUNT = false>
 __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
-                                             Best &best, const uint4 *scn, bool &tie, Counters &cnt, const uint4 *arec_in = nullptr, const bool live = true) {
+                                             Best &best, const uint4 *scn, bool &tie, Counters &cnt, const uint4 *arec_in = nullptr) {
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
     const uint4 *const arec = LDSS ? scn + P.lds_accel_off : (FAST ? nullptr : arec_in); // the accel records in LDS, if they are there (lvl_set)
     static_assert(!(FAST && PRUNE), "the fast mode prunes its own trees by its own rule");
@@ -1192,7 +1061,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     unsigned long long ret_acc[7] = {0, 0, 0, 0, 0, 0, 0}; // inside phase C: loop entry, frame + parent fetch, level record, ray, prune constants, next state; iterations
 #endif
     best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
-    if (COUNT && live) cnt.entries++; // the root accel
+    if (COUNT) cnt.entries++; // the root accel
     uint32_t *const stk = stack + stride; // entry -1 of an empty stack is fetched (never used): one guard entry below
     Lvl L;
     lvl_set<LDSS, FAST>(P, arec, L, 0u);
@@ -1207,7 +1076,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     double four_a = 4.0 * dd;           // 4.0 * a of its discriminant b*b - 4.0*a*c (core/math.rs:16: (4.0 * a) * c)
     uint32_t negmask = neg_mask_x(ray); // dir_is_neg (bvh.rs:463), + SIGNS_NOT_PLAIN
     uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0, lcb = 0;
-    uint32_t state = live ? ST_NODE : ST_DONE;
+    uint32_t state = ST_NODE;
     // ---- PRUNE: per-axis limits of the level the lane is in, and the level's margin
     V3 plim{INFINITY, INFINITY, INFINITY};
     double peps = INFINITY;
@@ -1367,33 +1236,22 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
 #ifdef LG_STAMPS
         if (wave_any(state == ST_LEAF && mesh)) stamp_cnt[1] += 1;
 #endif
-        const bool mleaf = state == ST_LEAF && mesh;
-        LeafCull lc{INFINITY, INFINITY, dd, lcb, 0.0f, 0.0f, 0.0f};
-        unsigned long long kept = 0ull;
-        bool have_kept = false;
-        if (mleaf) { // every slot of a mesh accel is a triangle
+        if (state == ST_LEAF && mesh) { // every slot of a mesh accel is a triangle
             if (!FAST) tri = tri_setup(ray); // per fat leaf: amortises the three divides (triangle.rs:186-201)
+            bool done;
+            LeafCull lc{INFINITY, INFINITY, dd, lcb, 0.0f, 0.0f, 0.0f};
             if (PRUNE) { // the level's limits, as prune_limits made them: the dominant axis carries lb + eps * |1/d_kz|
                 const double lim = anyhit ? 1.0 : best.t;
                 lc.lb = lim + lim * PRUNE_LIMIT_REL;
                 lc.ekz = peps * fabs(tri.kz == 0 ? ray.dinv.x : tri.kz == 1 ? ray.dinv.y : ray.dinv.z);
-#if !defined(LG_DIR_PER_RECORD) || defined(LG_COOP)
+#ifndef LG_DIR_PER_RECORD
                 const float inv_len = __frsqrt_rn((float)dd) * (1.0f - 4e-6f);
                 lc.dhx = (float)ray.d.x * inv_len; lc.dhy = (float)ray.d.y * inv_len; lc.dhz = (float)ray.d.z * inv_len;
 #endif
             }
-        }
-#ifdef LG_COOP
-        if (COOP && PRUNE && !FAST && !(COUNT && P.audit) && wave_any(mleaf)) { // the leaf's records, tested by the wave together (every lane of the wave lends itself)
-            have_kept = mleaf && lc.ekz < INFINITY && (lcb >> 24) != 0u && (lcb >> 24) <= 64u;
-            if (wave_any(have_kept)) kept = coop_cull_records<COUNT>(P, stack, have_kept, ray, (uint32_t)tri.kz, lc, cnt);
-        }
-#endif
-        if (mleaf) {
-            bool done;
-            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc, kept, have_kept);
-            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc, kept, have_kept);
-            else done = mesh_leaf2<2, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc, kept, have_kept);
+            if (tri.kz == 0) done = mesh_leaf2<0, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
+            else if (tri.kz == 1) done = mesh_leaf2<1, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
+            else done = mesh_leaf2<2, LDSS, FAST, COUNT, PRUNE>(P, scn, ray, tri, li, le, L.soup_delta, L.accel, anyhit, best, tie, cnt, lc);
             if (FAST) limit = prune_limit(best.t, anyhit);
             if (PRUNE && !anyhit) prune_limits(best.t);
             if (done) state = ST_DONE;
@@ -1822,16 +1680,15 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
 //   * any-hit: an occluder counts if the reference tree would have tested it (the reference then finds it or one before it);
 //     "not occluded" stands unless a tie / NaN makes the reference's own answer depend on its visit order;
 // otherwise the ray is traced again with the reference walk over the tables in HBM / L2.
-template <bool LDSS, bool FAST, bool PRUNE = false, bool COUNT = false, bool COOP = false>
+template <bool LDSS, bool FAST, bool PRUNE = false, bool COUNT = false>
 __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const bool anyhit, uint32_t *stack, const uint32_t stride, Best &best,
-                                     const uint4 *scn, Counters &cnt, const uint4 *arec = nullptr, const bool live = true) {
-    static_assert(!(COOP && FAST), "the cooperative leaf belongs to the pruned reference walk");
+                                     const uint4 *scn, Counters &cnt, const uint4 *arec = nullptr) {
     bool tie = false;
 #ifndef LG_FAST_ONE_NODE
     if (FAST) traverse_fast<COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt);
     else
 #endif
-    traverse_ref<LDSS, FAST, PRUNE, COUNT, COOP>(P, ray, anyhit, stack, stride, best, scn, tie, cnt, arec, live);
+    traverse_ref<LDSS, FAST, PRUNE, COUNT>(P, ray, anyhit, stack, stride, best, scn, tie, cnt, arec);
     if (!FAST) return;
     if (COUNT) dbg_event(P, 9.0, tie ? 1.0 : 0.0, best.t, (double)best.ref);
     bool redo;
