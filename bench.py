@@ -242,8 +242,8 @@ def mesh_roofline(G, la, stream):
                            "triangles_tested": st_ref["triangles_tested"], "nodes_tested": st_ref["nodes_tested"]},
             "reference_work_rate_frac": flops_ref / (ms * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS,
             "note": "byte-identical to the oracle in tests/test_gpu_configs.py.  `frac` prices the tests the pruned walk still makes against the unfused f64 rate "
-                    "(profiles/r04_config4_pmc.txt: the kernel issues VALU instructions ~70 % of the time at ~59 % lane use -- it is bound by the instruction stream "
-                    "of its node, culling-record and triangle tests, not by L2; a triangle reached through the strips of a kept run is priced at the reference's 36 operations "
+                    "(profiles/r05_config4_pmc.txt: the kernel issues VALU instructions ~72 % of the time at ~60 % lane use; round 5's A/Bs -- DESIGN.md 3.5 -- show it "
+                    "latency-bound at four waves per SIMD rather than issue-bound: 8 % fewer VALU instructions bought 0.6 %; a triangle reached through the strips of a kept run is priced at the reference's 36 operations "
                     "although the strip answers its sign test with ~20); `plain_walk` is the same frame with every test the reference makes, "
                     "`reference_work_rate_frac` that work over the pruned walk's time (what skipping buys, not a roofline fraction)"}
 
