@@ -883,6 +883,7 @@ struct TuneKey {
     bool operator<(const TuneKey &o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
 };
 std::mutex g_tune_mtx;
+std::mutex g_tune_run_mtx; // one measurement at a time in the process: two accels of one kind measuring side by side would time each other
 std::map<TuneKey, int> &g_tuned = *new std::map<TuneKey, int>(); // never destroyed (see g_pool)
 bool autotune_enabled() {
     static const bool on = [] { const char *e = std::getenv("LASGUN_AUTOTUNE"); return !(e && e[0] == '0'); }();
@@ -916,6 +917,12 @@ static Org tuned_org(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx &c
     const Org rule = org_by_rule(a, P, false);
     const TuneKey key = tune_key(a, P);
     {
+        std::lock_guard<std::mutex> g(g_tune_mtx);
+        auto it = g_tuned.find(key);
+        if (it != g_tuned.end()) return (Org)it->second;
+    }
+    std::lock_guard<std::mutex> run(g_tune_run_mtx);
+    {   // (another accel of this kind may have measured while this one waited)
         std::lock_guard<std::mutex> g(g_tune_mtx);
         auto it = g_tuned.find(key);
         if (it != g_tuned.end()) return (Org)it->second;

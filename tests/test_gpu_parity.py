@@ -572,6 +572,32 @@ def test_capture_subsets_in_every_organisation():
         assert np.array_equal(buf.reshape(-1, 4), want), org
 
 
+def test_the_default_organisation_is_measured_once_per_kind_and_changes_no_byte():
+    """lg_accel_set_streaming(1), the default: the first launch of a kind renders with every organisation that can take it and keeps the
+    fastest for the process (capi.cpp, tuned_org); later launches -- of another accel of the same scene too -- only enqueue.  The film is
+    the oracle's whichever organisation wins, and a forced organisation is reported as such."""
+    w, h = 200, 136
+    o = oracle()
+    build = lambda api: S.kitchen_sink_scene(api, "perspective")
+    want = o.render(build(o), (w, h)).pixels()
+    names = {0: "megakernel", 2: "wavefront", 3: "queue"}
+    picked = []
+    for _ in range(3):  # three accels of one scene: one kind
+        acc = G.Accel(build(G))
+        assert G.last_organisation(acc) is None
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        assert np.array_equal(film.pixels(), want)
+        picked.append(G.last_organisation(acc))
+        assert picked[-1] in names.values()
+    assert len(set(picked)) == 1, picked  # remembered, not measured again with another outcome
+    for code, name in names.items():
+        G.set_streaming(acc, code)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        assert np.array_equal(film.pixels(), want) and G.last_organisation(acc) == name
+
+
 def test_capture_rebuilds_and_render_matches():
     w, h = 64, 48
     scene = S.simple_scene(G, 1)
