@@ -109,6 +109,17 @@ def test_fuzz_campaign(gen):
             differs = (film.pixels() != ofilm_libm.pixels()).any(axis=-1)
             if (differs & ~libm_sensitive).any():
                 done["mismatches"].append([seed, streaming, fast, packet, prune, "vs-libm"])
+        # the batched progressive entry (lg_capture_subsets, addressing mode 3): the five subsets of n = 5 in two batches are the film
+        G.set_streaming(acc, 2 if seed % 2 else 0)
+        G.set_prune(acc, None)
+        G.set_mode(acc, False)
+        buf = np.full((h, w, 4), 9, np.uint8)
+        bfilm = G.Film.new_with_output(w, h, buf)
+        G.capture_subsets([3, 0], 5, acc, bfilm)
+        G.capture_subsets([1, 4, 2], 5, acc, bfilm)
+        done["renders"] += 2
+        if not np.array_equal(buf, ofilm.pixels()):
+            done["mismatches"].append([seed, "capture_subsets"])
         if done["scenes"] % 25 == 0:
             print("fuzz %s: %d scenes, %d renders, %d mismatches" % (gen, done["scenes"], done["renders"], len(done["mismatches"])), flush=True)
     log = os.environ.get("LASGUN_FUZZ_LOG")
