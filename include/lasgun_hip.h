@@ -247,7 +247,11 @@ int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel defaul
  * runs deep levels with a few lanes per wave and the level-by-level pipeline ends every launch with its slowest wave's tail.
  * Returns non-zero (lg_last_error) for any other value. */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
-int lg_accel_last_organisation(const lg_accel *); /* what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue; -1: none yet */
+int lg_accel_last_organisation(const lg_accel *); /* what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 when its tiles were claimed bottom-up; -1: none yet */
+/* The direction in which the megakernel and the queue organisation claim a launch's 8x8 tiles: 0 = from the film's top (row order), 1 = from
+ * its bottom, -1 (default) = top-down unless the measurement above finds the other faster (a launch ends with the recursion trees of its last
+ * tiles: 6-9 % either way on scenes with mirrors / glass, profiles/r05_ab_tile_order.jsonl).  Which tile is rendered when never changes a pixel. */
+int lg_accel_set_tile_order(const lg_accel *, int order);
 
 /* The WAVEFRONT pipeline is li() level by level: per recursion level a closest-hit pass (hits compacted into a queue, misses
  * finished on the spot), an any-hit shadow pass and a shade pass that appends the specular children to the next level's ray

@@ -325,7 +325,8 @@ struct lg_accel {
     uint32_t queue_blocks = 1;                    // grid of the queue organisation's persistent kernel (256-lane form)
     mutable uint32_t *q_err = nullptr;            // the queue organisation's sticky error word (pinned host memory, g_err_words): taken at its first launch
     mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
-    mutable int last_org = -1;                    // what the last launch ran as: 0 megakernel, 1 level by level, 2 queue (lg_accel_last_organisation)
+    mutable int last_org = -1;                    // what the last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 with its tiles claimed bottom-up (lg_accel_last_organisation)
+    mutable int tile_order = -1;                  // lg_accel_set_tile_order: 0 top-down, 1 bottom-up, -1 = top-down unless the measured choice says otherwise
     bool queue_default = false;                   // glass / mirror over a big mesh: long uneven walks, sparse deep levels (k_queue.hip)
     mutable size_t queue_budget = 0;              // bytes one launch context may hold for it (0 = from the free memory at first use)
     unsigned long long queue_min_items = 1ull << 16; // launches below this many pixels stay with the megakernel
@@ -860,8 +861,9 @@ static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, 
         a.events.emplace_back(e0, e1);
     }
 }
-static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Org org, bool stats, hipStream_t stream) { // (P by value: an organisation fills in its own fields)
+static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Org org, bool rev, bool stats, hipStream_t stream) { // (P by value: an organisation fills in its own fields)
     P.tile_counter = c.tile_counter.p;
+    P.tile_rev = rev && org != ORG_WAVEFRONT ? 1u : 0u; // (the level-by-level passes are short and alike: one direction)
     if (org == ORG_QUEUE) enqueue_queue(a, P, c, stream);
     else if (org == ORG_WAVEFRONT) enqueue_wavefront(a, P, c, stream);
     else enqueue_mega(a, P, c, stats, stream);
@@ -869,19 +871,24 @@ static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Or
 
 // The MEASURED choice (round 5; the rule above was a fit to eight scenes and wrong by 6-22 % on the first scene that was not among
 // them).  Every organisation renders the same bytes, so which one runs is a question of time alone, and the answer is taken from
-// the clock: the first launch of a KIND -- the scene's shape (table sizes, lights, recursion, samples per pixel, traversal mode,
-// LDS residency), the device, the launch's size class (log2 of its pixels) and addressing mode -- renders the launch with every
-// organisation that can take it (a warm-up pass, then three timed passes over the candidates in turn, HIP events on the caller's stream, the host
-// waiting; the best of each), keeps the
-// fastest (the rule's own choice unless another beats it by 2 %) and remembers it for the process: capture() rebuilds its accel for
-// every frame (lib.rs:64), so the memory is keyed by the scene's shape, not by the accel.  The launch itself is then enqueued as
-// usual; what the measurement rendered into the caller's film are the same pixels.  Overridden by lg_accel_set_streaming(0 / 2 / 3)
-// (lg_accel_last_organisation says what a launch ran as); LASGUN_AUTOTUNE=0 keeps the rule.
+// the clock: the first launch of a KIND -- the scene's shape (table sizes, materials, lights, recursion, samples per pixel, traversal
+// mode, LDS residency), the device, the launch's size class (log2 of its pixels) and addressing mode -- renders the launch with every
+// CANDIDATE that can take it (a warm-up pass, then three timed passes over the candidates in turn, HIP events on the caller's stream,
+// the host waiting; the best of each), keeps the fastest (the rule's own choice unless another beats it by 2 %) and remembers it for
+// the process: capture() rebuilds its accel for every frame (lib.rs:64), so the memory is keyed by the scene's shape, not by the accel.
+// A candidate is an organisation and, for the megakernel and the queue organisation, the DIRECTION the launch's tiles are claimed in:
+// a launch ends with the recursion trees of its last tiles, and whether the film's top or its bottom should come last is the scene's
+// and the camera's business -- simple.rs at 9 spp and the metal torus gain 6-9 % from the bottom up, the glass torus loses 3 %
+// (profiles/r05_ab_tile_order.jsonl); which tile is rendered when never changes a pixel.  (The kind does not know the camera: a
+// direction measured for one view is kept for the next.)  The launch itself is then enqueued as usual; what the measurement rendered
+// into the caller's film are the same pixels.  Overridden by lg_accel_set_streaming(0 / 2 / 3) and lg_accel_set_tile_order
+// (lg_accel_last_organisation says what a launch ran as); LASGUN_AUTOTUNE=0 keeps the rule and the top-down direction.
 namespace {
 struct TuneKey {
     uint64_t v[12];
     bool operator<(const TuneKey &o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
 };
+constexpr int TUNE_REV = 16; // a remembered choice: organisation | TUNE_REV when the tiles go bottom-up
 std::mutex g_tune_mtx;
 std::mutex g_tune_run_mtx; // one measurement at a time in the process: two accels of one kind measuring side by side would time each other
 std::map<TuneKey, int> &g_tuned = *new std::map<TuneKey, int>(); // never destroyed (see g_pool)
@@ -910,32 +917,40 @@ static TuneKey tune_key(const lg_accel &a, const DParams &P) {
         k.v[9] = hsh ^ ((uint64_t)a.device << 56);
     }
     k.v[10] = cls;
-    k.v[11] = P.mode == 0u ? 0u : 1u;
+    k.v[11] = (P.mode == 0u ? 0u : 1u) | (a.tile_order >= 0 ? 2u + (uint64_t)a.tile_order : 0u); // (a forced direction is a kind of its own: only the organisations race)
     return k;
 }
-static Org tuned_org(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx &c, hipStream_t stream) {
+static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx &c, hipStream_t stream) {
     const Org rule = org_by_rule(a, P, false);
     const TuneKey key = tune_key(a, P);
     {
         std::lock_guard<std::mutex> g(g_tune_mtx);
         auto it = g_tuned.find(key);
-        if (it != g_tuned.end()) return (Org)it->second;
+        if (it != g_tuned.end()) return it->second;
     }
     std::lock_guard<std::mutex> run(g_tune_run_mtx);
     {   // (another accel of this kind may have measured while this one waited)
         std::lock_guard<std::mutex> g(g_tune_mtx);
         auto it = g_tuned.find(key);
-        if (it != g_tuned.end()) return (Org)it->second;
+        if (it != g_tuned.end()) return it->second;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     const bool was_profiling = a.profiling;
     a.profiling = false; // (the measurement's launches are not the caller's: lg_profile_read must not count them)
-    float best_ms[3] = {INFINITY, INFINITY, INFINITY};
-    bool in_race[3];
-    for (int org = 0; org < 3; ++org)
-        in_race[org] = org_possible(a, P, false, (Org)org) &&
-                       !(org == ORG_QUEUE && (unsigned long long)P.ntiles * 64ull < 4096ull && rule != ORG_QUEUE); // (a persistent scheduler for a handful of tiles: never ahead)
+    // candidates: [organisation][top-down, bottom-up]
+    constexpr int NC = 6;
+    float best_ms[NC];
+    bool in_race[NC];
+    const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
+    for (int k = 0; k < NC; ++k) {
+        const int org = k >> 1, rev = k & 1;
+        best_ms[k] = INFINITY;
+        in_race[k] = org_possible(a, P, false, (Org)org) &&
+                     !(org == ORG_QUEUE && items < 4096ull && rule != ORG_QUEUE) && // (a persistent scheduler for a handful of tiles: never ahead)
+                     !(rev && (org == ORG_WAVEFRONT || P.ntiles < 2u)) &&           // (one direction for the level-by-level passes and for a single tile)
+                     (a.tile_order < 0 || rev == a.tile_order);                    // (lg_accel_set_tile_order: only the organisations race)
+    }
     try {
         // pass 0 warms every candidate up (buffers, code, clocks); passes 1-3 time them IN TURN, so that a drift of the clocks or a
         // neighbour's launch hits all alike, and the best of the three counts (the persistent kernels' own run-to-run spread is ~5 %:
@@ -943,21 +958,21 @@ static Org tuned_org(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx &c
         // is 1.3 x behind after a pass is out, and launches of a quarter second measure themselves in one pass
         for (int pass = 0; pass < 4; ++pass) {
             float fastest = INFINITY;
-            for (int org = 0; org < 3; ++org) {
-                if (!in_race[org]) continue;
+            for (int k = 0; k < NC; ++k) {
+                if (!in_race[k]) continue;
                 HIP_TRY(hipEventRecord(e0, stream));
-                enqueue_org(a, P, c, (Org)org, false, stream);
+                enqueue_org(a, P, c, (Org)(k >> 1), (k & 1) != 0, false, stream);
                 HIP_TRY(hipEventRecord(e1, stream));
                 HIP_TRY(hipEventSynchronize(e1));
                 float ms = 0.0f;
                 HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-                if ((pass > 0 || ms > 250.0f) && ms < best_ms[org]) best_ms[org] = ms;
-                fastest = std::min(fastest, pass > 0 || ms > 250.0f ? best_ms[org] : ms);
+                if ((pass > 0 || ms > 250.0f) && ms < best_ms[k]) best_ms[k] = ms;
+                fastest = std::min(fastest, pass > 0 || ms > 250.0f ? best_ms[k] : ms);
             }
             int left = 0;
-            for (int org = 0; org < 3; ++org) {
-                if (in_race[org] && pass > 0 && best_ms[org] > 1.3f * fastest) in_race[org] = false;
-                left += in_race[org] ? 1 : 0;
+            for (int k = 0; k < NC; ++k) {
+                if (in_race[k] && pass > 0 && best_ms[k] > 1.3f * fastest) in_race[k] = false;
+                left += in_race[k] ? 1 : 0;
             }
             if (left <= 1 && pass > 0) break;
             if (fastest > 250.0f) break;
@@ -970,15 +985,17 @@ static Org tuned_org(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx &c
     a.profiling = was_profiling;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     check_queue_error(a);
-    int best = (int)rule;
-    for (int org = 0; org < 3; ++org)
-        if (best_ms[org] < best_ms[best] * 0.98f) best = org;
+    int best = (int)rule * 2 + (a.tile_order == 1 && rule != ORG_WAVEFRONT ? 1 : 0);
+    for (int k = 0; k < NC; ++k)
+        if (best_ms[k] < best_ms[best] * 0.98f) best = k;
+    const int choice = (best >> 1) | ((best & 1) ? TUNE_REV : 0);
     if (std::getenv("LASGUN_DEBUG"))
-        std::fprintf(stderr, "[lasgun] organisation measured for %llu pixels: megakernel %.3f ms, level by level %.3f ms, queue %.3f ms -> %d (rule: %d)\n",
-                     (unsigned long long)P.ntiles * 64ull, best_ms[0], best_ms[1], best_ms[2], best, (int)rule);
+        std::fprintf(stderr, "[lasgun] measured for %llu pixels (top-down / bottom-up): megakernel %.3f / %.3f ms, level by level %.3f ms, queue %.3f / %.3f ms -> %s%s (rule: %d)\n",
+                     items, best_ms[0], best_ms[1], best_ms[2], best_ms[4], best_ms[5], (best >> 1) == 0 ? "megakernel" : (best >> 1) == 1 ? "level by level" : "queue",
+                     (best & 1) ? ", bottom-up" : "", (int)rule);
     std::lock_guard<std::mutex> g(g_tune_mtx);
-    g_tuned[key] = best;
-    return (Org)best;
+    g_tuned[key] = choice;
+    return choice;
 }
 
 // Enqueue one render on `stream`.  Caller holds a.mtx.
@@ -987,16 +1004,21 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     check_queue_error(a); // (an earlier launch on a caller's stream that stalled: reported here at the latest)
     lg_accel::LaunchCtx &c = ctx_for(a, stream);
     Org org;
-    if (stats) org = ORG_MEGA;                                                                   // the counting variant
+    bool rev = a.tile_order == 1; // lg_accel_set_tile_order(1); -1: top-down unless measured otherwise
+    if (stats) { org = ORG_MEGA; rev = false; }                                                  // the counting variant
     else if (a.queue == 1) org = org_possible(a, P, stats, ORG_QUEUE) ? ORG_QUEUE : org_by_rule(a, P, stats); // lg_accel_set_streaming(3)
     else if (!a.streaming) org = ORG_MEGA;                                                       // lg_accel_set_streaming(0)
     else if (a.streaming_forced) org = org_possible(a, P, stats, ORG_WAVEFRONT) ? ORG_WAVEFRONT : ORG_MEGA; // lg_accel_set_streaming(2)
     else if (a.queue == 0 || !autotune_enabled()) {                                              // the fitted rule (queue ruled out by set_streaming(0 .. 2))
         org = org_by_rule(a, P, stats);
         if (a.queue == 0 && org == ORG_QUEUE) org = ORG_MEGA;
-    } else org = tuned_org(a, P, c, stream);
-    a.last_org = (int)org;
-    enqueue_org(a, P, c, org, stats, stream);
+    } else {
+        const int choice = tuned_choice(a, P, c, stream);
+        org = (Org)(choice & (TUNE_REV - 1));
+        rev = (choice & TUNE_REV) != 0;
+    }
+    a.last_org = (int)org | (rev && org != ORG_WAVEFRONT ? TUNE_REV : 0);
+    enqueue_org(a, P, c, org, rev, stats, stream);
 }
 
 static void set_rect(DParams &P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
@@ -1946,7 +1968,13 @@ int lg_accel_set_streaming(const lg_accel *a, int enabled) {
     a->queue = enabled == 3 ? 1 : enabled == 1 ? -1 : 0; // 3 = the queue organisation whatever the scene; 1 = the accel's defaults
     return 0;
 }
-int lg_accel_last_organisation(const lg_accel *a) { // what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue; -1 before the first
+int lg_accel_set_tile_order(const lg_accel *a, int order) { // the direction the megakernel and the queue organisation claim a launch's tiles in
+    std::lock_guard<std::mutex> g(a->mtx);
+    if (order < -1 || order > 1) return fail("tile order must be -1 (default: measured), 0 (top-down) or 1 (bottom-up)");
+    a->tile_order = order;
+    return 0;
+}
+int lg_accel_last_organisation(const lg_accel *a) { // what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 when its tiles were claimed bottom-up; -1 before the first
     std::lock_guard<std::mutex> g(a->mtx);
     return a->last_org;
 }

@@ -246,6 +246,7 @@ struct DParams {
     unsigned long long sub_k, sub_n, sub_count;
     uint32_t sub_m; // mode 3: how many subsets
     uint32_t ntiles;
+    uint32_t tile_rev; // the megakernel and the queue organisation claim the launch's tiles from the LAST to the first (which tile is rendered when never changes a pixel; capi.cpp, tuned_org)
     uint32_t out_row0; // row of the image stored at out_rgba[0] (0 for a full film, y0 for a row tile)
     uint32_t out_x0;   // mode 0: column of the image stored at out_rgba[0] (0 unless the output is a crop)
     uint32_t out_pitch; // mode 0: pixels per row of the output buffer (w unless the output is a crop)

@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_N
         const uint32_t tile = claim_tile_single(P.tile_counter, P.ntiles, final);
         if (tile == NO_TILE) break; // (a wave leaves here, or after one of the launch's last tiles: kcommon.h)
 
-        const Pixel px = pixel_of(P, tile, lane);
+        const Pixel px = pixel_of(P, P.tile_rev ? P.ntiles - 1u - tile : tile, lane); // (claimed from the last tile down: DParams::tile_rev)
         const uint32_t x = px.x, y = px.y;
         const bool active = px.active;
         if (!active) continue; // lanes past the edge idle for this tile

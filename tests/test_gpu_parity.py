@@ -589,13 +589,18 @@ def test_the_default_organisation_is_measured_once_per_kind_and_changes_no_byte(
         G.capture_subset(0, 1, acc, film)
         assert np.array_equal(film.pixels(), want)
         picked.append(G.last_organisation(acc))
-        assert picked[-1] in names.values()
+        assert picked[-1].split(",")[0] in names.values()  # ("megakernel, bottom-up": the direction its tiles are claimed in is measured with it)
     assert len(set(picked)) == 1, picked  # remembered, not measured again with another outcome
     for code, name in names.items():
         G.set_streaming(acc, code)
-        film = G.Film(w, h)
-        G.capture_subset(0, 1, acc, film)
-        assert np.array_equal(film.pixels(), want) and G.last_organisation(acc) == name
+        for order in (0, 1, None):  # lg_accel_set_tile_order: the tiles claimed from the film's top, from its bottom, as measured -- the same film
+            G.set_tile_order(acc, order)
+            film = G.Film(w, h)
+            G.capture_subset(0, 1, acc, film)
+            assert np.array_equal(film.pixels(), want), (name, order)
+            assert G.last_organisation(acc) == name + (", bottom-up" if order == 1 and name != "wavefront" else "")
+    with pytest.raises(la.LasgunError):
+        G.set_tile_order(acc, 2)
 
 
 def test_capture_rebuilds_and_render_matches():
