@@ -1613,7 +1613,11 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) {
             y1 = std::min(h, (uint32_t)((unsigned long long)rows8 * (j + 1) / nbands) * 8u);
         };
         hipStream_t copy_stream = nullptr;
-        std::vector<hipEvent_t> rendered;
+        struct Events { // (destroyed on every way out: an enqueue that throws must not leak the bands' events)
+            std::vector<hipEvent_t> v;
+            ~Events() { for (hipEvent_t e : v) (void)hipEventDestroy(e); }
+        } rendered_events;
+        std::vector<hipEvent_t> &rendered = rendered_events.v;
         {
             std::lock_guard<std::mutex> g(a->mtx);
             use_device(a->device);
@@ -1624,18 +1628,23 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) {
             if (nbands > 1) {
                 ensure_aux_streams(*a, 1);
                 copy_stream = a->aux_streams[0];
-                for (unsigned j = 0; j < nbands; ++j) {
-                    uint32_t y0, y1;
-                    band_rows(j, y0, y1);
-                    hipEvent_t ev = nullptr;
-                    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-                    rendered.push_back(ev);
-                    if (y1 > y0) {
-                        DParams B = P;
-                        set_rect(B, 0, y0, w, y1);
-                        enqueue(*a, B, false, a->stream);
+                try {
+                    for (unsigned j = 0; j < nbands; ++j) {
+                        uint32_t y0, y1;
+                        band_rows(j, y0, y1);
+                        hipEvent_t ev = nullptr;
+                        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                        rendered.push_back(ev);
+                        if (y1 > y0) {
+                            DParams B = P;
+                            set_rect(B, 0, y0, w, y1);
+                            enqueue(*a, B, false, a->stream);
+                        }
+                        HIP_TRY(hipEventRecord(ev, a->stream));
                     }
-                    HIP_TRY(hipEventRecord(ev, a->stream));
+                } catch (...) {
+                    (void)hipStreamSynchronize(a->stream); // (the bands already enqueued still write `buf`, which goes back to the pool on the way out)
+                    throw;
                 }
             } else {
                 if (whole) set_rect(P, 0, 0, w, h);
@@ -1657,7 +1666,6 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) {
             }
             if (err == hipSuccess) err = hipStreamSynchronize(copy_stream);
             const hipError_t err2 = hipStreamSynchronize(a->stream); // (nothing may still write `buf` when it goes back to the pool)
-            for (hipEvent_t ev : rendered) (void)hipEventDestroy(ev);
             if (err != hipSuccess || err2 != hipSuccess) throw Error(std::string("banded capture: ") + hipGetErrorString(err != hipSuccess ? err : err2));
             std::lock_guard<std::mutex> g(a->mtx);
             check_queue_error(*a);
