@@ -302,7 +302,12 @@ struct lg_accel {
         DevBuf<double> frames, stash;                          // megakernel: Whitted frame stack, parked shading frame
         DevBuf<uint8_t> wf_mem;                                // wavefront pipeline: every per-level array of a chunk, carved from one allocation
         DevBuf<uint32_t> wf_counters;                          // its queue counts and per-launch tile counters
-        DevBuf<unsigned long long> ks;                         // lg_capture_subsets: the batch's k values (addressing mode 3)
+        // lg_capture_subsets: the k tables of the batches in flight on this stream (addressing mode 3), each with the event that says
+        // its launch is through -- a table is written by a blocking copy into a buffer of its own before its launch is enqueued, so
+        // neither a later batch on the stream nor the caller's freed array can reach it
+        struct KsTable { DevBuf<unsigned long long> buf; hipEvent_t done = nullptr; };
+        std::vector<std::unique_ptr<KsTable>> ks_live;
+        ~LaunchCtx() { for (auto &k : ks_live) if (k->done) (void)hipEventDestroy(k->done); }
     };
     mutable std::vector<std::unique_ptr<LaunchCtx>> ctxs;
     // wavefront pipeline, big launches: the frame is cut into bands rendered on internal streams (each with a launch context
@@ -1062,10 +1067,26 @@ static SubsetBatch make_batch(const size_t *ks, size_t count, size_t n, uint32_t
 // the batch as addressing mode 3 on `stream` (its k table lives in the stream's launch context).  Caller holds a.mtx.
 static void set_subsets(const lg_accel &a, DParams &P, const SubsetBatch &b, hipStream_t stream) {
     lg_accel::LaunchCtx &c = ctx_for(a, stream);
-    if (c.ks.n < b.ks.size()) { HIP_TRY(hipDeviceSynchronize()); c.ks.alloc(std::max<size_t>(b.ks.size(), 256)); } // (an earlier launch may still read the old table)
-    HIP_TRY(hipMemcpyAsync(c.ks.p, b.ks.data(), b.ks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream)); // (pageable source: staged before the call returns)
-    P.mode = 3; P.pixel_list = c.ks.p; P.sub_m = (uint32_t)b.ks.size(); P.sub_n = b.n; P.sub_k = 0; P.sub_count = b.items;
+    for (size_t i = 0; i < c.ks_live.size();) { // tables whose launch is through go back to the pool
+        if (c.ks_live[i]->done && hipEventQuery(c.ks_live[i]->done) == hipSuccess) {
+            (void)hipEventDestroy(c.ks_live[i]->done);
+            c.ks_live.erase(c.ks_live.begin() + (long)i);
+        } else ++i;
+    }
+    (void)hipGetLastError(); // (hipEventQuery's "not ready" is not an error of this call)
+    c.ks_live.emplace_back(new lg_accel::LaunchCtx::KsTable());
+    lg_accel::LaunchCtx::KsTable &t = *c.ks_live.back();
+    t.buf.alloc(std::max<size_t>(b.ks.size(), 128));
+    HIP_TRY(hipMemcpy(t.buf.p, b.ks.data(), b.ks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    P.mode = 3; P.pixel_list = t.buf.p; P.sub_m = (uint32_t)b.ks.size(); P.sub_n = b.n; P.sub_k = 0; P.sub_count = b.items;
     P.ntiles = (uint32_t)((b.items + 63ull) / 64ull);
+}
+// ... and once the batch's launch is enqueued: the event that releases its table
+static void subsets_enqueued(const lg_accel &a, hipStream_t stream) {
+    lg_accel::LaunchCtx &c = ctx_for(a, stream);
+    if (c.ks_live.empty() || c.ks_live.back()->done) return;
+    HIP_TRY(hipEventCreateWithFlags(&c.ks_live.back()->done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c.ks_live.back()->done, stream));
 }
 
 template <class F> static int guarded(F f) {
@@ -1696,6 +1717,7 @@ int lg_capture_subsets_device(const size_t *ks, size_t count, size_t n, const lg
         P.out_row0 = 0;
         P.out_rgba = (uint8_t *)dev_rgba;
         enqueue(*a, P, false, (hipStream_t)hip_stream);
+        if (!b.whole) subsets_enqueued(*a, (hipStream_t)hip_stream);
     });
 }
 int lg_capture_subsets(const size_t *ks, size_t count, size_t n, const lg_accel *a, lg_film *film) {
@@ -1718,6 +1740,7 @@ int lg_capture_subsets(const size_t *ks, size_t count, size_t n, const lg_accel 
             P.out_row0 = 0;
             P.out_rgba = (uint8_t *)buf.p;
             enqueue(*a, P, false, a->stream);
+            subsets_enqueued(*a, a->stream);
             HIP_TRY(hipMemcpyAsync(host.data(), buf.p, (size_t)b.items * 4, hipMemcpyDeviceToHost, a->stream));
         }
         use_device(a->device);

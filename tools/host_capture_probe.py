@@ -14,7 +14,9 @@ import lasgun_amd as la  # noqa: E402
 G, S = la.api, la.scenes
 G.set_device(0)
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-scene = S.spheres_scene(G)
+which = sys.argv[2] if len(sys.argv) > 2 else "spheres"  # spheres (config 3) | simple (src/examples/simple.rs, 9 spp) | cornell_glass | spooky
+scene = {"spheres": lambda: S.spheres_scene(G), "simple": lambda: S.simple_scene(G, 2), "cornell_glass": lambda: S.cornell_scene(G, "glass", 2),
+         "spooky": lambda: S.spooky_scene(G)}[which]()
 
 
 def timed(fn, n=5):
@@ -29,7 +31,7 @@ def timed(fn, n=5):
     return round(min(ts), 3), round(sorted(ts)[len(ts) // 2], 3)
 
 
-out = {"size": size}
+out = {"size": size, "scene": which}
 film = G.Film.new(size, size)
 out["capture_pageable_film_ms(min,median)"] = timed(lambda: G.capture(scene, film))
 pinned = torch.empty((size, size, 4), dtype=torch.uint8, pin_memory=True)
