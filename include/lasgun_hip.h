@@ -247,11 +247,19 @@ int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel defaul
  * runs deep levels with a few lanes per wave and the level-by-level pipeline ends every launch with its slowest wave's tail.
  * Returns non-zero (lg_last_error) for any other value. */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
-int lg_accel_last_organisation(const lg_accel *); /* what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 when its tiles were claimed bottom-up; -1: none yet */
+int lg_accel_last_organisation(const lg_accel *); /* what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 when its tiles were claimed bottom-up, + 32 when the megakernel took a supersampled pixel's samples one after the other (otherwise side by side: every organisation's way since round 5); -1: none yet */
 /* The direction in which the megakernel and the queue organisation claim a launch's 8x8 tiles: 0 = from the film's top (row order), 1 = from
  * its bottom, -1 (default) = top-down unless the measurement above finds the other faster (a launch ends with the recursion trees of its last
  * tiles: 6-9 % either way on scenes with mirrors / glass, profiles/r05_ab_tile_order.jsonl).  Which tile is rendered when never changes a pixel. */
 int lg_accel_set_tile_order(const lg_accel *, int order);
+/* A supersampled pixel's samples (Camera::sample, camera.rs:113-146; integrate.rs:17-20 sums them in their order): 0 = SIDE BY SIDE -- a
+ * launch's level-0 work items are (8x8 tile, sample) pairs, every sample's li() is parked as three doubles and a resolve pass sums each
+ * pixel's samples in the reference's order, so the film is the same bytes; a 9-sample 512^2 frame then fills the machine nine times over
+ * instead of running nine thin launch chains (level by level, queue) or nine samples in a row on each wave (megakernel): 1.2 - 10 x on the
+ * reference's example scenes at their own sizes (profiles/r05_ss_par.jsonl).  1 = one sample after the other (rounds 1-4).  -1 (default) =
+ * side by side, except that the megakernel's form is one more thing the measurement above times (frames of 1024^2 and more of a cheap
+ * scene run faster with the samples in a row: a ninth of the tile claims). */
+int lg_accel_set_sample_order(const lg_accel *, int order);
 
 /* The WAVEFRONT pipeline is li() level by level: per recursion level a closest-hit pass (hits compacted into a queue, misses
  * finished on the spot), an any-hit shadow pass and a shade pass that appends the specular children to the next level's ray

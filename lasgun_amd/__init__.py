@@ -43,6 +43,7 @@ _EXTRA = {
     "accel_get_prune": (_C.c_int, [_C.c_void_p]),
     "accel_last_organisation": (_C.c_int, [_C.c_void_p]),
     "accel_set_tile_order": (_C.c_int, [_C.c_void_p, _C.c_int]),
+    "accel_set_sample_order": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_lds_scene": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_wf_split": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
@@ -99,12 +100,22 @@ class HipApi(Api):
         """What the accel's last launch ran as: "megakernel", "wavefront" (level by level), "queue"; None before the first."""
         v = self.call("accel_last_organisation", accel.h)
         name = {0: "megakernel", 1: "wavefront", 2: "queue"}.get(v & 15) if v >= 0 else None
-        return name + ", bottom-up" if name and (v & 16) else name
+        if name and (v & 16):
+            name += ", bottom-up"
+        if name and (v & 32):
+            name += ", samples in a row"
+        return name
 
     def set_tile_order(self, accel, order):
         """The direction the megakernel and the queue organisation claim a launch's tiles in: 0 top-down, 1 bottom-up, None / -1 = measured
         (include/lasgun_hip.h, lg_accel_set_tile_order).  Same bytes either way."""
         if self.call("accel_set_tile_order", accel.h, -1 if order is None else int(order)):
+            raise LasgunError(self.last_error())
+
+    def set_sample_order(self, accel, order):
+        """A supersampled pixel's samples: 0 side by side in one launch chain, 1 one after the other, None / -1 = the default (side by side;
+        the megakernel's form measured) (include/lasgun_hip.h, lg_accel_set_sample_order).  Same bytes either way."""
+        if self.call("accel_set_sample_order", accel.h, -1 if order is None else int(order)):
             raise LasgunError(self.last_error())
 
     def get_prune(self, accel):

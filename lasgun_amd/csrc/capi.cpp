@@ -27,6 +27,7 @@ hipError_t trace_occupancy(uint32_t stack_depth, bool fast, size_t extra_lds, in
 hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream);
 hipError_t launch_wf_shade(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t launch_wf_combine(const DParams &P, uint32_t blocks, hipStream_t stream);
+hipError_t launch_wf_resolve(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t wf_trace_occupancy(uint32_t stack_depth, bool fast, size_t extra_lds, int *blocks_per_cu);
 hipError_t launch_queue(const DParams &P, uint32_t blocks, hipStream_t stream);
 hipError_t queue_occupancy(uint32_t stack_depth, size_t extra_lds, int *blocks_per_cu);
@@ -331,6 +332,7 @@ struct lg_accel {
     mutable uint32_t *q_err = nullptr;            // the queue organisation's sticky error word (pinned host memory, g_err_words): taken at its first launch
     mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
     mutable int last_org = -1;                    // what the last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 with its tiles claimed bottom-up (lg_accel_last_organisation)
+    mutable int sample_order = -1;                // lg_accel_set_sample_order: 0 a pixel's samples side by side, 1 one after the other, -1 = side by side (megakernel: rule / measured)
     mutable int tile_order = -1;                  // lg_accel_set_tile_order: 0 top-down, 1 bottom-up, -1 = top-down unless the measured choice says otherwise
     bool queue_default = false;                   // glass / mirror over a big mesh: long uneven walks, sparse deep levels (k_queue.hip)
     mutable size_t queue_budget = 0;              // bytes one launch context may hold for it (0 = from the free memory at first use)
@@ -468,7 +470,13 @@ constexpr size_t WF_FULL_MIN_HOST = 48; // == WF_FULL_MIN of k_wavefront.hip
 static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c, hipStream_t stream) {
     const uint32_t levels = (a.flat.has_specular && P0.recursion > 0) ? P0.recursion + 1u : 1u;
     const uint32_t nsamples = P0.ss_root * P0.ss_root;
-    // bytes per pixel of a chunk
+    // A supersampled launch runs its samples SIDE BY SIDE (DParams::ss_par): level 0 holds pixels x samples work items, one chain of
+    // launches per chunk instead of one per sample, and a resolve pass sums each pixel's samples in their order.  The levels of a 9-sample
+    // frame are nine times as wide -- a 512^2 film of glass fills the machine at its deep levels, which one sample at a time does not.
+    // lg_accel_set_sample_order(1) / LASGUN_SS_SERIAL=1 (A/B): one chain per sample, summed as they come.
+    static const bool ss_serial = [] { const char *e = std::getenv("LASGUN_SS_SERIAL"); return e && e[0] == '1'; }();
+    const uint32_t S = nsamples > 1 && !ss_serial && a.sample_order != 1 ? nsamples : 1u; // level-0 work items per pixel
+    // bytes per level-0 work item of a chunk
     auto level_bytes = [&](uint32_t d) -> size_t {
         size_t b = 0;
         if (d >= 1) b += 6 * 8;                       // ray queue
@@ -476,9 +484,10 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
         if (d + 1 < levels) b += 8 * 8 + 2 * 4;       // children's weights and indices
         return b;
     };
-    size_t per_pixel = (nsamples > 1 ? 3 * 8 : 0);
-    for (uint32_t d = 0; d < levels; ++d) per_pixel += level_bytes(d) << d;
-    per_pixel += ((size_t)(4 + STASH_DOUBLES * 8 + 4) << (levels - 1)) * 7 / 4; // hit queue, frame, visibility of the widest level: dense part + appended part
+    size_t per_item = (nsamples > 1 ? 3 * 8 : 0);
+    for (uint32_t d = 0; d < levels; ++d) per_item += level_bytes(d) << d;
+    per_item += ((size_t)(4 + STASH_DOUBLES * 8 + 4) << (levels - 1)) * 7 / 4; // hit queue, frame, visibility of the widest level: dense part + appended part
+    const size_t per_pixel = per_item * S;
     if (a.wf_budget == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -492,7 +501,7 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
         a.wf_budget = budget < (64ull << 20) ? (64ull << 20) : budget;
     }
     unsigned long long chunk_tiles = a.wf_budget / (per_pixel * 64);
-    const unsigned long long cap_limit = (0xFFFFFFF0ull >> (levels - 1)) / 64ull; // ray indices are 32-bit
+    const unsigned long long cap_limit = (0xFFFFFFF0ull >> (levels - 1)) / (64ull * S); // ray indices are 32-bit
     if (chunk_tiles > cap_limit) chunk_tiles = cap_limit;
     if (chunk_tiles < 1) chunk_tiles = 1;
     if (chunk_tiles > P0.ntiles) chunk_tiles = P0.ntiles;
@@ -513,8 +522,8 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
     const uint32_t nlaunch = 4 * levels;
     const uint32_t CL = TILE_COUNTER_WORDS; // the queue counts (3 per level) in the first block, then a block of tile heads per launch (one head per XCD, each on a line of its own)
     auto size_chunk = [&] {
-        n0 = chunk_tiles * 64ull;
-        need = (size_t)n0 * per_pixel + 4096 * (3 * levels + 4);
+        n0 = chunk_tiles * 64ull * S;
+        need = (size_t)n0 * per_item + 4096 * (3 * levels + 4);
         hit_cap = (size_t)n0 << (levels - 1);
         hit_len = hit_cap + hit_cap / 64 * (WF_FULL_MIN_HOST - 1); // appended part: fewer than WF_FULL_MIN hits per block of 64 rays
         nchunks = (P0.ntiles + chunk_tiles - 1) / chunk_tiles;
@@ -594,7 +603,9 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
         double *const frame = K.frame, *const accum = K.accum;
         DParams P = P0;
         P.tile0 = (uint32_t)t0;
-        P.ntiles = (uint32_t)std::min<unsigned long long>(chunk_tiles, P0.ntiles - t0);
+        const uint32_t pixel_tiles = (uint32_t)std::min<unsigned long long>(chunk_tiles, P0.ntiles - t0);
+        P.ntiles = pixel_tiles * S; // level 0's work tiles
+        P.ss_par = S;
         P.n_items = n0; // stride of the sample accumulator
         P.accum = accum;
         P.wf_levels = levels;
@@ -613,7 +624,7 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
         const uint32_t flat_blocks0 = (uint32_t)(((unsigned long long)P.ntiles * 64ull + 255ull) / 256ull); // level 0: one thread per pixel
         // level-0 shade: one wave per dense tile and per tile the appended hits can fill (< WF_FULL_MIN of every 64 rays)
         const uint32_t shade_blocks0 = (uint32_t)(((unsigned long long)P.ntiles + ((unsigned long long)P.ntiles * (WF_FULL_MIN_HOST - 1) + 63ull) / 64ull + 3ull) / 4ull);
-        for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
+        for (uint32_t sidx = 0; sidx < nsamples / S; ++sidx) {
             P.sample_index = sidx;
             HIP_TRY(hipMemsetAsync(K.counters, 0, CL * (1 + nlaunch) * sizeof(uint32_t), ls));
             uint32_t launch_no = 0;
@@ -643,6 +654,11 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
                 timed(1, [&] { return launch_wf_combine(P, d == 0 ? flat_blocks0 : flat_cap, ls); });
             }
         }
+        if (S > 1) {
+            DParams R = P;
+            R.ntiles = pixel_tiles;
+            timed(1, [&] { return launch_wf_resolve(R, (uint32_t)(((unsigned long long)pixel_tiles * 64ull + 255ull) / 256ull), ls); });
+        }
     }
     for (unsigned j = 0; j < nstreams; ++j) { // join: the caller's stream continues when every band is done
         HIP_TRY(hipEventRecord(a.aux_done[j], a.aux_streams[j]));
@@ -659,6 +675,8 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
 static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c, hipStream_t stream) {
     const uint32_t levels = (a.flat.has_specular && P0.recursion > 0) ? P0.recursion + 1u : 1u;
     const uint32_t nsamples = P0.ss_root * P0.ss_root;
+    static const bool ss_serial = [] { const char *e = std::getenv("LASGUN_SS_SERIAL"); return e && e[0] == '1'; }();
+    const uint32_t S = nsamples > 1 && !ss_serial && a.sample_order != 1 ? nsamples : 1u; // samples side by side (enqueue_wavefront): level-0 tiles per pixel tile
     auto level_bytes = [&](uint32_t d) -> size_t { // per ray of level d
         size_t b = 0;
         if (d >= 1) b += 6 * 8;                       // ray queue
@@ -666,8 +684,9 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
         if (d + 1 < levels) b += 8 * 8 + 2 * 4;       // children's weights and indices
         return b;
     };
-    size_t per_pixel = (nsamples > 1 ? 3 * 8 : 0) + 1;
-    for (uint32_t d = 0; d < levels; ++d) per_pixel += level_bytes(d) << d;
+    size_t per_item = (nsamples > 1 ? 3 * 8 : 0) + 1;
+    for (uint32_t d = 0; d < levels; ++d) per_item += level_bytes(d) << d;
+    const size_t per_pixel = per_item * S;
     if (a.queue_budget == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -682,7 +701,7 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
         a.queue_budget = !from_env && budget < (64ull << 20) ? (64ull << 20) : budget;
     }
     unsigned long long chunk_tiles = a.queue_budget / (per_pixel * 64);
-    const unsigned long long cap_limit = (0xFFFFFF00ull >> (levels - 1)) / 64ull; // ray indices are 32-bit
+    const unsigned long long cap_limit = (0xFFFFFF00ull >> (levels - 1)) / (64ull * S); // ray indices are 32-bit
     if (chunk_tiles > cap_limit) chunk_tiles = cap_limit;
     if (chunk_tiles < 1) chunk_tiles = 1;
     if (chunk_tiles > P0.ntiles) chunk_tiles = P0.ntiles;
@@ -708,9 +727,9 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
     } K;
     for (;;) { // memory that is not there: halve the chunk and carve again
         try {
-            n0 = chunk_tiles * 64ull;
-            need = (size_t)n0 * per_pixel + 4096 * (4 * levels + 4);
-            nready = (size_t)chunk_tiles * ((1ull << levels) - 2ull) + (size_t)levels * QR_SLACK; // one word per packet of the levels >= 1, + slack per level
+            n0 = chunk_tiles * 64ull * S;
+            need = (size_t)n0 * per_item + 4096 * (4 * levels + 4);
+            nready = (size_t)chunk_tiles * S * ((1ull << levels) - 2ull) + (size_t)levels * QR_SLACK; // one word per packet of the levels >= 1, + slack per level
             if (c.wf_mem.n < need) { HIP_TRY(hipDeviceSynchronize()); c.wf_mem.alloc(need); }
             if (c.wf_counters.n < QC_WORDS + nready) { HIP_TRY(hipDeviceSynchronize()); c.wf_counters.alloc(QC_WORDS + nready); }
             if (P0.nlights > 0 && c.stash.n < (size_t)threads * STASH_DOUBLES) { HIP_TRY(hipDeviceSynchronize()); c.stash.alloc((size_t)threads * STASH_DOUBLES); }
@@ -751,14 +770,16 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
     for (unsigned long long t0 = 0; t0 < P0.ntiles; t0 += chunk_tiles) {
         DParams P = P0;
         P.tile0 = (uint32_t)t0;
-        P.ntiles = (uint32_t)std::min<unsigned long long>(chunk_tiles, P0.ntiles - t0);
+        const uint32_t pixel_tiles = (uint32_t)std::min<unsigned long long>(chunk_tiles, P0.ntiles - t0);
+        P.ntiles = pixel_tiles * S; // level 0's tiles
+        P.ss_par = S;
         P.n_items = n0; // SoA stride of level 0's arrays and of the sample accumulator
         P.accum = K.accum;
         P.wf_levels = levels;
         P.q_ctl = c.wf_counters.p; P.q_ready = c.wf_counters.p + QC_WORDS; P.q_err = a.q_err;
         P.q_unit_tiles = levels > 1 ? unit_tiles : 1u;
         // the tile sequence: rectangles whose chunk is whole tile rows go block by block, XCD by XCD (k_queue.hip, q_seq_tile)
-        P.q_order = (order_blocks && !ldss && P.mode == 0u && P.tiles_x != 0u && t0 % P.tiles_x == 0u && P.ntiles % P.tiles_x == 0u) ? 1u : 0u;
+        P.q_order = (order_blocks && !ldss && S == 1u && P.mode == 0u && P.tiles_x != 0u && t0 % P.tiles_x == 0u && P.ntiles % P.tiles_x == 0u) ? 1u : 0u;
         P.q_tiles_y = P.q_order ? P.ntiles / P.tiles_x : 0u;
         P.q_blocks_x = P.q_order ? (P.tiles_x + 31u) / 32u : 0u;
         P.q_seq_len = P.q_order ? P.q_blocks_x * ((P.q_tiles_y + 31u) / 32u) * 1024u : P.ntiles;
@@ -771,7 +792,7 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
         }
         const uint32_t blocks = ldss ? blocks_cap : std::min(blocks_cap, (P.q_units + 3u) / 4u);
         const size_t nready_now = nready;
-        for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
+        for (uint32_t sidx = 0; sidx < nsamples / S; ++sidx) {
             P.sample_index = sidx;
             HIP_TRY(hipMemsetAsync(c.wf_counters.p, 0, (QC_WORDS + (levels > 1 ? nready_now : 0)) * sizeof(uint32_t), stream));
             timed(4, [&] { return launch_queue(P, blocks, stream); });
@@ -782,6 +803,11 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
                 const uint32_t flat_blocks0 = (uint32_t)(((unsigned long long)P.ntiles * 64ull + 255ull) / 256ull);
                 timed(1, [&] { return launch_wf_combine(P, d == 0 ? flat_blocks0 : flat_cap, stream); });
             }
+        }
+        if (S > 1) { // a pixel's samples summed in their order (k_wavefront.hip, wf_resolve_kernel)
+            DParams R = P;
+            R.ntiles = pixel_tiles;
+            timed(1, [&] { return launch_wf_resolve(R, (uint32_t)(((unsigned long long)pixel_tiles * 64ull + 255ull) / 256ull), stream); });
         }
     }
     if (a.profiling) { HIP_TRY(hipEventRecord(e1, stream)); a.events.emplace_back(e0, e1); }
@@ -817,7 +843,33 @@ static Org org_by_rule(const lg_accel &a, const DParams &P, bool stats) {
 }
 
 // the megakernel (k_mega.hip): the whole of li() per lane
-static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, bool stats, hipStream_t stream) {
+// The megakernel with a pixel's samples SIDE BY SIDE (DParams::ss_par, enqueue_wavefront): the launch hands out (tile, sample) pairs,
+// so that a wave's share is 1 / samples of what it was and the launch's tail with it; the samples are parked (24 bytes each) and summed
+// in their order by the resolve pass.  Measured (tools/ss_probe.py, profiles/r05_ss_par.jsonl): 4- and 9-sample frames of 256^2 .. 1024^2
+// 1.2 - 10 x faster (a 512^2 film is one tile per wave of the grid: nine samples in a row on each, or nine times the tiles); frames of
+// 1024^2 and more of a cheap scene 30-50 % SLOWER (nine times the claims on one head word, 8 ns each).  So: possible while the parked
+// samples fit 1 GiB, the rule below where nothing is measured, and one more thing the measured choice times.
+constexpr unsigned long long SS_PAR_WAVES = 4;
+static bool mega_par_possible(const DParams &P, bool stats) {
+    const unsigned long long nsamples = (unsigned long long)P.ss_root * P.ss_root;
+    return nsamples > 1 && !stats && (unsigned long long)P.ntiles * 64ull * nsamples * 24ull <= (1ull << 30);
+}
+static bool mega_par_by_rule(const lg_accel &a, const DParams &P, bool stats) {
+    static const int ss_mega = [] { const char *e = std::getenv("LASGUN_SS_MEGA"); return e ? std::atoi(e) : -1; }(); // A/B: 0 never, 1 always
+    if (!mega_par_possible(P, stats) || a.sample_order == 1) return false;
+    if (a.sample_order == 0) return true;
+    const bool lds_form = !a.fast && a.lds_scene && a.ldss_blocks;
+    const unsigned long long grid_waves = lds_form ? (unsigned long long)a.ldss_blocks * (a.mega_narrow ? 12u : 16u) : (unsigned long long)(a.fast ? a.max_blocks_fast : a.max_blocks) * 4ull;
+    return ss_mega >= 0 ? ss_mega == 1 : P.ntiles < SS_PAR_WAVES * grid_waves;
+}
+static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, bool par, bool stats, hipStream_t stream) {
+    const uint32_t nsamples = P.ss_root * P.ss_root;
+    par = par && mega_par_possible(P, stats);
+    if (par) {
+        const size_t n_items = (size_t)P.ntiles * 64ull * nsamples, need = n_items * 3 * 8;
+        if (c.wf_mem.n < need) { HIP_TRY(hipDeviceSynchronize()); c.wf_mem.alloc(need); }
+        P.accum = reinterpret_cast<double *>(c.wf_mem.p); P.n_items = n_items; P.ss_par = nsamples; P.ntiles *= nsamples;
+    }
     uint32_t cap = a.fast ? a.max_blocks_fast : a.max_blocks;
     uint32_t blocks = (P.ntiles + 3u) / 4u;
     if (blocks > cap) blocks = cap;
@@ -861,17 +913,22 @@ static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, 
         HIP_TRY(hipEventRecord(e0, stream));
     }
     HIP_TRY(launch_trace(P, stats, a.fast, blocks, a.fast ? a.stack_depth_fast1 : a.stack_depth, stream));
+    if (par) {
+        DParams R = P;
+        R.ntiles = P.ntiles / nsamples; R.tile_rev = 0u;
+        HIP_TRY(launch_wf_resolve(R, (uint32_t)(((unsigned long long)R.ntiles * 64ull + 255ull) / 256ull), stream));
+    }
     if (a.profiling) {
         HIP_TRY(hipEventRecord(e1, stream));
         a.events.emplace_back(e0, e1);
     }
 }
-static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Org org, bool rev, bool stats, hipStream_t stream) { // (P by value: an organisation fills in its own fields)
+static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Org org, bool rev, bool ss_serial, bool stats, hipStream_t stream) { // (P by value: an organisation fills in its own fields)
     P.tile_counter = c.tile_counter.p;
     P.tile_rev = rev && org != ORG_WAVEFRONT ? 1u : 0u; // (the level-by-level passes are short and alike: one direction)
     if (org == ORG_QUEUE) enqueue_queue(a, P, c, stream);
     else if (org == ORG_WAVEFRONT) enqueue_wavefront(a, P, c, stream);
-    else enqueue_mega(a, P, c, stats, stream);
+    else enqueue_mega(a, P, c, !ss_serial, stats, stream);
 }
 
 // The MEASURED choice (round 5; the rule above was a fit to eight scenes and wrong by 6-22 % on the first scene that was not among
@@ -893,7 +950,8 @@ struct TuneKey {
     uint64_t v[12];
     bool operator<(const TuneKey &o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
 };
-constexpr int TUNE_REV = 16; // a remembered choice: organisation | TUNE_REV when the tiles go bottom-up
+constexpr int TUNE_REV = 16;    // a remembered choice: organisation | TUNE_REV when the tiles go bottom-up
+constexpr int TUNE_SERIAL = 32; //   | TUNE_SERIAL when the megakernel takes a pixel's samples one after the other (enqueue_mega)
 std::mutex g_tune_mtx;
 std::mutex g_tune_run_mtx; // one measurement at a time in the process: two accels of one kind measuring side by side would time each other
 std::map<TuneKey, int> &g_tuned = *new std::map<TuneKey, int>(); // never destroyed (see g_pool)
@@ -922,7 +980,7 @@ static TuneKey tune_key(const lg_accel &a, const DParams &P) {
         k.v[9] = hsh ^ ((uint64_t)a.device << 56);
     }
     k.v[10] = cls;
-    k.v[11] = (P.mode == 0u ? 0u : 1u) | (a.tile_order >= 0 ? 2u + (uint64_t)a.tile_order : 0u); // (a forced direction is a kind of its own: only the organisations race)
+    k.v[11] = (P.mode == 0u ? 0u : 1u) | (a.tile_order >= 0 ? 2u + (uint64_t)a.tile_order : 0u) | ((uint64_t)(a.sample_order + 1) << 4); // (a forced direction is a kind of its own: only the organisations race)
     return k;
 }
 static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx &c, hipStream_t stream) {
@@ -943,15 +1001,17 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     const bool was_profiling = a.profiling;
     a.profiling = false; // (the measurement's launches are not the caller's: lg_profile_read must not count them)
-    // candidates: [organisation][top-down, bottom-up]
-    constexpr int NC = 6;
+    // candidates: [organisation][samples side by side, one after the other (megakernel only)][top-down, bottom-up]
+    constexpr int NC = 12;
     float best_ms[NC];
     bool in_race[NC];
     const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
     for (int k = 0; k < NC; ++k) {
-        const int org = k >> 1, rev = k & 1;
+        const int org = k >> 2, ser = (k >> 1) & 1, rev = k & 1;
         best_ms[k] = INFINITY;
         in_race[k] = org_possible(a, P, false, (Org)org) &&
+                     (ser ? org == ORG_MEGA : (org != ORG_MEGA || mega_par_possible(P, false))) &&
+                     !(org == ORG_MEGA && mega_par_possible(P, false) && a.sample_order >= 0 && ser != a.sample_order) && // (lg_accel_set_sample_order) // (one form of the megakernel for a frame of one sample per pixel: the serial one)
                      !(org == ORG_QUEUE && items < 4096ull && rule != ORG_QUEUE) && // (a persistent scheduler for a handful of tiles: never ahead)
                      !(rev && (org == ORG_WAVEFRONT || P.ntiles < 2u)) &&           // (one direction for the level-by-level passes and for a single tile)
                      (a.tile_order < 0 || rev == a.tile_order);                    // (lg_accel_set_tile_order: only the organisations race)
@@ -966,7 +1026,7 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
             for (int k = 0; k < NC; ++k) {
                 if (!in_race[k]) continue;
                 HIP_TRY(hipEventRecord(e0, stream));
-                enqueue_org(a, P, c, (Org)(k >> 1), (k & 1) != 0, false, stream);
+                enqueue_org(a, P, c, (Org)(k >> 2), (k & 1) != 0, (k & 2) != 0, false, stream);
                 HIP_TRY(hipEventRecord(e1, stream));
                 HIP_TRY(hipEventSynchronize(e1));
                 float ms = 0.0f;
@@ -990,14 +1050,14 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     a.profiling = was_profiling;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     check_queue_error(a);
-    int best = (int)rule * 2 + (a.tile_order == 1 && rule != ORG_WAVEFRONT ? 1 : 0);
+    int best = (int)rule * 4 + (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? 2 : 0) + (a.tile_order == 1 && rule != ORG_WAVEFRONT ? 1 : 0);
     for (int k = 0; k < NC; ++k)
         if (best_ms[k] < best_ms[best] * 0.98f) best = k;
-    const int choice = (best >> 1) | ((best & 1) ? TUNE_REV : 0);
+    const int choice = (best >> 2) | ((best & 1) ? TUNE_REV : 0) | ((best & 2) ? TUNE_SERIAL : 0);
     if (std::getenv("LASGUN_DEBUG"))
-        std::fprintf(stderr, "[lasgun] measured for %llu pixels (top-down / bottom-up): megakernel %.3f / %.3f ms, level by level %.3f ms, queue %.3f / %.3f ms -> %s%s (rule: %d)\n",
-                     items, best_ms[0], best_ms[1], best_ms[2], best_ms[4], best_ms[5], (best >> 1) == 0 ? "megakernel" : (best >> 1) == 1 ? "level by level" : "queue",
-                     (best & 1) ? ", bottom-up" : "", (int)rule);
+        std::fprintf(stderr, "[lasgun] measured for %llu pixels (top-down / bottom-up): megakernel %.3f / %.3f ms (samples in a row: %.3f / %.3f), level by level %.3f ms, queue %.3f / %.3f ms -> %s%s%s (rule: %d)\n",
+                     items, best_ms[0], best_ms[1], best_ms[2], best_ms[3], best_ms[4], // (one sample per pixel: "in a row" is the megakernel) best_ms[8], best_ms[9], (best >> 2) == 0 ? "megakernel" : (best >> 2) == 1 ? "level by level" : "queue",
+                     (best & 1) ? ", bottom-up" : "", (best & 2) ? ", samples in a row" : "", (int)rule);
     std::lock_guard<std::mutex> g(g_tune_mtx);
     g_tuned[key] = choice;
     return choice;
@@ -1010,6 +1070,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     lg_accel::LaunchCtx &c = ctx_for(a, stream);
     Org org;
     bool rev = a.tile_order == 1; // lg_accel_set_tile_order(1); -1: top-down unless measured otherwise
+    bool ss_serial = !mega_par_by_rule(a, P, stats); // the megakernel's samples: by the rule unless measured
     if (stats) { org = ORG_MEGA; rev = false; }                                                  // the counting variant
     else if (a.queue == 1) org = org_possible(a, P, stats, ORG_QUEUE) ? ORG_QUEUE : org_by_rule(a, P, stats); // lg_accel_set_streaming(3)
     else if (!a.streaming) org = ORG_MEGA;                                                       // lg_accel_set_streaming(0)
@@ -1021,9 +1082,10 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         const int choice = tuned_choice(a, P, c, stream);
         org = (Org)(choice & (TUNE_REV - 1));
         rev = (choice & TUNE_REV) != 0;
+        ss_serial = (choice & TUNE_SERIAL) != 0;
     }
-    a.last_org = (int)org | (rev && org != ORG_WAVEFRONT ? TUNE_REV : 0);
-    enqueue_org(a, P, c, org, rev, stats, stream);
+    a.last_org = (int)org | (rev && org != ORG_WAVEFRONT ? TUNE_REV : 0) | (org == ORG_MEGA && ss_serial && P.ss_root > 1 ? TUNE_SERIAL : 0);
+    enqueue_org(a, P, c, org, rev, ss_serial, stats, stream);
 }
 
 static void set_rect(DParams &P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
@@ -2003,6 +2065,12 @@ int lg_accel_set_tile_order(const lg_accel *a, int order) { // the direction the
     std::lock_guard<std::mutex> g(a->mtx);
     if (order < -1 || order > 1) return fail("tile order must be -1 (default: measured), 0 (top-down) or 1 (bottom-up)");
     a->tile_order = order;
+    return 0;
+}
+int lg_accel_set_sample_order(const lg_accel *a, int order) { // a supersampled pixel's samples: side by side in one launch chain, or one after the other
+    std::lock_guard<std::mutex> g(a->mtx);
+    if (order < -1 || order > 1) return fail("sample order must be -1 (default), 0 (side by side) or 1 (one after the other)");
+    a->sample_order = order;
     return 0;
 }
 int lg_accel_last_organisation(const lg_accel *a) { // what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 when its tiles were claimed bottom-up; -1 before the first

@@ -266,6 +266,10 @@ struct DParams {
     uint32_t *vis;              // [n_items] bit l set <=> light l is visible from the hit
     double *accum;              // [3][n_items] running sum over the pixel's samples (integrate.rs:17-18)
     uint32_t sample_index;      // which supersample this pass renders
+    // the level-by-level pipeline with the samples of a pixel SIDE BY SIDE (round 5): a level-0 work tile vt is pixel tile vt / ss_par
+    // at sample vt % ss_par, every sample's li() is parked in `accum` ([3][n_items], n_items = pixel tiles * ss_par * 64) and a resolve
+    // pass sums a pixel's samples in their order (integrate.rs:17-20).  0 / 1: one sample per launch chain, `accum` the running sum.
+    uint32_t ss_par;
     // ---- wavefront pipeline: li() level by level.  Level d holds the rays of recursion depth d
     // (level 0: the chunk's pixels, dense; deeper: a compacted queue fed by the level above).  Per level: closest-hit
     // pass (misses are finished on the spot, hits are COMPACTED into a hit queue and get their shading frame), any-hit

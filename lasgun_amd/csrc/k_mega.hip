@@ -38,7 +38,10 @@ __global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_N
         const uint32_t tile = claim_tile_single(P.tile_counter, P.ntiles, final);
         if (tile == NO_TILE) break; // (a wave leaves here, or after one of the launch's last tiles: kcommon.h)
 
-        const Pixel px = pixel_of(P, P.tile_rev ? P.ntiles - 1u - tile : tile, lane); // (claimed from the last tile down: DParams::tile_rev)
+        // (claimed from the last tile down: DParams::tile_rev; samples side by side: a tile is a pixel tile at ONE of its samples, DParams::ss_par)
+        const uint32_t vtile = P.tile_rev ? P.ntiles - 1u - tile : tile;
+        uint32_t s_first;
+        const Pixel px = pixel_of(P, l0_tile(P, vtile, s_first), lane);
         const uint32_t x = px.x, y = px.y;
         const bool active = px.active;
         if (!active) continue; // lanes past the edge idle for this tile
@@ -55,7 +58,8 @@ __global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_N
         const double weight = 1. / (double)nsamples;
 
         V3 color = vzero(); // integrate.rs:17
-        for (uint32_t sidx = 0; sidx < nsamples; ++sidx) {
+        const uint32_t s_end = P.ss_par > 1u ? s_first + 1u : nsamples;
+        for (uint32_t sidx = s_first; sidx < s_end; ++sidx) {
             Ray pray; // the ray of the li() invocation being evaluated
             {
                 V3 cam_o = P.cam_origin + ((soy * P.pixel_separation) * P.cam_up) + ((sox * P.pixel_separation) * P.cam_aux);
@@ -218,6 +222,11 @@ __global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_N
                 if (finished) break;
             }
             color = color + value;
+        }
+        if (P.ss_par > 1u) { // this sample's li() (0 + value) parked; wf_resolve_kernel sums the pixel's samples in their order
+            const unsigned long long i = (unsigned long long)vtile * 64ull + lane;
+            P.accum[i] = color.x; P.accum[P.n_items + i] = color.y; P.accum[2 * P.n_items + i] = color.z;
+            continue;
         }
         color = color * weight; // integrate.rs:19
 

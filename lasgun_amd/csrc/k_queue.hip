@@ -247,9 +247,10 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
             Ray ray = ray_new(V3{0.0, 0.0, 0.0}, V3{0.0, 0.0, 1.0});
             bool valid;
             if (d == 0u) {
-                px = pixel_of(P, P.tile0 + pkt, lane);
+                uint32_t sample; // (samples side by side: a level-0 tile is a pixel tile at ONE of its samples, DParams::ss_par)
+                px = pixel_of(P, P.tile0 + l0_tile(P, pkt, sample), lane);
                 valid = px.active;
-                if (valid) ray = camera_ray(P, px.x, px.y, P.sample_index);
+                if (valid) ray = camera_ray(P, px.x, px.y, sample);
             } else {
                 valid = lane < nrays;
                 if (valid) {

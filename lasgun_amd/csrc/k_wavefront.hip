@@ -129,8 +129,10 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
             px.active = false;
             Ray ray = ray_new(V3{0.0, 0.0, 0.0}, V3{0.0, 0.0, 1.0});
             if (L0) {
-                px = pixel_of(P, P.tile0 + tile, lane);
-                if (px.active) ray = camera_ray(P, px.x, px.y, P.sample_index);
+                uint32_t sample;
+                const uint32_t ptile = l0_tile(P, tile, sample);
+                px = pixel_of(P, P.tile0 + ptile, lane);
+                if (px.active) ray = camera_ray(P, px.x, px.y, sample);
             } else if (lane < lpt && i < n_work) {
                 px.active = true;
                 ray = wf_load_ray(P, i);
@@ -228,8 +230,10 @@ __global__ void __launch_bounds__(LG_BLOCK, 3) wf_shade_kernel(const DParams P) 
             j = P.wf_hq[h];
             Ray ray;
             if (L0) {
-                px = pixel_of(P, P.tile0 + (uint32_t)(j >> 6), (uint32_t)(j & 63u));
-                ray = camera_ray(P, px.x, px.y, P.sample_index);
+                uint32_t sample;
+                const uint32_t ptile = l0_tile(P, (uint32_t)(j >> 6), sample);
+                px = pixel_of(P, P.tile0 + ptile, (uint32_t)(j & 63u));
+                ray = camera_ray(P, px.x, px.y, sample);
             } else ray = wf_load_ray(P, j);
             const unsigned long long n = P.wf_hit_stride;
             const double *f = P.frame + h;
@@ -297,7 +301,8 @@ __global__ void __launch_bounds__(LG_BLOCK) wf_combine_kernel(const DParams P) {
     for (unsigned long long j = (unsigned long long)blockIdx.x * LG_BLOCK + threadIdx.x; j < n_work; j += (unsigned long long)gridDim.x * LG_BLOCK) {
         Pixel px;
         if (level == 0u) {
-            px = pixel_of(P, P.tile0 + (uint32_t)(j >> 6), (uint32_t)(j & 63u));
+            uint32_t sample;
+            px = pixel_of(P, P.tile0 + l0_tile(P, (uint32_t)(j >> 6), sample), (uint32_t)(j & 63u));
             if (!px.active) continue;
         }
         V3 value{P.wf_out[j], P.wf_out[n + j], P.wf_out[2 * n + j]};
@@ -322,7 +327,30 @@ __global__ void __launch_bounds__(LG_BLOCK) wf_combine_kernel(const DParams P) {
 }
 
 
+// W5 (samples side by side, DParams::ss_par): a pixel's samples summed in their order, * weight, quantised (integrate.rs:16-20, img.rs:46-67).
+// P.ntiles = the chunk's PIXEL tiles; the parked li() of pixel tile t, sample s, lane l sits at accum[(t * ss_par + s) * 64 + l].
+__global__ void __launch_bounds__(LG_BLOCK) wf_resolve_kernel(const DParams P) {
+    const unsigned long long n_pix = (unsigned long long)P.ntiles * 64ull;
+    const uint32_t S = P.ss_par;
+    const double weight = 1. / (double)(P.ss_root * P.ss_root);
+    for (unsigned long long q = (unsigned long long)blockIdx.x * LG_BLOCK + threadIdx.x; q < n_pix; q += (unsigned long long)gridDim.x * LG_BLOCK) {
+        const uint32_t t = (uint32_t)(q >> 6), l = (uint32_t)(q & 63u);
+        const Pixel px = pixel_of(P, P.tile0 + t, l);
+        if (!px.active) continue;
+        V3 color = vzero();
+        for (uint32_t sidx = 0; sidx < S; ++sidx) {
+            const unsigned long long i = ((unsigned long long)t * S + sidx) * 64ull + l;
+            color = color + V3{P.accum[i], P.accum[P.n_items + i], P.accum[2 * P.n_items + i]};
+        }
+        write_pixel(P, px, color * weight);
+    }
+}
+
 // ---- host-callable launchers (used by capi.cpp)
+hipError_t launch_wf_resolve(const DParams &P, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_resolve_kernel, dim3(blocks), dim3(LG_BLOCK), 0, stream, P);
+    return hipGetLastError();
+}
 hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
     const bool ldss = P.lds_image && !fast; // LDS-resident scene: `blocks` = one workgroup per CU
     const bool l0 = !shadow && P.wf_level == 0u;

@@ -319,9 +319,31 @@ __device__ __forceinline__ void stash_get(const DParams &P, unsigned long long g
     sh.ts = cross(sh.ns, sh.ss);
 }
 
+// level 0 of the level-by-level pipeline: the pixel tile and the sample a work tile stands for (DParams::ss_par)
+__device__ __forceinline__ uint32_t l0_tile(const DParams &P, uint32_t vt, uint32_t &sample) {
+    if (P.ss_par <= 1u) { sample = P.sample_index; return vt; }
+    const uint32_t t = vt / P.ss_par;
+    sample = vt - t * P.ss_par;
+    return t;
+}
+// the film word / radiance triple of a finished pixel (img.rs:46-67)
+__device__ __forceinline__ void write_pixel(const DParams &P, const Pixel &px, V3 color) {
+    const unsigned long long pix = px.pix;
+    if (P.out_rgba) {
+        uint32_t rgba = to_byte(color.x) | (to_byte(color.y) << 8) | (to_byte(color.z) << 16) | (255u << 24);
+        reinterpret_cast<uint32_t *>(P.out_rgba)[pix] = rgba;
+    }
+    if (P.out_radiance) {
+        P.out_radiance[3 * pix] = color.x; P.out_radiance[3 * pix + 1] = color.y; P.out_radiance[3 * pix + 2] = color.z;
+    }
+}
 // integrate(): sum over the pixel's samples, then * weight; Img::set (integrate.rs:16-20, img.rs:46-67)
 __device__ __forceinline__ void finish_pixel(const DParams &P, const Pixel &px, unsigned long long widx, V3 value) {
     const uint32_t nsamples = P.ss_root * P.ss_root;
+    if (P.ss_par > 1u) { // samples side by side: this sample's li() is parked; the resolve pass sums the pixel's samples in their order
+        P.accum[widx] = value.x; P.accum[P.n_items + widx] = value.y; P.accum[2 * P.n_items + widx] = value.z;
+        return;
+    }
     V3 color = vzero();
     if (P.sample_index > 0) color = V3{P.accum[widx], P.accum[P.n_items + widx], P.accum[2 * P.n_items + widx]};
     color = color + value;
@@ -331,14 +353,7 @@ __device__ __forceinline__ void finish_pixel(const DParams &P, const Pixel &px, 
     }
     const double weight = 1. / (double)nsamples;
     color = color * weight;
-    const unsigned long long pix = px.pix;
-    if (P.out_rgba) {
-        uint32_t rgba = to_byte(color.x) | (to_byte(color.y) << 8) | (to_byte(color.z) << 16) | (255u << 24);
-        reinterpret_cast<uint32_t *>(P.out_rgba)[pix] = rgba;
-    }
-    if (P.out_radiance) {
-        P.out_radiance[3 * pix] = color.x; P.out_radiance[3 * pix + 1] = color.y; P.out_radiance[3 * pix + 2] = color.z;
-    }
+    write_pixel(P, px, color);
 }
 // li() of a hit up to its specular children: the lights in order, then the ambient term (integrate.rs:47-67).  `vis` bit l:
 // light l is visible from the hit (PointLight::sample, point.rs:49).  Shared by the level-by-level shade pass and the queue kernel.

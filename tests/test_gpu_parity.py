@@ -320,6 +320,76 @@ def test_queue_organisation_in_small_chunks():
             del os.environ["LASGUN_QUEUE_BUDGET_MB"]
 
 
+SUPERSAMPLED = {
+    "simple_ss3": (lambda api: S.simple_scene(api, 3), 104, 72),
+    "simple_reflect_ss2": (lambda api: S.simple_scene(api, 2, True), 96, 96),
+    "cornell_glass_ss2": (lambda api: S.cornell_scene(api, "glass", supersampling=2), 96, 80),
+    "kitchen_sink_ss2_rec3": (lambda api: S.kitchen_sink_scene(api, "perspective", recursion=3, supersampling=2), 88, 64),
+    "mesh_glass_ss2": (lambda api: S.mesh_scene(api, 32, 32, "glass", supersampling=2), 72, 72),
+    "ragged_ss3_13x9": (lambda api: S.cornell_scene(api, "glass", supersampling=3), 13, 9),
+}
+
+
+@pytest.mark.parametrize("name", list(SUPERSAMPLED))
+def test_a_pixels_samples_side_by_side_or_in_a_row_are_the_same_film(name):
+    """lg_accel_set_sample_order: a supersampled launch's level-0 work items as (tile, sample) pairs, every sample's li() parked and summed in
+    the reference's order by the resolve pass (integrate.rs:17-20) -- against one sample after the other (rounds 1-4) and against the oracle,
+    in every organisation: bytes, radiance bits, a strided subset, a batch of subsets."""
+    builder, w, h = SUPERSAMPLED[name]
+    o = oracle()
+    oacc = o.Accel(builder(o))
+    ofilm = o.Film(w, h)
+    o.capture_subset_mt(0, 1, oacc, ofilm, 8)
+    o.set_trig_mode(1)
+    try:
+        orad = o.capture_radiance(oacc, w, h, nthreads=8)
+    finally:
+        o.set_trig_mode(0)
+    want = ofilm.pixels().reshape(-1, 4)
+    acc = G.Accel(builder(G))
+    for org in (0, 2, 3, 1):
+        G.set_streaming(acc, org)
+        for order in (0, 1, None):
+            G.set_sample_order(acc, order)
+            film = G.Film(w, h)
+            G.capture_subset(0, 1, acc, film)
+            assert np.array_equal(film.pixels(), ofilm.pixels()), (org, order)
+            if org == 0 and order is not None:
+                assert G.last_organisation(acc) == "megakernel" + (", samples in a row" if order == 1 else "")
+            assert np.array_equal(bits(G.capture_radiance(acc, w, h)), bits(orad)), (org, order)
+            buf = np.full((h, w, 4), 7, np.uint8)
+            G.capture_subset(2, 5, acc, G.Film.new_with_output(w, h, buf))
+            G.capture_subsets((0, 3), 5, acc, G.Film.new_with_output(w, h, buf))
+            got = buf.reshape(-1, 4)
+            for k in (0, 2, 3):
+                assert np.array_equal(got[k::5], want[k::5]), (org, order, k)
+            for k in (1, 4):
+                assert np.all(got[k::5] == 7), (org, order, k)
+    with pytest.raises(la.LasgunError):
+        G.set_sample_order(acc, 2)
+
+
+def test_samples_side_by_side_in_small_chunks():
+    """The level-by-level pipeline and the queue organisation under a memory budget that cuts a supersampled film into many chunks (a chunk
+    holds pixel tiles x samples work items): same film."""
+    w, h = 168, 120
+    o = oracle()
+    builder = lambda api: S.kitchen_sink_scene(api, "perspective", recursion=3, supersampling=2)
+    ofilm = o.Film(w, h)
+    o.capture_subset_mt(0, 1, o.Accel(builder(o)), ofilm, 8)
+    for env, org in (("LASGUN_WF_BUDGET_MB", 2), ("LASGUN_QUEUE_BUDGET_MB", 3)):
+        os.environ[env] = "4"
+        try:
+            acc = G.Accel(builder(G))
+            G.set_streaming(acc, org)
+            for _ in range(2):
+                film = G.Film(w, h)
+                G.capture_subset(0, 1, acc, film)
+                assert np.array_equal(film.pixels(), ofilm.pixels()), org
+        finally:
+            del os.environ[env]
+
+
 @pytest.mark.parametrize("name", ["spheres_512", "cornell_plastic_ss1", "simple_ss2_160", "mixed_128", "instanced_mesh_176", "ragged_5x131", "one_pixel"])
 def test_streaming_pipeline_and_megakernel_agree(name):
     """The kernel organisations (and both traversal modes under each) give the same bytes and bits."""

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Supersampled frames in every organisation: the film of each against the megakernel's (bytes), and the frame time of each.
+python tools/ss_probe.py [size ...]     (LASGUN_SS_SERIAL=1: the level-by-level pipeline one sample at a time, for the A/B)"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import lasgun_amd as la  # noqa: E402
+
+G, S = la.api, la.scenes
+G.set_device(0)
+sizes = [int(a) for a in sys.argv[1:]] or [512]
+SCENES = {
+    "simple_ss3": lambda: S.simple_scene(G, 3),
+    "simple_reflect_ss3": lambda: S.simple_scene(G, 3, True),
+    "cornell_glass_ss2": lambda: S.cornell_scene(G, "glass", 2),
+    "cornell_glass_ss3": lambda: S.cornell_scene(G, "glass", 3),
+    "spooky_ss2": lambda: S.spooky_scene(G),
+    "playground_ss2": lambda: S.playground_scene(G),
+    "simplecows_ss2": lambda: S.simplecows_scene(G),
+    "kitchen_sink_ss2": lambda: S.kitchen_sink_scene(G, "perspective", 2, 2),
+    "spheres1024_ss2": lambda: S.spheres_scene(G, supersampling=2),
+    "mesh_glass_ss2": lambda: S.mesh_scene(G, supersampling=2),
+    "mesh_plastic_ss2": lambda: S.mesh_scene(G, material="plastic", supersampling=2),
+    "mixed_ss2": lambda: S.mixed_scene(G, supersampling=2),
+}
+only = os.environ.get("SS_PROBE_SCENES")
+if only:
+    SCENES = {k: v for k, v in SCENES.items() if k in only.split(",")}
+ORGS = {"megakernel": 0, "wavefront": 2, "queue": 3, "default": 1}
+
+
+def frame_ms(acc, size, dev, n=7):
+    st = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    G.capture_rows_device(acc, size, size, 0, size, dev.data_ptr(), row0=0, stream=st)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0.record()
+        G.capture_rows_device(acc, size, size, 0, size, dev.data_ptr(), row0=0, stream=st)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return round(min(ts), 3)
+
+
+for size in sizes:
+    for name, make in SCENES.items():
+        scene = make()
+        out = {"scene": name, "size": size, "ss_serial": os.environ.get("LASGUN_SS_SERIAL", "0"), "ss_mega": os.environ.get("LASGUN_SS_MEGA", "rule")}
+        ref = None
+        for org, code in ORGS.items():
+            acc = G.Accel(scene)
+            G.set_streaming(acc, code)
+            dev = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
+            out[org + "_ms"] = frame_ms(acc, size, dev)
+            if org == "default":
+                out["default_is"] = G.last_organisation(acc)
+            film = dev.cpu()
+            if ref is None:
+                ref = film
+            else:
+                out[org + "_differs"] = int((film != ref).any(dim=-1).sum())
+        print(json.dumps(out), flush=True)
