@@ -1056,7 +1056,8 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     const int choice = (best >> 2) | ((best & 1) ? TUNE_REV : 0) | ((best & 2) ? TUNE_SERIAL : 0);
     if (std::getenv("LASGUN_DEBUG"))
         std::fprintf(stderr, "[lasgun] measured for %llu pixels (top-down / bottom-up): megakernel %.3f / %.3f ms (samples in a row: %.3f / %.3f), level by level %.3f ms, queue %.3f / %.3f ms -> %s%s%s (rule: %d)\n",
-                     items, best_ms[0], best_ms[1], best_ms[2], best_ms[3], best_ms[4], // (one sample per pixel: "in a row" is the megakernel) best_ms[8], best_ms[9], (best >> 2) == 0 ? "megakernel" : (best >> 2) == 1 ? "level by level" : "queue",
+                     items, best_ms[0], best_ms[1], best_ms[2], best_ms[3], best_ms[4], best_ms[8], best_ms[9], // (one sample per pixel: "in a row" is the megakernel)
+                     (best >> 2) == 0 ? "megakernel" : (best >> 2) == 1 ? "level by level" : "queue",
                      (best & 1) ? ", bottom-up" : "", (best & 2) ? ", samples in a row" : "", (int)rule);
     std::lock_guard<std::mutex> g(g_tune_mtx);
     g_tuned[key] = choice;

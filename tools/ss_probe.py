@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Supersampled frames in every organisation: the film of each against the megakernel's (bytes), and the frame time of each.
-python tools/ss_probe.py [size ...]     (LASGUN_SS_SERIAL=1: the level-by-level pipeline one sample at a time, for the A/B)"""
+"""Supersampled frames, a pixel's samples one after the other (rounds 1-4) against side by side (lg_accel_set_sample_order), in every
+organisation and as the default picks: frame time of each, and that every film is the same bytes.
+python tools/ss_probe.py [size ...]     (SS_PROBE_SCENES=a,b: only those)"""
 import json
 import os
 import sys
@@ -50,18 +51,22 @@ def frame_ms(acc, size, dev, n=7):
 for size in sizes:
     for name, make in SCENES.items():
         scene = make()
-        out = {"scene": name, "size": size, "ss_serial": os.environ.get("LASGUN_SS_SERIAL", "0"), "ss_mega": os.environ.get("LASGUN_SS_MEGA", "rule")}
+        out = {"scene": name, "size": size}
         ref = None
+        differs = 0
         for org, code in ORGS.items():
-            acc = G.Accel(scene)
-            G.set_streaming(acc, code)
-            dev = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
-            out[org + "_ms"] = frame_ms(acc, size, dev)
-            if org == "default":
-                out["default_is"] = G.last_organisation(acc)
-            film = dev.cpu()
-            if ref is None:
-                ref = film
-            else:
-                out[org + "_differs"] = int((film != ref).any(dim=-1).sum())
+            for order, oname in ((1, "in_a_row"), (0, "side_by_side")) if org != "default" else ((None, "ms"),):
+                acc = G.Accel(scene)
+                G.set_streaming(acc, code)
+                G.set_sample_order(acc, order)
+                dev = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
+                out[org + "_" + oname] = frame_ms(acc, size, dev)
+                if org == "default":
+                    out["default_is"] = G.last_organisation(acc)
+                film = dev.cpu()
+                if ref is None:
+                    ref = film
+                else:
+                    differs += int((film != ref).any(dim=-1).sum())
+        out["pixels_that_differ_between_any_two"] = differs
         print(json.dumps(out), flush=True)
