@@ -849,7 +849,7 @@ static Org org_by_rule(const lg_accel &a, const DParams &P, bool stats) {
 // 1.2 - 10 x faster (a 512^2 film is one tile per wave of the grid: nine samples in a row on each, or nine times the tiles); frames of
 // 1024^2 and more of a cheap scene 30-50 % SLOWER (nine times the claims on one head word, 8 ns each).  So: possible while the parked
 // samples fit 1 GiB, the rule below where nothing is measured, and one more thing the measured choice times.
-constexpr unsigned long long SS_PAR_WAVES = 4;
+constexpr unsigned long long SS_PAR_WAVES = 8; // the rule: side by side below this many pixel tiles per wave of the grid (9 of 12 scenes faster at 1024^2, none at 2048^2)
 static bool mega_par_possible(const DParams &P, bool stats) {
     const unsigned long long nsamples = (unsigned long long)P.ss_root * P.ss_root;
     return nsamples > 1 && !stats && (unsigned long long)P.ntiles * 64ull * nsamples * 24ull <= (1ull << 30);
@@ -2413,6 +2413,9 @@ extern "C" int lg_debug_queue_packets(const lg_accel *a, void *hip_stream, unsig
             std::vector<uint32_t> w(QC_WORDS);
             HIP_TRY(hipMemcpy(w.data(), c->wf_counters.p, QC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
             for (uint32_t d = 0; d < QC_MAX_LEVELS; ++d) out[d] = w[QC_LEVEL0 + QC_LEVEL_WORDS * d + QC_COUNT];
+#ifdef LG_QIDLE // diagnostic build: [7] = the waves' idle time (100 MHz ticks, summed), k_queue.hip
+            out[7] = (unsigned long long)w[QC_ERROR] | ((unsigned long long)w[QC_ERROR + 1] << 32);
+#endif
         }
     });
 }

@@ -218,7 +218,13 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
         lvl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lvl);
         if (lvl == Q_EXIT) break; // every wave reaches this exit (or the poll limit below)
         if (lvl == NO_TILE) {
+#ifdef LG_QIDLE // diagnostic build (tools/queue_idle.py): the time this wave spends with nothing to claim, in 100 MHz ticks
+            const unsigned long long idle_t0 = wall_clock64();
+#endif
             for (uint32_t s = 0; s < backoff; ++s) __builtin_amdgcn_s_sleep(127);
+#ifdef LG_QIDLE
+            if (lane == 0u) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + QC_ERROR), wall_clock64() - idle_t0);
+#endif
             backoff = backoff < 8u ? backoff * 2u : 8u;
             if (++idle > Q_POLL_LIMIT) {
                 if (lane == 0u && P.q_err) __hip_atomic_store(P.q_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // sticky, in host memory: no later launch clears it
