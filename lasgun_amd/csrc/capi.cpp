@@ -1380,8 +1380,8 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         // triangle.  The band in which that happens is ~ 64 u R^2 / edge wide: negligible for a tessellated surface seen from nearby,
         // not for a mesh whose coordinates dwarf its small triangles (round 4's progression_soup_scene: triangles at 1e9 beside
         // triangles of 0.05 -- 5 wrong pixels in 4,100 scenes).  Such a mesh is refused, like a transform that does not invert.
-        for (const auto &m : a->scene->meshes) {
-            if (!m) continue;
+        for (const auto &m : a->scene->meshes) { // (a question about the fast mode: asked when its trees are built -- every lg_accel_set_mode(1) goes through such a build first)
+            if (!m || !with_fast) continue;
             double max_abs = 0.0, min_edge = INFINITY;
             for (float v : m->position) if (std::isfinite(v)) max_abs = std::fmax(max_abs, std::fabs((double)v));
             for (size_t t = 0; t + 2 < m->tri.size(); t += 3) {

@@ -6,6 +6,7 @@
 #include <array>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -295,6 +296,10 @@ class Builder {
     BuiltBVH run() {
         size_t n = pb_.size();
         if (n == 0) throw Error("empty aggregate: the reference recurses without bound in build_upper_sah (bvh.rs:355-424)");
+        const bool TT = n > 50000 && std::getenv("LASGUN_DEBUG_TIMES");
+        auto tnow = [] { return std::chrono::steady_clock::now(); };
+        auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto q0 = tnow();
         out_.order.assign(n, 0xFFFFFFFFu);
         centroid_.resize(n);
         Bounds all = b_none();
@@ -302,6 +307,7 @@ class Builder {
             centroid_[i] = 0.5 * pb_[i].min + 0.5 * pb_[i].max; // bvh.rs:530
             all = b_union(all, pb_[i]);
         }
+        const auto q1 = tnow();
         // Morton codes + stable LSD radix sort, 5 passes of 6 bits (bvh.rs:217-229,600-635)
         std::vector<std::pair<uint32_t, uint32_t>> cur(n), tmp(n); // (code, prim)
         for (size_t i = 0; i < n; ++i) cur[i] = {morton_zyz(b_offset(all, centroid_[i]) * 1024.0), (uint32_t)i};
@@ -317,6 +323,7 @@ class Builder {
         }
         code_.resize(n); prim_.resize(n);
         for (size_t i = 0; i < n; ++i) { code_[i] = cur[i].first; prim_[i] = cur[i].second; }
+        const auto q2 = tnow();
         // treelets: runs of equal top-12 bits (bvh.rs:240-265)
         std::vector<int32_t> roots;
         size_t start = 0;
@@ -326,11 +333,14 @@ class Builder {
                 start = end;
             }
         }
+        const auto q3 = tnow();
         int32_t root = upper(roots.data(), roots.size(), 0);
+        const auto q4 = tnow();
         out_.nodes.resize(pool_.size() - dead_);
         uint32_t off = 0;
         emit_linear(root, off);
         out_.nodes.resize(off);
+        if (TT) std::fprintf(stderr, "[lasgun] BVH of %zu: centroids %.3f, morton + sort %.3f, treelets %.3f (%zu roots), upper SAH %.3f, linearise %.3f ms\n", n, tms(q0, q1), tms(q1, q2), tms(q2, q3), roots.size(), tms(q3, q4), tms(q4, tnow()));
         return std::move(out_);
     }
 
@@ -572,6 +582,7 @@ struct Flattener {
     FlatScene &out;
     std::vector<MeshTables> meshes;
     bool with_fast = false;
+    double mesh_build_ms = 0.0; // (LASGUN_DEBUG_TIMES)
 
     int32_t add_material(const Material &m) {
         DMaterial d{};
@@ -792,6 +803,7 @@ struct Flattener {
 
     void dump(const BuiltBVH &bvh, bool has_mat, bool swap, const Transform &t) {
         auto &f = out.dump_f; auto &i = out.dump_i;
+        f.reserve(f.size() + bvh.nodes.size() * 6 + 32); i.reserve(i.size() + bvh.nodes.size() * 3 + bvh.order.size() + 4);
         i.push_back((int64_t)bvh.nodes.size()); i.push_back((int64_t)bvh.order.size());
         i.push_back(has_mat ? 1 : 0); i.push_back(swap ? 1 : 0);
         for (const LinNode &n : bvh.nodes) {
@@ -810,6 +822,9 @@ struct Flattener {
         if (mt.built) return mt;
         const Obj &obj = *scene.meshes[id];
         size_t nf = obj.tri.size() / 3;
+        auto tnow = [] { return std::chrono::steady_clock::now(); };
+        auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto ts0 = tnow();
         mt.has_n = !obj.normal.empty();
         mt.has_uv = !obj.texture.empty();
         uint32_t vbase = (uint32_t)(out.vpos.size() / 3), nbase = (uint32_t)(out.vnorm.size() / 3), tbase = (uint32_t)(out.vtex.size() / 2);
@@ -818,36 +833,54 @@ struct Flattener {
         out.vtex.insert(out.vtex.end(), obj.texture.begin(), obj.texture.end());
         mt.tri_base = (uint32_t)(out.tri_v.size() / 3);
         std::vector<Bounds> pb(nf);
-        for (size_t f = 0; f < nf; ++f) {
-            V3 p[3];
-            for (int k = 0; k < 3; ++k) {
-                const Obj::Tuple &tp = obj.tri[3 * f + k];
-                if (mt.has_n && tp.n < 0) throw Error("mesh has normals but a face lacks a vn index (the reference panics, triangle.rs:60)");
-                if (mt.has_uv && tp.t < 0) throw Error("mesh has vt but a face lacks a vt index (the reference panics, triangle.rs:96)");
-                const float *v = &obj.position[3 * (size_t)tp.v];
-                p[k] = V3{(double)v[0], (double)v[1], (double)v[2]};
-                out.tri_v.push_back(vbase + tp.v);
-                out.tri_n.push_back(mt.has_n ? nbase + (uint32_t)tp.n : 0u);
-                out.tri_t.push_back(mt.has_uv ? tbase + (uint32_t)tp.t : 0u);
+        {
+            const size_t at = out.tri_v.size();
+            out.tri_v.resize(at + 3 * nf); out.tri_n.resize(at + 3 * nf); out.tri_t.resize(at + 3 * nf);
+            uint32_t *tv = out.tri_v.data() + at, *tn = out.tri_n.data() + at, *tt = out.tri_t.data() + at;
+            const bool has_n = mt.has_n, has_uv = mt.has_uv;
+            for (size_t f = 0; f < nf; ++f) {
+                V3 p[3];
+                for (int k = 0; k < 3; ++k) {
+                    const Obj::Tuple &tp = obj.tri[3 * f + k];
+                    if (has_n && tp.n < 0) throw Error("mesh has normals but a face lacks a vn index (the reference panics, triangle.rs:60)");
+                    if (has_uv && tp.t < 0) throw Error("mesh has vt but a face lacks a vt index (the reference panics, triangle.rs:96)");
+                    const float *v = &obj.position[3 * (size_t)tp.v];
+                    p[k] = V3{(double)v[0], (double)v[1], (double)v[2]};
+                    tv[3 * f + k] = vbase + tp.v;
+                    tn[3 * f + k] = has_n ? nbase + (uint32_t)tp.n : 0u;
+                    tt[3 * f + k] = has_uv ? tbase + (uint32_t)tp.t : 0u;
+                }
+                pb[f] = b_add_point(b_new(p[0], p[1]), p[2]); // triangle.rs:157-159
             }
-            pb[f] = b_add_point(b_new(p[0], p[1]), p[2]); // triangle.rs:157-159
         }
+        const auto ts1 = tnow();
         mt.bvh = Builder(pb, nf).run();
+        const auto ts2 = tnow();
+        mesh_build_ms += tms(ts1, ts2);
         append_nodes(mt.bvh, mt.node_base);
         record_parents(mt.bvh, mt.node_base);
         const std::vector<uint32_t> ref_leaf = ref_leaf_of_prims(mt.bvh, nf);
         out.tri_ref_leaf.resize((size_t)mt.tri_base + nf, NO_HIT);
         for (size_t f = 0; f < nf; ++f) out.tri_ref_leaf[mt.tri_base + f] = ref_leaf[f];
         mt.prim_base = (uint32_t)out.primref.size();
-        out.leaf_soup.resize(mt.prim_base, DLeafRec{}); // keep slot j of the soup aligned with primref[j]
-        for (uint32_t o : mt.bvh.order) {
-            out.primref.push_back((PK_TRIANGLE << 30) | (mt.tri_base + o));
-            // leaf-ordered copy of the three positions (f32, exactly the table entries), padded to 48 B
-            DLeafRec rec{};
-            for (int k = 0; k < 3; ++k)
-                std::memcpy(&rec.w[3 * k], &obj.position[3 * (size_t)obj.tri[3 * (size_t)o + k].v], 12);
-            out.leaf_soup.push_back(rec);
+        {
+            const size_t no = mt.bvh.order.size();
+            out.primref.resize(mt.prim_base + no);
+            out.leaf_soup.resize(mt.prim_base + no, DLeafRec{}); // slot j of the soup is aligned with primref[j]
+            uint32_t *pr = out.primref.data() + mt.prim_base;
+            DLeafRec *soup = out.leaf_soup.data() + mt.prim_base;
+            const uint32_t tri_base = mt.tri_base;
+            const uint32_t *order = mt.bvh.order.data();
+            for (size_t j = 0; j < no; ++j) {
+                const uint32_t o = order[j];
+                pr[j] = (PK_TRIANGLE << 30) | (tri_base + o);
+                // leaf-ordered copy of the three positions (f32, exactly the table entries), padded to 48 B
+                for (int k = 0; k < 3; ++k)
+                    std::memcpy(&soup[j].w[3 * k], &obj.position[3 * (size_t)obj.tri[3 * (size_t)o + k].v], 12);
+            }
         }
+        if (std::getenv("LASGUN_DEBUG_TIMES"))
+            std::fprintf(stderr, "[lasgun] mesh %u (%zu triangles): vertex + index tables, boxes %.3f ms, BVH %.3f ms, nodes + slots + leaf soup %.3f ms\n", id, nf, tms(ts0, ts1), tms(ts1, ts2), tms(ts2, tnow()));
         mt.nnodes = (uint32_t)mt.bvh.nodes.size();
         mt.norder = (uint32_t)mt.bvh.order.size();
         mt.root_bounds = mt.bvh.nodes[0].b;
@@ -1101,7 +1134,8 @@ static DChunk make_record(const FlatScene &out, size_t a, size_t b) {
     k.count = (uint32_t)(b - a);
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     double g2 = 0.0, hmin = INFINITY;
-    std::vector<V3> normals;
+    std::vector<V3> normals; // (one allocation, sized for the record: a run or a group of runs)
+    normals.reserve(b - a);
     bool degenerate = false;
     V3 nsum{0, 0, 0};
     for (size_t s = a; s < b; ++s) {
@@ -1152,26 +1186,31 @@ static DChunk make_record(const FlatScene &out, size_t a, size_t b) {
 // vertices emitted) the longest is emitted, until none is left.  Vertices are identified by their f32 bits (what the reference's transforms see); winding plays no
 // part (the sign test the strips serve is indifferent to it).  Returns the number of entries.
 static uint32_t make_strips(const FlatScene &out, size_t a, size_t b, std::vector<DStrip> &strips) {
+    // (fixed-size storage: a run has <= 32 triangles, hence <= 96 distinct vertices and <= 32 triangles at any of them -- this function
+    // is where the accel build of a mesh spends its time, and with vectors of vectors most of that was the allocator)
+    constexpr size_t MAXT = (size_t)1 << CHUNK_SHIFT, MAXV = 3 * MAXT;
     const size_t n = b - a;
+    if (n > MAXT) throw Error("internal: a run of more than 32 triangles");
     struct T { uint32_t raw[3][3]; int v[3]; uint32_t slot; bool used; };
-    std::vector<T> t(n);
-    std::vector<std::array<uint32_t, 3>> verts; // the run's distinct vertices (by their f32 bits)
+    T t[MAXT];
+    uint32_t verts[MAXV][3]; // the run's distinct vertices (by their f32 bits)
+    size_t nverts = 0;
     for (size_t i = 0; i < n; ++i) {
         T &x = t[i];
         std::memcpy(x.raw, out.leaf_soup2[a + i].w, 36);
         x.slot = out.leaf_soup2[a + i].w[9];
         x.used = false;
         for (int k = 0; k < 3; ++k) {
-            const std::array<uint32_t, 3> key{x.raw[k][0], x.raw[k][1], x.raw[k][2]};
             size_t id = 0;
-            while (id < verts.size() && verts[id] != key) ++id;
-            if (id == verts.size()) verts.push_back(key);
+            while (id < nverts && !(verts[id][0] == x.raw[k][0] && verts[id][1] == x.raw[k][1] && verts[id][2] == x.raw[k][2])) ++id;
+            if (id == nverts) { verts[id][0] = x.raw[k][0]; verts[id][1] = x.raw[k][1]; verts[id][2] = x.raw[k][2]; ++nverts; }
             x.v[k] = (int)id;
         }
     }
     // who touches each vertex (a strip step looks for an unused triangle that holds the last two vertices)
-    std::vector<std::vector<int>> at(verts.size());
-    for (size_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) at[(size_t)t[i].v[k]].push_back((int)i);
+    uint8_t at[MAXV][3 * MAXT], at_n[MAXV];
+    for (size_t v = 0; v < nverts; ++v) at_n[v] = 0;
+    for (size_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { const size_t v = (size_t)t[i].v[k]; at[v][at_n[v]++] = (uint8_t)i; }
     auto emit = [&](const uint32_t *p, uint32_t code) {
         DStrip e;
         std::memcpy(&e.x, p, 12);
@@ -1179,15 +1218,18 @@ static uint32_t make_strips(const FlatScene &out, size_t a, size_t b, std::vecto
         strips.push_back(e);
     };
     const size_t before = strips.size();
-    std::vector<char> taken(n, 0);
+    char taken[MAXT];
+    for (size_t i = 0; i < n; ++i) taken[i] = 0;
+    struct Step { int tri, third; };
     // the triangles a strip started at triangle i0 in rotation rot would take, in order (nothing is marked for good)
-    auto follow = [&](size_t i0, int rot, std::vector<std::pair<int, int>> &path) {
-        path.clear();
+    auto follow = [&](size_t i0, int rot, Step *path) -> size_t {
+        size_t len = 0;
         taken[i0] = 1;
         int l0 = t[i0].v[(rot + 1) % 3], l1 = t[i0].v[(rot + 2) % 3];
         for (;;) {
             int next = -1, third = -1;
-            for (int j : at[(size_t)l0]) {
+            for (size_t e = 0; e < at_n[(size_t)l0]; ++e) {
+                const int j = at[(size_t)l0][e];
                 if (t[(size_t)j].used || taken[(size_t)j]) continue;
                 const T &y = t[(size_t)j];
                 int p = -1, q = -1;
@@ -1196,22 +1238,22 @@ static uint32_t make_strips(const FlatScene &out, size_t a, size_t b, std::vecto
                 if (p >= 0 && q >= 0) { next = j; third = 3 - p - q; break; }
             }
             if (next < 0) break;
-            path.emplace_back(next, third);
+            path[len++] = Step{next, third};
             taken[(size_t)next] = 1;
             l0 = l1;
             l1 = t[(size_t)next].v[third];
         }
         taken[i0] = 0;
-        for (const auto &st : path) taken[(size_t)st.first] = 0;
+        for (size_t e = 0; e < len; ++e) taken[(size_t)path[e].tri] = 0;
+        return len;
     };
     static const bool exhaustive = std::getenv("LASGUN_STRIPS_EXHAUSTIVE") != nullptr;
     size_t left = n;
-    std::vector<std::pair<int, int>> path, best_path;
+    Step path[MAXT], best_path[MAXT];
     while (left != 0) {
         // the longest strip any unused triangle can start (ties: the first in run order, the lowest rotation)
-        size_t bi = n;
+        size_t bi = n, best_len = 0;
         int brot = 0;
-        best_path.clear();
         // candidates: every unused triangle (LASGUN_STRIPS_EXHAUSTIVE: 1.32 entries per triangle on the 100k-triangle torus, at twice
         // the build time), or just the one with the fewest unused neighbours across its edges -- a corner of what is left, from which
         // the strips run along the patch instead of cutting it up (1.40; the first unused triangle: 1.52)
@@ -1224,7 +1266,8 @@ static uint32_t make_strips(const FlatScene &out, size_t a, size_t b, std::vecto
                 for (int k = 0; k < 3; ++k) {
                     const int u = t[i0].v[k], w = t[i0].v[(k + 1) % 3];
                     bool nb = false;
-                    for (int j : at[(size_t)u]) {
+                    for (size_t e = 0; e < at_n[(size_t)u]; ++e) {
+                        const int j = at[(size_t)u][e];
                         if ((size_t)j == i0 || t[(size_t)j].used) continue;
                         const T &y = t[(size_t)j];
                         if (y.v[0] == w || y.v[1] == w || y.v[2] == w) { nb = true; break; }
@@ -1237,8 +1280,8 @@ static uint32_t make_strips(const FlatScene &out, size_t a, size_t b, std::vecto
         for (size_t i0 = 0; i0 < n; ++i0) {
             if (t[i0].used || (only != n && i0 != only)) continue;
             for (int rot = 0; rot < 3; ++rot) {
-                follow(i0, rot, path);
-                if (bi == n || path.size() > best_path.size()) { bi = i0; brot = rot; best_path = path; }
+                const size_t len = follow(i0, rot, path);
+                if (bi == n || len > best_len) { bi = i0; brot = rot; best_len = len; std::copy(path, path + len, best_path); }
             }
         }
         T &x = t[bi];
@@ -1247,9 +1290,10 @@ static uint32_t make_strips(const FlatScene &out, size_t a, size_t b, std::vecto
         emit(x.raw[(brot + 2) % 3], STRIP_TRI | x.slot);
         x.used = true;
         --left;
-        for (const auto &st : best_path) {
-            emit(t[(size_t)st.first].raw[st.second], STRIP_TRI | t[(size_t)st.first].slot);
-            t[(size_t)st.first].used = true;
+        for (size_t e = 0; e < best_len; ++e) {
+            const Step &st = best_path[e];
+            emit(t[(size_t)st.tri].raw[st.third], STRIP_TRI | t[(size_t)st.tri].slot);
+            t[(size_t)st.tri].used = true;
             --left;
         }
     }
@@ -1390,12 +1434,20 @@ void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     out.default_material = fl.add_material(material_default());
     Bounds b;
     uint32_t need = 0, fneed1 = 0;
+    static const bool times = std::getenv("LASGUN_DEBUG_TIMES") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     fl.aggregate(*scene.root, -1, b, need, fneed1);
+    const auto t1 = std::chrono::steady_clock::now();
     out.max_stack = need;
     out.max_stack_fast1 = fneed1;
     if (out.primref.size() > 80000000u) throw Error("too many primitive slots for the 32-bit record offsets of the triangle stream");
     out.leaf_soup.resize(out.primref.size() + 2, DLeafRec{}); // two spare records: the mesh leaf loop keeps the next slot in flight
     build_chunks(out);
+    if (times) {
+        const auto t2 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[lasgun] flatten: scene graph + BVHs %.3f ms (mesh BVH builds %.3f of it), culling records + strips %.3f ms\n", ms(t0, t1), fl.mesh_build_ms, ms(t1, t2));
+    }
     out.boxes_finite = true;
     for (const DNode &nd : out.nodes)
         for (int k = 0; k < 3; ++k) // finite AND ordered: slab_intersects_sg takes the near / far plane from the ray's sign, which is the reference's min / max only for bmin <= bmax

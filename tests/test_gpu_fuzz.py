@@ -120,6 +120,16 @@ def test_fuzz_campaign(gen):
         done["renders"] += 2
         if not np.array_equal(buf, ofilm.pixels()):
             done["mismatches"].append([seed, "capture_subsets"])
+        # a supersampled pixel's samples one after the other (lg_accel_set_sample_order(1); the renders above took them side by side, the
+        # default since round 5), in one organisation per seed: the same film
+        G.set_streaming(acc, (0, 2, 3)[seed % 3])
+        G.set_sample_order(acc, 1)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        G.set_sample_order(acc, None)
+        done["renders"] += 1
+        if not np.array_equal(film.pixels(), ofilm.pixels()):
+            done["mismatches"].append([seed, "samples-in-a-row", (0, 2, 3)[seed % 3]])
         if done["scenes"] % 25 == 0:
             print("fuzz %s: %d scenes, %d renders, %d mismatches" % (gen, done["scenes"], done["renders"], len(done["mismatches"])), flush=True)
     log = os.environ.get("LASGUN_FUZZ_LOG")
