@@ -230,11 +230,13 @@ int lg_accel_set_mode(const lg_accel *, int mode);
 int lg_accel_set_prune(const lg_accel *, int enabled);
 int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel default, LASGUN_PRUNE, lg_accel_set_prune, fast mode): 0 / 1 */
 
-/* Kernel organisation (same arithmetic, same bytes either way).  1 (default): the organisation of a launch is MEASURED -- the first
- * launch of a kind (the scene's shape, the device, the launch's size class and addressing mode) renders with every organisation
- * that can take it, on the caller's stream with the host waiting, and the fastest is kept for the process (capture() rebuilds its
- * accel per frame, so the memory is keyed by the scene's shape); later launches of the kind only enqueue.  LASGUN_AUTOTUNE=0 keeps
- * the fitted rule of rounds 2-4 instead: level by level in the WAVEFRONT pipeline (below) for scenes with <= 32 lights and at least
+/* Kernel organisation (same arithmetic, same bytes either way).  1 (default): the organisation of a launch is MEASURED -- the SECOND
+ * launch of a kind in the process (the scene's shape, the device, the launch's size class and addressing mode) renders with every
+ * organisation that can take it, on the caller's stream with the host waiting, and the fastest is kept for the process (capture()
+ * rebuilds its accel per frame, so the memory is keyed by the scene's shape); later launches of the kind only enqueue.  The kind's
+ * FIRST launch takes the fitted rule's choice, so that a program that renders one frame and exits pays nothing for a measurement worth
+ * 30-50 frames (LASGUN_AUTOTUNE=2: measure at the first launch already -- benchmarks).  LASGUN_AUTOTUNE=0 keeps
+ * the fitted rule of rounds 2-4 throughout: level by level in the WAVEFRONT pipeline (below) for scenes with <= 32 lights and at least
  * 512 spheres / boxes from 2^21 pixels a launch, and for a scene small enough to live in LDS glass / mirror frames of up to 2^20
  * pixels and plain frames of one sample per pixel from 2^18; the queue organisation for glass / mirror over a big mesh; the single
  * persistent megakernel for everything else.  0 = the megakernel only.

@@ -835,9 +835,13 @@ static Org org_by_rule(const lg_accel &a, const DParams &P, bool stats) {
     const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
     if (org_possible(a, P, stats, ORG_QUEUE) && a.streaming && a.queue_default && items >= a.queue_min_items) return ORG_QUEUE;
     const bool lds_resident = !a.fast && a.lds_scene && a.ldss_blocks, specular = a.flat.has_specular && P.recursion > 0;
-    const bool small_specular = lds_resident && specular && items <= a.specular_small_items;
-    const bool light_scene = lds_resident && !specular && !a.streaming_pays && P.ss_root == 1u && items >= (1ull << 18);
-    if (a.streaming && org_possible(a, P, stats, ORG_WAVEFRONT) && (small_specular || light_scene || (a.streaming_pays && items >= a.streaming_min_items)))
+    // (level 0's work items: with a pixel's samples side by side -- round 5 -- a 9-sample frame is nine times as wide as its film;
+    // profiles/r05_ss_par.jsonl: Cornell glass at 9 spp goes level by level at 256^2 and in the megakernel from 512^2, like its
+    // one-sample frames of nine times the pixels; simple.rs at 16 spp level by level at every size)
+    const unsigned long long work = items * (a.sample_order != 1 ? (unsigned long long)P.ss_root * P.ss_root : 1ull);
+    const bool small_specular = lds_resident && specular && work <= a.specular_small_items;
+    const bool light_scene = lds_resident && !specular && !a.streaming_pays && (P.ss_root == 1u || a.sample_order != 1) && work >= (1ull << 18);
+    if (a.streaming && org_possible(a, P, stats, ORG_WAVEFRONT) && (small_specular || light_scene || (a.streaming_pays && work >= a.streaming_min_items)))
         return ORG_WAVEFRONT;
     return ORG_MEGA;
 }
@@ -933,7 +937,7 @@ static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Or
 
 // The MEASURED choice (round 5; the rule above was a fit to eight scenes and wrong by 6-22 % on the first scene that was not among
 // them).  Every organisation renders the same bytes, so which one runs is a question of time alone, and the answer is taken from
-// the clock: the first launch of a KIND -- the scene's shape (table sizes, materials, lights, recursion, samples per pixel, traversal
+// the clock: the second launch of a KIND in the process (its first: the rule's choice at no cost, autotune_mode below) -- the scene's shape (table sizes, materials, lights, recursion, samples per pixel, traversal
 // mode, LDS residency), the device, the launch's size class (log2 of its pixels) and addressing mode -- renders the launch with every
 // CANDIDATE that can take it (a warm-up pass, then three timed passes over the candidates in turn, HIP events on the caller's stream,
 // the host waiting; the best of each), keeps the fastest (the rule's own choice unless another beats it by 2 %) and remembers it for
@@ -955,10 +959,16 @@ constexpr int TUNE_SERIAL = 32; //   | TUNE_SERIAL when the megakernel takes a p
 std::mutex g_tune_mtx;
 std::mutex g_tune_run_mtx; // one measurement at a time in the process: two accels of one kind measuring side by side would time each other
 std::map<TuneKey, int> &g_tuned = *new std::map<TuneKey, int>(); // never destroyed (see g_pool)
-bool autotune_enabled() {
-    static const bool on = [] { const char *e = std::getenv("LASGUN_AUTOTUNE"); return !(e && e[0] == '0'); }();
-    return on;
+std::map<TuneKey, unsigned> &g_seen = *new std::map<TuneKey, unsigned>(); // launches of a kind before it was measured (guarded by g_tune_mtx)
+// LASGUN_AUTOTUNE: 0 = never measure (the fitted rule), 1 (default) = measure a kind at its SECOND launch, 2 = at its first.
+// A program that renders one frame and exits (every example of the reference) gets the rule's choice at no cost -- timing seven
+// candidates three times over costs 30-50 frames' worth; whatever renders a kind twice (an animation, the progressive front end's hundred
+// subsets, a benchmark) is measured from then on.
+int autotune_mode() {
+    static const int mode = [] { const char *e = std::getenv("LASGUN_AUTOTUNE"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
+    return mode;
 }
+bool autotune_enabled() { return autotune_mode() != 0; }
 } // namespace
 static TuneKey tune_key(const lg_accel &a, const DParams &P) {
     const FlatScene &f = a.flat;
@@ -990,6 +1000,8 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
         std::lock_guard<std::mutex> g(g_tune_mtx);
         auto it = g_tuned.find(key);
         if (it != g_tuned.end()) return it->second;
+        if (autotune_mode() == 1 && g_seen[key]++ == 0u) // the first launch of the kind: the rule's choice, at no cost
+            return (int)rule | (a.tile_order == 1 && rule != ORG_WAVEFRONT ? TUNE_REV : 0) | (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? TUNE_SERIAL : 0);
     }
     std::lock_guard<std::mutex> run(g_tune_run_mtx);
     {   // (another accel of this kind may have measured while this one waited)

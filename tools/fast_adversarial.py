@@ -5,6 +5,7 @@ primitives), fast traversal vs the reference traversal on the GPU (films and rad
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+os.environ.setdefault("LASGUN_AUTOTUNE", "2")  # measure a kind of launch at its FIRST launch (the library's default: at its second), so that no timed frame holds a measurement
 import lasgun_amd as la
 G = la.api; S = la.scenes
 M = G.Material

@@ -1,3 +1,4 @@
+import os
 #!/usr/bin/env python3
 """Frame time against film size, per kernel organisation, on the small scenes (python tools/size_sweep.py readme|plastic|glass|spheres|simple1|simple2
 [sizes]): where a launch's fixed cost -- claims, cold code, one wave's latency -- and where its throughput sets the time.  Round 4's default rules
@@ -5,6 +6,7 @@
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
+os.environ.setdefault("LASGUN_AUTOTUNE", "2")  # measure a kind of launch at its FIRST launch (the library's default: at its second), so that no timed frame holds a measurement
 import lasgun_amd as la
 G = la.api; S = la.scenes
 G.set_device(0)

@@ -1,3 +1,4 @@
+import os
 #!/usr/bin/env python3
 """Where the reference walk spends its cycles (diagnostic build: make -C lasgun_amd/csrc EXTRA_DEVFLAGS=-DLG_STAMPS
 EXTRA_HOSTFLAGS=-DLG_STAMPS OUT=../liblasgun_hip_stamps.so, then LASGUN_HIP_LIB=lasgun_amd/liblasgun_hip_stamps.so python tools/stamp_phases.py).
@@ -7,6 +8,7 @@ import ctypes as C
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ.setdefault("LASGUN_AUTOTUNE", "2")  # measure a kind of launch at its FIRST launch (the library's default: at its second), so that no timed frame holds a measurement
 import lasgun_amd as la
 G = la.api
 lib = G.lib
