@@ -249,10 +249,12 @@ int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel defaul
  * runs deep levels with a few lanes per wave and the level-by-level pipeline ends every launch with its slowest wave's tail.
  * Returns non-zero (lg_last_error) for any other value. */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
-int lg_accel_last_organisation(const lg_accel *); /* what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 when its tiles were claimed bottom-up, + 32 when the megakernel took a supersampled pixel's samples one after the other (otherwise side by side: every organisation's way since round 5); -1: none yet */
+int lg_accel_last_organisation(const lg_accel *); /* what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 when its tiles were claimed bottom-up, + 64 when from the middle row outwards, + 32 when the megakernel took a supersampled pixel's samples one after the other (otherwise side by side: every organisation's way since round 5); -1: none yet */
 /* The direction in which the megakernel and the queue organisation claim a launch's 8x8 tiles: 0 = from the film's top (row order), 1 = from
- * its bottom, -1 (default) = top-down unless the measurement above finds the other faster (a launch ends with the recursion trees of its last
- * tiles: 6-9 % either way on scenes with mirrors / glass, profiles/r05_ab_tile_order.jsonl).  Which tile is rendered when never changes a pixel. */
+ * its bottom, 2 = from its middle row outwards (what a frame shows tends to sit in its middle, and a launch should END on cheap tiles: the
+ * 100k-triangle glass torus 36.2 -> 32.8 ms in the megakernel, profiles/r05_ab_tile_middle.jsonl), -1 (default) = middle-out unless the
+ * measurement above finds another faster (a launch ends with the recursion trees of its last tiles: 6-9 % either way on scenes with
+ * mirrors / glass, profiles/r05_ab_tile_order.jsonl).  Which tile is rendered when never changes a pixel. */
 int lg_accel_set_tile_order(const lg_accel *, int order);
 /* A supersampled pixel's samples (Camera::sample, camera.rs:113-146; integrate.rs:17-20 sums them in their order): 0 = SIDE BY SIDE -- a
  * launch's level-0 work items are (8x8 tile, sample) pairs, every sample's li() is parked as three doubles and a resolve pass sums each

@@ -102,12 +102,14 @@ class HipApi(Api):
         name = {0: "megakernel", 1: "wavefront", 2: "queue"}.get(v & 15) if v >= 0 else None
         if name and (v & 16):
             name += ", bottom-up"
+        if name and (v & 64):
+            name += ", middle-out"
         if name and (v & 32):
             name += ", samples in a row"
         return name
 
     def set_tile_order(self, accel, order):
-        """The direction the megakernel and the queue organisation claim a launch's tiles in: 0 top-down, 1 bottom-up, None / -1 = measured
+        """The direction the megakernel and the queue organisation claim a launch's tiles in: 0 top-down, 1 bottom-up, 2 from the middle row outwards, None / -1 = middle-out unless measured otherwise
         (include/lasgun_hip.h, lg_accel_set_tile_order).  Same bytes either way."""
         if self.call("accel_set_tile_order", accel.h, -1 if order is None else int(order)):
             raise LasgunError(self.last_error())

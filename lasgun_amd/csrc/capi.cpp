@@ -333,7 +333,7 @@ struct lg_accel {
     mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
     mutable int last_org = -1;                    // what the last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 with its tiles claimed bottom-up (lg_accel_last_organisation)
     mutable int sample_order = -1;                // lg_accel_set_sample_order: 0 a pixel's samples side by side, 1 one after the other, -1 = side by side (megakernel: rule / measured)
-    mutable int tile_order = -1;                  // lg_accel_set_tile_order: 0 top-down, 1 bottom-up, -1 = top-down unless the measured choice says otherwise
+    mutable int tile_order = -1;                  // lg_accel_set_tile_order: 0 top-down, 1 bottom-up, 2 from the middle row outwards, -1 = middle-out unless the measured choice says otherwise
     bool queue_default = false;                   // glass / mirror over a big mesh: long uneven walks, sparse deep levels (k_queue.hip)
     mutable size_t queue_budget = 0;              // bytes one launch context may hold for it (0 = from the free memory at first use)
     unsigned long long queue_min_items = 1ull << 16; // launches below this many pixels stay with the megakernel
@@ -927,9 +927,9 @@ static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, 
         a.events.emplace_back(e0, e1);
     }
 }
-static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Org org, bool rev, bool ss_serial, bool stats, hipStream_t stream) { // (P by value: an organisation fills in its own fields)
+static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Org org, int dir, bool ss_serial, bool stats, hipStream_t stream) { // (P by value: an organisation fills in its own fields)
     P.tile_counter = c.tile_counter.p;
-    P.tile_rev = rev && org != ORG_WAVEFRONT ? 1u : 0u; // (the level-by-level passes are short and alike: one direction)
+    P.tile_rev = org != ORG_WAVEFRONT ? (uint32_t)dir : 0u; // 0 top-down, 1 bottom-up, 2 from the middle outwards (the level-by-level passes are short and alike: one direction)
     if (org == ORG_QUEUE) enqueue_queue(a, P, c, stream);
     else if (org == ORG_WAVEFRONT) enqueue_wavefront(a, P, c, stream);
     else enqueue_mega(a, P, c, !ss_serial, stats, stream);
@@ -955,6 +955,14 @@ struct TuneKey {
     bool operator<(const TuneKey &o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
 };
 constexpr int TUNE_REV = 16;    // a remembered choice: organisation | TUNE_REV when the tiles go bottom-up
+constexpr int TUNE_MID = 64;    //   | TUNE_MID when they go from the middle row outwards
+static int dir_bits(int dir) { return dir == 1 ? TUNE_REV : dir == 2 ? TUNE_MID : 0; }
+static int dir_of(int choice) { return (choice & TUNE_REV) ? 1 : (choice & TUNE_MID) ? 2 : 0; }
+// The direction a launch's tiles are claimed in when nothing is forced or measured: from the middle row outwards.  What a frame shows
+// tends to sit in its middle, and a launch should END on cheap tiles: config 4 in the megakernel 36.2 -> 32.8 ms, 4m 13.1 -> 12.7,
+// simple.rs 0.55 -> 0.53, nothing slower among the configs (profiles/r05_ab_tile_middle.jsonl).
+constexpr int DIR_DEFAULT = 2;
+static int dir_unmeasured(const lg_accel &a, Org org) { return org == ORG_WAVEFRONT ? 0 : a.tile_order >= 0 ? a.tile_order : DIR_DEFAULT; }
 constexpr int TUNE_SERIAL = 32; //   | TUNE_SERIAL when the megakernel takes a pixel's samples one after the other (enqueue_mega)
 std::mutex g_tune_mtx;
 std::mutex g_tune_run_mtx; // one measurement at a time in the process: two accels of one kind measuring side by side would time each other
@@ -1001,7 +1009,7 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
         auto it = g_tuned.find(key);
         if (it != g_tuned.end()) return it->second;
         if (autotune_mode() == 1 && g_seen[key]++ == 0u) // the first launch of the kind: the rule's choice, at no cost
-            return (int)rule | (a.tile_order == 1 && rule != ORG_WAVEFRONT ? TUNE_REV : 0) | (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? TUNE_SERIAL : 0);
+            return (int)rule | dir_bits(dir_unmeasured(a, rule)) | (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? TUNE_SERIAL : 0);
     }
     std::lock_guard<std::mutex> run(g_tune_run_mtx);
     {   // (another accel of this kind may have measured while this one waited)
@@ -1013,20 +1021,20 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     const bool was_profiling = a.profiling;
     a.profiling = false; // (the measurement's launches are not the caller's: lg_profile_read must not count them)
-    // candidates: [organisation][samples side by side, one after the other (megakernel only)][top-down, bottom-up]
-    constexpr int NC = 12;
+    // candidates: [organisation][samples side by side, one after the other (megakernel only)][top-down, bottom-up, middle-out]
+    constexpr int NC = 18;
     float best_ms[NC];
     bool in_race[NC];
     const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
     for (int k = 0; k < NC; ++k) {
-        const int org = k >> 2, ser = (k >> 1) & 1, rev = k & 1;
+        const int org = k / 6, ser = (k / 3) & 1, dir = k % 3;
         best_ms[k] = INFINITY;
         in_race[k] = org_possible(a, P, false, (Org)org) &&
                      (ser ? org == ORG_MEGA : (org != ORG_MEGA || mega_par_possible(P, false))) &&
                      !(org == ORG_MEGA && mega_par_possible(P, false) && a.sample_order >= 0 && ser != a.sample_order) && // (lg_accel_set_sample_order) // (one form of the megakernel for a frame of one sample per pixel: the serial one)
                      !(org == ORG_QUEUE && items < 4096ull && rule != ORG_QUEUE) && // (a persistent scheduler for a handful of tiles: never ahead)
-                     !(rev && (org == ORG_WAVEFRONT || P.ntiles < 2u)) &&           // (one direction for the level-by-level passes and for a single tile)
-                     (a.tile_order < 0 || rev == a.tile_order);                    // (lg_accel_set_tile_order: only the organisations race)
+                     !(dir != 0 && (org == ORG_WAVEFRONT || P.ntiles < 2u)) &&      // (one direction for the level-by-level passes and for a single tile)
+                     (a.tile_order < 0 || org == ORG_WAVEFRONT || dir == a.tile_order); // (lg_accel_set_tile_order: only the organisations race)
     }
     try {
         // pass 0 warms every candidate up (buffers, code, clocks); passes 1-3 time them IN TURN, so that a drift of the clocks or a
@@ -1038,7 +1046,7 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
             for (int k = 0; k < NC; ++k) {
                 if (!in_race[k]) continue;
                 HIP_TRY(hipEventRecord(e0, stream));
-                enqueue_org(a, P, c, (Org)(k >> 2), (k & 1) != 0, (k & 2) != 0, false, stream);
+                enqueue_org(a, P, c, (Org)(k / 6), k % 3, ((k / 3) & 1) != 0, false, stream);
                 HIP_TRY(hipEventRecord(e1, stream));
                 HIP_TRY(hipEventSynchronize(e1));
                 float ms = 0.0f;
@@ -1062,15 +1070,15 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     a.profiling = was_profiling;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     check_queue_error(a);
-    int best = (int)rule * 4 + (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? 2 : 0) + (a.tile_order == 1 && rule != ORG_WAVEFRONT ? 1 : 0);
+    int best = (int)rule * 6 + (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? 3 : 0) + (P.ntiles < 2u ? 0 : dir_unmeasured(a, rule));
     for (int k = 0; k < NC; ++k)
         if (best_ms[k] < best_ms[best] * 0.98f) best = k;
-    const int choice = (best >> 2) | ((best & 1) ? TUNE_REV : 0) | ((best & 2) ? TUNE_SERIAL : 0);
+    const int choice = (best / 6) | dir_bits(best % 3) | (((best / 3) & 1) ? TUNE_SERIAL : 0);
     if (std::getenv("LASGUN_DEBUG"))
-        std::fprintf(stderr, "[lasgun] measured for %llu pixels (top-down / bottom-up): megakernel %.3f / %.3f ms (samples in a row: %.3f / %.3f), level by level %.3f ms, queue %.3f / %.3f ms -> %s%s%s (rule: %d)\n",
-                     items, best_ms[0], best_ms[1], best_ms[2], best_ms[3], best_ms[4], best_ms[8], best_ms[9], // (one sample per pixel: "in a row" is the megakernel)
-                     (best >> 2) == 0 ? "megakernel" : (best >> 2) == 1 ? "level by level" : "queue",
-                     (best & 1) ? ", bottom-up" : "", (best & 2) ? ", samples in a row" : "", (int)rule);
+        std::fprintf(stderr, "[lasgun] measured for %llu pixels (top-down / bottom-up / middle-out): megakernel %.3f / %.3f / %.3f ms (samples in a row: %.3f / %.3f / %.3f), level by level %.3f ms, queue %.3f / %.3f / %.3f ms -> %s%s%s (rule: %d)\n",
+                     items, best_ms[0], best_ms[1], best_ms[2], best_ms[3], best_ms[4], best_ms[5], best_ms[6], best_ms[12], best_ms[13], best_ms[14], // (one sample per pixel: "in a row" is the megakernel)
+                     best / 6 == 0 ? "megakernel" : best / 6 == 1 ? "level by level" : "queue",
+                     best % 3 == 1 ? ", bottom-up" : best % 3 == 2 ? ", middle-out" : "", ((best / 3) & 1) ? ", samples in a row" : "", (int)rule);
     std::lock_guard<std::mutex> g(g_tune_mtx);
     g_tuned[key] = choice;
     return choice;
@@ -1082,9 +1090,9 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     check_queue_error(a); // (an earlier launch on a caller's stream that stalled: reported here at the latest)
     lg_accel::LaunchCtx &c = ctx_for(a, stream);
     Org org;
-    bool rev = a.tile_order == 1; // lg_accel_set_tile_order(1); -1: top-down unless measured otherwise
+    int dir = -1; // lg_accel_set_tile_order; -1: from the middle outwards unless measured otherwise (dir_unmeasured)
     bool ss_serial = !mega_par_by_rule(a, P, stats); // the megakernel's samples: by the rule unless measured
-    if (stats) { org = ORG_MEGA; rev = false; }                                                  // the counting variant
+    if (stats) { org = ORG_MEGA; dir = 0; }                                                      // the counting variant
     else if (a.queue == 1) org = org_possible(a, P, stats, ORG_QUEUE) ? ORG_QUEUE : org_by_rule(a, P, stats); // lg_accel_set_streaming(3)
     else if (!a.streaming) org = ORG_MEGA;                                                       // lg_accel_set_streaming(0)
     else if (a.streaming_forced) org = org_possible(a, P, stats, ORG_WAVEFRONT) ? ORG_WAVEFRONT : ORG_MEGA; // lg_accel_set_streaming(2)
@@ -1094,11 +1102,13 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     } else {
         const int choice = tuned_choice(a, P, c, stream);
         org = (Org)(choice & (TUNE_REV - 1));
-        rev = (choice & TUNE_REV) != 0;
+        dir = dir_of(choice);
         ss_serial = (choice & TUNE_SERIAL) != 0;
     }
-    a.last_org = (int)org | (rev && org != ORG_WAVEFRONT ? TUNE_REV : 0) | (org == ORG_MEGA && ss_serial && P.ss_root > 1 ? TUNE_SERIAL : 0);
-    enqueue_org(a, P, c, org, rev, ss_serial, stats, stream);
+    if (dir < 0) dir = P.ntiles < 2u ? 0 : dir_unmeasured(a, org);
+    if (org == ORG_WAVEFRONT) dir = 0;
+    a.last_org = (int)org | dir_bits(dir) | (org == ORG_MEGA && ss_serial && P.ss_root > 1 ? TUNE_SERIAL : 0);
+    enqueue_org(a, P, c, org, dir, ss_serial, stats, stream);
 }
 
 static void set_rect(DParams &P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
@@ -2076,7 +2086,7 @@ int lg_accel_set_streaming(const lg_accel *a, int enabled) {
 }
 int lg_accel_set_tile_order(const lg_accel *a, int order) { // the direction the megakernel and the queue organisation claim a launch's tiles in
     std::lock_guard<std::mutex> g(a->mtx);
-    if (order < -1 || order > 1) return fail("tile order must be -1 (default: measured), 0 (top-down) or 1 (bottom-up)");
+    if (order < -1 || order > 2) return fail("tile order must be -1 (default: measured), 0 (top-down), 1 (bottom-up) or 2 (from the middle outwards)");
     a->tile_order = order;
     return 0;
 }

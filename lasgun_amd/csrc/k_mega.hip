@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_N
         if (tile == NO_TILE) break; // (a wave leaves here, or after one of the launch's last tiles: kcommon.h)
 
         // (claimed from the last tile down: DParams::tile_rev; samples side by side: a tile is a pixel tile at ONE of its samples, DParams::ss_par)
-        const uint32_t vtile = P.tile_rev ? P.ntiles - 1u - tile : tile;
+        const uint32_t vtile = tile_in_order(P, tile);
         uint32_t s_first;
         const Pixel px = pixel_of(P, l0_tile(P, vtile, s_first), lane);
         const uint32_t x = px.x, y = px.y;

@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t q_compact_bits(uint32_t x) { // bits 0, 2, 4
     return (x | (x >> 8)) & 0x0000FFFFu;
 }
 __device__ __forceinline__ uint32_t q_seq_tile(const DParams &P, uint32_t s) { // sequence index -> tile of the chunk (NO_TILE: a hole of the block grid)
-    if (P.q_order == 0u) return s < P.ntiles ? (P.tile_rev ? P.ntiles - 1u - s : s) : NO_TILE; // (tile_rev: from the last tile down)
+    if (P.q_order == 0u) return s < P.ntiles ? tile_in_order(P, s) : NO_TILE; // (tile_rev: from the last tile down, or from the middle outwards)
     const uint32_t block = s >> 10, w = s & 1023u;
     const uint32_t tx = (block % P.q_blocks_x) * 32u + q_compact_bits(w), ty = (block / P.q_blocks_x) * 32u + q_compact_bits(w >> 1);
     return tx < P.tiles_x && ty < P.q_tiles_y ? ty * P.tiles_x + tx : NO_TILE;

@@ -319,6 +319,13 @@ __device__ __forceinline__ void stash_get(const DParams &P, unsigned long long g
     sh.ts = cross(sh.ns, sh.ss);
 }
 
+// the s-th tile a launch hands out (DParams::tile_rev): 0 = in order, 1 = from the last tile down, 2 = from the middle outwards
+__device__ __forceinline__ uint32_t tile_in_order(const DParams &P, uint32_t s) {
+    if (P.tile_rev == 0u) return s;
+    if (P.tile_rev == 1u) return P.ntiles - 1u - s;
+    const uint32_t mid = P.ntiles >> 1;
+    return (s & 1u) ? mid - 1u - (s >> 1) : mid + (s >> 1);
+}
 // level 0 of the level-by-level pipeline: the pixel tile and the sample a work tile stands for (DParams::ss_par)
 __device__ __forceinline__ uint32_t l0_tile(const DParams &P, uint32_t vt, uint32_t &sample) {
     if (P.ss_par <= 1u) { sample = P.sample_index; return vt; }

@@ -355,7 +355,7 @@ def test_a_pixels_samples_side_by_side_or_in_a_row_are_the_same_film(name):
             G.capture_subset(0, 1, acc, film)
             assert np.array_equal(film.pixels(), ofilm.pixels()), (org, order)
             if org == 0 and order is not None:
-                assert G.last_organisation(acc) == "megakernel" + (", samples in a row" if order == 1 else "")
+                assert G.last_organisation(acc) == "megakernel, middle-out" + (", samples in a row" if order == 1 else "")
             assert np.array_equal(bits(G.capture_radiance(acc, w, h)), bits(orad)), (org, order)
             buf = np.full((h, w, 4), 7, np.uint8)
             G.capture_subset(2, 5, acc, G.Film.new_with_output(w, h, buf))
@@ -665,14 +665,14 @@ def test_the_default_organisation_is_measured_once_per_kind_and_changes_no_byte(
     assert len(set(picked)) == 1, picked  # remembered, not measured again with another outcome
     for code, name in names.items():
         G.set_streaming(acc, code)
-        for order in (0, 1, None):  # lg_accel_set_tile_order: the tiles claimed from the film's top, from its bottom, as measured -- the same film
+        for order in (0, 1, 2, None):  # lg_accel_set_tile_order: the tiles claimed from the film's top, from its bottom, from its middle outwards (the default of a forced organisation) -- the same film
             G.set_tile_order(acc, order)
             film = G.Film(w, h)
             G.capture_subset(0, 1, acc, film)
             assert np.array_equal(film.pixels(), want), (name, order)
-            assert G.last_organisation(acc) == name + (", bottom-up" if order == 1 and name != "wavefront" else "")
+            assert G.last_organisation(acc) == name + ("" if name == "wavefront" else {0: "", 1: ", bottom-up", 2: ", middle-out", None: ", middle-out"}[order])
     with pytest.raises(la.LasgunError):
-        G.set_tile_order(acc, 2)
+        G.set_tile_order(acc, 3)
 
 
 def test_capture_rebuilds_and_render_matches():

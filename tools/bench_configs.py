@@ -171,6 +171,9 @@ def main():
             G.set_streaming(acc, 2)
         elif org == "queue":
             G.set_streaming(acc, 3)
+        order = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--tile-order=")]  # 0 top-down | 1 bottom-up | 2 middle-out (default: the library's)
+        if order:
+            G.set_tile_order(acc, int(order[0]))
         film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
         stream = torch.cuda.current_stream().cuda_stream
         G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)
