@@ -1,12 +1,15 @@
 #!/bin/bash
 # Round-end evidence run on the 1-GPU box: bench, rocprofv3 kernel stats, PMC passes, all configs.
-# usage (gpurun): bash tools/final_profile.sh  -> gpurun_out/final5/ ; then python3 tools/summarize_profiles.py gpurun_out/final5 profiles r05
+# usage (gpurun, two calls of <= 20 minutes): bash tools/final_profile.sh a ; bash tools/final_profile.sh b  -> gpurun_out/final5/ ;
+# then python3 tools/summarize_profiles.py gpurun_out/final5 profiles r05
 set -u
 export TMPDIR=/tmp
 # the profiler's preloaded library initialises HIP before bench.py can set this: the frames in flight need a hardware queue each
 export GPU_MAX_HW_QUEUES=16
 cd "${GRAFT_REPO_ROOT:?}"
-O=gpurun_out/final5; rm -rf "$O"; mkdir -p "$O"
+part=${1:-a}
+O=gpurun_out/final5; mkdir -p "$O"
+if [ "$part" = a ]; then
 timeout -k 10 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"
 # per-kernel durations: frames one after the other (the form bench.py's roofline.kernel_ms_avg is measured in) ...
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -- python3 bench.py --steps 5 --warmup 1 --no-extras --sequential > "$O/prof.log" 2>&1; echo "stats rc=$?"
@@ -32,11 +35,19 @@ LASGUN_MULTI_FORCE_RCCL=1 timeout -k 10 200 python3 tools/bench_multi.py --devic
 # config 4's kernel (the queue organisation's persistent launch): counter passes of its own
 bash tools/pmc_cmd.sh c4 tools/bench_configs.py "4 mesh" > "$O/pmc_c4.log" 2>&1; cp gpurun_out/pmcc_c4/summary.txt "$O/config4_pmc.txt" 2>/dev/null
 bash tools/pmc_cmd.sh c5 tools/bench_configs.py "5 mixed" > "$O/pmc_c5.log" 2>&1; cp gpurun_out/pmcc_c5/summary.txt "$O/config5_pmc.txt" 2>/dev/null
+tail -c 400 "$O/bench.json"
+exit 0
+fi
 timeout -k 10 400 python3 tools/bench_configs.py --progressive=100 > "$O/progressive.jsonl" 2>/dev/null
 timeout -k 10 300 python3 tools/bench_configs.py --progressive=7 "3 sph" "2G" >> "$O/progressive.jsonl" 2>/dev/null
 timeout -k 10 600 python3 tools/bench_configs.py --org-choice > "$O/org_choice.jsonl" 2>/dev/null; echo "org choice rc=$?"
 timeout -k 10 200 python3 tools/host_capture_probe.py > "$O/host_capture.json" 2>/dev/null
 LASGUN_CAPTURE_BANDS=1 timeout -k 10 200 python3 tools/host_capture_probe.py > "$O/host_capture_one_band.json" 2>/dev/null
 timeout -k 10 300 python3 tools/queue_levels.py glass > "$O/queue_levels.jsonl" 2>/dev/null
+timeout -k 10 600 python3 tools/ss_probe.py 256 512 1024 > "$O/ss_par.jsonl" 2>/dev/null; echo "ss_par rc=$?"
+timeout -k 10 300 python3 tools/tail_probe.py "3 sph" "4 mesh" "4m" "5 mixed" > "$O/tail_probe.jsonl" 2>/dev/null
+(timeout -k 10 100 python3 tools/host_capture_probe.py 512 simple; timeout -k 10 100 python3 tools/host_capture_probe.py 512 cornell_glass; timeout -k 10 100 python3 tools/host_capture_probe.py 768 spooky) > "$O/host_capture_examples.jsonl" 2>/dev/null
+LASGUN_DEBUG_TIMES=1 timeout -k 10 200 python3 tools/build_times.py > "$O/build_times.log" 2>&1
+(LASGUN_AUTOTUNE=0 timeout -k 10 600 python3 tools/ss_probe.py 256 512 1024; LASGUN_AUTOTUNE=0 timeout -k 10 300 python3 tools/bench_configs.py) > "$O/rule_first_launch.jsonl" 2>/dev/null
 LASGUN_AUDIT_SEEDS=100:300 LASGUN_AUDIT_LOG="$O/prune_audit.jsonl" timeout -k 10 600 python3 -m pytest tests/test_gpu_prune_audit.py -m gpu -x -q > "$O/audit.log" 2>&1; tail -2 "$O/audit.log"
-tail -c 400 "$O/bench.json"
+ls "$O" | wc -l
