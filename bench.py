@@ -188,8 +188,8 @@ def profiled_traffic(kernel_name, world, size):
 def mesh_roofline(G, la, stream):
     """configs[3] (generated 100k-triangle torus of glass + mirror sphere, recursion 3, 4096^2) on this GPU, two untimed
     frames after a warm-up: the triangle-test side of the path (the reference's 254-triangle leaves), in the organisation and
-    traversal mode the accel picks by default for such a scene (round 4: the queue organisation -- every recursion level in one
-    persistent launch -- over the pruned reference walk).  Counters from the counting instantiation of the same walk."""
+    traversal mode the accel picks by default for such a scene (the pruned reference walk; the organisation and the direction its tiles are
+    claimed in as MEASURED: `organisation` in the result says which).  Counters from the counting instantiation of the same walk."""
     size = 4096
     acc = G.Accel(la.scenes.mesh_scene(G, 224, 224, "glass"))
     film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
@@ -206,13 +206,15 @@ def mesh_roofline(G, la, stream):
 
     ms = frame_ms()
     default_film = film.clone()
+    ran_as = G.last_organisation(acc) or "?"
+    kernel_of = {"megakernel": "lg::trace_kernel<false, false, false, true, 1024>", "queue": "lg::queue_kernel<false, true>", "wavefront": "lg::wf_trace_kernel<...> (level by level)"}
     G.profile_enable(acc, True)
     G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
     torch.cuda.synchronize()
     kinds = {k: v[0] / v[1] for k, v in G.profile_read_kinds(acc).items() if v[1]}
     G.profile_read(acc)
     G.profile_enable(acc, False)
-    kernel_ms = kinds.get("trace_kernel", ms)  # HIP events around the persistent kernel on its launch stream
+    kernel_ms = kinds.get("trace_kernel", ms) if ran_as.split(",")[0] != "wavefront" else ms  # HIP events around the persistent kernel on its launch stream
     st = G.capture_stats(acc, size, size, 0, size)
     rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
     flops = algorithmic_flops(st)
@@ -222,6 +224,9 @@ def mesh_roofline(G, la, stream):
     G.set_streaming(acc, 0)
     ms_mega = frame_ms()
     same = bool(torch.equal(film, default_film))
+    G.set_streaming(acc, 3)
+    ms_queue = frame_ms()
+    same = same and bool(torch.equal(film, default_film))
     G.set_streaming(acc, 1)
     G.set_prune(acc, False)
     st_ref = G.capture_stats(acc, size, size, 0, size)
@@ -233,17 +238,16 @@ def mesh_roofline(G, la, stream):
     return {"workload": "configs[3]: 4096x4096, 100,352-triangle torus (glass) in a transformed group + mirror sphere in the Cornell shell, recursion 3",
             "ms_per_frame": ms, "value": rays / ms / 1e3, "unit": "Mrays/s", "rays_per_frame": rays,
             "bound": "valu_f64", "achieved": tops, "peak": VALU_F64_PEAK_TOPS, "frac": tops / VALU_F64_PEAK_TOPS,
-            "kernel": "lg::queue_kernel<false, true>", "kernel_ms_avg": kernel_ms, "algorithmic_flops_per_frame": flops,
+            "organisation": ran_as, "kernel": kernel_of.get(ran_as.split(",")[0], ran_as), "kernel_ms_avg": kernel_ms, "algorithmic_flops_per_frame": flops,
             "work_per_frame": {k: st[k] for k in ("nodes_tested", "spheres_tested", "cuboids_tested", "triangles_tested", "accel_entries", "hits")},
-            "traversal": "reference tree, pruned walk (lg_accel_set_prune default for a scene with a big mesh), queue organisation (k_queue.hip: one persistent launch "
-                         "for all recursion levels + the bottom-up combine passes)",
-            "megakernel": {"ms_per_frame": ms_mega, "film_identical": same},
+            "traversal": "reference tree, pruned walk (lg_accel_set_prune default for a scene with a big mesh); organisation and tile direction as measured (`organisation`)",
+            "megakernel": {"ms_per_frame": ms_mega, "film_identical": same}, "queue": {"ms_per_frame": ms_queue, "film_identical": same},
             "plain_walk": {"ms_per_frame": ms_plain, "algorithmic_flops_per_frame": flops_ref, "frac": flops_ref / (ms_plain * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS,
                            "triangles_tested": st_ref["triangles_tested"], "nodes_tested": st_ref["nodes_tested"]},
             "reference_work_rate_frac": flops_ref / (ms * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS,
             "note": "byte-identical to the oracle in tests/test_gpu_configs.py.  `frac` prices the tests the pruned walk still makes against the unfused f64 rate "
-                    "(profiles/r05_config4_pmc.txt: the kernel issues VALU instructions ~72 % of the time at ~60 % lane use; round 5's A/Bs -- DESIGN.md 3.5 -- show it "
-                    "latency-bound at four waves per SIMD rather than issue-bound: 8 % fewer VALU instructions bought 0.6 %; a triangle reached through the strips of a kept run is priced at the reference's 36 operations "
+                    "(profiles/r05_config4_pmc.txt: either persistent kernel issues the same 1.52e10 VALU wave-instructions, ~75 % of the issue slots at ~60 % lane use; round 5's A/Bs -- DESIGN.md 3.5 -- "
+                    "moved the frame by the ORDER of its tiles, not by its instruction count: 8 % fewer VALU instructions bought 0.6 %, tiles from the middle row outwards 10 %; a triangle reached through the strips of a kept run is priced at the reference's 36 operations "
                     "although the strip answers its sign test with ~20); `plain_walk` is the same frame with every test the reference makes, "
                     "`reference_work_rate_frac` that work over the pruned walk's time (what skipping buys, not a roofline fraction)"}
 

@@ -249,7 +249,7 @@ int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel defaul
  * runs deep levels with a few lanes per wave and the level-by-level pipeline ends every launch with its slowest wave's tail.
  * Returns non-zero (lg_last_error) for any other value. */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
-int lg_accel_last_organisation(const lg_accel *); /* what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 when its tiles were claimed bottom-up, + 64 when from the middle row outwards, + 32 when the megakernel took a supersampled pixel's samples one after the other (otherwise side by side: every organisation's way since round 5); -1: none yet */
+int lg_accel_last_organisation(const lg_accel *); /* what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 when its tiles were claimed bottom-up, + 64 when from the middle row outwards, + 128 when the megakernel handed its tiles out in parts, + 32 when the megakernel took a supersampled pixel's samples one after the other (otherwise side by side: every organisation's way since round 5); -1: none yet */
 /* The direction in which the megakernel and the queue organisation claim a launch's 8x8 tiles: 0 = from the film's top (row order), 1 = from
  * its bottom, 2 = from its middle row outwards (what a frame shows tends to sit in its middle, and a launch should END on cheap tiles: the
  * 100k-triangle glass torus 36.2 -> 32.8 ms in the megakernel, profiles/r05_ab_tile_middle.jsonl), -1 (default) = middle-out unless the
@@ -264,6 +264,12 @@ int lg_accel_set_tile_order(const lg_accel *, int order);
  * side by side, except that the megakernel's form is one more thing the measurement above times (frames of 1024^2 and more of a cheap
  * scene run faster with the samples in a row: a ninth of the tile claims). */
 int lg_accel_set_sample_order(const lg_accel *, int order);
+/* The megakernel's work item: a whole 8x8 tile per wave (1), or a tile in 2 / 4 / 8 parts of 32 / 16 / 8 lanes each.  A launch of fewer
+ * tiles than the grid has waves is as slow as its slowest tile's recursion tree; a part is a shorter tree, and four times the waves are at
+ * work (the kitchen sink at 512^2 2.40 -> 1.73 ms, the 100k-triangle metal torus at 256^2 2.23 -> 1.82; cheap scenes and big frames lose:
+ * profiles/r05_ab_split.jsonl).  -1 (default) = whole tiles unless the measurement above finds quarters faster for a small launch
+ * (lg_accel_last_organisation: + 128).  Same bytes either way. */
+int lg_accel_set_tile_parts(const lg_accel *, int parts);
 
 /* The WAVEFRONT pipeline is li() level by level: per recursion level a closest-hit pass (hits compacted into a queue, misses
  * finished on the spot), an any-hit shadow pass and a shade pass that appends the specular children to the next level's ray

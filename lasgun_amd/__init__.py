@@ -44,6 +44,7 @@ _EXTRA = {
     "accel_last_organisation": (_C.c_int, [_C.c_void_p]),
     "accel_set_tile_order": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_sample_order": (_C.c_int, [_C.c_void_p, _C.c_int]),
+    "accel_set_tile_parts": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_lds_scene": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_set_wf_split": (_C.c_int, [_C.c_void_p, _C.c_int]),
     "accel_synchronize": (_C.c_int, [_C.c_void_p]),
@@ -106,12 +107,20 @@ class HipApi(Api):
             name += ", middle-out"
         if name and (v & 32):
             name += ", samples in a row"
+        if name and (v & 128):
+            name += ", tiles in parts"
         return name
 
     def set_tile_order(self, accel, order):
         """The direction the megakernel and the queue organisation claim a launch's tiles in: 0 top-down, 1 bottom-up, 2 from the middle row outwards, None / -1 = middle-out unless measured otherwise
         (include/lasgun_hip.h, lg_accel_set_tile_order).  Same bytes either way."""
         if self.call("accel_set_tile_order", accel.h, -1 if order is None else int(order)):
+            raise LasgunError(self.last_error())
+
+    def set_tile_parts(self, accel, parts):
+        """The megakernel's work item: a whole tile per wave (1) or a tile in 2 / 4 / 8 parts; None / -1 = whole unless measured otherwise for
+        a small launch (include/lasgun_hip.h, lg_accel_set_tile_parts).  Same bytes either way."""
+        if self.call("accel_set_tile_parts", accel.h, -1 if parts is None else int(parts)):
             raise LasgunError(self.last_error())
 
     def set_sample_order(self, accel, order):

@@ -332,6 +332,7 @@ struct lg_accel {
     mutable uint32_t *q_err = nullptr;            // the queue organisation's sticky error word (pinned host memory, g_err_words): taken at its first launch
     mutable int queue = -1;                       // lg_accel_set_streaming(3) forces the queue organisation, (0..2) rule it out; -1 = queue_default
     mutable int last_org = -1;                    // what the last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 with its tiles claimed bottom-up (lg_accel_last_organisation)
+    mutable int tile_parts = -1;                  // lg_accel_set_tile_parts: the megakernel hands a tile out whole (1) or in 2 / 4 / 8 parts; -1 = whole unless the measured choice says quarters
     mutable int sample_order = -1;                // lg_accel_set_sample_order: 0 a pixel's samples side by side, 1 one after the other, -1 = side by side (megakernel: rule / measured)
     mutable int tile_order = -1;                  // lg_accel_set_tile_order: 0 top-down, 1 bottom-up, 2 from the middle row outwards, -1 = middle-out unless the measured choice says otherwise
     bool queue_default = false;                   // glass / mirror over a big mesh: long uneven walks, sparse deep levels (k_queue.hip)
@@ -866,13 +867,30 @@ static bool mega_par_by_rule(const lg_accel &a, const DParams &P, bool stats) {
     const unsigned long long grid_waves = lds_form ? (unsigned long long)a.ldss_blocks * (a.mega_narrow ? 12u : 16u) : (unsigned long long)(a.fast ? a.max_blocks_fast : a.max_blocks) * 4ull;
     return ss_mega >= 0 ? ss_mega == 1 : P.ntiles < SS_PAR_WAVES * grid_waves;
 }
-static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, bool par, bool stats, hipStream_t stream) {
+// A SMALL launch may hand its tiles out in QUARTERS (DParams::split: 16 lanes of a tile per wave, four times the waves at work): a frame of
+// fewer tiles than the grid has waves is as slow as its slowest tile's recursion tree, and a quarter of a tile is a shorter tree walked by
+// fewer diverging lanes.  Measured (tools/split_probe.py, profiles/r05_ab_split.jsonl): the kitchen sink at 512^2 2.40 -> 1.73 ms, the
+// 100k-triangle metal torus at 256^2 2.23 -> 1.82; cheap scenes and frames of 1024^2 and more lose (idle lanes are then lost throughput).
+// One more candidate of the measured choice; never by rule.
+constexpr uint32_t MEGA_SPLIT = 4;
+static bool mega_split_possible(const lg_accel &a, const DParams &P, bool stats) {
+    const bool lds_form = !a.fast && a.lds_scene && a.ldss_blocks;
+    const unsigned long long grid_waves = lds_form ? (unsigned long long)a.ldss_blocks * (a.mega_narrow ? 12u : 16u) : (unsigned long long)(a.fast ? a.max_blocks_fast : a.max_blocks) * 4ull;
+    const unsigned long long work = (unsigned long long)P.ntiles * (mega_par_by_rule(a, P, stats) ? (unsigned long long)P.ss_root * P.ss_root : 1ull);
+    return !stats && P.ntiles >= 2u && work <= 4ull * grid_waves;
+}
+static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, bool par, bool split, bool stats, hipStream_t stream) {
     const uint32_t nsamples = P.ss_root * P.ss_root;
     par = par && mega_par_possible(P, stats);
     if (par) {
         const size_t n_items = (size_t)P.ntiles * 64ull * nsamples, need = n_items * 3 * 8;
         if (c.wf_mem.n < need) { HIP_TRY(hipDeviceSynchronize()); c.wf_mem.alloc(need); }
         P.accum = reinterpret_cast<double *>(c.wf_mem.p); P.n_items = n_items; P.ss_par = nsamples; P.ntiles *= nsamples;
+    }
+    { // tiles handed out in parts: the measured choice's candidate, or LASGUN_MEGA_SPLIT=2|4|8 (A/B)
+        static const uint32_t split_env = [] { const char *e = std::getenv("LASGUN_MEGA_SPLIT"); const int v = e ? std::atoi(e) : 0; return v == 2 || v == 4 || v == 8 ? (uint32_t)v : 1u; }();
+        const uint32_t parts = a.tile_parts >= 1 ? (uint32_t)a.tile_parts : split_env > 1u ? split_env : split ? MEGA_SPLIT : 1u;
+        if (parts > 1u && !stats && (unsigned long long)P.ntiles * parts < (1ull << 31)) { P.split = parts; P.ntiles *= parts; }
     }
     uint32_t cap = a.fast ? a.max_blocks_fast : a.max_blocks;
     uint32_t blocks = (P.ntiles + 3u) / 4u;
@@ -916,10 +934,13 @@ static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, 
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, stream));
     }
+#ifdef LG_QIDLE // diagnostic build: the waves' start / exit times of this launch (k_mega.hip), read by lg_debug_stats
+    if (!stats) { P.stats = a.stats.p; HIP_TRY(hipMemsetAsync(a.stats.p, 0, sizeof(DStats), stream)); }
+#endif
     HIP_TRY(launch_trace(P, stats, a.fast, blocks, a.fast ? a.stack_depth_fast1 : a.stack_depth, stream));
     if (par) {
         DParams R = P;
-        R.ntiles = P.ntiles / nsamples; R.tile_rev = 0u;
+        R.ntiles = P.ntiles / nsamples / (P.split > 1u ? P.split : 1u); R.tile_rev = 0u; R.split = 0u;
         HIP_TRY(launch_wf_resolve(R, (uint32_t)(((unsigned long long)R.ntiles * 64ull + 255ull) / 256ull), stream));
     }
     if (a.profiling) {
@@ -927,12 +948,12 @@ static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, 
         a.events.emplace_back(e0, e1);
     }
 }
-static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Org org, int dir, bool ss_serial, bool stats, hipStream_t stream) { // (P by value: an organisation fills in its own fields)
+static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Org org, int dir, bool ss_serial, bool split, bool stats, hipStream_t stream) { // (P by value: an organisation fills in its own fields)
     P.tile_counter = c.tile_counter.p;
     P.tile_rev = org != ORG_WAVEFRONT ? (uint32_t)dir : 0u; // 0 top-down, 1 bottom-up, 2 from the middle outwards (the level-by-level passes are short and alike: one direction)
     if (org == ORG_QUEUE) enqueue_queue(a, P, c, stream);
     else if (org == ORG_WAVEFRONT) enqueue_wavefront(a, P, c, stream);
-    else enqueue_mega(a, P, c, !ss_serial, stats, stream);
+    else enqueue_mega(a, P, c, !ss_serial, split, stats, stream);
 }
 
 // The MEASURED choice (round 5; the rule above was a fit to eight scenes and wrong by 6-22 % on the first scene that was not among
@@ -963,6 +984,7 @@ static int dir_of(int choice) { return (choice & TUNE_REV) ? 1 : (choice & TUNE_
 // simple.rs 0.55 -> 0.53, nothing slower among the configs (profiles/r05_ab_tile_middle.jsonl).
 constexpr int DIR_DEFAULT = 2;
 static int dir_unmeasured(const lg_accel &a, Org org) { return org == ORG_WAVEFRONT ? 0 : a.tile_order >= 0 ? a.tile_order : DIR_DEFAULT; }
+constexpr int TUNE_SPLIT = 128; //   | TUNE_SPLIT when the megakernel hands a small launch's tiles out in quarters (enqueue_mega)
 constexpr int TUNE_SERIAL = 32; //   | TUNE_SERIAL when the megakernel takes a pixel's samples one after the other (enqueue_mega)
 std::mutex g_tune_mtx;
 std::mutex g_tune_run_mtx; // one measurement at a time in the process: two accels of one kind measuring side by side would time each other
@@ -998,7 +1020,7 @@ static TuneKey tune_key(const lg_accel &a, const DParams &P) {
         k.v[9] = hsh ^ ((uint64_t)a.device << 56);
     }
     k.v[10] = cls;
-    k.v[11] = (P.mode == 0u ? 0u : 1u) | (a.tile_order >= 0 ? 2u + (uint64_t)a.tile_order : 0u) | ((uint64_t)(a.sample_order + 1) << 4); // (a forced direction is a kind of its own: only the organisations race)
+    k.v[11] = (P.mode == 0u ? 0u : 1u) | (a.tile_order >= 0 ? 2u + (uint64_t)a.tile_order : 0u) | ((uint64_t)(a.sample_order + 1) << 4) | ((uint64_t)(a.tile_parts + 1) << 8); // (a forced direction is a kind of its own: only the organisations race)
     return k;
 }
 static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx &c, hipStream_t stream) {
@@ -1022,13 +1044,14 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     const bool was_profiling = a.profiling;
     a.profiling = false; // (the measurement's launches are not the caller's: lg_profile_read must not count them)
     // candidates: [organisation][samples side by side, one after the other (megakernel only)][top-down, bottom-up, middle-out]
-    constexpr int NC = 18;
+    constexpr int NC = 19, K_SPLIT = 18; // (+ the megakernel with its tiles in quarters: sample order by the rule, middle-out)
     float best_ms[NC];
     bool in_race[NC];
     const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
     for (int k = 0; k < NC; ++k) {
-        const int org = k / 6, ser = (k / 3) & 1, dir = k % 3;
         best_ms[k] = INFINITY;
+        if (k == K_SPLIT) { in_race[k] = mega_split_possible(a, P, false) && a.tile_parts < 0 && (a.tile_order < 0 || a.tile_order == DIR_DEFAULT); continue; }
+        const int org = k / 6, ser = (k / 3) & 1, dir = k % 3;
         in_race[k] = org_possible(a, P, false, (Org)org) &&
                      (ser ? org == ORG_MEGA : (org != ORG_MEGA || mega_par_possible(P, false))) &&
                      !(org == ORG_MEGA && mega_par_possible(P, false) && a.sample_order >= 0 && ser != a.sample_order) && // (lg_accel_set_sample_order) // (one form of the megakernel for a frame of one sample per pixel: the serial one)
@@ -1046,7 +1069,8 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
             for (int k = 0; k < NC; ++k) {
                 if (!in_race[k]) continue;
                 HIP_TRY(hipEventRecord(e0, stream));
-                enqueue_org(a, P, c, (Org)(k / 6), k % 3, ((k / 3) & 1) != 0, false, stream);
+                if (k == K_SPLIT) enqueue_org(a, P, c, ORG_MEGA, DIR_DEFAULT, !mega_par_by_rule(a, P, false), true, false, stream);
+                else enqueue_org(a, P, c, (Org)(k / 6), k % 3, ((k / 3) & 1) != 0, false, false, stream);
                 HIP_TRY(hipEventRecord(e1, stream));
                 HIP_TRY(hipEventSynchronize(e1));
                 float ms = 0.0f;
@@ -1073,12 +1097,14 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     int best = (int)rule * 6 + (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? 3 : 0) + (P.ntiles < 2u ? 0 : dir_unmeasured(a, rule));
     for (int k = 0; k < NC; ++k)
         if (best_ms[k] < best_ms[best] * 0.98f) best = k;
-    const int choice = (best / 6) | dir_bits(best % 3) | (((best / 3) & 1) ? TUNE_SERIAL : 0);
+    const int choice = best == K_SPLIT ? (int)ORG_MEGA | dir_bits(DIR_DEFAULT) | (!mega_par_by_rule(a, P, false) ? TUNE_SERIAL : 0) | TUNE_SPLIT
+                                       : (best / 6) | dir_bits(best % 3) | (((best / 3) & 1) ? TUNE_SERIAL : 0);
     if (std::getenv("LASGUN_DEBUG"))
         std::fprintf(stderr, "[lasgun] measured for %llu pixels (top-down / bottom-up / middle-out): megakernel %.3f / %.3f / %.3f ms (samples in a row: %.3f / %.3f / %.3f), level by level %.3f ms, queue %.3f / %.3f / %.3f ms -> %s%s%s (rule: %d)\n",
                      items, best_ms[0], best_ms[1], best_ms[2], best_ms[3], best_ms[4], best_ms[5], best_ms[6], best_ms[12], best_ms[13], best_ms[14], // (one sample per pixel: "in a row" is the megakernel)
-                     best / 6 == 0 ? "megakernel" : best / 6 == 1 ? "level by level" : "queue",
-                     best % 3 == 1 ? ", bottom-up" : best % 3 == 2 ? ", middle-out" : "", ((best / 3) & 1) ? ", samples in a row" : "", (int)rule);
+                     best == K_SPLIT ? "megakernel, tiles in quarters" : best / 6 == 0 ? "megakernel" : best / 6 == 1 ? "level by level" : "queue",
+                     best == K_SPLIT ? "" : best % 3 == 1 ? ", bottom-up" : best % 3 == 2 ? ", middle-out" : "", best != K_SPLIT && ((best / 3) & 1) ? ", samples in a row" : "", (int)rule);
+    if (std::getenv("LASGUN_DEBUG") && in_race[K_SPLIT]) std::fprintf(stderr, "[lasgun]   (megakernel with its tiles in quarters: %.3f ms)\n", best_ms[K_SPLIT]);
     std::lock_guard<std::mutex> g(g_tune_mtx);
     g_tuned[key] = choice;
     return choice;
@@ -1092,6 +1118,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     Org org;
     int dir = -1; // lg_accel_set_tile_order; -1: from the middle outwards unless measured otherwise (dir_unmeasured)
     bool ss_serial = !mega_par_by_rule(a, P, stats); // the megakernel's samples: by the rule unless measured
+    bool split = false;                              // its tiles in quarters: only as measured
     if (stats) { org = ORG_MEGA; dir = 0; }                                                      // the counting variant
     else if (a.queue == 1) org = org_possible(a, P, stats, ORG_QUEUE) ? ORG_QUEUE : org_by_rule(a, P, stats); // lg_accel_set_streaming(3)
     else if (!a.streaming) org = ORG_MEGA;                                                       // lg_accel_set_streaming(0)
@@ -1104,11 +1131,12 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
         org = (Org)(choice & (TUNE_REV - 1));
         dir = dir_of(choice);
         ss_serial = (choice & TUNE_SERIAL) != 0;
+        split = (choice & TUNE_SPLIT) != 0;
     }
     if (dir < 0) dir = P.ntiles < 2u ? 0 : dir_unmeasured(a, org);
     if (org == ORG_WAVEFRONT) dir = 0;
-    a.last_org = (int)org | dir_bits(dir) | (org == ORG_MEGA && ss_serial && P.ss_root > 1 ? TUNE_SERIAL : 0);
-    enqueue_org(a, P, c, org, dir, ss_serial, stats, stream);
+    a.last_org = (int)org | dir_bits(dir) | (org == ORG_MEGA && ss_serial && P.ss_root > 1 ? TUNE_SERIAL : 0) | (org == ORG_MEGA && (split || a.tile_parts > 1) ? TUNE_SPLIT : 0);
+    enqueue_org(a, P, c, org, dir, ss_serial, split, stats, stream);
 }
 
 static void set_rect(DParams &P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
@@ -2090,6 +2118,12 @@ int lg_accel_set_tile_order(const lg_accel *a, int order) { // the direction the
     a->tile_order = order;
     return 0;
 }
+int lg_accel_set_tile_parts(const lg_accel *a, int parts) { // the megakernel: a tile handed out whole or in parts of 64 / parts lanes
+    std::lock_guard<std::mutex> g(a->mtx);
+    if (!(parts == -1 || parts == 1 || parts == 2 || parts == 4 || parts == 8)) return fail("tile parts must be -1 (default), 1, 2, 4 or 8");
+    a->tile_parts = parts;
+    return 0;
+}
 int lg_accel_set_sample_order(const lg_accel *a, int order) { // a supersampled pixel's samples: side by side in one launch chain, or one after the other
     std::lock_guard<std::mutex> g(a->mtx);
     if (order < -1 || order > 1) return fail("sample order must be -1 (default), 0 (side by side) or 1 (one after the other)");
@@ -2442,7 +2476,7 @@ extern "C" int lg_debug_queue_packets(const lg_accel *a, void *hip_stream, unsig
     });
 }
 
-#if defined(LG_PKT_STATS) || defined(LG_STAMPS)
+#if defined(LG_PKT_STATS) || defined(LG_STAMPS) || defined(LG_QIDLE)
 extern "C" int lg_debug_stats(const lg_accel *a, int clear, unsigned long long *out9) { // analysis builds only
     return guarded([&] {
         use_device(a->device);

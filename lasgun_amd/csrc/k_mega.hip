@@ -30,6 +30,9 @@ __global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_N
     const uint4 *const arec = (LDSS || FAST) ? nullptr : load_accel_image(P, P.stack_depth * LG_BLOCK);
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!wave_has_work(P.ntiles)) return; // (after the workgroup's barrier: a small film leaves most of the grid nothing to claim)
+#ifdef LG_QIDLE // diagnostic build (tools/queue_idle.py): when this wave started and left, in 100 MHz ticks -> how much of the launch its waves sit out
+    const unsigned long long idle_t0 = wall_clock64();
+#endif
 
     for (bool final = false; !final;) {
         // ---- fetch the next 64-pixel tile for this wavefront.  (One head word for the whole chip here: the per-XCD bands of
@@ -39,11 +42,12 @@ __global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_N
         if (tile == NO_TILE) break; // (a wave leaves here, or after one of the launch's last tiles: kcommon.h)
 
         // (claimed from the last tile down: DParams::tile_rev; samples side by side: a tile is a pixel tile at ONE of its samples, DParams::ss_par)
-        const uint32_t vtile = tile_in_order(P, tile);
+        uint32_t vtile = tile_in_order(P, tile), part = 0u;
+        if (P.split > 1u) { part = vtile % P.split; vtile /= P.split; } // (a small launch: 64 / split lanes of the tile per wave, DParams::split)
         uint32_t s_first;
         const Pixel px = pixel_of(P, l0_tile(P, vtile, s_first), lane);
         const uint32_t x = px.x, y = px.y;
-        const bool active = px.active;
+        const bool active = px.active && (P.split <= 1u || lane / (64u / P.split) == part);
         if (!active) continue; // lanes past the edge idle for this tile
 
         // ---- Camera::sample (camera.rs:113-146)
@@ -241,6 +245,15 @@ __global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_N
         }
     }
 
+#ifdef LG_QIDLE
+    if (!STATS && lane == 0u && P.stats) {
+        const unsigned long long t1 = wall_clock64();
+        atomicMax(&P.stats->primary_rays, (1ull << 62) - idle_t0); // the earliest start
+        atomicMax(&P.stats->shadow_rays, t1);                       // the last exit
+        atomicAdd(&P.stats->secondary_rays, t1);                    // sum of the exits
+        atomicAdd(&P.stats->nodes_tested, 1ull);                    // waves
+    }
+#endif
     if (STATS) {
         atomicAdd(&P.stats->primary_rays, (unsigned long long)cnt.primary);
         atomicAdd(&P.stats->shadow_rays, (unsigned long long)cnt.shadow);

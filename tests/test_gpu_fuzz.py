@@ -130,6 +130,15 @@ def test_fuzz_campaign(gen):
         done["renders"] += 1
         if not np.array_equal(film.pixels(), ofilm.pixels()):
             done["mismatches"].append([seed, "samples-in-a-row", (0, 2, 3)[seed % 3]])
+        # the megakernel handing its tiles out in quarters (lg_accel_set_tile_parts(4): what the measured choice may pick for a small launch)
+        G.set_streaming(acc, 0)
+        G.set_tile_parts(acc, 4 if seed % 2 else 2)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        G.set_tile_parts(acc, None)
+        done["renders"] += 1
+        if not np.array_equal(film.pixels(), ofilm.pixels()):
+            done["mismatches"].append([seed, "tiles-in-parts"])
         if done["scenes"] % 25 == 0:
             print("fuzz %s: %d scenes, %d renders, %d mismatches" % (gen, done["scenes"], done["renders"], len(done["mismatches"])), flush=True)
     log = os.environ.get("LASGUN_FUZZ_LOG")

@@ -369,6 +369,45 @@ def test_a_pixels_samples_side_by_side_or_in_a_row_are_the_same_film(name):
         G.set_sample_order(acc, 2)
 
 
+@pytest.mark.parametrize("name", ["cornell_glass_256", "kitchen_sink_persp", "mesh_glass_128", "ragged_67x13", "one_pixel", "spooky_ss2_256", "simple_ss2_160"])
+def test_megakernel_tiles_in_parts_are_the_same_film(name):
+    """lg_accel_set_tile_parts: the megakernel hands a tile out whole or in 2 / 4 / 8 parts of 32 / 16 / 8 lanes (more waves at work on a small
+    launch) -- bytes, radiance bits, a strided subset and a batch of subsets against the oracle, with a pixel's samples side by side and in a row."""
+    builder, w, h = MID[name]
+    o = oracle()
+    oacc = o.Accel(builder(o))
+    ofilm = o.Film(w, h)
+    o.capture_subset_mt(0, 1, oacc, ofilm, 8)
+    o.set_trig_mode(1)
+    try:
+        orad = o.capture_radiance(oacc, w, h, nthreads=8)
+    finally:
+        o.set_trig_mode(0)
+    want = ofilm.pixels().reshape(-1, 4)
+    acc = G.Accel(builder(G))
+    G.set_streaming(acc, 0)
+    for parts in (2, 4, 8, 1, None):
+        G.set_tile_parts(acc, parts)
+        for order in (0, 1):
+            G.set_sample_order(acc, order)
+            film = G.Film(w, h)
+            G.capture_subset(0, 1, acc, film)
+            assert np.array_equal(film.pixels(), ofilm.pixels()), (parts, order)
+            if w * h > 64:
+                assert ("tiles in parts" in G.last_organisation(acc)) == (parts in (2, 4, 8)), (parts, G.last_organisation(acc))
+            assert np.array_equal(bits(G.capture_radiance(acc, w, h)), bits(orad)), (parts, order)
+            buf = np.full((h, w, 4), 7, np.uint8)
+            G.capture_subset(2, 5, acc, G.Film.new_with_output(w, h, buf))
+            G.capture_subsets((0, 3), 5, acc, G.Film.new_with_output(w, h, buf))
+            got = buf.reshape(-1, 4)
+            for k in (0, 2, 3):
+                assert np.array_equal(got[k::5], want[k::5]), (parts, order, k)
+            for k in (1, 4):
+                assert np.all(got[k::5] == 7), (parts, order, k)
+    with pytest.raises(la.LasgunError):
+        G.set_tile_parts(acc, 3)
+
+
 def test_samples_side_by_side_in_small_chunks():
     """The level-by-level pipeline and the queue organisation under a memory budget that cuts a supersampled film into many chunks (a chunk
     holds pixel tiles x samples work items): same film."""
