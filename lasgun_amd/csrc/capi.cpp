@@ -890,7 +890,7 @@ static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, 
     { // tiles handed out in parts: the measured choice's candidate, or LASGUN_MEGA_SPLIT=2|4|8 (A/B)
         static const uint32_t split_env = [] { const char *e = std::getenv("LASGUN_MEGA_SPLIT"); const int v = e ? std::atoi(e) : 0; return v == 2 || v == 4 || v == 8 ? (uint32_t)v : 1u; }();
         const uint32_t parts = a.tile_parts >= 1 ? (uint32_t)a.tile_parts : split_env > 1u ? split_env : split ? MEGA_SPLIT : 1u;
-        if (parts > 1u && !stats && (unsigned long long)P.ntiles * parts < (1ull << 31)) { P.split = parts; P.ntiles *= parts; }
+        if (parts > 1u && !stats && (unsigned long long)P.ntiles * parts < (1ull << 31)) { P.split_shift = parts == 2u ? 1u : parts == 4u ? 2u : 3u; P.ntiles *= parts; }
     }
     uint32_t cap = a.fast ? a.max_blocks_fast : a.max_blocks;
     uint32_t blocks = (P.ntiles + 3u) / 4u;
@@ -940,7 +940,7 @@ static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, 
     HIP_TRY(launch_trace(P, stats, a.fast, blocks, a.fast ? a.stack_depth_fast1 : a.stack_depth, stream));
     if (par) {
         DParams R = P;
-        R.ntiles = P.ntiles / nsamples / (P.split > 1u ? P.split : 1u); R.tile_rev = 0u; R.split = 0u;
+        R.ntiles = (P.ntiles >> P.split_shift) / nsamples; R.tile_rev = 0u; R.split_shift = 0u;
         HIP_TRY(launch_wf_resolve(R, (uint32_t)(((unsigned long long)R.ntiles * 64ull + 255ull) / 256ull), stream));
     }
     if (a.profiling) {
@@ -961,7 +961,7 @@ static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Or
 // the clock: the second launch of a KIND in the process (its first: the rule's choice at no cost, autotune_mode below) -- the scene's shape (table sizes, materials, lights, recursion, samples per pixel, traversal
 // mode, LDS residency), the device, the launch's size class (log2 of its pixels) and addressing mode -- renders the launch with every
 // CANDIDATE that can take it (a warm-up pass, then three timed passes over the candidates in turn, HIP events on the caller's stream,
-// the host waiting; the best of each), keeps the fastest (the rule's own choice unless another beats it by 2 %) and remembers it for
+// the host waiting; the best of each), keeps the fastest (the rule's own choice unless another beats it by 1 %) and remembers it for
 // the process: capture() rebuilds its accel for every frame (lib.rs:64), so the memory is keyed by the scene's shape, not by the accel.
 // A candidate is an organisation and, for the megakernel and the queue organisation, the DIRECTION the launch's tiles are claimed in:
 // a launch ends with the recursion trees of its last tiles, and whether the film's top or its bottom should come last is the scene's
@@ -1096,7 +1096,7 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     check_queue_error(a);
     int best = (int)rule * 6 + (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? 3 : 0) + (P.ntiles < 2u ? 0 : dir_unmeasured(a, rule));
     for (int k = 0; k < NC; ++k)
-        if (best_ms[k] < best_ms[best] * 0.98f) best = k;
+        if (best_ms[k] < best_ms[best] * 0.99f) best = k; // (the rule's choice unless another beats it by 1 %: equal candidates do not flip from run to run)
     const int choice = best == K_SPLIT ? (int)ORG_MEGA | dir_bits(DIR_DEFAULT) | (!mega_par_by_rule(a, P, false) ? TUNE_SERIAL : 0) | TUNE_SPLIT
                                        : (best / 6) | dir_bits(best % 3) | (((best / 3) & 1) ? TUNE_SERIAL : 0);
     if (std::getenv("LASGUN_DEBUG"))

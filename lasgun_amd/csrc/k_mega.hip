@@ -42,12 +42,21 @@ __global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_N
         if (tile == NO_TILE) break; // (a wave leaves here, or after one of the launch's last tiles: kcommon.h)
 
         // (claimed from the last tile down: DParams::tile_rev; samples side by side: a tile is a pixel tile at ONE of its samples, DParams::ss_par)
-        uint32_t vtile = tile_in_order(P, tile), part = 0u;
-        if (P.split > 1u) { part = vtile % P.split; vtile /= P.split; } // (a small launch: 64 / split lanes of the tile per wave, DParams::split)
+        // (a small launch may hand a tile out in 2^split_shift parts of 64 >> split_shift lanes each, DParams::split_shift: scalar shifts and one
+        // compare -- written with a division by the part count this cost the kernel 5-8 % on configs 4, 4m and 5 through its register allocation)
+        uint32_t vtile = tile_in_order(P, tile);
+#ifndef LG_NO_SPLIT
+        const uint32_t part = vtile & ((1u << P.split_shift) - 1u);
+        vtile >>= P.split_shift;
+#endif
         uint32_t s_first;
         const Pixel px = pixel_of(P, l0_tile(P, vtile, s_first), lane);
         const uint32_t x = px.x, y = px.y;
-        const bool active = px.active && (P.split <= 1u || lane / (64u / P.split) == part);
+#ifndef LG_NO_SPLIT
+        const bool active = px.active && (lane >> (6u - P.split_shift)) == part;
+#else
+        const bool active = px.active;
+#endif
         if (!active) continue; // lanes past the edge idle for this tile
 
         // ---- Camera::sample (camera.rs:113-146)
