@@ -225,8 +225,10 @@ int lg_accel_set_mode(const lg_accel *, int mode);
  * more than a margin derived from the rounding of the reference's own intersection formulas: every
  * primitive below such a node would be rejected by the reference's `t >= isect.t` (sphere.rs:86, cuboid.rs:95,
  * triangle.rs:251), so every pixel is what the unpruned walk gives.  Nodes over a nested BVHAccel are never skipped; inside a
- * mesh only the ray's dominant axis counts.  -1 (default): on for scenes that carry a mesh of >= 256 triangles (the
- * reference's 254-triangle leaves are where it pays), off otherwise; 0 / 1: off / on. */
+ * mesh only the ray's dominant axis counts.  -1 (default): on for scenes that carry a mesh of >= 4096 triangles (the
+ * reference's 254-triangle leaves are where it pays; below that it measured 5-30 % slower and its leaf records are a third to a half of
+ * the accel build: profiles/r05_prune_threshold.jsonl -- rounds 3-5 had 256), off otherwise; 0 / 1: off / on (1 on an accel whose
+ * tables were built without the leaf records builds them then). */
 int lg_accel_set_prune(const lg_accel *, int enabled);
 int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel default, LASGUN_PRUNE, lg_accel_set_prune, fast mode): 0 / 1 */
 

@@ -92,7 +92,7 @@ class HipApi(Api):
             raise LasgunError(self.last_error())
 
     def set_prune(self, accel, enabled):
-        """Pruned form of the reference traversal: None / -1 = the accel's default (on for scenes with a mesh of >= 256
+        """Pruned form of the reference traversal: None / -1 = the accel's default (on for scenes with a mesh of >= 4096
         triangles), False / True = off / on (include/lasgun_hip.h, lg_accel_set_prune)."""
         if self.call("accel_set_prune", accel.h, -1 if enabled is None or enabled == -1 else (1 if enabled else 0)):
             raise LasgunError(self.last_error())

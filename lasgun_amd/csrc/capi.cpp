@@ -854,6 +854,7 @@ static Org org_by_rule(const lg_accel &a, const DParams &P, bool stats) {
 // 1.2 - 10 x faster (a 512^2 film is one tile per wave of the grid: nine samples in a row on each, or nine times the tiles); frames of
 // 1024^2 and more of a cheap scene 30-50 % SLOWER (nine times the claims on one head word, 8 ns each).  So: possible while the parked
 // samples fit 1 GiB, the rule below where nothing is measured, and one more thing the measured choice times.
+constexpr size_t PRUNE_MIN_TRIS = 4096; // the pruned walk (and its leaf records) by default: from this many triangles in one mesh
 constexpr unsigned long long SS_PAR_WAVES = 8; // the rule: side by side below this many pixel tiles per wave of the grid (9 of 12 scenes faster at 1024^2, none at 2048^2)
 static bool mega_par_possible(const DParams &P, bool stats) {
     const unsigned long long nsamples = (unsigned long long)P.ss_root * P.ss_root;
@@ -1378,7 +1379,13 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
     a->ldss_blocks = 0; a->lds_image_n16 = 0; a->fast_available = true;
         static const bool times = std::getenv("LASGUN_DEBUG_TIMES") != nullptr; // (where lg_accel_from's time goes: flatten / upload / derived)
         const auto t_begin = std::chrono::steady_clock::now();
-        flatten_scene(*a->scene, a->flat, with_fast); // host HLBVH build + flatten (throws on what the reference would panic on)
+        // The culling records and strips of the pruned walk's mesh leaves are built when that walk will run: by default from PRUNE_MIN_TRIS
+        // triangles in a mesh (below: on), when LASGUN_PRUNE=1 or lg_accel_set_prune(1) ask for it (ensure_records).
+        size_t big_mesh_tris = 0;
+        for (const auto &m : a->scene->meshes) if (m && m->tri.size() / 3 > big_mesh_tris) big_mesh_tris = m->tri.size() / 3;
+        static const int prune_env = [] { const char *e = std::getenv("LASGUN_PRUNE"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();
+        const bool with_records = a->prune == 1 || (a->prune < 0 && (prune_env == 1 || (prune_env < 0 && big_mesh_tris >= PRUNE_MIN_TRIS)));
+        flatten_scene(*a->scene, a->flat, with_fast, with_records); // host HLBVH build + flatten (throws on what the reference would panic on)
         const auto t_flat = std::chrono::steady_clock::now();
         use_device(a->device);
         const FlatScene &f = a->flat;
@@ -1589,7 +1596,10 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
             // 512^2: 0.81 ms level by level, 0.80 ms in the megakernel since both walk with traverse_ref), and with a big mesh the deeper
             // levels are few, long, incoherent walks through 254-triangle leaves whose slowest wave sets each launch's length
             // (100k-triangle glass torus: 226 against 136 ms): those stay in the megakernel, where other tiles fill the gaps.
-            a->prune_default = big_mesh >= 256; // the reference's mesh leaves hold up to 254 triangles (bvh.rs:187,289): skipping one pays for many node steps
+            // the reference's mesh leaves hold up to 254 triangles (bvh.rs:187,289): skipping one pays for many node steps -- from PRUNE_MIN_TRIS
+            // triangles (tools/prune_threshold_probe.py, profiles/r05_prune_threshold.jsonl: below that the pruned walk is 5-30 % SLOWER on
+            // 1024^2 frames and its records are a third to a half of the accel build; rounds 3-5 had 256)
+            a->prune_default = big_mesh >= PRUNE_MIN_TRIS;
             a->streaming_pays = f.spheres.size() + f.cuboids.size() >= 512 && !(f.has_specular && big_mesh >= 4096);
             a->mega_narrow = f.spheres.size() + f.cuboids.size() < 512;
             if (const char *e = std::getenv("LASGUN_MEGA_LANES")) a->mega_narrow = std::atoi(e) == 768; // (A/B)
@@ -1636,14 +1646,17 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.device_bytes, y.device_bytes); swap(x.fast_available, y.fast_available); swap(x.fast_refusal, y.fast_refusal);
     swap(x.streaming_pays, y.streaming_pays); swap(x.streaming_min_items, y.streaming_min_items); swap(x.mega_narrow, y.mega_narrow);
 }
-static void ensure_fast_trees(const lg_accel *ca) {
-    if (ca->flat.has_fast) return;
+// the tables once more, with what was left out of them: the fast mode's trees (lg_accel_set_mode(1)), the pruned walk's leaf records (ensure_records)
+static void ensure_fast_trees(const lg_accel *ca, bool fast = true) {
+    if (fast && ca->flat.has_fast) return;
     lg_accel *a = const_cast<lg_accel *>(ca);
     use_device(a->device);
     std::unique_ptr<lg_accel> next(new lg_accel());
     next->scene = a->scene;
     next->device = a->device;
-    build_and_upload(next.get(), true); // throws: `a` is untouched
+    next->prune = a->prune == 1 || a->flat.has_records ? 1 : a->prune; // (what the tables hold stays in them)
+    build_and_upload(next.get(), fast || a->flat.has_fast); // throws: `a` is untouched
+    next->prune = a->prune;
     // (bit patterns, not values: a NaN bound of a degenerate scene equals itself here)
     if (next->flat.dump_f.size() != a->flat.dump_f.size() ||
         (!a->flat.dump_f.empty() && std::memcmp(next->flat.dump_f.data(), a->flat.dump_f.data(), a->flat.dump_f.size() * sizeof(a->flat.dump_f[0])) != 0) ||
@@ -2074,6 +2087,12 @@ int lg_audit_prune(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint3
         std::lock_guard<std::mutex> g(a->mtx);
         if (a->fast) throw Error("the audit is of the pruned REFERENCE walk: not available in fast mode");
         use_device(a->device);
+        if (!a->flat.has_records) { // the audit is of the pruned walk as it runs when it is on: with the mesh leaves' records
+            const int before = a->prune;
+            a->prune = 1;
+            try { ensure_fast_trees(a, false); } catch (...) { a->prune = before; throw; }
+            a->prune = before;
+        }
         DParams P = base_params(*a, w, h);
         set_rect(P, 0, y0, w, y1);
         P.out_row0 = y0;
@@ -2141,7 +2160,12 @@ int lg_accel_get_prune(const lg_accel *a) { // the EFFECTIVE setting of the prun
 int lg_accel_set_prune(const lg_accel *a, int enabled) {
     if (enabled < -1 || enabled > 1) return fail("prune must be -1 (default), 0 or 1");
     std::lock_guard<std::mutex> g(a->mtx);
+    const int before = a->prune;
     a->prune = enabled;
+    if (enabled == 1 && !a->flat.has_records) { // the mesh leaves' culling records were left out of this accel's tables (a small mesh): build them now
+        int rc = guarded([&] { ensure_fast_trees(a, false); });
+        if (rc) { a->prune = before; return rc; }
+    }
     return 0;
 }
 int lg_accel_set_mode(const lg_accel *a, int mode) {

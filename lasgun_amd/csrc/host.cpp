@@ -1426,7 +1426,7 @@ static void build_chunks(FlatScene &out) {
     out.strips.resize(out.strips.size() + 2, DStrip{0.f, 0.f, 0.f, 0u}); // two spare entries: the leaf loop keeps the next entry in flight
 }
 
-void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
+void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast, bool with_records) {
     out = FlatScene();
     Flattener fl{scene, out, {}, with_fast};
     out.has_fast = with_fast;
@@ -1442,7 +1442,8 @@ void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast) {
     out.max_stack_fast1 = fneed1;
     if (out.primref.size() > 80000000u) throw Error("too many primitive slots for the 32-bit record offsets of the triangle stream");
     out.leaf_soup.resize(out.primref.size() + 2, DLeafRec{}); // two spare records: the mesh leaf loop keeps the next slot in flight
-    build_chunks(out);
+    if (with_records) build_chunks(out);
+    out.has_records = with_records;
     if (times) {
         const auto t2 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

@@ -131,12 +131,15 @@ struct FlatScene {
     uint32_t max_stack_fast1 = 0; // the fast trees under the wide walk (one word per pending child, 3-word level frames)
     bool has_specular = false;   // any glass / mirror material present
     bool has_fast = false;       // the fast mode's trees are part of the tables
+    bool has_records = false;    // the mesh leaves' culling records and strips are part of the tables (or there is no mesh)
     bool boxes_finite = false;   // every node box is finite with bmin <= bmax on every axis (DParams::boxes_finite: the sign-specialised slab test is exact then)
     // structure dump in the same format as the oracle's orc_accel_dump (build-parity tests)
     std::vector<double> dump_f;
     std::vector<int64_t> dump_i;
 };
 // `with_fast`: also build the fast mode's trees (binned SAH; 5-10x the reference build's time): only when that mode is asked for
-void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast = false); // throws Error
+// (with_records: the culling records and strips of the pruned walk's mesh leaves -- a third to a half of a mesh accel's build; without them
+// every mesh leaf is walked in the reference's order, pruned walk or not)
+void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast = false, bool with_records = true); // throws Error
 
 } // namespace lg

@@ -303,6 +303,33 @@ def test_multi_device_all_gather_form_single_rank(w, h, block_rows):
     m2.close()
 
 
+def test_the_pruned_walks_leaf_records_are_built_when_it_will_run():
+    """The pruned walk is the default from 4096 triangles in a mesh (below that it measured slower, and its leaf records are up to half the
+    accel build: profiles/r05_prune_threshold.jsonl); lg_accel_set_prune(1) on an accel built without the records builds them then, and the
+    film is the same either way."""
+    if os.environ.get("LASGUN_PRUNE"):
+        pytest.skip("LASGUN_PRUNE overrides the defaults this test is about")
+    w, h = 160, 120
+    small = G.Accel(S.mesh_scene(G, 24, 16, "glass"))  # 768 triangles
+    assert not G.get_prune(small)
+    plain = G.Film(w, h)
+    G.capture_subset(0, 1, small, plain)
+    G.set_prune(small, True)
+    assert G.get_prune(small)
+    pruned = G.Film(w, h)
+    G.capture_subset(0, 1, small, pruned)
+    assert np.array_equal(plain.pixels(), pruned.pixels())
+    r = G.audit_prune(small, w, h)
+    assert r["violations"] == 0 and r["skipped_runs"] > 0, r  # (the records are there: runs of a leaf get skipped)
+    G.set_prune(small, None)
+    assert not G.get_prune(small)
+    again = G.Film(w, h)
+    G.capture_subset(0, 1, small, again)
+    assert np.array_equal(plain.pixels(), again.pixels())
+    big = G.Accel(S.mesh_scene(G, 48, 48, "metal"))  # 4608 triangles
+    assert G.get_prune(big)
+
+
 def test_capture_takes_every_visible_device_by_default_and_prune_switch():
     """A process that never names a device (like a program written against the reference) gets every visible one from
     lg_capture (lib.rs:58-62: every core); and lg_accel_set_prune takes -1 / 0 / 1 only, the film is the same in each."""
