@@ -266,10 +266,11 @@ int lg_accel_set_tile_order(const lg_accel *, int order);
  * side by side, except that the megakernel's form is one more thing the measurement above times (frames of 1024^2 and more of a cheap
  * scene run faster with the samples in a row: a ninth of the tile claims). */
 int lg_accel_set_sample_order(const lg_accel *, int order);
-/* The megakernel's work item: a whole 8x8 tile per wave (1), or a tile in 2 / 4 / 8 parts of 32 / 16 / 8 lanes each.  A launch of fewer
- * tiles than the grid has waves is as slow as its slowest tile's recursion tree; a part is a shorter tree, and four times the waves are at
- * work (the kitchen sink at 512^2 2.40 -> 1.73 ms, the 100k-triangle metal torus at 256^2 2.23 -> 1.82; cheap scenes and big frames lose:
- * profiles/r05_ab_split.jsonl).  -1 (default) = whole tiles unless the measurement above finds quarters faster for a small launch
+/* The work item of the megakernel and of the queue organisation's level 0: a whole 8x8 tile per wave (1), or a tile in 2 / 4 / 8 parts of
+ * 32 / 16 / 8 lanes each.  A launch of fewer tiles than the grid has waves is as slow as its slowest tile's recursion tree; a part is a shorter
+ * tree, four times the waves are at work, and the queue organisation's deeper packets stay as narrow (the 100k-triangle glass torus at 256^2
+ * 8.46 -> 5.42 ms in the queue organisation, the metal torus 2.19 -> 1.81 in the megakernel; cheap scenes and big frames lose:
+ * profiles/r05_ab_split.jsonl, r05_ab_split_orgs.jsonl).  -1 (default) = whole tiles unless the measurement above finds quarters faster for a small launch
  * (lg_accel_last_organisation: + 128).  Same bytes either way. */
 int lg_accel_set_tile_parts(const lg_accel *, int parts);
 

@@ -118,7 +118,7 @@ class HipApi(Api):
             raise LasgunError(self.last_error())
 
     def set_tile_parts(self, accel, parts):
-        """The megakernel's work item: a whole tile per wave (1) or a tile in 2 / 4 / 8 parts; None / -1 = whole unless measured otherwise for
+        """The work item of the megakernel and of the queue organisation's level 0: a whole tile per wave (1) or a tile in 2 / 4 / 8 parts; None / -1 = whole unless measured otherwise for
         a small launch (include/lasgun_hip.h, lg_accel_set_tile_parts).  Same bytes either way."""
         if self.call("accel_set_tile_parts", accel.h, -1 if parts is None else int(parts)):
             raise LasgunError(self.last_error())

@@ -468,6 +468,7 @@ static void ensure_aux_streams(const lg_accel &a, unsigned n) {
 // shadow, shade), then the combine passes bottom-up.  Queue capacities are worst case (level d holds at most 2^d rays per
 // pixel of the chunk), so the chunk is sized to the memory budget of the launch context: nothing can overflow.
 constexpr size_t WF_FULL_MIN_HOST = 48; // == WF_FULL_MIN of k_wavefront.hip
+constexpr uint32_t MEGA_SPLIT = 4;      // the parts a small launch's tiles are handed out in where the measured choice found that faster (enqueue_mega, enqueue_queue)
 static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c, hipStream_t stream) {
     const uint32_t levels = (a.flat.has_specular && P0.recursion > 0) ? P0.recursion + 1u : 1u;
     const uint32_t nsamples = P0.ss_root * P0.ss_root;
@@ -673,11 +674,14 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
 // with the level-by-level pipeline.  Queue capacities are worst case (level d: 2^d rays per pixel of the chunk), so nothing can
 // overflow; a recursive scene may take a large share of the HBM for it (a 4096^2 frame at recursion 3: 26 GB of 288) and keeps ONE
 // chunk in flight per launch context.
-static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c, hipStream_t stream) {
+static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c, bool split, hipStream_t stream) {
     const uint32_t levels = (a.flat.has_specular && P0.recursion > 0) ? P0.recursion + 1u : 1u;
     const uint32_t nsamples = P0.ss_root * P0.ss_root;
     static const bool ss_serial = [] { const char *e = std::getenv("LASGUN_SS_SERIAL"); return e && e[0] == '1'; }();
-    const uint32_t S = nsamples > 1 && !ss_serial && a.sample_order != 1 ? nsamples : 1u; // samples side by side (enqueue_wavefront): level-0 tiles per pixel tile
+    // level 0's tiles in parts (enqueue_mega, DParams::split_shift): the children's packets are then as narrow as their parents -- a small
+    // launch's recursion chains are walked by four times the waves, 16 lanes each
+    const uint32_t parts = a.tile_parts >= 1 ? (uint32_t)a.tile_parts : split ? MEGA_SPLIT : 1u, split_shift = parts == 8u ? 3u : parts == 4u ? 2u : parts == 2u ? 1u : 0u;
+    const uint32_t S = (nsamples > 1 && !ss_serial && a.sample_order != 1 ? nsamples : 1u) * parts; // samples side by side (enqueue_wavefront) x parts: level-0 tiles per pixel tile
     auto level_bytes = [&](uint32_t d) -> size_t { // per ray of level d
         size_t b = 0;
         if (d >= 1) b += 6 * 8;                       // ray queue
@@ -773,7 +777,7 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
         P.tile0 = (uint32_t)t0;
         const uint32_t pixel_tiles = (uint32_t)std::min<unsigned long long>(chunk_tiles, P0.ntiles - t0);
         P.ntiles = pixel_tiles * S; // level 0's tiles
-        P.ss_par = S;
+        P.ss_par = S / parts; P.split_shift = split_shift;
         P.n_items = n0; // SoA stride of level 0's arrays and of the sample accumulator
         P.accum = K.accum;
         P.wf_levels = levels;
@@ -793,7 +797,7 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
         }
         const uint32_t blocks = ldss ? blocks_cap : std::min(blocks_cap, (P.q_units + 3u) / 4u);
         const size_t nready_now = nready;
-        for (uint32_t sidx = 0; sidx < nsamples / S; ++sidx) {
+        for (uint32_t sidx = 0; sidx < nsamples / (S / parts); ++sidx) {
             P.sample_index = sidx;
             HIP_TRY(hipMemsetAsync(c.wf_counters.p, 0, (QC_WORDS + (levels > 1 ? nready_now : 0)) * sizeof(uint32_t), stream));
             timed(4, [&] { return launch_queue(P, blocks, stream); });
@@ -805,7 +809,7 @@ static void enqueue_queue(const lg_accel &a, DParams &P0, lg_accel::LaunchCtx &c
                 timed(1, [&] { return launch_wf_combine(P, d == 0 ? flat_blocks0 : flat_cap, stream); });
             }
         }
-        if (S > 1) { // a pixel's samples summed in their order (k_wavefront.hip, wf_resolve_kernel)
+        if (S / parts > 1) { // a pixel's samples summed in their order (k_wavefront.hip, wf_resolve_kernel)
             DParams R = P;
             R.ntiles = pixel_tiles;
             timed(1, [&] { return launch_wf_resolve(R, (uint32_t)(((unsigned long long)pixel_tiles * 64ull + 255ull) / 256ull), stream); });
@@ -873,7 +877,6 @@ static bool mega_par_by_rule(const lg_accel &a, const DParams &P, bool stats) {
 // fewer diverging lanes.  Measured (tools/split_probe.py, profiles/r05_ab_split.jsonl): the kitchen sink at 512^2 2.40 -> 1.73 ms, the
 // 100k-triangle metal torus at 256^2 2.23 -> 1.82; cheap scenes and frames of 1024^2 and more lose (idle lanes are then lost throughput).
 // One more candidate of the measured choice; never by rule.
-constexpr uint32_t MEGA_SPLIT = 4;
 static bool mega_split_possible(const lg_accel &a, const DParams &P, bool stats) {
     const bool lds_form = !a.fast && a.lds_scene && a.ldss_blocks;
     const unsigned long long grid_waves = lds_form ? (unsigned long long)a.ldss_blocks * (a.mega_narrow ? 12u : 16u) : (unsigned long long)(a.fast ? a.max_blocks_fast : a.max_blocks) * 4ull;
@@ -952,7 +955,7 @@ static void enqueue_mega(const lg_accel &a, DParams &P, lg_accel::LaunchCtx &c, 
 static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Org org, int dir, bool ss_serial, bool split, bool stats, hipStream_t stream) { // (P by value: an organisation fills in its own fields)
     P.tile_counter = c.tile_counter.p;
     P.tile_rev = org != ORG_WAVEFRONT ? (uint32_t)dir : 0u; // 0 top-down, 1 bottom-up, 2 from the middle outwards (the level-by-level passes are short and alike: one direction)
-    if (org == ORG_QUEUE) enqueue_queue(a, P, c, stream);
+    if (org == ORG_QUEUE) enqueue_queue(a, P, c, split, stream);
     else if (org == ORG_WAVEFRONT) enqueue_wavefront(a, P, c, stream);
     else enqueue_mega(a, P, c, !ss_serial, split, stats, stream);
 }
@@ -1045,13 +1048,14 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     const bool was_profiling = a.profiling;
     a.profiling = false; // (the measurement's launches are not the caller's: lg_profile_read must not count them)
     // candidates: [organisation][samples side by side, one after the other (megakernel only)][top-down, bottom-up, middle-out]
-    constexpr int NC = 19, K_SPLIT = 18; // (+ the megakernel with its tiles in quarters: sample order by the rule, middle-out)
+    constexpr int NC = 20, K_SPLIT = 18, K_QSPLIT = 19; // (+ the megakernel / the queue organisation with their tiles in quarters: sample order by the rule, middle-out)
     float best_ms[NC];
     bool in_race[NC];
     const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
     for (int k = 0; k < NC; ++k) {
         best_ms[k] = INFINITY;
         if (k == K_SPLIT) { in_race[k] = mega_split_possible(a, P, false) && a.tile_parts < 0 && (a.tile_order < 0 || a.tile_order == DIR_DEFAULT); continue; }
+        if (k == K_QSPLIT) { in_race[k] = org_possible(a, P, false, ORG_QUEUE) && items >= 4096ull && mega_split_possible(a, P, false) && a.tile_parts < 0 && (a.tile_order < 0 || a.tile_order == DIR_DEFAULT); continue; }
         const int org = k / 6, ser = (k / 3) & 1, dir = k % 3;
         in_race[k] = org_possible(a, P, false, (Org)org) &&
                      (ser ? org == ORG_MEGA : (org != ORG_MEGA || mega_par_possible(P, false))) &&
@@ -1071,6 +1075,7 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
                 if (!in_race[k]) continue;
                 HIP_TRY(hipEventRecord(e0, stream));
                 if (k == K_SPLIT) enqueue_org(a, P, c, ORG_MEGA, DIR_DEFAULT, !mega_par_by_rule(a, P, false), true, false, stream);
+                else if (k == K_QSPLIT) enqueue_org(a, P, c, ORG_QUEUE, DIR_DEFAULT, false, true, false, stream);
                 else enqueue_org(a, P, c, (Org)(k / 6), k % 3, ((k / 3) & 1) != 0, false, false, stream);
                 HIP_TRY(hipEventRecord(e1, stream));
                 HIP_TRY(hipEventSynchronize(e1));
@@ -1099,13 +1104,14 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     for (int k = 0; k < NC; ++k)
         if (best_ms[k] < best_ms[best] * 0.99f) best = k; // (the rule's choice unless another beats it by 1 %: equal candidates do not flip from run to run)
     const int choice = best == K_SPLIT ? (int)ORG_MEGA | dir_bits(DIR_DEFAULT) | (!mega_par_by_rule(a, P, false) ? TUNE_SERIAL : 0) | TUNE_SPLIT
-                                       : (best / 6) | dir_bits(best % 3) | (((best / 3) & 1) ? TUNE_SERIAL : 0);
+                     : best == K_QSPLIT ? (int)ORG_QUEUE | dir_bits(DIR_DEFAULT) | TUNE_SPLIT
+                                        : (best / 6) | dir_bits(best % 3) | (((best / 3) & 1) ? TUNE_SERIAL : 0);
     if (std::getenv("LASGUN_DEBUG"))
         std::fprintf(stderr, "[lasgun] measured for %llu pixels (top-down / bottom-up / middle-out): megakernel %.3f / %.3f / %.3f ms (samples in a row: %.3f / %.3f / %.3f), level by level %.3f ms, queue %.3f / %.3f / %.3f ms -> %s%s%s (rule: %d)\n",
                      items, best_ms[0], best_ms[1], best_ms[2], best_ms[3], best_ms[4], best_ms[5], best_ms[6], best_ms[12], best_ms[13], best_ms[14], // (one sample per pixel: "in a row" is the megakernel)
-                     best == K_SPLIT ? "megakernel, tiles in quarters" : best / 6 == 0 ? "megakernel" : best / 6 == 1 ? "level by level" : "queue",
-                     best == K_SPLIT ? "" : best % 3 == 1 ? ", bottom-up" : best % 3 == 2 ? ", middle-out" : "", best != K_SPLIT && ((best / 3) & 1) ? ", samples in a row" : "", (int)rule);
-    if (std::getenv("LASGUN_DEBUG") && in_race[K_SPLIT]) std::fprintf(stderr, "[lasgun]   (megakernel with its tiles in quarters: %.3f ms)\n", best_ms[K_SPLIT]);
+                     best == K_SPLIT ? "megakernel, tiles in quarters" : best == K_QSPLIT ? "queue, tiles in quarters" : best / 6 == 0 ? "megakernel" : best / 6 == 1 ? "level by level" : "queue",
+                     best >= K_SPLIT ? "" : best % 3 == 1 ? ", bottom-up" : best % 3 == 2 ? ", middle-out" : "", best < K_SPLIT && ((best / 3) & 1) ? ", samples in a row" : "", (int)rule);
+    if (std::getenv("LASGUN_DEBUG") && (in_race[K_SPLIT] || in_race[K_QSPLIT])) std::fprintf(stderr, "[lasgun]   (tiles in quarters: megakernel %.3f ms, queue %.3f ms)\n", best_ms[K_SPLIT], best_ms[K_QSPLIT]);
     std::lock_guard<std::mutex> g(g_tune_mtx);
     g_tuned[key] = choice;
     return choice;
@@ -1136,7 +1142,7 @@ static void enqueue(const lg_accel &a, DParams &P, bool stats, hipStream_t strea
     }
     if (dir < 0) dir = P.ntiles < 2u ? 0 : dir_unmeasured(a, org);
     if (org == ORG_WAVEFRONT) dir = 0;
-    a.last_org = (int)org | dir_bits(dir) | (org == ORG_MEGA && ss_serial && P.ss_root > 1 ? TUNE_SERIAL : 0) | (org == ORG_MEGA && (split || a.tile_parts > 1) ? TUNE_SPLIT : 0);
+    a.last_org = (int)org | dir_bits(dir) | (org == ORG_MEGA && ss_serial && P.ss_root > 1 ? TUNE_SERIAL : 0) | (org != ORG_WAVEFRONT && (split || a.tile_parts > 1) ? TUNE_SPLIT : 0);
     enqueue_org(a, P, c, org, dir, ss_serial, split, stats, stream);
 }
 

@@ -270,7 +270,7 @@ struct DParams {
     // at sample vt % ss_par, every sample's li() is parked in `accum` ([3][n_items], n_items = pixel tiles * ss_par * 64) and a resolve
     // pass sums a pixel's samples in their order (integrate.rs:17-20).  0 / 1: one sample per launch chain, `accum` the running sum.
     uint32_t ss_par;
-    uint32_t split_shift; // megakernel, small launches: a tile handed out in 2^split_shift parts of 64 >> split_shift lanes each (0: whole tiles)
+    uint32_t split_shift; // megakernel and queue organisation, small launches: a tile handed out in 2^split_shift parts of 64 >> split_shift lanes each (0: whole tiles)
     // ---- wavefront pipeline: li() level by level.  Level d holds the rays of recursion depth d
     // (level 0: the chunk's pixels, dense; deeper: a compacted queue fed by the level above).  Per level: closest-hit
     // pass (misses are finished on the spot, hits are COMPACTED into a hit queue and get their shading frame), any-hit

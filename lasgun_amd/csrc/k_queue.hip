@@ -253,9 +253,10 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
             Ray ray = ray_new(V3{0.0, 0.0, 0.0}, V3{0.0, 0.0, 1.0});
             bool valid;
             if (d == 0u) {
-                uint32_t sample; // (samples side by side: a level-0 tile is a pixel tile at ONE of its samples, DParams::ss_par)
-                px = pixel_of(P, P.tile0 + l0_tile(P, pkt, sample), lane);
-                valid = px.active;
+                uint32_t sample; // (samples side by side: a level-0 tile is a pixel tile at ONE of its samples, DParams::ss_par; a small launch's tiles
+                // in parts: 64 >> split_shift of its lanes, DParams::split_shift -- the children's packets are then as narrow as their parents)
+                px = pixel_of(P, P.tile0 + l0_tile(P, pkt >> P.split_shift, sample), lane);
+                valid = px.active && (lane >> (6u - P.split_shift)) == (pkt & ((1u << P.split_shift) - 1u));
                 if (valid) ray = camera_ray(P, px.x, px.y, sample);
             } else {
                 valid = lane < nrays;

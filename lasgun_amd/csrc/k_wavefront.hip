@@ -302,7 +302,9 @@ __global__ void __launch_bounds__(LG_BLOCK) wf_combine_kernel(const DParams P) {
         Pixel px;
         if (level == 0u) {
             uint32_t sample;
-            px = pixel_of(P, P.tile0 + l0_tile(P, (uint32_t)(j >> 6), sample), (uint32_t)(j & 63u));
+            const uint32_t vt = (uint32_t)(j >> 6), l = (uint32_t)(j & 63u);
+            if ((l >> (6u - P.split_shift)) != (vt & ((1u << P.split_shift) - 1u))) continue; // (the queue organisation's tiles in parts: this lane belongs to another part)
+            px = pixel_of(P, P.tile0 + l0_tile(P, vt >> P.split_shift, sample), l);
             if (!px.active) continue;
         }
         V3 value{P.wf_out[j], P.wf_out[n + j], P.wf_out[2 * n + j]};
@@ -339,7 +341,7 @@ __global__ void __launch_bounds__(LG_BLOCK) wf_resolve_kernel(const DParams P) {
         if (!px.active) continue;
         V3 color = vzero();
         for (uint32_t sidx = 0; sidx < S; ++sidx) {
-            const unsigned long long i = ((unsigned long long)t * S + sidx) * 64ull + l;
+            const unsigned long long i = ((((unsigned long long)t * S + sidx) << P.split_shift) + (l >> (6u - P.split_shift))) * 64ull + l; // (split_shift: the queue organisation's tiles in parts)
             color = color + V3{P.accum[i], P.accum[P.n_items + i], P.accum[2 * P.n_items + i]};
         }
         write_pixel(P, px, color * weight);

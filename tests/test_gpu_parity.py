@@ -370,9 +370,11 @@ def test_a_pixels_samples_side_by_side_or_in_a_row_are_the_same_film(name):
 
 
 @pytest.mark.parametrize("name", ["cornell_glass_256", "kitchen_sink_persp", "mesh_glass_128", "ragged_67x13", "one_pixel", "spooky_ss2_256", "simple_ss2_160"])
-def test_megakernel_tiles_in_parts_are_the_same_film(name):
-    """lg_accel_set_tile_parts: the megakernel hands a tile out whole or in 2 / 4 / 8 parts of 32 / 16 / 8 lanes (more waves at work on a small
-    launch) -- bytes, radiance bits, a strided subset and a batch of subsets against the oracle, with a pixel's samples side by side and in a row."""
+@pytest.mark.parametrize("org", [0, 3])
+def test_tiles_in_parts_are_the_same_film(name, org):
+    """lg_accel_set_tile_parts: the megakernel and the queue organisation hand a tile out whole or in 2 / 4 / 8 parts of 32 / 16 / 8 lanes (more
+    waves at work on a small launch; the queue's deeper packets are then as narrow as their parents) -- bytes, radiance bits, a strided subset
+    and a batch of subsets against the oracle, with a pixel's samples side by side and in a row."""
     builder, w, h = MID[name]
     o = oracle()
     oacc = o.Accel(builder(o))
@@ -385,7 +387,7 @@ def test_megakernel_tiles_in_parts_are_the_same_film(name):
         o.set_trig_mode(0)
     want = ofilm.pixels().reshape(-1, 4)
     acc = G.Accel(builder(G))
-    G.set_streaming(acc, 0)
+    G.set_streaming(acc, org)
     for parts in (2, 4, 8, 1, None):
         G.set_tile_parts(acc, parts)
         for order in (0, 1):

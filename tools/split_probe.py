@@ -18,9 +18,9 @@ for size in [int(a) for a in sys.argv[1:]] or [256, 512]:
         st = torch.cuda.current_stream().cuda_stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         out = {"scene": name, "size": size}
-        for org, code in (("megakernel", 0), ("megakernel_quarters", 0), ("wavefront", 2), ("queue", 3), ("default", 1)):
+        for org, code in (("megakernel", 0), ("megakernel_quarters", 0), ("wavefront", 2), ("queue", 3), ("queue_quarters", 3), ("default", 1)):
             G.set_streaming(acc, code)
-            G.set_tile_parts(acc, 4 if org == "megakernel_quarters" else None)
+            G.set_tile_parts(acc, 4 if org.endswith("_quarters") else None)
             ts = []
             for i in range(8):
                 e0.record(); G.capture_rows_device(acc, size, size, 0, size, dev.data_ptr(), row0=0, stream=st); e1.record(); torch.cuda.synchronize()
