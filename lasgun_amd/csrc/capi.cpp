@@ -1386,7 +1386,7 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
         static const bool times = std::getenv("LASGUN_DEBUG_TIMES") != nullptr; // (where lg_accel_from's time goes: flatten / upload / derived)
         const auto t_begin = std::chrono::steady_clock::now();
         // The culling records and strips of the pruned walk's mesh leaves are built when that walk will run: by default from PRUNE_MIN_TRIS
-        // triangles in a mesh (below: on), when LASGUN_PRUNE=1 or lg_accel_set_prune(1) ask for it (ensure_records).
+        // triangles in a mesh (below: on), when LASGUN_PRUNE=1 or lg_accel_set_prune(1) ask for it (rebuild_tables).
         size_t big_mesh_tris = 0;
         for (const auto &m : a->scene->meshes) if (m && m->tri.size() / 3 > big_mesh_tris) big_mesh_tris = m->tri.size() / 3;
         static const int prune_env = [] { const char *e = std::getenv("LASGUN_PRUNE"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();
@@ -1652,8 +1652,8 @@ static void swap_tables(lg_accel &x, lg_accel &y) {
     swap(x.device_bytes, y.device_bytes); swap(x.fast_available, y.fast_available); swap(x.fast_refusal, y.fast_refusal);
     swap(x.streaming_pays, y.streaming_pays); swap(x.streaming_min_items, y.streaming_min_items); swap(x.mega_narrow, y.mega_narrow);
 }
-// the tables once more, with what was left out of them: the fast mode's trees (lg_accel_set_mode(1)), the pruned walk's leaf records (ensure_records)
-static void ensure_fast_trees(const lg_accel *ca, bool fast = true) {
+// the tables once more, with what was left out of them: the fast mode's trees (lg_accel_set_mode(1)), the pruned walk's leaf records (lg_accel_set_prune(1), lg_audit_prune)
+static void rebuild_tables(const lg_accel *ca, bool fast) {
     if (fast && ca->flat.has_fast) return;
     lg_accel *a = const_cast<lg_accel *>(ca);
     use_device(a->device);
@@ -2096,7 +2096,7 @@ int lg_audit_prune(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint3
         if (!a->flat.has_records) { // the audit is of the pruned walk as it runs when it is on: with the mesh leaves' records
             const int before = a->prune;
             a->prune = 1;
-            try { ensure_fast_trees(a, false); } catch (...) { a->prune = before; throw; }
+            try { rebuild_tables(a, false); } catch (...) { a->prune = before; throw; }
             a->prune = before;
         }
         DParams P = base_params(*a, w, h);
@@ -2169,7 +2169,7 @@ int lg_accel_set_prune(const lg_accel *a, int enabled) {
     const int before = a->prune;
     a->prune = enabled;
     if (enabled == 1 && !a->flat.has_records) { // the mesh leaves' culling records were left out of this accel's tables (a small mesh): build them now
-        int rc = guarded([&] { ensure_fast_trees(a, false); });
+        int rc = guarded([&] { rebuild_tables(a, false); });
         if (rc) { a->prune = before; return rc; }
     }
     return 0;
@@ -2178,7 +2178,7 @@ int lg_accel_set_mode(const lg_accel *a, int mode) {
     if (mode != 0 && mode != 1) return fail("mode must be 0 (reference traversal) or 1 (fast)");
     std::lock_guard<std::mutex> g(a->mtx);
     if (mode == 1) {
-        int rc = guarded([&] { ensure_fast_trees(a); });
+        int rc = guarded([&] { rebuild_tables(a, true); });
         if (rc) return rc;
     }
     if (mode == 1 && !a->fast_available) return fail(a->fast_refusal);
@@ -2413,7 +2413,7 @@ int lg_trace_pixel(const lg_accel *a, uint32_t w, uint32_t h, uint32_t x, uint32
         use_device(a->device);
         const size_t need = 7 + 2 * a->flat.lights.size();
         if (out_len < need) throw Error("output too small: 7 + 2 * lights doubles");
-        if (fast) ensure_fast_trees(a);
+        if (fast) rebuild_tables(a, true);
         if (fast && !a->fast_available) throw Error(a->fast_refusal);
         DParams P = base_params(*a, w, h);
         DevBuf<double> dout, dlog;
