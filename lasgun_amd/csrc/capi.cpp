@@ -1159,6 +1159,13 @@ static void set_subset(DParams &P, size_t k, size_t n, uint32_t w, uint32_t h) {
     P.mode = 1; P.sub_k = k; P.sub_n = n;
     P.sub_count = k < area ? (area - k + n - 1) / n : 0;
     P.ntiles = (uint32_t)((P.sub_count + 63ull) / 64ull);
+    // The subset tile by lattice column (mode 4, shade.h: 64 rows x <= n pixels per tile instead of 64 consecutive i) where that is the denser
+    // window: a period shorter than the film's width and longer than a tile's 64 pixels in a row would be.  LASGUN_SUBSET_LATTICE=0: never (A/B).
+    static const bool lattice = [] { const char *e = std::getenv("LASGUN_SUBSET_LATTICE"); return !(e && e[0] == '0'); }();
+    const unsigned long long cols = (w + n - 1) / n, tiles4 = ((unsigned long long)h + 63ull) / 64ull * cols;
+    if (lattice && P.sub_count != 0 && n >= 8 && n <= w && h >= 16 && tiles4 < (1ull << 31) && tiles4 <= 2ull * P.ntiles + 8ull) {
+        P.mode = 4; P.sub_cols = (uint32_t)cols; P.ntiles = (uint32_t)tiles4;
+    }
 }
 
 // Several subsets {k_j + i*n} of one n as ONE render (lg_capture_subsets): the k values sorted and without repeats or empty subsets,

@@ -236,7 +236,7 @@ struct DParams {
     uint32_t w, h;
     double winv, hinv, aspect;
     // ---- work: either a rectangle of 8x8 tiles or a strided pixel subset (lib.rs:152)
-    uint32_t mode; // 0 = rectangle [x0,x1) x [y0,y1); 1 = subset {k + i*n}; 2 = the pixel offsets listed in pixel_list[0 .. sub_count);
+    uint32_t mode; // 0 = rectangle [x0,x1) x [y0,y1); 1 = subset {k + i*n}, 64 consecutive i per tile (4 = the same subset, 64 rows of a lattice column per tile); 2 = the pixel offsets listed in pixel_list[0 .. sub_count);
                    // 3 = the sub_m subsets {ks[j] + q*n} of one n, ks = pixel_list[0 .. sub_m) ascending, work item i = q * sub_m + j
     uint32_t x0, y0, x1, y1;
     uint32_t tiles_x;
@@ -245,6 +245,7 @@ struct DParams {
     uint32_t ilv_n, ilv_r, ilv_b;
     unsigned long long sub_k, sub_n, sub_count;
     uint32_t sub_m; // mode 3: how many subsets
+    uint32_t sub_cols; // mode 4 (the subset {k + i*n} tile by lattice column, shade.h): lattice columns per row = ceil(w / n)
     uint32_t ntiles;
     uint32_t tile_rev; // the megakernel and the queue organisation claim the launch's tiles from the LAST to the first (which tile is rendered when never changes a pixel; capi.cpp, tuned_org)
     uint32_t out_row0; // row of the image stored at out_rgba[0] (0 for a full film, y0 for a row tile)

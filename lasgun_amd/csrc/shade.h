@@ -236,6 +236,20 @@ __device__ __forceinline__ Pixel pixel_of(const DParams &P, uint32_t tile, uint3
         px.active = px.x < P.x1 && vy < P.y1;
         px.y = P.ilv_n > 1u ? ((vy / P.ilv_b) * P.ilv_n + P.ilv_r) * P.ilv_b + vy % P.ilv_b : vy;
         px.pix = (unsigned long long)(vy - P.out_row0) * P.out_pitch + (px.x - P.out_x0);
+    } else if (P.mode == 4) {
+        // The strided subset {k + i*n} (lib.rs:152) as the LATTICE it is: its pixels sit at x = (k - y*w) mod n + n*m in row y, one per period
+        // of n.  A tile is 64 consecutive rows of one lattice column m -- a window of 64 rows x <= n pixels, the densest 64 of the subset's pixels
+        // there are -- instead of 64 consecutive i (for the progressive front end's n = 100 on a 4096-wide film: a strip 6,400 pixels long and a
+        // row and a half high, whose rays share no node of a BVH).  Which lane takes which pixel of the subset never changes a pixel.
+        const uint32_t ty = tile / P.sub_cols, m = tile - ty * P.sub_cols;
+        const unsigned long long y = (unsigned long long)ty * 64ull + lane;
+        const unsigned long long r = (y * P.w) % P.sub_n, kk = P.sub_k % P.sub_n;
+        const unsigned long long x = (kk >= r ? kk - r : kk + P.sub_n - r) + P.sub_n * m;
+        const unsigned long long off = y * P.w + x;
+        px.active = y < P.h && x < P.w && off >= P.sub_k;
+        px.x = px.active ? (uint32_t)x : 0u;
+        px.y = px.active ? (uint32_t)y : 0u;
+        px.pix = px.active ? (P.out_compact ? (off - P.sub_k) / P.sub_n : off) : 0ull; // (compact output: at the pixel's place i in the subset)
     } else {
         unsigned long long i = (unsigned long long)tile * 64ull + lane;
         px.active = i < P.sub_count;

@@ -620,6 +620,35 @@ def test_capture_subset_partitions_and_preserves_other_pixels():
     assert np.array_equal(buf, want)
 
 
+@pytest.mark.parametrize("w, h, n, ks", [(96, 80, 10, (0, 3, 9)), (200, 131, 100, (0, 57, 99)), (131, 67, 8, (7, 2)), (64, 200, 64, (0, 63, 31)),
+                                         (257, 19, 33, (32, 5)), (120, 72, 16, (120 * 72 - 3, 130, 15 + 16 * 7)), (97, 61, 97, (0, 96)), (97, 61, 50, (49,))])
+def test_strided_subsets_tile_by_lattice_column(w, h, n, ks):
+    """capture_subset(k, n) with 8 <= n <= w is addressed as the lattice it is (shade.h, mode 4: a tile = 64 rows of one lattice column): exactly
+    the pixels {k + i*n} get the frame's bytes -- into a host film (compact device output scattered by the host) and into a device film, in every
+    organisation, k >= n included -- and nothing else is touched."""
+    import torch
+    scene = S.kitchen_sink_scene(G, "perspective", recursion=2, supersampling=1)
+    acc = G.Accel(scene)
+    full = G.Film(w, h)
+    G.capture_subset(0, 1, acc, full)
+    want = full.pixels().reshape(-1, 4)
+    for org in (0, 2, 3):
+        G.set_streaming(acc, org)
+        buf = np.full((h, w, 4), 9, np.uint8)
+        film = G.Film.new_with_output(w, h, buf)
+        dev = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda")
+        done = np.zeros(w * h, bool)
+        for k in ks:
+            G.capture_subset(k, n, acc, film)
+            G.capture_subset_device(k, n, acc, w, h, dev.data_ptr())
+            done[k::n] = True
+        G.synchronize(acc)
+        torch.cuda.synchronize()
+        for got in (buf.reshape(-1, 4), dev.cpu().numpy().reshape(-1, 4)):
+            assert np.array_equal(got[done], want[done]), (org, w, h, n)
+            assert np.all(got[~done] == 9), (org, w, h, n)
+
+
 def test_capture_subsets_batch_equals_the_single_calls_and_the_oracle():
     """lg_capture_subsets: several subsets of one n as ONE render (the progressive caller's batch, www/renderer.ts:103-120) writes
     exactly what the single capture_subset calls write -- which the oracle's capture_subset (lib.rs:110-162) pins -- and nothing else."""
