@@ -872,7 +872,7 @@ static bool mega_par_by_rule(const lg_accel &a, const DParams &P, bool stats) {
     const unsigned long long grid_waves = lds_form ? (unsigned long long)a.ldss_blocks * (a.mega_narrow ? 12u : 16u) : (unsigned long long)(a.fast ? a.max_blocks_fast : a.max_blocks) * 4ull;
     return ss_mega >= 0 ? ss_mega == 1 : P.ntiles < SS_PAR_WAVES * grid_waves;
 }
-// A SMALL launch may hand its tiles out in QUARTERS (DParams::split: 16 lanes of a tile per wave, four times the waves at work): a frame of
+// A SMALL launch may hand its tiles out in QUARTERS (DParams::split_shift: 16 lanes of a tile per wave, four times the waves at work): a frame of
 // fewer tiles than the grid has waves is as slow as its slowest tile's recursion tree, and a quarter of a tile is a shorter tree walked by
 // fewer diverging lanes.  Measured (tools/split_probe.py, profiles/r05_ab_split.jsonl): the kitchen sink at 512^2 2.40 -> 1.73 ms, the
 // 100k-triangle metal torus at 256^2 2.23 -> 1.82; cheap scenes and frames of 1024^2 and more lose (idle lanes are then lost throughput).
