@@ -1207,6 +1207,14 @@ static void set_subsets(const lg_accel &a, DParams &P, const SubsetBatch &b, hip
     HIP_TRY(hipMemcpy(t.buf.p, b.ks.data(), b.ks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     P.mode = 3; P.pixel_list = t.buf.p; P.sub_m = (uint32_t)b.ks.size(); P.sub_n = b.n; P.sub_k = 0; P.sub_count = b.items;
     P.ntiles = (uint32_t)((b.items + 63ull) / 64ull);
+    // the batch tile by lattice column (mode 5, shade.h: 64 / m rows x <= n pixels per tile instead of 64 consecutive work items -- 64 / m
+    // periods of one row) where that wastes few lanes; LASGUN_SUBSET_LATTICE=0: never (A/B)
+    static const bool lattice = [] { const char *e = std::getenv("LASGUN_SUBSET_LATTICE"); return !(e && e[0] == '0'); }();
+    const unsigned long long m = b.ks.size(), rows = m != 0 && m <= 64 ? 64ull / m : 0ull, cols = (P.w + b.n - 1) / b.n;
+    const unsigned long long tiles5 = rows ? ((unsigned long long)P.h + rows - 1ull) / rows * cols : ~0ull;
+    if (lattice && rows >= 2 && b.n >= 8 && b.n <= P.w && tiles5 < (1ull << 31) && tiles5 * 3ull <= (unsigned long long)P.ntiles * 4ull + 24ull) {
+        P.mode = 5; P.sub_cols = (uint32_t)cols; P.sub_rows = (uint32_t)rows; P.ntiles = (uint32_t)tiles5;
+    }
 }
 // ... and once the batch's launch is enqueued: the event that releases its table
 static void subsets_enqueued(const lg_accel &a, hipStream_t stream) {

@@ -245,7 +245,8 @@ struct DParams {
     uint32_t ilv_n, ilv_r, ilv_b;
     unsigned long long sub_k, sub_n, sub_count;
     uint32_t sub_m; // mode 3: how many subsets
-    uint32_t sub_cols; // mode 4 (the subset {k + i*n} tile by lattice column, shade.h): lattice columns per row = ceil(w / n)
+    uint32_t sub_cols; // modes 4 / 5 (a subset {k + i*n} / several of them tile by lattice column, shade.h): lattice columns per row = ceil(w / n)
+    uint32_t sub_rows; // mode 5: rows per tile = 64 / sub_m
     uint32_t ntiles;
     uint32_t tile_rev; // the megakernel and the queue organisation claim the launch's tiles from the LAST to the first (which tile is rendered when never changes a pixel; capi.cpp, tuned_org)
     uint32_t out_row0; // row of the image stored at out_rgba[0] (0 for a full film, y0 for a row tile)

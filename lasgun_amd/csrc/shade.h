@@ -250,6 +250,20 @@ __device__ __forceinline__ Pixel pixel_of(const DParams &P, uint32_t tile, uint3
         px.x = px.active ? (uint32_t)x : 0u;
         px.y = px.active ? (uint32_t)y : 0u;
         px.pix = px.active ? (P.out_compact ? (off - P.sub_k) / P.sub_n : off) : 0ull; // (compact output: at the pixel's place i in the subset)
+    } else if (P.mode == 5) {
+        // SEVERAL subsets of one n (lg_capture_subsets) by lattice column, as mode 4 does one: a tile is sub_rows = 64 / m consecutive rows of one
+        // lattice column, lane = row * m + j -- a window of 64 / m rows x <= n pixels holding the m subsets' pixels of every row
+        const uint32_t ty = tile / P.sub_cols, c = tile - ty * P.sub_cols;
+        const uint32_t r = lane / P.sub_m, j = lane - r * P.sub_m;
+        const unsigned long long y = (unsigned long long)ty * P.sub_rows + r;
+        const unsigned long long kj = P.pixel_list[j];
+        const unsigned long long rr = (y * P.w) % P.sub_n, kk = kj % P.sub_n;
+        const unsigned long long x = (kk >= rr ? kk - rr : kk + P.sub_n - rr) + P.sub_n * c;
+        const unsigned long long off = y * P.w + x;
+        px.active = r < P.sub_rows && y < P.h && x < P.w && off >= kj;
+        px.x = px.active ? (uint32_t)x : 0u;
+        px.y = px.active ? (uint32_t)y : 0u;
+        px.pix = px.active ? (P.out_compact ? ((off - kj) / P.sub_n) * P.sub_m + j : off) : 0ull; // (compact output: work item q * m + j, as in mode 3)
     } else {
         unsigned long long i = (unsigned long long)tile * 64ull + lane;
         px.active = i < P.sub_count;

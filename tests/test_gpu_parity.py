@@ -644,7 +644,14 @@ def test_strided_subsets_tile_by_lattice_column(w, h, n, ks):
             done[k::n] = True
         G.synchronize(acc)
         torch.cuda.synchronize()
-        for got in (buf.reshape(-1, 4), dev.cpu().numpy().reshape(-1, 4)):
+        # ... and the same subsets as ONE batch (lg_capture_subsets: mode 5, 64 / m rows of a lattice column per tile)
+        bbuf = np.full((h, w, 4), 9, np.uint8)
+        G.capture_subsets(list(ks), n, acc, G.Film.new_with_output(w, h, bbuf))
+        bdev = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda")
+        G.capture_subsets_device(list(ks), n, acc, w, h, bdev.data_ptr())
+        G.synchronize(acc)
+        torch.cuda.synchronize()
+        for got in (buf.reshape(-1, 4), dev.cpu().numpy().reshape(-1, 4), bbuf.reshape(-1, 4), bdev.cpu().numpy().reshape(-1, 4)):
             assert np.array_equal(got[done], want[done]), (org, w, h, n)
             assert np.all(got[~done] == 9), (org, w, h, n)
 
