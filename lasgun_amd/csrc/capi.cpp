@@ -303,6 +303,7 @@ struct lg_accel {
         DevBuf<double> frames, stash;                          // megakernel: Whitted frame stack, parked shading frame
         DevBuf<uint8_t> wf_mem;                                // wavefront pipeline: every per-level array of a chunk, carved from one allocation
         DevBuf<uint32_t> wf_counters;                          // its queue counts and per-launch tile counters
+        DevBuf<DRowTab> rowtab; uint32_t rt_w = 0, rt_h = 0; unsigned long long rt_n = 0; // strided subsets by lattice column (shade.h, modes 4 / 5): (floor(y*w / n), (y*w) mod n) per row of the last (w, h, n)
         // lg_capture_subsets: the k tables of the batches in flight on this stream (addressing mode 3), each with the event that says
         // its launch is through -- a table is written by a blocking copy into a buffer of its own before its launch is enqueued, so
         // neither a later batch on the stream nor the caller's freed array can reach it
@@ -1068,7 +1069,9 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
         // pass 0 warms every candidate up (buffers, code, clocks); passes 1-3 time them IN TURN, so that a drift of the clocks or a
         // neighbour's launch hits all alike, and the best of the three counts (the persistent kernels' own run-to-run spread is ~5 %:
         // config 4m's megakernel / queue pair, 6 % apart, was called wrongly by one warm-up + best of two in a row); a candidate that
-        // is 1.3 x behind after a pass is out, and launches of a quarter second measure themselves in one pass
+        // is 1.3 x behind after a pass is out, and launches of a quarter second measure themselves in one pass.  A launch of 20 ms and more is
+        // timed twice, and 1.1 x behind is out after the first time: its spread is a per cent or two, and seven candidates of 50 ms three
+        // times over were a second and a half of the caller's time (config 5: 1.68 s -> ~0.8 s for the same choice)
         for (int pass = 0; pass < 4; ++pass) {
             float fastest = INFINITY;
             for (int k = 0; k < NC; ++k) {
@@ -1085,12 +1088,13 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
                 fastest = std::min(fastest, pass > 0 || ms > 250.0f ? best_ms[k] : ms);
             }
             int left = 0;
+            const bool long_launch = fastest > 20.0f;
             for (int k = 0; k < NC; ++k) {
-                if (in_race[k] && pass > 0 && best_ms[k] > 1.3f * fastest) in_race[k] = false;
+                if (in_race[k] && pass > 0 && best_ms[k] > (long_launch ? 1.1f : 1.3f) * fastest) in_race[k] = false;
                 left += in_race[k] ? 1 : 0;
             }
             if (left <= 1 && pass > 0) break;
-            if (fastest > 250.0f) break;
+            if (fastest > 250.0f || (long_launch && pass >= 2)) break;
         }
     } catch (...) {
         a.profiling = was_profiling;
@@ -1154,7 +1158,21 @@ static void set_rect(DParams &P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t
     P.ilv_n = 1; P.ilv_r = 0; P.ilv_b = 1;
     P.out_x0 = 0; P.out_pitch = P.w;
 }
-static void set_subset(DParams &P, size_t k, size_t n, uint32_t w, uint32_t h) {
+// the row table of the lattice addressing for (w, h, n): made once per launch context and kept while the caller stays with that film and period
+// (the progressive front end's hundred calls share it)
+static const DRowTab *lattice_rows(const lg_accel &a, hipStream_t stream, uint32_t w, uint32_t h, unsigned long long n) {
+    lg_accel::LaunchCtx &c = ctx_for(a, stream);
+    if (c.rt_w != w || c.rt_h != h || c.rt_n != n || c.rowtab.n < h) {
+        std::vector<DRowTab> t(h);
+        for (uint32_t y = 0; y < h; ++y) { const unsigned long long o = (unsigned long long)y * w; t[y] = DRowTab{(uint32_t)(o / n), (uint32_t)(o % n)}; }
+        HIP_TRY(hipDeviceSynchronize()); // (an earlier launch may still read the table that is being replaced)
+        if (c.rowtab.n < h) c.rowtab.alloc(h);
+        HIP_TRY(hipMemcpy(c.rowtab.p, t.data(), (size_t)h * sizeof(DRowTab), hipMemcpyHostToDevice));
+        c.rt_w = w; c.rt_h = h; c.rt_n = n;
+    }
+    return c.rowtab.p;
+}
+static void set_subset(const lg_accel &a, hipStream_t stream, DParams &P, size_t k, size_t n, uint32_t w, uint32_t h) {
     unsigned long long area = (unsigned long long)w * h;
     P.mode = 1; P.sub_k = k; P.sub_n = n;
     P.sub_count = k < area ? (area - k + n - 1) / n : 0;
@@ -1163,8 +1181,10 @@ static void set_subset(DParams &P, size_t k, size_t n, uint32_t w, uint32_t h) {
     // window: a period shorter than the film's width and longer than a tile's 64 pixels in a row would be.  LASGUN_SUBSET_LATTICE=0: never (A/B).
     static const bool lattice = [] { const char *e = std::getenv("LASGUN_SUBSET_LATTICE"); return !(e && e[0] == '0'); }();
     const unsigned long long cols = (w + n - 1) / n, tiles4 = ((unsigned long long)h + 63ull) / 64ull * cols;
-    if (lattice && P.sub_count != 0 && n >= 8 && n <= w && h >= 16 && tiles4 < (1ull << 31) && tiles4 <= 2ull * P.ntiles + 8ull) {
-        P.mode = 4; P.sub_cols = (uint32_t)cols; P.ntiles = (uint32_t)tiles4;
+    if (lattice && P.sub_count != 0 && n >= 8 && n <= w && h >= 16 && area < (1ull << 32) && tiles4 < (1ull << 31) && tiles4 <= 2ull * P.ntiles + 8ull) {
+        P.mode = 4; P.sub_cols = (uint32_t)cols; P.sub_rows = 64u; P.ntiles = (uint32_t)tiles4;
+        P.sub_kk = (uint32_t)(k % n); P.sub_kdiv = (uint32_t)(k / n);
+        P.sub_rowtab = lattice_rows(a, stream, w, h, n);
     }
 }
 
@@ -1203,8 +1223,10 @@ static void set_subsets(const lg_accel &a, DParams &P, const SubsetBatch &b, hip
     (void)hipGetLastError(); // (hipEventQuery's "not ready" is not an error of this call)
     c.ks_live.emplace_back(new lg_accel::LaunchCtx::KsTable());
     lg_accel::LaunchCtx::KsTable &t = *c.ks_live.back();
-    t.buf.alloc(std::max<size_t>(b.ks.size(), 128));
-    HIP_TRY(hipMemcpy(t.buf.p, b.ks.data(), b.ks.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    std::vector<unsigned long long> tab(b.ks); // the m values of k, then (k mod n) | (k / n) << 32 of each (the lattice form, shade.h mode 5)
+    for (unsigned long long k : b.ks) tab.push_back((k % b.n) | ((k / b.n) << 32));
+    t.buf.alloc(std::max<size_t>(tab.size(), 128));
+    HIP_TRY(hipMemcpy(t.buf.p, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     P.mode = 3; P.pixel_list = t.buf.p; P.sub_m = (uint32_t)b.ks.size(); P.sub_n = b.n; P.sub_k = 0; P.sub_count = b.items;
     P.ntiles = (uint32_t)((b.items + 63ull) / 64ull);
     // the batch tile by lattice column (mode 5, shade.h: 64 / m rows x <= n pixels per tile instead of 64 consecutive work items -- 64 / m
@@ -1212,8 +1234,9 @@ static void set_subsets(const lg_accel &a, DParams &P, const SubsetBatch &b, hip
     static const bool lattice = [] { const char *e = std::getenv("LASGUN_SUBSET_LATTICE"); return !(e && e[0] == '0'); }();
     const unsigned long long m = b.ks.size(), rows = m != 0 && m <= 64 ? 64ull / m : 0ull, cols = (P.w + b.n - 1) / b.n;
     const unsigned long long tiles5 = rows ? ((unsigned long long)P.h + rows - 1ull) / rows * cols : ~0ull;
-    if (lattice && rows >= 2 && b.n >= 8 && b.n <= P.w && tiles5 < (1ull << 31) && tiles5 * 3ull <= (unsigned long long)P.ntiles * 4ull + 24ull) {
+    if (lattice && rows >= 2 && b.n >= 8 && b.n <= P.w && (unsigned long long)P.w * P.h < (1ull << 32) && tiles5 < (1ull << 31) && tiles5 * 3ull <= (unsigned long long)P.ntiles * 4ull + 24ull) {
         P.mode = 5; P.sub_cols = (uint32_t)cols; P.sub_rows = (uint32_t)rows; P.ntiles = (uint32_t)tiles5;
+        P.sub_rowtab = lattice_rows(a, stream, P.w, P.h, b.n);
     }
 }
 // ... and once the batch's launch is enqueued: the event that releases its table
@@ -1747,7 +1770,7 @@ int lg_capture_subset_device(size_t k, size_t n, const lg_accel *a, uint32_t w, 
         use_device(a->device);
         DParams P = base_params(*a, w, h);
         if (n == 1 && k == 0) set_rect(P, 0, 0, w, h);
-        else set_subset(P, k, n, w, h);
+        else set_subset(*a, (hipStream_t)hip_stream, P, k, n, w, h);
         P.out_row0 = 0;
         P.out_rgba = (uint8_t *)dev_rgba;
         enqueue(*a, P, false, (hipStream_t)hip_stream);
@@ -1816,7 +1839,7 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) {
                 }
             } else {
                 if (whole) set_rect(P, 0, 0, w, h);
-                else { set_subset(P, k, n, w, h); P.out_compact = 1; }
+                else { set_subset(*a, a->stream, P, k, n, w, h); P.out_compact = 1; }
                 enqueue(*a, P, false, a->stream);
                 if (whole) HIP_TRY(hipMemcpyAsync(film->px, buf.p, (size_t)area * 4, hipMemcpyDeviceToHost, a->stream));
             }
@@ -2067,7 +2090,7 @@ int lg_capture_radiance(size_t k, size_t n, const lg_accel *a, uint32_t w, uint3
         HIP_TRY(hipMemcpyAsync(a->staging_rad.p, rgb, count * 8, hipMemcpyHostToDevice, a->stream));
         DParams P = base_params(*a, w, h);
         if (n == 1 && k == 0) set_rect(P, 0, 0, w, h);
-        else set_subset(P, k, n, w, h);
+        else set_subset(*a, a->stream, P, k, n, w, h);
         P.out_row0 = 0;
         P.out_radiance = a->staging_rad.p;
         enqueue(*a, P, false, a->stream);

@@ -197,6 +197,8 @@ struct DStats { // per-launch counters (stats kernel variant only)
 constexpr int FRAME_DOUBLES = 18;
 constexpr int STASH_DOUBLES = 13; // p(3) ng(3) ns(3) ss(3) material id
 
+struct DRowTab { uint32_t base, rem; }; // a film row's floor(y*w / n) and (y*w) mod n (strided subsets by lattice column: shade.h, modes 4 / 5)
+
 struct DParams {
     // ---- scene tables
     const DNode *nodes;
@@ -246,7 +248,9 @@ struct DParams {
     unsigned long long sub_k, sub_n, sub_count;
     uint32_t sub_m; // mode 3: how many subsets
     uint32_t sub_cols; // modes 4 / 5 (a subset {k + i*n} / several of them tile by lattice column, shade.h): lattice columns per row = ceil(w / n)
-    uint32_t sub_rows; // mode 5: rows per tile = 64 / sub_m
+    uint32_t sub_rows; // rows per tile: 64 (mode 4), 64 / sub_m (mode 5)
+    uint32_t sub_kk, sub_kdiv; // mode 4: k mod n, k / n
+    const DRowTab *sub_rowtab; // per film row y: (floor(y*w / n), (y*w) mod n)
     uint32_t ntiles;
     uint32_t tile_rev; // the megakernel and the queue organisation claim the launch's tiles from the LAST to the first (which tile is rendered when never changes a pixel; capi.cpp, tuned_org)
     uint32_t out_row0; // row of the image stored at out_rgba[0] (0 for a full film, y0 for a row tile)

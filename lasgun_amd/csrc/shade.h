@@ -236,34 +236,36 @@ __device__ __forceinline__ Pixel pixel_of(const DParams &P, uint32_t tile, uint3
         px.active = px.x < P.x1 && vy < P.y1;
         px.y = P.ilv_n > 1u ? ((vy / P.ilv_b) * P.ilv_n + P.ilv_r) * P.ilv_b + vy % P.ilv_b : vy;
         px.pix = (unsigned long long)(vy - P.out_row0) * P.out_pitch + (px.x - P.out_x0);
-    } else if (P.mode == 4) {
-        // The strided subset {k + i*n} (lib.rs:152) as the LATTICE it is: its pixels sit at x = (k - y*w) mod n + n*m in row y, one per period
-        // of n.  A tile is 64 consecutive rows of one lattice column m -- a window of 64 rows x <= n pixels, the densest 64 of the subset's pixels
-        // there are -- instead of 64 consecutive i (for the progressive front end's n = 100 on a 4096-wide film: a strip 6,400 pixels long and a
-        // row and a half high, whose rays share no node of a BVH).  Which lane takes which pixel of the subset never changes a pixel.
-        const uint32_t ty = tile / P.sub_cols, m = tile - ty * P.sub_cols;
-        const unsigned long long y = (unsigned long long)ty * 64ull + lane;
-        const unsigned long long r = (y * P.w) % P.sub_n, kk = P.sub_k % P.sub_n;
-        const unsigned long long x = (kk >= r ? kk - r : kk + P.sub_n - r) + P.sub_n * m;
-        const unsigned long long off = y * P.w + x;
-        px.active = y < P.h && x < P.w && off >= P.sub_k;
-        px.x = px.active ? (uint32_t)x : 0u;
-        px.y = px.active ? (uint32_t)y : 0u;
-        px.pix = px.active ? (P.out_compact ? (off - P.sub_k) / P.sub_n : off) : 0ull; // (compact output: at the pixel's place i in the subset)
-    } else if (P.mode == 5) {
-        // SEVERAL subsets of one n (lg_capture_subsets) by lattice column, as mode 4 does one: a tile is sub_rows = 64 / m consecutive rows of one
-        // lattice column, lane = row * m + j -- a window of 64 / m rows x <= n pixels holding the m subsets' pixels of every row
+#ifndef LG_NO_LATTICE // (A/B: what this branch costs the kernels it is inlined into)
+    } else if (P.mode == 4 || P.mode == 5) {
+        // A strided subset {k + i*n} (lib.rs:152) -- mode 4 -- or several of one n (lg_capture_subsets) -- mode 5 -- as the LATTICE it is: its
+        // pixels sit at x = (k - y*w) mod n + n*c in row y, one per period of n.  A tile is 64 (mode 5: sub_rows = 64 / m) consecutive rows of one
+        // lattice column c -- a window of <= 64 rows x <= n pixels, the densest 64 pixels of the subset there are -- instead of 64 consecutive i
+        // (for the progressive front end's n = 100 on a 4096-wide film: a strip 6,400 pixels long and a row and a half high, whose rays share no
+        // node of a BVH).  Which lane takes which pixel of the subset never changes a pixel.  No division here (this function is inlined into
+        // kernels that live at their register budget: the first form, with 64-bit remainders, cost configs 4 / 4m / 5 3-6 %): the host tabulates
+        // floor(y*w / n) and (y*w) mod n per row (sub_rowtab, one table per (w, h, n) and launch context) and k mod n, k / n per subset.
         const uint32_t ty = tile / P.sub_cols, c = tile - ty * P.sub_cols;
-        const uint32_t r = lane / P.sub_m, j = lane - r * P.sub_m;
-        const unsigned long long y = (unsigned long long)ty * P.sub_rows + r;
-        const unsigned long long kj = P.pixel_list[j];
-        const unsigned long long rr = (y * P.w) % P.sub_n, kk = kj % P.sub_n;
-        const unsigned long long x = (kk >= rr ? kk - rr : kk + P.sub_n - rr) + P.sub_n * c;
-        const unsigned long long off = y * P.w + x;
-        px.active = r < P.sub_rows && y < P.h && x < P.w && off >= kj;
-        px.x = px.active ? (uint32_t)x : 0u;
-        px.y = px.active ? (uint32_t)y : 0u;
-        px.pix = px.active ? (P.out_compact ? ((off - kj) / P.sub_n) * P.sub_m + j : off) : 0ull; // (compact output: work item q * m + j, as in mode 3)
+        uint32_t r = lane, j = 0u, kk = P.sub_kk, kdiv = P.sub_kdiv;
+        if (P.mode == 5) {
+            r = lane / P.sub_m; j = lane - r * P.sub_m;
+            const unsigned long long kd = P.pixel_list[P.sub_m + j]; // (k_j mod n) | (k_j / n) << 32, behind the m values of k
+            kk = (uint32_t)kd; kdiv = (uint32_t)(kd >> 32);
+        }
+        const uint32_t y = ty * P.sub_rows + r;
+        const bool in = r < P.sub_rows && y < P.h;
+        const DRowTab rt = P.sub_rowtab[in ? y : 0u]; // (floor(y*w / n), (y*w) mod n)
+        int32_t ph = (int32_t)kk - (int32_t)rt.rem;
+        const uint32_t wrapped = ph < 0 ? 1u : 0u;
+        if (wrapped) ph += (int32_t)P.sub_n;
+        const uint32_t x = (uint32_t)ph + (uint32_t)P.sub_n * c;
+        const long long q = (long long)rt.base + (long long)c + (long long)wrapped - (long long)kdiv; // the pixel's place in its subset (negative: before k)
+        px.active = in && x < P.w && q >= 0;
+        px.x = px.active ? x : 0u;
+        px.y = px.active ? y : 0u;
+        const unsigned long long place = P.mode == 5 ? (unsigned long long)q * P.sub_m + j : (unsigned long long)q; // (mode 3's work item q * m + j)
+        px.pix = px.active ? (P.out_compact ? place : (unsigned long long)y * P.w + x) : 0ull;
+#endif
     } else {
         unsigned long long i = (unsigned long long)tile * 64ull + lane;
         px.active = i < P.sub_count;

@@ -9,38 +9,52 @@ import itertools
 import pytest
 
 
+def rows(w, h, n):
+    """the host's table (capi.cpp, lattice_rows): floor(y*w / n) and (y*w) mod n per film row"""
+    return [divmod(y * w, n) for y in range(h)]
+
+
+def place(rt, kk, kdiv, c, n):
+    """shade.h: the pixel's x within its row and its place q in its subset, without a division: (x, q)"""
+    base, rem = rt
+    ph = kk - rem
+    wrapped = 1 if ph < 0 else 0
+    if wrapped:
+        ph += n
+    return ph + n * c, base + c + wrapped - kdiv
+
+
 def single(w, h, n, k):
-    """mode 4: a tile = 64 consecutive rows of one lattice column m; -> [(offset, compact index)]"""
-    cols = -(-w // n)
+    """mode 4: a tile = 64 consecutive rows of one lattice column c; -> [(offset, compact index)]"""
+    cols, tab = -(-w // n), rows(w, h, n)
     out = []
     for tile in range(-(-h // 64) * cols):
-        ty, m = divmod(tile, cols)
+        ty, c = divmod(tile, cols)
         for lane in range(64):
             y = ty * 64 + lane
-            r, kk = (y * w) % n, k % n
-            x = (kk - r if kk >= r else kk + n - r) + n * m
-            off = y * w + x
-            if y < h and x < w and off >= k:
-                out.append((off, (off - k) // n))
+            if y >= h:
+                continue
+            x, q = place(tab[y], k % n, k // n, c, n)
+            if x < w and q >= 0:
+                out.append((y * w + x, q))
     return out
 
 
 def batch(w, h, n, ks):
     """mode 5: a tile = 64 // m rows of one lattice column, lane = row * m + j; -> [(offset, j, compact index q * m + j)]"""
     m = len(ks)
-    rows, cols = 64 // m, -(-w // n)
+    nrows, cols, tab = 64 // m, -(-w // n), rows(w, h, n)
     out = []
-    for tile in range(-(-h // rows) * cols):
+    for tile in range(-(-h // nrows) * cols):
         ty, c = divmod(tile, cols)
         for lane in range(64):
             r, j = divmod(lane, m)
-            y = ty * rows + r
-            kj = ks[j]
-            rr, kk = (y * w) % n, kj % n
-            x = (kk - rr if kk >= rr else kk + n - rr) + n * c
-            off = y * w + x
-            if r < rows and y < h and x < w and off >= kj:
-                out.append((off, j, ((off - kj) // n) * m + j))
+            y = ty * nrows + r
+            if r >= nrows or y >= h:
+                continue
+            x, q = place(tab[y], ks[j] % n, ks[j] // n, c, n)
+            if x < w and q >= 0:
+                out.append((y * w + x, j, q * m + j))
     return out
 
 
