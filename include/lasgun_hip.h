@@ -100,6 +100,10 @@ void lg_accel_free(lg_accel *);
  * more (the reference takes every core, lib.rs:58-62; `scene.threads` caps the count) -- one accel per device, one RCCL gather --
  * and the HIP current device for smaller films (an accel and a communicator per GPU would cost more than the render). */
 int lg_capture(const lg_scene *, lg_film *);                                       /* lib.rs:55 */
+/* capture_subset(k, n, &accel, &mut img) (lib.rs:110-162): exactly the pixels {k + i*n < w*h} of the row-major film, no other byte touched;
+ * callable over and over on one film (www/renderer.ts:103-120).  Which lane renders which pixel of the subset is the build's business: for
+ * 8 <= n <= width a 64-lane tile is 64 rows of one LATTICE COLUMN of the subset (x = (k - y*w) mod n + n*c) -- the densest 64 pixels there are --
+ * instead of 64 consecutive i, a strip n*64 pixels long (LASGUN_SUBSET_LATTICE=0: the latter). */
 int lg_capture_subset(size_t k, size_t n, const lg_accel *, lg_film *);            /* lib.rs:110 */
 lg_film *lg_render(const lg_scene *, uint32_t width, uint32_t height);             /* lib.rs:46 */
 
