@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""lg_accel_from of every config and of the reference's example scenes, four times each (LASGUN_DEBUG_TIMES=1: the build's stages on stderr)."""
 import os, sys, time, json
 sys.path.insert(0, '/root/repo' if os.path.isdir('/root/repo/lasgun_amd') else '.')
 sys.path.insert(0, 'tools')
