@@ -252,6 +252,131 @@ def mesh_roofline(G, la, stream):
                     "`reference_work_rate_frac` that work over the pruned walk's time (what skipping buys, not a roofline fraction)"}
 
 
+def mixed_roofline(G, la, stream):
+    """configs[4] (8192x8192, config 3's 1024 spheres + the 100,352-triangle torus, plastic) on ONE GPU, whole: the bookkeeping of `roofline` for
+    BASELINE's sharded config -- frame time, Mrays/s, the dominant kernel by HIP events on its launch stream with its algorithmic f64 operations
+    (the counting instantiation of the same walk, per kind of ray), the organisation that ran."""
+    size = 8192
+    acc = G.Accel(la.scenes.mixed_scene(G))
+    film = torch.zeros((size, size, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+
+    def frame_ms(reps=2):
+        G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    ms = frame_ms()
+    ran_as = G.last_organisation(acc) or "?"
+    G.profile_enable(acc, True)
+    G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    kinds = {k: v[0] / v[1] for k, v in G.profile_read_kinds(acc).items() if v[1]}
+    G.profile_read(acc)
+    G.profile_enable(acc, False)
+    st = G.capture_stats(acc, size, size, 0, size)
+    rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
+    if ran_as.split(",")[0] == "wavefront" and kinds:
+        dom = max(kinds, key=kinds.get)
+        dom_ms = kinds[dom]
+        dst = dict(G.capture_stats_kind(acc, size, size, 2 if "shadow" in dom else 1, 0, size)) if dom.startswith("trace<") else st
+        kernel = "lg::wf_trace_kernel<false, %s, false, %s, true>" % ("true" if "shadow" in dom else "false", "false" if "shadow" in dom else "true") if dom.startswith("trace<") else dom
+    else:
+        dom, dom_ms, dst = "trace_kernel", kinds.get("trace_kernel", ms), st
+        kernel = {"megakernel": "lg::trace_kernel<false, false, false, true, 1024>", "queue": "lg::queue_kernel<false, true>"}.get(ran_as.split(",")[0], ran_as)
+    flops, fl_frame = algorithmic_flops(dst), algorithmic_flops(st)
+    tops = flops / (dom_ms * 1e-3) / 1e12
+    del film
+    torch.cuda.empty_cache()
+    return {"workload": WORKLOADS["configs4"]["desc"] % (size, size) + "; ONE GPU, the whole film (BASELINE shards it over 8)",
+            "ms_per_frame": ms, "value": rays / ms / 1e3, "unit": "Mrays/s", "rays_per_frame": rays,
+            "bound": "valu_f64", "achieved": tops, "peak": VALU_F64_PEAK_TOPS, "frac": tops / VALU_F64_PEAK_TOPS,
+            "frame_frac": fl_frame / (ms * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS,
+            "organisation": ran_as, "kernel": kernel, "kernel_ms_avg": dom_ms, "kernels_ms_avg": kinds,
+            "algorithmic_flops_per_launch": flops, "algorithmic_flops_per_frame": fl_frame, "algorithmic_bytes_per_frame": algorithmic_bytes(st),
+            "traffic": None,
+            "work_per_frame": {k: st[k] for k in ("nodes_tested", "spheres_tested", "cuboids_tested", "triangles_tested", "accel_entries", "hits")},
+            "traversal": "reference tree, pruned walk (default for a scene with a mesh of >= 4096 triangles)",
+            "note": "byte-identical to the oracle on strided samples in tests/test_gpu_configs.py; rocprofv3 summary of the same frame: profiles/r06_config5_*"}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(nproc, argv):
+    """`python3 bench.py --gpus N` (no launcher, WORLD_SIZE unset): one process per GPU through torch.distributed.run, as a child of this
+    process -- which has not touched the GPU -- with the same arguments; the child's stdout (rank 0's JSON line) is this process's
+    stdout and its exit code this process's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=env)
+    sys.exit(rc)
+
+
+def library_collective(args):
+    """--collective library: the product's own multi-device path, timed like the torch one.  ONE process, lg_multi_* (multi.cpp): an accel per
+    device, every device renders its 64-row blocks, ONE grouped ncclSend / ncclRecv brings them into the root device's film (what lg_capture
+    does on a multi-GPU box, lib.rs:55-104's fan-out).  K synchronous frames after W warm-ups; the film is compared with one device's own."""
+    os.environ.setdefault("LASGUN_AUTOTUNE", "2")
+    import lasgun_amd as la
+    G = la.api
+    ndev = G.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py --collective library: no HIP device")
+    devices = [i % ndev for i in range(args.gpus)]  # fewer devices than ranks: same-device shares (a rehearsal; LASGUN_MULTI_FORCE_RCCL=1 sends them through RCCL)
+    wl = WORKLOADS[args.workload]
+    w = h = args.size or wl["size"]
+    scene = wl["build"](la.scenes, G)
+    t0 = time.perf_counter()
+    m = G.Multi(scene, devices, BLOCK_ROWS)
+    create_s = time.perf_counter() - t0
+    torch.cuda.set_device(devices[0])
+    film = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(max(args.warmup, 1)):
+        m.capture_device(w, h, film.data_ptr())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.capture_device(w, h, film.data_ptr())  # synchronous: every device's render + the exchange
+    elapsed = time.perf_counter() - t0
+    st = G.capture_stats(m.accel(0), w, h)
+    rays = st["primary_rays"] + st["shadow_rays"]
+    acc = G.Accel(scene)
+    ref = torch.zeros_like(film)
+    G.capture_rows_device(acc, w, h, 0, h, ref.data_ptr(), row0=0)
+    G.synchronize(acc)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        G.capture_rows_device(acc, w, h, 0, h, ref.data_ptr(), row0=0)
+    G.synchronize(acc)
+    single_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    same = bool(torch.equal(film, ref))
+    out = {"metric": "Mrays/s (primary+shadow) at 4096x4096; bit-exact RGBA8 vs CPU", "value": rays * args.steps / elapsed / 1e6, "unit": "Mrays/s",
+           "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": wl["desc"] % (w, h), "workload_key": args.workload, "rays_per_frame": rays,
+                      "parallelism": "ONE process, lg_multi_capture_device: 64-row blocks dealt round-robin over %d share(s) on device(s) %s, one grouped RCCL exchange per frame, frames one after the other"
+                                     % (args.gpus, sorted(set(devices)))},
+           "collective": "library", "uses_rccl": bool(m.uses_rccl), "rccl_ranks": m.ranks if m.uses_rccl else 0, "distinct_devices": len(set(devices)),
+           "multi_create_s": create_s, "single_device_ms_per_step": single_ms, "gathered_equals_single_gpu": same,
+           "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+    if not same:
+        sys.exit(4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,7 +394,18 @@ def main():
                     help="the end-of-frame collective is ONE all-gather (every rank ends with the film) instead of ONE gather to rank 0")
     ap.add_argument("--force-dist", action="store_true",
                     help="world size 1 with a process group and a real gather: RCCL rehearsal on a 1-GPU box")
+    ap.add_argument("--collective", default="torch", choices=["torch", "library"],
+                    help="torch = one process per GPU, torch.distributed gather (the driver's contract); library = ONE process drives the N devices "
+                         "through the product's own lg_multi_capture_device (multi.cpp: one grouped RCCL send / recv into the root's film)")
     args = ap.parse_args()
+
+    if args.collective == "library":
+        return library_collective(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` without a launcher: start one process per GPU as a CHILD, before this process has made any
+        # GPU call (importing torch does not initialise the device; a process that has must never be replaced by another), hand
+        # its stdout -- rank 0's one JSON line -- through, and exit with its code.
+        return spawn_ranks(args.gpus, sys.argv[1:])
 
     exit_code = 0
     # stdout carries ONE line, the JSON record: whatever libraries print there (RCCL's version banner at communicator
@@ -282,8 +418,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     os.environ.setdefault("LASGUN_AUTOTUNE", "2")  # measure a kind of launch at its FIRST launch (the library's default: at its second), so that no timed frame holds a measurement
@@ -427,9 +561,24 @@ def main():
     rdev = "cuda" if args.backend == "nccl" else "cpu"
     vec = torch.tensor([st[k] for k in keys] + [0], dtype=torch.float64, device=rdev)
     tmax = torch.tensor([elapsed, kernel_ms / max(launches, 1), latency_ms] + repeats, dtype=torch.float64, device=rdev)
+    # per rank: ms per timed step as this rank saw it, and its own share rendered alone (no collective): what the gather adds to a frame
+    render_only_ms = latency_ms
+    if multi and balanced:
+        alone = []
+        for _ in range(3):
+            fence()
+            t1 = time.perf_counter()
+            G.capture_interleaved_device(acc, w, h, BLOCK_ROWS, world, rank, (cuda_tile if cuda_tile is not None else ig.tiles[0]).data_ptr(), stream=cur_stream.cuda_stream)
+            torch.cuda.synchronize()
+            alone.append(time.perf_counter() - t1)
+        render_only_ms = min(alone) * 1e3
+    per_rank = torch.zeros((max(world, 1), 3), dtype=torch.float64, device=rdev)
+    per_rank[rank if multi else 0] = torch.tensor([elapsed / args.steps * 1e3, latency_ms, render_only_ms], dtype=torch.float64, device=rdev)
     if multi:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+    per_rank = per_rank.tolist()
     total = {k: int(v) for k, v in zip(keys, vec.tolist())}
     elapsed, latency_ms = float(tmax[0]), float(tmax[2])
     repeats = [float(x) for x in tmax[3:]]
@@ -450,7 +599,7 @@ def main():
         del ref
 
     extras = rank == 0 and world == 1 and not args.no_extras and not args.force_dist
-    e2e_ms = fast_info = probes = mesh_info = None
+    e2e_ms = fast_info = probes = mesh_info = mixed_info = None
     if extras:
         # PCIe-inclusive figure (never `value`): lg_capture into a HOST film = host BVH build + upload + render + 64 MiB D2H
         film = G.Film(w, h)
@@ -483,6 +632,7 @@ def main():
         torch.cuda.empty_cache()
         probes = {"hbm_copy_GBps": G.probe_rate("hbm_copy"), "lds_read_GBps": G.probe_rate("lds_read")}
         mesh_info = mesh_roofline(G, la, cur_stream) if (args.size == 4096 and headline) else None
+        mixed_info = mixed_roofline(G, la, cur_stream) if (args.size == 4096 and headline) else None
 
     if rank == 0:
         value = rays * args.steps / elapsed / 1e6
@@ -545,6 +695,8 @@ def main():
             out["fast_mode"] = fast_info
         if mesh_info is not None:
             out["roofline_mesh"] = mesh_info
+        if mixed_info is not None:
+            out["roofline_mixed"] = mixed_info
         check = None
         if world == 1 and not args.no_cpu_baseline and not args.force_dist and not args.no_extras:
             out["cpu_baseline"], check = cpu_baseline(w, h, timed_film, build=wl["build"])
@@ -556,6 +708,11 @@ def main():
             out["gathered_equals_single_gpu"] = gathered_ok
             out["rccl_ranks"] = dist.get_world_size()
             out["collective_backend"] = args.backend
+            out["collective"] = "torch"
+            # per rank: ms per timed step (frames overlapped), one frame alone with its gather, the rank's share alone without it;
+            # gather_ms = what the collective adds to a frame issued alone, slowest rank
+            out["per_rank_ms"] = [{"rank": r, "ms_per_step": v[0], "latency_ms": v[1], "render_only_ms": v[2]} for r, v in enumerate(per_rank)]
+            out["gather_ms"] = max(v[1] for v in per_rank) - max(v[2] for v in per_rank)
         out["bit_exact"] = check["bit_exact"] if check else None       # null: the oracle leg did not run (--no-cpu-baseline)
         out["mismatched_bytes"] = check["mismatched_bytes"] if check else None
         out["bit_exact_check"] = check

@@ -317,6 +317,24 @@ pub fn capture_subsets(ks: &[usize], n: usize, root: &Accel, img: &mut impl Img)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The table of measured kernel-organisation choices (no counterpart in the reference; include/lasgun_hip.h, lg_tune_*):
+// export it once, import it at start-up, and no launch of a known kind is ever measured again.
+// ---------------------------------------------------------------------------------------------------------------
+pub mod tune {
+    use super::*;
+    pub use sys::lg_tune_entry as Entry;
+    pub fn export() -> Vec<Entry> {
+        let n = unsafe { sys::lg_tune_export(std::ptr::null_mut(), 0) };
+        let mut v = vec![Entry::default(); n];
+        let m = unsafe { sys::lg_tune_export(v.as_mut_ptr(), n) };
+        v.truncate(m.min(n));
+        v
+    }
+    pub fn import(entries: &[Entry]) { if unsafe { sys::lg_tune_import(entries.as_ptr(), entries.len()) } != 0 { panic!("lasgun: {}", last_error()) } }
+    pub fn clear() { unsafe { sys::lg_tune_clear() } }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // output::render (src/output.rs:5-18): render to a PNG file
 // ---------------------------------------------------------------------------------------------------------------
 pub mod output {

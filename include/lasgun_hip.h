@@ -237,11 +237,15 @@ int lg_accel_set_prune(const lg_accel *, int enabled);
 int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel default, LASGUN_PRUNE, lg_accel_set_prune, fast mode): 0 / 1 */
 
 /* Kernel organisation (same arithmetic, same bytes either way).  1 (default): the organisation of a launch is MEASURED -- the SECOND
- * launch of a kind in the process (the scene's shape, the device, the launch's size class and addressing mode) renders with every
- * organisation that can take it, on the caller's stream with the host waiting, and the fastest is kept for the process (capture()
- * rebuilds its accel per frame, so the memory is keyed by the scene's shape); later launches of the kind only enqueue.  The kind's
- * FIRST launch takes the fitted rule's choice, so that a program that renders one frame and exits pays nothing for a measurement worth
- * 30-50 frames (LASGUN_AUTOTUNE=2: measure at the first launch already -- benchmarks).  LASGUN_AUTOTUNE=0 keeps
+ * API CALL that launches a kind in the process (the scene's shape, the device, the launch's size class and addressing mode) renders with
+ * every organisation that can take it, on the caller's stream WITH THE HOST WAITING (this is the one place where a *_device entry point
+ * blocks: once per kind; never on a stream that is being captured into a graph; pin choices with lg_tune_import, or set
+ * LASGUN_AUTOTUNE=0, where that cannot be had), and the fastest is kept for the process (capture() rebuilds its accel per frame, so the
+ * memory is keyed by the scene's shape); later launches of the kind only enqueue.  An organisation that cannot run (no memory for its
+ * buffers) drops out of the measurement instead of failing the render.  The FIRST call that launches a kind -- all of its launches: the
+ * four row bands of a big lg_capture, the shares of lg_multi_* -- takes the fitted rule's choice, so that a program that renders one
+ * frame and exits pays nothing for a measurement worth 30-50 frames (LASGUN_AUTOTUNE=2: measure at the first call already --
+ * benchmarks).  LASGUN_AUTOTUNE=0 keeps
  * the fitted rule of rounds 2-4 throughout: level by level in the WAVEFRONT pipeline (below) for scenes with <= 32 lights and at least
  * 512 spheres / boxes from 2^21 pixels a launch, and for a scene small enough to live in LDS glass / mirror frames of up to 2^20
  * pixels and plain frames of one sample per pixel from 2^18; the queue organisation for glass / mirror over a big mesh; the single
@@ -255,6 +259,15 @@ int lg_accel_get_prune(const lg_accel *); /* the effective setting (accel defaul
  * runs deep levels with a few lanes per wave and the level-by-level pipeline ends every launch with its slowest wave's tail.
  * Returns non-zero (lg_last_error) for any other value. */
 int lg_accel_set_streaming(const lg_accel *, int enabled);
+/* The table of measured choices from outside.  An entry is a kind of launch (twelve opaque words) and the choice remembered for it (the
+ * encoding of lg_accel_last_organisation).  lg_tune_export writes up to `capacity` entries and returns how many the table holds
+ * (out = NULL: just the count); lg_tune_import pins entries -- a kind that has one is never measured, and an entry the launch cannot
+ * take (another build, less memory) falls back to the fitted rule's choice instead of failing; lg_tune_clear forgets every choice and
+ * every first sight.  A caller that knows its workload exports once and imports at start-up; a test runs on a fixed table. */
+typedef struct lg_tune_entry { uint64_t key[12]; int32_t choice; int32_t reserved; } lg_tune_entry;
+size_t lg_tune_export(lg_tune_entry *out, size_t capacity);
+int lg_tune_import(const lg_tune_entry *entries, size_t count);
+void lg_tune_clear(void);
 int lg_accel_last_organisation(const lg_accel *); /* what the accel's last launch ran as: 0 megakernel, 1 level by level, 2 queue, + 16 when its tiles were claimed bottom-up, + 64 when from the middle row outwards, + 128 when the megakernel handed its tiles out in parts, + 32 when the megakernel took a supersampled pixel's samples one after the other (otherwise side by side: every organisation's way since round 5); -1: none yet */
 /* The direction in which the megakernel and the queue organisation claim a launch's 8x8 tiles: 0 = from the film's top (row order), 1 = from
  * its bottom, 2 = from its middle row outwards (what a frame shows tends to sit in its middle, and a launch should END on cheap tiles: the

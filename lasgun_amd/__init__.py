@@ -59,6 +59,9 @@ _EXTRA = {
     "profile_read": (_C.c_int, [_C.c_void_p, _C.POINTER(_C.c_double), _C.POINTER(_C.c_uint64)]),
     "probe_rate": (_C.c_int, [_C.c_int, _C.POINTER(_C.c_double)]),
     "accel_from_on": (_C.c_void_p, [_C.c_void_p, _C.c_int]),
+    "tune_export": (_C.c_size_t, [_C.c_void_p, _C.c_size_t]),
+    "tune_import": (_C.c_int, [_C.c_void_p, _C.c_size_t]),
+    "tune_clear": (None, []),
     "multi_create": (_C.c_void_p, [_C.c_void_p, _C.POINTER(_C.c_int), _C.c_int, _C.c_uint32]),
     "multi_free": (None, [_C.c_void_p]),
     "multi_capture_device": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
@@ -74,6 +77,10 @@ _EXTRA = {
     "host_check_wide_records": (_C.c_int, [_C.c_void_p, _C.c_uint64 * 8]),
     "host_check_strips": (_C.c_int, [_C.c_void_p, _C.c_uint64 * 8]),
 }
+
+
+class TuneEntry(_C.Structure):  # lg_tune_entry (include/lasgun_hip.h)
+    _fields_ = [("key", _C.c_uint64 * 12), ("choice", _C.c_int32), ("reserved", _C.c_int32)]
 
 
 class HipApi(Api):
@@ -315,6 +322,26 @@ class HipApi(Api):
             raise LasgunError(self.last_error())
         keys = ("records", "children", "leaves", "deepest_stack", "violations", "reserved_stack")
         return dict(zip(keys, [int(v) for v in out]))
+
+    # ---- the table of measured organisation choices (lg_tune_*): entries are (twelve key words, choice) tuples
+    def tune_export(self):
+        n = int(self.call("tune_export", None, 0))
+        buf = (TuneEntry * max(n, 1))()
+        m = int(self.call("tune_export", _C.cast(buf, _C.c_void_p), n))
+        return [(tuple(int(x) for x in buf[i].key), int(buf[i].choice)) for i in range(min(n, m))]
+
+    def tune_import(self, entries):
+        entries = list(entries)
+        buf = (TuneEntry * max(len(entries), 1))()
+        for i, (key, choice) in enumerate(entries):
+            for j in range(12):
+                buf[i].key[j] = int(key[j])
+            buf[i].choice = int(choice)
+        if self.call("tune_import", _C.cast(buf, _C.c_void_p), len(entries)):
+            raise LasgunError(self.last_error())
+
+    def tune_clear(self):
+        self.call("tune_clear")
 
     def Multi(self, scene, devices, block_rows=64):
         """One film on several GPUs of this process, gathered on devices[0] over xGMI with one grouped RCCL exchange

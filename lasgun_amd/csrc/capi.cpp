@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 
 #include "../../include/lasgun_hip.h"
 #include "host.h"
+#include "tune.h"
 
 namespace lg {
 // k_mega.hip, k_wavefront.hip, k_queue.hip, k_probe.hip
@@ -226,6 +228,48 @@ struct StreamPool {
 StreamPool &g_streams = *new StreamPool(); // never destroyed (see g_pool)
 } // namespace
 
+// Pinned host staging for the small tables a *_device entry point uploads (a batch's k table, a lattice row table): the copy is
+// enqueued on the caller's stream from memory that stays put until the copy is through, so the call only enqueues (round 5 used a blocking
+// hipMemcpy, and a device-wide synchronise when a row table changed: ADVICE r5).  Blocks are powers of two, recycled per process.
+namespace {
+struct PinnedPool {
+    std::mutex mtx;
+    std::vector<std::pair<size_t, void *>> spare;
+    void *take(size_t bytes, size_t *capacity) {
+        size_t cap = 4096;
+        while (cap < bytes) cap <<= 1;
+        *capacity = cap;
+        {
+            std::lock_guard<std::mutex> g(mtx);
+            for (size_t i = 0; i < spare.size(); ++i)
+                if (spare[i].first == cap) { void *q = spare[i].second; spare.erase(spare.begin() + (long)i); return q; }
+        }
+        void *q = nullptr;
+        hipError_t e = hipHostMalloc(&q, cap, hipHostMallocPortable);
+        if (e != hipSuccess) throw Error(std::string("hipHostMalloc(staging): ") + hipGetErrorString(e));
+        return q;
+    }
+    void give(size_t cap, void *q) {
+        if (!q) return;
+        {
+            std::lock_guard<std::mutex> g(mtx);
+            if (spare.size() < 64) { spare.emplace_back(cap, q); return; }
+        }
+        (void)hipHostFree(q);
+    }
+};
+PinnedPool &g_pinned = *new PinnedPool(); // never destroyed (see g_pool)
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    void need(size_t bytes) { if (cap < bytes) { g_pinned.give(cap, p); p = nullptr; cap = 0; p = g_pinned.take(bytes, &cap); } }
+    ~PinnedBuf() { g_pinned.give(cap, p); }
+};
+} // namespace
+
 // Sticky error words of the queue organisation (k_queue.hip: a wave that gave up waiting for work).  They live in PINNED HOST memory
 // that every device writes straight into (system-scope store), one word per accel, handed out from pages of 1024: the host reads
 // a word without a HIP call -- after any synchronise, at the head of every enqueue, in lg_accel_synchronize -- and only the host
@@ -303,13 +347,21 @@ struct lg_accel {
         DevBuf<double> frames, stash;                          // megakernel: Whitted frame stack, parked shading frame
         DevBuf<uint8_t> wf_mem;                                // wavefront pipeline: every per-level array of a chunk, carved from one allocation
         DevBuf<uint32_t> wf_counters;                          // its queue counts and per-launch tile counters
-        DevBuf<DRowTab> rowtab; uint32_t rt_w = 0, rt_h = 0; unsigned long long rt_n = 0; // strided subsets by lattice column (shade.h, modes 4 / 5): (floor(y*w / n), (y*w) mod n) per row of the last (w, h, n)
+        // strided subsets by lattice column (shade.h, modes 4 / 5): (floor(y*w / n), (y*w) mod n) per film row -- one table per (w, h, n), the
+        // last MAX_ROW_TABLES of them kept (a caller that alternates periods or films on one stream finds each again), each uploaded from
+        // pinned staging of its own on the context's stream (`up`: that copy is through; the staging may be rewritten)
+        struct RowTable { uint32_t w = 0, h = 0; unsigned long long n = 0, last_use = 0; DevBuf<DRowTab> buf; PinnedBuf stage; hipEvent_t up = nullptr; };
+        std::vector<std::unique_ptr<RowTable>> rowtabs;
+        unsigned long long rowtab_clock = 0;
         // lg_capture_subsets: the k tables of the batches in flight on this stream (addressing mode 3), each with the event that says
-        // its launch is through -- a table is written by a blocking copy into a buffer of its own before its launch is enqueued, so
-        // neither a later batch on the stream nor the caller's freed array can reach it
-        struct KsTable { DevBuf<unsigned long long> buf; hipEvent_t done = nullptr; };
+        // its launch is through -- a table is copied (from pinned staging of its own, on the stream) into a buffer of its own before its
+        // launch is enqueued, so neither a later batch on the stream nor the caller's freed array can reach it
+        struct KsTable { DevBuf<unsigned long long> buf; PinnedBuf stage; hipEvent_t done = nullptr; };
         std::vector<std::unique_ptr<KsTable>> ks_live;
-        ~LaunchCtx() { for (auto &k : ks_live) if (k->done) (void)hipEventDestroy(k->done); }
+        ~LaunchCtx() {
+            for (auto &k : ks_live) if (k->done) (void)hipEventDestroy(k->done);
+            for (auto &r : rowtabs) if (r->up) (void)hipEventDestroy(r->up);
+        }
     };
     mutable std::vector<std::unique_ptr<LaunchCtx>> ctxs;
     // wavefront pipeline, big launches: the frame is cut into bands rendered on internal streams (each with a launch context
@@ -962,24 +1014,25 @@ static void enqueue_org(const lg_accel &a, DParams P, lg_accel::LaunchCtx &c, Or
 }
 
 // The MEASURED choice (round 5; the rule above was a fit to eight scenes and wrong by 6-22 % on the first scene that was not among
-// them).  Every organisation renders the same bytes, so which one runs is a question of time alone, and the answer is taken from
-// the clock: the second launch of a KIND in the process (its first: the rule's choice at no cost, autotune_mode below) -- the scene's shape (table sizes, materials, lights, recursion, samples per pixel, traversal
-// mode, LDS residency), the device, the launch's size class (log2 of its pixels) and addressing mode -- renders the launch with every
-// CANDIDATE that can take it (a warm-up pass, then three timed passes over the candidates in turn, HIP events on the caller's stream,
-// the host waiting; the best of each), keeps the fastest (the rule's own choice unless another beats it by 1 %) and remembers it for
+// them; round 6: the table and the race live in tune.cpp, this file supplies the kind, the candidates and how one is launched).
+// Every organisation renders the same bytes, so which one runs is a question of time alone, and the answer is taken from the clock: the
+// second API call that launches a KIND in the process (the first gets the rule's choice at no cost) -- the scene's shape (table sizes,
+// materials, lights, recursion, samples per pixel, traversal mode, LDS residency), the device, the launch's size class (log2 of its pixels)
+// and addressing mode -- renders the launch with every CANDIDATE that can take it (a warm-up pass, then three timed passes over the
+// candidates in turn, HIP events on the caller's stream, the HOST WAITING -- the one place where a *_device entry point blocks; never on a
+// stream that is being captured), keeps the fastest (the rule's own choice unless another beats it by 1 %) and remembers it for
 // the process: capture() rebuilds its accel for every frame (lib.rs:64), so the memory is keyed by the scene's shape, not by the accel.
+// A candidate that cannot run (no memory for its buffers) drops out of the race instead of failing the caller's render.
 // A candidate is an organisation and, for the megakernel and the queue organisation, the DIRECTION the launch's tiles are claimed in:
 // a launch ends with the recursion trees of its last tiles, and whether the film's top or its bottom should come last is the scene's
 // and the camera's business -- simple.rs at 9 spp and the metal torus gain 6-9 % from the bottom up, the glass torus loses 3 %
 // (profiles/r05_ab_tile_order.jsonl); which tile is rendered when never changes a pixel.  (The kind does not know the camera: a
 // direction measured for one view is kept for the next.)  The launch itself is then enqueued as usual; what the measurement rendered
 // into the caller's film are the same pixels.  Overridden by lg_accel_set_streaming(0 / 2 / 3) and lg_accel_set_tile_order
-// (lg_accel_last_organisation says what a launch ran as); LASGUN_AUTOTUNE=0 keeps the rule and the top-down direction.
+// (lg_accel_last_organisation says what a launch ran as); LASGUN_AUTOTUNE=0 keeps the rule and the middle-out direction;
+// lg_tune_export / lg_tune_import / lg_tune_clear read, pin and forget choices.
 namespace {
-struct TuneKey {
-    uint64_t v[12];
-    bool operator<(const TuneKey &o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
-};
+using TuneKey = lg::tune::Key;
 constexpr int TUNE_REV = 16;    // a remembered choice: organisation | TUNE_REV when the tiles go bottom-up
 constexpr int TUNE_MID = 64;    //   | TUNE_MID when they go from the middle row outwards
 static int dir_bits(int dir) { return dir == 1 ? TUNE_REV : dir == 2 ? TUNE_MID : 0; }
@@ -991,20 +1044,26 @@ constexpr int DIR_DEFAULT = 2;
 static int dir_unmeasured(const lg_accel &a, Org org) { return org == ORG_WAVEFRONT ? 0 : a.tile_order >= 0 ? a.tile_order : DIR_DEFAULT; }
 constexpr int TUNE_SPLIT = 128; //   | TUNE_SPLIT when the megakernel hands a small launch's tiles out in quarters (enqueue_mega)
 constexpr int TUNE_SERIAL = 32; //   | TUNE_SERIAL when the megakernel takes a pixel's samples one after the other (enqueue_mega)
-std::mutex g_tune_mtx;
-std::mutex g_tune_run_mtx; // one measurement at a time in the process: two accels of one kind measuring side by side would time each other
-std::map<TuneKey, int> &g_tuned = *new std::map<TuneKey, int>(); // never destroyed (see g_pool)
-std::map<TuneKey, unsigned> &g_seen = *new std::map<TuneKey, unsigned>(); // launches of a kind before it was measured (guarded by g_tune_mtx)
-// LASGUN_AUTOTUNE: 0 = never measure (the fitted rule), 1 (default) = measure a kind at its SECOND launch, 2 = at its first.
-// A program that renders one frame and exits (every example of the reference) gets the rule's choice at no cost -- timing seven
-// candidates three times over costs 30-50 frames' worth; whatever renders a kind twice (an animation, the progressive front end's hundred
-// subsets, a benchmark) is measured from then on.
-int autotune_mode() {
-    static const int mode = [] { const char *e = std::getenv("LASGUN_AUTOTUNE"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
-    return mode;
-}
-bool autotune_enabled() { return autotune_mode() != 0; }
+// LASGUN_AUTOTUNE (tune.cpp: mode()): 0 = never measure (the fitted rule), 1 (default) = measure a kind at the second API CALL that
+// launches it, 2 = at the first.  A program that renders one frame and exits (every example of the reference) gets the rule's choice at no
+// cost -- timing seven candidates three times over costs 30-50 frames' worth; whatever renders a kind twice (an animation, the progressive
+// front end's hundred subsets, a benchmark) is measured from then on.  What counts is the CALL, not the launch: one lg_capture of a big
+// film launches its kind four times (row bands), lg_multi_* once per share of a device (round 5 counted launches and measured inside
+// the first frame: ADVICE r5).
+bool autotune_enabled() { return lg::tune::mode() != 0; }
+// Which API call is running: bumped when a call enters the library from outside (CallScope in guarded(), lg_capture, lg_multi_*:
+// calls nested in it, on this thread or on the threads it starts, belong to it).
+std::atomic<uint64_t> g_call_serial{1};
+std::atomic<int> g_call_depth{0};
+struct CallScope {
+    CallScope() { if (g_call_depth.fetch_add(1) == 0) g_call_serial.fetch_add(1); }
+    ~CallScope() { g_call_depth.fetch_sub(1); }
+};
 } // namespace
+extern "C" void lg_internal_call_scope(int enter) { // (multi.cpp: one lg_multi_capture* is one call, whatever its shares launch)
+    if (enter) { if (g_call_depth.fetch_add(1) == 0) g_call_serial.fetch_add(1); }
+    else g_call_depth.fetch_sub(1);
+}
 static TuneKey tune_key(const lg_accel &a, const DParams &P) {
     const FlatScene &f = a.flat;
     const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
@@ -1028,97 +1087,73 @@ static TuneKey tune_key(const lg_accel &a, const DParams &P) {
     k.v[11] = (P.mode == 0u ? 0u : 1u) | (a.tile_order >= 0 ? 2u + (uint64_t)a.tile_order : 0u) | ((uint64_t)(a.sample_order + 1) << 4) | ((uint64_t)(a.tile_parts + 1) << 8); // (a forced direction is a kind of its own: only the organisations race)
     return k;
 }
+// a remembered choice (measured here, or pinned by lg_tune_import for a kind this build may see differently) that the launch cannot take
+// falls back to the rule's
+static int rule_choice(const lg_accel &a, const DParams &P) {
+    const Org rule = org_by_rule(a, P, false);
+    return (int)rule | dir_bits(P.ntiles < 2u ? 0 : dir_unmeasured(a, rule)) | (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? TUNE_SERIAL : 0);
+}
+static bool choice_possible(const lg_accel &a, const DParams &P, int choice) {
+    const int org = choice & (TUNE_REV - 1);
+    if (org < 0 || org > (int)ORG_QUEUE || !org_possible(a, P, false, (Org)org)) return false;
+    if ((choice & TUNE_SPLIT) && !mega_split_possible(a, P, false)) return false;
+    if (org == (int)ORG_MEGA && !(choice & TUNE_SERIAL) && P.ss_root > 1 && !mega_par_possible(P, false)) return false;
+    return true;
+}
 static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx &c, hipStream_t stream) {
     const Org rule = org_by_rule(a, P, false);
     const TuneKey key = tune_key(a, P);
-    {
-        std::lock_guard<std::mutex> g(g_tune_mtx);
-        auto it = g_tuned.find(key);
-        if (it != g_tuned.end()) return it->second;
-        if (autotune_mode() == 1 && g_seen[key]++ == 0u) // the first launch of the kind: the rule's choice, at no cost
-            return (int)rule | dir_bits(dir_unmeasured(a, rule)) | (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? TUNE_SERIAL : 0);
+    int known;
+    if (lg::tune::lookup(key, &known)) return choice_possible(a, P, known) ? known : rule_choice(a, P);
+    if (lg::tune::mode() == 1 && lg::tune::first_call_of_kind(key, g_call_serial.load())) return rule_choice(a, P); // the first call that launches the kind: the rule's choice, at no cost
+    {   // a stream that is being captured into a graph cannot be waited on: no race there (the next plain launch of the kind measures)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+        else if (cs != hipStreamCaptureStatusNone) return rule_choice(a, P);
     }
-    std::lock_guard<std::mutex> run(g_tune_run_mtx);
-    {   // (another accel of this kind may have measured while this one waited)
-        std::lock_guard<std::mutex> g(g_tune_mtx);
-        auto it = g_tuned.find(key);
-        if (it != g_tuned.end()) return it->second;
-    }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    const bool was_profiling = a.profiling;
-    a.profiling = false; // (the measurement's launches are not the caller's: lg_profile_read must not count them)
     // candidates: [organisation][samples side by side, one after the other (megakernel only)][top-down, bottom-up, middle-out]
     constexpr int NC = 20, K_SPLIT = 18, K_QSPLIT = 19; // (+ the megakernel / the queue organisation with their tiles in quarters: sample order by the rule, middle-out)
-    float best_ms[NC];
-    bool in_race[NC];
+    lg::tune::Candidate cand[NC];
     const unsigned long long items = (unsigned long long)P.ntiles * 64ull;
     for (int k = 0; k < NC; ++k) {
-        best_ms[k] = INFINITY;
-        if (k == K_SPLIT) { in_race[k] = mega_split_possible(a, P, false) && a.tile_parts < 0 && (a.tile_order < 0 || a.tile_order == DIR_DEFAULT); continue; }
-        if (k == K_QSPLIT) { in_race[k] = org_possible(a, P, false, ORG_QUEUE) && items >= 4096ull && mega_split_possible(a, P, false) && a.tile_parts < 0 && (a.tile_order < 0 || a.tile_order == DIR_DEFAULT); continue; }
+        if (k == K_SPLIT) {
+            cand[k].choice = (int)ORG_MEGA | dir_bits(DIR_DEFAULT) | (!mega_par_by_rule(a, P, false) ? TUNE_SERIAL : 0) | TUNE_SPLIT;
+            cand[k].in_race = mega_split_possible(a, P, false) && a.tile_parts < 0 && (a.tile_order < 0 || a.tile_order == DIR_DEFAULT);
+            continue;
+        }
+        if (k == K_QSPLIT) {
+            cand[k].choice = (int)ORG_QUEUE | dir_bits(DIR_DEFAULT) | TUNE_SPLIT;
+            cand[k].in_race = org_possible(a, P, false, ORG_QUEUE) && items >= 4096ull && mega_split_possible(a, P, false) && a.tile_parts < 0 && (a.tile_order < 0 || a.tile_order == DIR_DEFAULT);
+            continue;
+        }
         const int org = k / 6, ser = (k / 3) & 1, dir = k % 3;
-        in_race[k] = org_possible(a, P, false, (Org)org) &&
+        cand[k].choice = org | dir_bits(dir) | (ser ? TUNE_SERIAL : 0);
+        cand[k].in_race = org_possible(a, P, false, (Org)org) &&
                      (ser ? org == ORG_MEGA : (org != ORG_MEGA || mega_par_possible(P, false))) &&
                      !(org == ORG_MEGA && mega_par_possible(P, false) && a.sample_order >= 0 && ser != a.sample_order) && // (lg_accel_set_sample_order) // (one form of the megakernel for a frame of one sample per pixel: the serial one)
                      !(org == ORG_QUEUE && items < 4096ull && rule != ORG_QUEUE) && // (a persistent scheduler for a handful of tiles: never ahead)
                      !(dir != 0 && (org == ORG_WAVEFRONT || P.ntiles < 2u)) &&      // (one direction for the level-by-level passes and for a single tile)
                      (a.tile_order < 0 || org == ORG_WAVEFRONT || dir == a.tile_order); // (lg_accel_set_tile_order: only the organisations race)
     }
-    try {
-        // pass 0 warms every candidate up (buffers, code, clocks); passes 1-3 time them IN TURN, so that a drift of the clocks or a
-        // neighbour's launch hits all alike, and the best of the three counts (the persistent kernels' own run-to-run spread is ~5 %:
-        // config 4m's megakernel / queue pair, 6 % apart, was called wrongly by one warm-up + best of two in a row); a candidate that
-        // is 1.3 x behind after a pass is out, and launches of a quarter second measure themselves in one pass.  A launch of 20 ms and more is
-        // timed twice, and 1.1 x behind is out after the first time: its spread is a per cent or two, and seven candidates of 50 ms three
-        // times over were a second and a half of the caller's time (config 5: 1.68 s -> ~0.8 s for the same choice)
-        for (int pass = 0; pass < 4; ++pass) {
-            float fastest = INFINITY;
-            for (int k = 0; k < NC; ++k) {
-                if (!in_race[k]) continue;
-                HIP_TRY(hipEventRecord(e0, stream));
-                if (k == K_SPLIT) enqueue_org(a, P, c, ORG_MEGA, DIR_DEFAULT, !mega_par_by_rule(a, P, false), true, false, stream);
-                else if (k == K_QSPLIT) enqueue_org(a, P, c, ORG_QUEUE, DIR_DEFAULT, false, true, false, stream);
-                else enqueue_org(a, P, c, (Org)(k / 6), k % 3, ((k / 3) & 1) != 0, false, false, stream);
-                HIP_TRY(hipEventRecord(e1, stream));
-                HIP_TRY(hipEventSynchronize(e1));
-                float ms = 0.0f;
-                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-                if ((pass > 0 || ms > 250.0f) && ms < best_ms[k]) best_ms[k] = ms;
-                fastest = std::min(fastest, pass > 0 || ms > 250.0f ? best_ms[k] : ms);
-            }
-            int left = 0;
-            const bool long_launch = fastest > 20.0f;
-            for (int k = 0; k < NC; ++k) {
-                if (in_race[k] && pass > 0 && best_ms[k] > (long_launch ? 1.1f : 1.3f) * fastest) in_race[k] = false;
-                left += in_race[k] ? 1 : 0;
-            }
-            if (left <= 1 && pass > 0) break;
-            if (fastest > 250.0f || (long_launch && pass >= 2)) break;
-        }
-    } catch (...) {
-        a.profiling = was_profiling;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        throw;
-    }
-    a.profiling = was_profiling;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const int rule_k = (int)rule * 6 + (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? 3 : 0) + (P.ntiles < 2u ? 0 : dir_unmeasured(a, rule));
+    float best_ms[NC];
+    for (float &m : best_ms) m = INFINITY;
+    const bool was_profiling = a.profiling;
+    a.profiling = false; // (the measurement's launches are not the caller's: lg_profile_read must not count them)
+    struct Restore { const lg_accel &a; bool was; ~Restore() { a.profiling = was; } } restore{a, was_profiling};
+    const int choice = lg::tune::race(key, cand, NC, rule_k, stream, [&](int k) {
+        if (k == K_SPLIT) enqueue_org(a, P, c, ORG_MEGA, DIR_DEFAULT, !mega_par_by_rule(a, P, false), true, false, stream);
+        else if (k == K_QSPLIT) enqueue_org(a, P, c, ORG_QUEUE, DIR_DEFAULT, false, true, false, stream);
+        else enqueue_org(a, P, c, (Org)(k / 6), k % 3, ((k / 3) & 1) != 0, false, false, stream);
+    }, best_ms);
     check_queue_error(a);
-    int best = (int)rule * 6 + (rule == ORG_MEGA && !mega_par_by_rule(a, P, false) ? 3 : 0) + (P.ntiles < 2u ? 0 : dir_unmeasured(a, rule));
-    for (int k = 0; k < NC; ++k)
-        if (best_ms[k] < best_ms[best] * 0.99f) best = k; // (the rule's choice unless another beats it by 1 %: equal candidates do not flip from run to run)
-    const int choice = best == K_SPLIT ? (int)ORG_MEGA | dir_bits(DIR_DEFAULT) | (!mega_par_by_rule(a, P, false) ? TUNE_SERIAL : 0) | TUNE_SPLIT
-                     : best == K_QSPLIT ? (int)ORG_QUEUE | dir_bits(DIR_DEFAULT) | TUNE_SPLIT
-                                        : (best / 6) | dir_bits(best % 3) | (((best / 3) & 1) ? TUNE_SERIAL : 0);
-    if (std::getenv("LASGUN_DEBUG"))
-        std::fprintf(stderr, "[lasgun] measured for %llu pixels (top-down / bottom-up / middle-out): megakernel %.3f / %.3f / %.3f ms (samples in a row: %.3f / %.3f / %.3f), level by level %.3f ms, queue %.3f / %.3f / %.3f ms -> %s%s%s (rule: %d)\n",
+    if (std::getenv("LASGUN_DEBUG")) {
+        std::fprintf(stderr, "[lasgun] measured for %llu pixels (top-down / bottom-up / middle-out): megakernel %.3f / %.3f / %.3f ms (samples in a row: %.3f / %.3f / %.3f), level by level %.3f ms, queue %.3f / %.3f / %.3f ms -> choice %d (rule: %d)\n",
                      items, best_ms[0], best_ms[1], best_ms[2], best_ms[3], best_ms[4], best_ms[5], best_ms[6], best_ms[12], best_ms[13], best_ms[14], // (one sample per pixel: "in a row" is the megakernel)
-                     best == K_SPLIT ? "megakernel, tiles in quarters" : best == K_QSPLIT ? "queue, tiles in quarters" : best / 6 == 0 ? "megakernel" : best / 6 == 1 ? "level by level" : "queue",
-                     best >= K_SPLIT ? "" : best % 3 == 1 ? ", bottom-up" : best % 3 == 2 ? ", middle-out" : "", best < K_SPLIT && ((best / 3) & 1) ? ", samples in a row" : "", (int)rule);
-    if (std::getenv("LASGUN_DEBUG") && (in_race[K_SPLIT] || in_race[K_QSPLIT])) std::fprintf(stderr, "[lasgun]   (tiles in quarters: megakernel %.3f ms, queue %.3f ms)\n", best_ms[K_SPLIT], best_ms[K_QSPLIT]);
-    std::lock_guard<std::mutex> g(g_tune_mtx);
-    g_tuned[key] = choice;
-    return choice;
+                     choice, (int)rule);
+        if (std::isfinite(best_ms[K_SPLIT]) || std::isfinite(best_ms[K_QSPLIT])) std::fprintf(stderr, "[lasgun]   (tiles in quarters: megakernel %.3f ms, queue %.3f ms)\n", best_ms[K_SPLIT], best_ms[K_QSPLIT]);
+    }
+    return choice_possible(a, P, choice) ? choice : rule_choice(a, P);
 }
 
 // Enqueue one render on `stream`.  Caller holds a.mtx.
@@ -1160,22 +1195,39 @@ static void set_rect(DParams &P, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t
 }
 // the row table of the lattice addressing for (w, h, n): made once per launch context and kept while the caller stays with that film and period
 // (the progressive front end's hundred calls share it)
+constexpr size_t MAX_ROW_TABLES = 4;
 static const DRowTab *lattice_rows(const lg_accel &a, hipStream_t stream, uint32_t w, uint32_t h, unsigned long long n) {
     lg_accel::LaunchCtx &c = ctx_for(a, stream);
-    if (c.rt_w != w || c.rt_h != h || c.rt_n != n || c.rowtab.n < h) {
-        std::vector<DRowTab> t(h);
-        for (uint32_t y = 0; y < h; ++y) { const unsigned long long o = (unsigned long long)y * w; t[y] = DRowTab{(uint32_t)(o / n), (uint32_t)(o % n)}; }
-        HIP_TRY(hipDeviceSynchronize()); // (an earlier launch may still read the table that is being replaced)
-        if (c.rowtab.n < h) c.rowtab.alloc(h);
-        HIP_TRY(hipMemcpy(c.rowtab.p, t.data(), (size_t)h * sizeof(DRowTab), hipMemcpyHostToDevice));
-        c.rt_w = w; c.rt_h = h; c.rt_n = n;
+    using RowTable = lg_accel::LaunchCtx::RowTable;
+    for (auto &r : c.rowtabs)
+        if (r->w == w && r->h == h && r->n == n) { r->last_use = ++c.rowtab_clock; return r->buf.p; }
+    RowTable *r = nullptr;
+    if (c.rowtabs.size() < MAX_ROW_TABLES) {
+        c.rowtabs.emplace_back(new RowTable());
+        r = c.rowtabs.back().get();
+    } else { // the least recently used table makes room: launches that read it are ahead of the new copy in stream order, unless its buffer must grow
+        r = c.rowtabs[0].get();
+        for (auto &x : c.rowtabs) if (x->last_use < r->last_use) r = x.get();
+        if (r->up) HIP_TRY(hipEventSynchronize(r->up)); // (its staging is rewritten below)
+        if (r->buf.n < h) HIP_TRY(hipStreamSynchronize(stream)); // (a buffer goes back to the pool only when nothing can still read it)
     }
-    return c.rowtab.p;
+    r->w = 0; r->h = 0; r->n = 0; // (not a table of anything until the copy below is enqueued)
+    if (r->buf.n < h) r->buf.alloc(h);
+    r->stage.need((size_t)h * sizeof(DRowTab));
+    DRowTab *t = static_cast<DRowTab *>(r->stage.p);
+    for (uint32_t y = 0; y < h; ++y) { const unsigned long long o = (unsigned long long)y * w; t[y] = DRowTab{(uint32_t)(o / n), (uint32_t)(o % n)}; }
+    HIP_TRY(hipMemcpyAsync(r->buf.p, t, (size_t)h * sizeof(DRowTab), hipMemcpyHostToDevice, stream));
+    if (!r->up) HIP_TRY(hipEventCreateWithFlags(&r->up, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(r->up, stream));
+    r->w = w; r->h = h; r->n = n; r->last_use = ++c.rowtab_clock;
+    return r->buf.p;
 }
+// the pixels of the subset {k + i*n} of an `area`-pixel film (k < area, n > 0), without forming area - k + n - 1 (which wraps for n near SIZE_MAX)
+static unsigned long long subset_count(unsigned long long area, unsigned long long k, unsigned long long n) { return k < area ? 1ull + (area - 1ull - k) / n : 0ull; }
 static void set_subset(const lg_accel &a, hipStream_t stream, DParams &P, size_t k, size_t n, uint32_t w, uint32_t h) {
     unsigned long long area = (unsigned long long)w * h;
     P.mode = 1; P.sub_k = k; P.sub_n = n;
-    P.sub_count = k < area ? (area - k + n - 1) / n : 0;
+    P.sub_count = subset_count(area, k, n);
     P.ntiles = (uint32_t)((P.sub_count + 63ull) / 64ull);
     // The subset tile by lattice column (mode 4, shade.h: 64 rows x <= n pixels per tile instead of 64 consecutive i) where that is the denser
     // window: a period shorter than the film's width and longer than a tile's 64 pixels in a row would be.  LASGUN_SUBSET_LATTICE=0: never (A/B).
@@ -1204,7 +1256,7 @@ static SubsetBatch make_batch(const size_t *ks, size_t count, size_t n, uint32_t
     for (size_t j = 0; j < count; ++j) if (ks[j] < area) b.ks.push_back(ks[j]); // (a subset that starts behind the film has no pixel: lib.rs:152)
     std::sort(b.ks.begin(), b.ks.end());
     b.ks.erase(std::unique(b.ks.begin(), b.ks.end()), b.ks.end());
-    for (unsigned long long k : b.ks) b.periods = std::max(b.periods, (area - k + n - 1) / n);
+    for (unsigned long long k : b.ks) b.periods = std::max(b.periods, subset_count(area, k, n));
     b.items = (unsigned long long)b.ks.size() * b.periods;
     if (b.items >= 0xFFFFFFFFull) throw Error("too many pixels for one batch of subsets (2^32 work items)");
     b.whole = b.ks.size() == n;
@@ -1221,12 +1273,16 @@ static void set_subsets(const lg_accel &a, DParams &P, const SubsetBatch &b, hip
         } else ++i;
     }
     (void)hipGetLastError(); // (hipEventQuery's "not ready" is not an error of this call)
+    // (a table whose launch was never enqueued -- the call failed between set_subsets and subsets_enqueued -- has no event to wait for:
+    // subsets_abandoned() below takes it out again on that path)
     c.ks_live.emplace_back(new lg_accel::LaunchCtx::KsTable());
     lg_accel::LaunchCtx::KsTable &t = *c.ks_live.back();
-    std::vector<unsigned long long> tab(b.ks); // the m values of k, then (k mod n) | (k / n) << 32 of each (the lattice form, shade.h mode 5)
-    for (unsigned long long k : b.ks) tab.push_back((k % b.n) | ((k / b.n) << 32));
-    t.buf.alloc(std::max<size_t>(tab.size(), 128));
-    HIP_TRY(hipMemcpy(t.buf.p, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    const size_t m_ = b.ks.size();
+    t.stage.need(2 * m_ * sizeof(unsigned long long));
+    unsigned long long *tab = static_cast<unsigned long long *>(t.stage.p); // the m values of k, then (k mod n) | (k / n) << 32 of each (the lattice form, shade.h mode 5)
+    for (size_t j = 0; j < m_; ++j) { tab[j] = b.ks[j]; tab[m_ + j] = (b.ks[j] % b.n) | ((b.ks[j] / b.n) << 32); }
+    t.buf.alloc(std::max<size_t>(2 * m_, 128));
+    HIP_TRY(hipMemcpyAsync(t.buf.p, tab, 2 * m_ * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
     P.mode = 3; P.pixel_list = t.buf.p; P.sub_m = (uint32_t)b.ks.size(); P.sub_n = b.n; P.sub_k = 0; P.sub_count = b.items;
     P.ntiles = (uint32_t)((b.items + 63ull) / 64ull);
     // the batch tile by lattice column (mode 5, shade.h: 64 / m rows x <= n pixels per tile instead of 64 consecutive work items -- 64 / m
@@ -1247,8 +1303,20 @@ static void subsets_enqueued(const lg_accel &a, hipStream_t stream) {
     HIP_TRY(hipEventRecord(c.ks_live.back()->done, stream));
 }
 
+// ... and when the call fails before its launch is enqueued: the table set_subsets made has no launch that reads it and no event that
+// would ever release it (the copy into it may still be in flight: the stream is drained first)
+static void subsets_abandoned(const lg_accel &a, hipStream_t stream) {
+    for (auto &c : a.ctxs)
+        if (c->key == stream && !c->ks_live.empty() && !c->ks_live.back()->done) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipGetLastError();
+            c->ks_live.pop_back();
+        }
+}
+
 template <class F> static int guarded(F f) {
     try {
+        CallScope call; // (which API call a launch belongs to: the measured choice counts calls, tune.h)
         f();
         return 0;
     } catch (const std::exception &e) {
@@ -1260,6 +1328,35 @@ template <class F> static int guarded(F f) {
 extern "C" {
 
 const char *lg_last_error(void) { return tl_error.c_str(); }
+
+// ---- the measured choice's table from outside (tune.h): a caller that knows its workload pins the choice and never pays for a race;
+// a test runs with a fixed table.  An entry is the twelve words of a kind and the remembered choice, opaque to the caller.
+size_t lg_tune_export(lg_tune_entry *out, size_t capacity) {
+    const size_t n = lg::tune::snapshot(nullptr, nullptr, 0);
+    if (!out || capacity == 0) return n;
+    std::vector<lg::tune::Key> keys(capacity);
+    std::vector<int> choices(capacity);
+    const size_t m = lg::tune::snapshot(keys.data(), choices.data(), capacity);
+    for (size_t i = 0; i < std::min(m, capacity); ++i) {
+        std::memcpy(out[i].key, keys[i].v, sizeof out[i].key);
+        out[i].choice = choices[i];
+        out[i].reserved = 0;
+    }
+    return m;
+}
+int lg_tune_import(const lg_tune_entry *entries, size_t count) {
+    if (count != 0 && !entries) return fail("lg_tune_import: entries is NULL");
+    for (size_t i = 0; i < count; ++i) { // (a choice is checked against the launch when it is used: one the launch cannot take falls back to the rule's)
+        if (entries[i].choice < 0 || entries[i].choice >= 256 || (entries[i].choice & 15) > (int)ORG_QUEUE) return fail("lg_tune_import: entry " + std::to_string(i) + " holds no choice this library makes");
+    }
+    for (size_t i = 0; i < count; ++i) {
+        lg::tune::Key k;
+        std::memcpy(k.v, entries[i].key, sizeof k.v);
+        lg::tune::remember(k, entries[i].choice);
+    }
+    return 0;
+}
+void lg_tune_clear(void) { lg::tune::clear(); }
 void lg_set_last_error(const char *msg) { tl_error = msg ? msg : ""; } // (multi.cpp reports through the same thread-local message)
 
 static lg_material pack(const Material &m) { lg_material r; r.kind = m.kind; std::memcpy(r.p, m.p, sizeof r.p); return r; }
@@ -1788,7 +1885,7 @@ int lg_capture_subset(size_t k, size_t n, const lg_accel *a, lg_film *film) {
         const uint32_t w = film->w, h = film->h;
         const unsigned long long area = (unsigned long long)w * h;
         const bool whole = n == 1 && k == 0;
-        const unsigned long long count = whole ? area : (k < area ? (area - k + n - 1) / n : 0);
+        const unsigned long long count = whole ? area : subset_count(area, k, n);
         if (count == 0) return;
         DevBuf<uint32_t> buf; // this call's own output (returned to the pool when the call ends)
         // A whole film of 2^22 pixels and more goes out in ROW BANDS: the bands are rendered one after the other on the accel's stream, and
@@ -1882,12 +1979,14 @@ int lg_capture_subsets_device(const size_t *ks, size_t count, size_t n, const lg
         std::lock_guard<std::mutex> g(a->mtx);
         use_device(a->device);
         DParams P = base_params(*a, w, h);
-        if (b.whole) set_rect(P, 0, 0, w, h);
-        else set_subsets(*a, P, b, (hipStream_t)hip_stream);
-        P.out_row0 = 0;
-        P.out_rgba = (uint8_t *)dev_rgba;
-        enqueue(*a, P, false, (hipStream_t)hip_stream);
-        if (!b.whole) subsets_enqueued(*a, (hipStream_t)hip_stream);
+        try {
+            if (b.whole) set_rect(P, 0, 0, w, h);
+            else set_subsets(*a, P, b, (hipStream_t)hip_stream);
+            P.out_row0 = 0;
+            P.out_rgba = (uint8_t *)dev_rgba;
+            enqueue(*a, P, false, (hipStream_t)hip_stream);
+            if (!b.whole) subsets_enqueued(*a, (hipStream_t)hip_stream);
+        } catch (...) { subsets_abandoned(*a, (hipStream_t)hip_stream); throw; }
     });
 }
 int lg_capture_subsets(const size_t *ks, size_t count, size_t n, const lg_accel *a, lg_film *film) {
@@ -1905,12 +2004,14 @@ int lg_capture_subsets(const size_t *ks, size_t count, size_t n, const lg_accel 
             use_device(a->device);
             buf.alloc((size_t)b.items);
             DParams P = base_params(*a, w, h);
-            set_subsets(*a, P, b, a->stream);
-            P.out_compact = 1;
-            P.out_row0 = 0;
-            P.out_rgba = (uint8_t *)buf.p;
-            enqueue(*a, P, false, a->stream);
-            subsets_enqueued(*a, a->stream);
+            try {
+                set_subsets(*a, P, b, a->stream);
+                P.out_compact = 1;
+                P.out_row0 = 0;
+                P.out_rgba = (uint8_t *)buf.p;
+                enqueue(*a, P, false, a->stream);
+                subsets_enqueued(*a, a->stream);
+            } catch (...) { subsets_abandoned(*a, a->stream); throw; }
             HIP_TRY(hipMemcpyAsync(host.data(), buf.p, (size_t)b.items * 4, hipMemcpyDeviceToHost, a->stream));
         }
         use_device(a->device);
@@ -2017,6 +2118,7 @@ static int capture_share(const lg_scene *s, lg_film *film, int device, uint32_t 
 }
 
 int lg_capture(const lg_scene *s, lg_film *film) { // lib.rs:55-104: the BVH is (re)built inside every capture
+    CallScope call; // (one API call, whatever its bands, shares and host threads launch)
     // The reference splits the film over `scene.threads` CPU threads, 0 = all cores (lib.rs:58-62); here the film is
     // split over devices: the ones named with lg_set_devices, the one named with lg_set_device, or -- a process that
     // named none -- EVERY visible device, capped by `scene.threads` when that is non-zero.  Pixels are independent,

@@ -1443,7 +1443,11 @@ void flatten_scene(const Scene &scene, FlatScene &out, bool with_fast, bool with
     if (out.primref.size() > 80000000u) throw Error("too many primitive slots for the 32-bit record offsets of the triangle stream");
     out.leaf_soup.resize(out.primref.size() + 2, DLeafRec{}); // two spare records: the mesh leaf loop keeps the next slot in flight
     if (with_records) build_chunks(out);
-    out.has_records = with_records;
+    {   // (a scene without a mesh has no leaf that could carry records: nothing to build on demand -- host.h)
+        bool any_mesh = false;
+        for (const DAccel &A : out.accels) any_mesh = any_mesh || (A.flags & AF_MESH) != 0u;
+        out.has_records = with_records || !any_mesh;
+    }
     if (times) {
         const auto t2 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

@@ -195,7 +195,11 @@ lg_accel *lg_multi_accel(const lg_multi *m, int rank) { return rank >= 0 && rank
 int lg_multi_uses_rccl(const lg_multi *m) { return m->comms.empty() ? 0 : 1; }
 
 // The whole film into DEVICE memory of the root (the first device of the list).  Synchronous: on return the film is complete.
+extern "C" void lg_internal_call_scope(int enter); // capi.cpp: which API call a launch belongs to (the measured choice counts calls)
+namespace { struct CallScope { CallScope() { lg_internal_call_scope(1); } ~CallScope() { lg_internal_call_scope(0); } }; }
+
 int lg_multi_capture_device(lg_multi *m, uint32_t w, uint32_t h, void *dev_rgba_on_root) {
+    CallScope call; // ONE call, whatever its shares launch (two shares of one device are two launches of one kind)
     // declared in this order: on ANY exit path the guard first closes a still-open RCCL group (an error between GroupStart
     // and GroupEnd would otherwise leave every later RCCL call of this thread -- PyTorch's included -- queued and never
     // launched), destroys the events and puts the caller's device back; then the lock is released
@@ -295,6 +299,7 @@ int lg_multi_capture_device(lg_multi *m, uint32_t w, uint32_t h, void *dev_rgba_
 // group, on that device's render stream; contiguous tiles land in row order as they arrive, interleaved blocks are put in
 // row order by n strided device copies per device.  dev_rgba[r] = a w*h*4-byte buffer on rank r's device.
 int lg_multi_capture_device_all(lg_multi *m, uint32_t w, uint32_t h, void *const *dev_rgba) {
+    CallScope call;
     std::unique_lock<std::mutex> rccl_lock(g_rccl_mtx, std::defer_lock);
     ExchangeGuard guard;
     const uint32_t n = (uint32_t)m->shares.size();

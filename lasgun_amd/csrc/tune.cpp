@@ -1,0 +1,129 @@
+// lasgun_amd/csrc/tune.cpp -- see tune.h.  (Round 6: moved out of capi.cpp; the race no longer fails the caller's render when a
+// candidate cannot run, counts API calls instead of launches, and its table can be exported, imported and cleared.)
+#include "tune.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
+namespace lg {
+namespace tune {
+
+bool Key::operator<(const Key &o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
+
+namespace {
+std::mutex g_mtx;     // the two tables
+std::mutex g_run_mtx; // one race at a time in the process: two accels of one kind measuring side by side would time each other
+// never destroyed: launches at interpreter exit, after static destructors have begun, still find them
+std::map<Key, int> &g_tuned = *new std::map<Key, int>();
+std::map<Key, uint64_t> &g_first_seen = *new std::map<Key, uint64_t>(); // the API call a kind was first launched in
+} // namespace
+
+int mode() {
+    static const int m = [] { const char *e = std::getenv("LASGUN_AUTOTUNE"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
+    return m;
+}
+
+bool lookup(const Key &key, int *choice) {
+    std::lock_guard<std::mutex> g(g_mtx);
+    auto it = g_tuned.find(key);
+    if (it == g_tuned.end()) return false;
+    *choice = it->second;
+    return true;
+}
+
+bool first_call_of_kind(const Key &key, uint64_t serial) {
+    std::lock_guard<std::mutex> g(g_mtx);
+    auto it = g_first_seen.find(key);
+    if (it == g_first_seen.end()) { g_first_seen.emplace(key, serial); return true; }
+    return it->second == serial;
+}
+
+void remember(const Key &key, int choice) {
+    std::lock_guard<std::mutex> g(g_mtx);
+    g_tuned[key] = choice;
+}
+
+size_t snapshot(Key *keys, int *choices, size_t capacity) {
+    std::lock_guard<std::mutex> g(g_mtx);
+    size_t i = 0;
+    for (const auto &kv : g_tuned) {
+        if (i < capacity) { if (keys) keys[i] = kv.first; if (choices) choices[i] = kv.second; }
+        ++i;
+    }
+    return i;
+}
+
+void clear() {
+    std::lock_guard<std::mutex> g(g_mtx);
+    g_tuned.clear();
+    g_first_seen.clear();
+}
+
+int race(const Key &key, Candidate *cands, int n, int rule, hipStream_t stream, const std::function<void(int)> &launch, float *best_out) {
+    std::lock_guard<std::mutex> run(g_run_mtx);
+    {   // (another accel of this kind may have measured while this one waited)
+        int known;
+        if (lookup(key, &known)) return known;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { // no events, no race
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        return cands[rule].choice;
+    }
+    float *best_ms = new float[(size_t)n];
+    for (int k = 0; k < n; ++k) best_ms[k] = INFINITY;
+    // pass 0 warms every candidate up (buffers, code, clocks); passes 1-3 time them IN TURN, so that a drift of the clocks or a
+    // neighbour's launch hits all alike, and the best of the three counts (the persistent kernels' own run-to-run spread is ~5 %:
+    // config 4m's megakernel / queue pair, 6 % apart, was called wrongly by one warm-up + best of two in a row); a candidate that
+    // is 1.3 x behind after a pass is out, and launches of a quarter second measure themselves in one pass.  A launch of 20 ms and more is
+    // timed twice, and 1.1 x behind is out after the first time: its spread is a per cent or two, and seven candidates of 50 ms three
+    // times over were a second and a half of the caller's time (config 5: 1.68 s -> ~0.8 s for the same choice)
+    for (int pass = 0; pass < 4; ++pass) {
+        float fastest = INFINITY;
+        for (int k = 0; k < n; ++k) {
+            if (!cands[k].in_race) continue;
+            float ms = 0.0f;
+            bool ok = hipEventRecord(e0, stream) == hipSuccess;
+            if (ok) {
+                try { launch(k); } catch (...) { ok = false; } // (out of memory for this organisation's buffers, a refused launch: the others may still fit)
+            }
+            ok = ok && hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError(); // the failed call's sticky "last error" is not the caller's
+                cands[k].in_race = false;
+                best_ms[k] = INFINITY;
+                continue;
+            }
+            if ((pass > 0 || ms > 250.0f) && ms < best_ms[k]) best_ms[k] = ms;
+            fastest = std::min(fastest, pass > 0 || ms > 250.0f ? best_ms[k] : ms);
+        }
+        int left = 0;
+        const bool long_launch = fastest > 20.0f;
+        for (int k = 0; k < n; ++k) {
+            if (cands[k].in_race && pass > 0 && best_ms[k] > (long_launch ? 1.1f : 1.3f) * fastest) cands[k].in_race = false;
+            left += cands[k].in_race ? 1 : 0;
+        }
+        if (left == 0) break;
+        if (left <= 1 && pass > 0) break;
+        if (fastest > 250.0f || (long_launch && pass >= 2)) break;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    int best = -1;
+    if (std::isfinite(best_ms[rule])) best = rule;
+    for (int k = 0; k < n; ++k) {
+        if (!std::isfinite(best_ms[k])) continue;
+        if (best < 0 || best_ms[k] < best_ms[best] * 0.99f) best = k; // (the rule's choice unless another beats it by 1 %: equal candidates do not flip from run to run)
+    }
+    if (best_out) for (int k = 0; k < n; ++k) best_out[k] = best_ms[k];
+    delete[] best_ms;
+    if (best < 0) return cands[rule].choice; // nothing could be timed: the rule's choice, and the next launch of the kind tries again
+    remember(key, cands[best].choice);
+    return cands[best].choice;
+}
+
+} // namespace tune
+} // namespace lg

@@ -49,3 +49,21 @@ def test_bench_metric_is_baselines_metric():
     assert _line()["metric"] == want
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert want in src
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with no launcher in front spawns torch.distributed.run as a child and hands its exit code through (no GPU
+    here: the ranks fail at their first device call, and that failure -- not a usage message -- is what comes back)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "64", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        assert p.returncode == 0, p.stderr[-2000:]
+        return
+    assert p.returncode != 0 and "launch with" not in p.stderr
+    assert "torch.distributed" in p.stderr or "ChildFailedError" in p.stderr or "rank" in p.stderr.lower(), p.stderr[-2000:]

@@ -358,3 +358,36 @@ def test_capture_takes_every_visible_device_by_default_and_prune_switch():
     with pytest.raises(la.LasgunError):
         if G.call("accel_set_prune", acc.h, 2):
             raise la.LasgunError(G.last_error())
+
+
+def _bench_line(extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-500:], p.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_without_a_launcher():
+    """`python3 bench.py --gpus 2` as the driver would type it, with NO torch.distributed.run in front: bench.py starts its ranks itself (a child
+    process, before the parent has touched the GPU), stdout is rank 0's one JSON line and the exit code the child's.  gloo on this box's one GPU
+    (both ranks render on device 0, tiles staged through host memory): the gathered film == one GPU's film == the oracle sample.
+    Reference counterpart: the fan-out over threads, src/lib.rs:55-104."""
+    d = _bench_line(["--gpus", "2", "--backend", "gloo", "--size", "1024", "--steps", "3", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo" and d["collective"] == "torch"
+    assert d["gathered_equals_single_gpu"] is True and d["bit_exact"] is True
+    assert [r["rank"] for r in d["per_rank_ms"]] == [0, 1] and all(r["ms_per_step"] > 0.0 and r["render_only_ms"] > 0.0 for r in d["per_rank_ms"])
+    assert "gather_ms" in d and d["scaling"] == "strong" and d["value"] > 0.0
+
+
+def test_bench_library_collective_on_same_device_shares():
+    """`bench.py --gpus 2 --collective library`: the product's own exchange (lg_multi_capture_device, multi.cpp) timed by the same script --
+    here two shares on device 0; the film equals the single-device film."""
+    d = _bench_line(["--gpus", "2", "--collective", "library", "--size", "1024", "--steps", "3", "--warmup", "1"])
+    assert d["collective"] == "library" and d["n_gpus"] == 2 and d["gathered_equals_single_gpu"] is True and d["value"] > 0.0
