@@ -185,6 +185,34 @@ def profiled_traffic(kernel_name, world, size):
     return None, None
 
 
+def profiled_clock(kernel_name):
+    """The clock (GHz) the chip held under `kernel_name`, from the committed GRBM_GUI_ACTIVE passes (profiles/rNN_pmc.json: the counter summed
+    over the 8 XCDs / 8 / the dispatch's duration, median over dispatches), only if they were collected on these sources; else None."""
+    try:
+        import glob
+        import lasgun_amd
+        sha = lasgun_amd.device_source_sha16()
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_pmc.json")), reverse=True):
+            pmc = json.load(open(path))
+            c = (pmc.get("clock_ghz") or {}).get(kernel_name)
+            if c and pmc.get("device_source_sha16") == sha:
+                return float(c["median"]), "profiles/%s @ device sources %s (GRBM_GUI_ACTIVE / 8 / duration, %d dispatches, %.3f - %.3f GHz)" % (
+                    os.path.basename(path), sha, c["dispatches"], c["min"], c["max"])
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
+    return None, None
+
+
+def at_clock(block, kernel_name):
+    """`clock_ghz` and `frac_at_clock` beside a roofline block's nominal-clock `frac`: the same achieved rate against the peak at the clock
+    the chip actually held under this kernel (the nominal peak assumes 2.4 GHz, which no loaded MI355X holds)."""
+    ghz, src = profiled_clock(kernel_name)
+    block["clock_ghz"] = ghz
+    block["clock_source"] = src
+    block["frac_at_clock"] = (block["achieved"] / (VALU_F64_PEAK_TOPS * ghz / 2.4)) if ghz else None
+    return block
+
+
 def mesh_roofline(G, la, stream):
     """configs[3] (generated 100k-triangle torus of glass + mirror sphere, recursion 3, 4096^2) on this GPU, two untimed
     frames after a warm-up: the triangle-test side of the path (the reference's 254-triangle leaves), in the organisation and
@@ -275,20 +303,21 @@ def mixed_roofline(G, la, stream):
     G.profile_enable(acc, True)
     G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream.cuda_stream)
     torch.cuda.synchronize()
-    kinds = {k: v[0] / v[1] for k, v in G.profile_read_kinds(acc).items() if v[1]}
+    raw = {k: v for k, v in G.profile_read_kinds(acc).items() if v[1]}  # {kind: (total ms of the frame, launches)}: a film this size is cut into chunks
+    kinds = {k: v[0] / v[1] for k, v in raw.items()}
     G.profile_read(acc)
     G.profile_enable(acc, False)
     st = G.capture_stats(acc, size, size, 0, size)
     rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
     if ran_as.split(",")[0] == "wavefront" and kinds:
-        dom = max(kinds, key=kinds.get)
-        dom_ms = kinds[dom]
+        dom = max(raw, key=lambda k: raw[k][0])
+        dom_ms, launches = kinds[dom], int(raw[dom][1])
         dst = dict(G.capture_stats_kind(acc, size, size, 2 if "shadow" in dom else 1, 0, size)) if dom.startswith("trace<") else st
         kernel = "lg::wf_trace_kernel<false, %s, false, %s, true>" % ("true" if "shadow" in dom else "false", "false" if "shadow" in dom else "true") if dom.startswith("trace<") else dom
     else:
-        dom, dom_ms, dst = "trace_kernel", kinds.get("trace_kernel", ms), st
+        dom, dom_ms, dst, launches = "trace_kernel", kinds.get("trace_kernel", ms), st, int(raw.get("trace_kernel", (0, 1))[1])
         kernel = {"megakernel": "lg::trace_kernel<false, false, false, true, 1024>", "queue": "lg::queue_kernel<false, true>"}.get(ran_as.split(",")[0], ran_as)
-    flops, fl_frame = algorithmic_flops(dst), algorithmic_flops(st)
+    flops, fl_frame = algorithmic_flops(dst) / max(launches, 1), algorithmic_flops(st)  # per launch of the dominant kernel (the frame's work of that kind over its launches)
     tops = flops / (dom_ms * 1e-3) / 1e12
     del film
     torch.cuda.empty_cache()
@@ -296,7 +325,7 @@ def mixed_roofline(G, la, stream):
             "ms_per_frame": ms, "value": rays / ms / 1e3, "unit": "Mrays/s", "rays_per_frame": rays,
             "bound": "valu_f64", "achieved": tops, "peak": VALU_F64_PEAK_TOPS, "frac": tops / VALU_F64_PEAK_TOPS,
             "frame_frac": fl_frame / (ms * 1e-3) / 1e12 / VALU_F64_PEAK_TOPS,
-            "organisation": ran_as, "kernel": kernel, "kernel_ms_avg": dom_ms, "kernels_ms_avg": kinds,
+            "organisation": ran_as, "kernel": kernel, "kernel_ms_avg": dom_ms, "kernel_launches_per_frame": launches, "kernels_ms_avg": kinds,
             "algorithmic_flops_per_launch": flops, "algorithmic_flops_per_frame": fl_frame, "algorithmic_bytes_per_frame": algorithmic_bytes(st),
             "traffic": None,
             "work_per_frame": {k: st[k] for k in ("nodes_tested", "spheres_tested", "cuboids_tested", "triangles_tested", "accel_entries", "hits")},
@@ -691,6 +720,11 @@ def main():
                          "note": "unit = unfused f64 operations (no FMA: -ffp-contract=off is part of the parity contract); counts are lower bounds "
                                  "of the reference's algorithm (DESIGN.md, Roofline bookkeeping)"},
         }
+        at_clock(out["roofline"], kernel_name)
+        if mesh_info is not None:
+            at_clock(mesh_info, mesh_info["kernel"])
+        if mixed_info is not None:
+            at_clock(mixed_info, mixed_info["kernel"])
         if fast_info is not None:
             out["fast_mode"] = fast_info
         if mesh_info is not None:

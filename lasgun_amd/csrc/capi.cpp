@@ -358,9 +358,16 @@ struct lg_accel {
         // launch is enqueued, so neither a later batch on the stream nor the caller's freed array can reach it
         struct KsTable { DevBuf<unsigned long long> buf; PinnedBuf stage; hipEvent_t done = nullptr; };
         std::vector<std::unique_ptr<KsTable>> ks_live;
+        // the level-by-level chain of a SMALL frame as a HIP graph (enqueue_wavefront): what the chain was captured for (a hash of its
+        // parameters), and the chain the context saw last -- a chain is captured when it comes a second time in a row, so a one-frame
+        // program never pays for a capture
+        hipGraphExec_t wf_graph = nullptr;
+        uint64_t wf_graph_sig = 0, wf_last_sig = 0;
+        unsigned wf_graph_captures = 0;
         ~LaunchCtx() {
             for (auto &k : ks_live) if (k->done) (void)hipEventDestroy(k->done);
             for (auto &r : rowtabs) if (r->up) (void)hipEventDestroy(r->up);
+            if (wf_graph) (void)hipGraphExecDestroy(wf_graph);
         }
     };
     mutable std::vector<std::unique_ptr<LaunchCtx>> ctxs;
@@ -648,6 +655,42 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
     if (std::getenv("LASGUN_DEBUG"))
         std::fprintf(stderr, "[lasgun] wavefront: levels %u, %llu tiles in chunks of %llu on %u stream(s) (%.1f MiB per context), trace grid %u x %u, stack %u, max_blocks %u\n", levels,
                      (unsigned long long)P0.ntiles, chunk_tiles, nstreams ? nstreams : 1u, need / 1048576.0, trace_cap, ldss ? 1024u : 256u, depth, a.max_blocks);
+    // A SMALL frame's chain is a dozen dependent launches of a few microseconds each (Cornell glass 512^2: 16 launches for 0.4 ms), and
+    // what separates them on a stream is the runtime's launch path per kernel.  The chain has no host decision in it -- fixed grids, counts
+    // on the device -- so it is captured ONCE into a HIP graph and replayed: frames of <= 2^20 work items, one chunk, the caller's own
+    // stream (not the null stream), not profiling; captured when the same chain (a hash of every parameter: scene tables, camera, film
+    // pointer, carved arrays, grids) comes a second time in a row on the context, so a program that renders one frame never pays
+    // for a capture, and re-captured at most MAX_GRAPH_CAPTURES times per context (a caller that changes the film every frame gains nothing
+    // and stops paying).  LASGUN_GRAPH=0: never (A/B); the bytes are the same launches' bytes.
+    static const bool graphs_on = [] { const char *e = std::getenv("LASGUN_GRAPH"); return !(e && e[0] == '0'); }();
+    constexpr unsigned MAX_GRAPH_CAPTURES = 8;
+    bool capturing = false;
+    if (graphs_on && stream != nullptr && nstreams == 0 && nchunks == 1 && !a.profiling && (unsigned long long)P0.ntiles * 64ull * S <= (1ull << 20)) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+        if (cs == hipStreamCaptureStatusNone) {
+            uint64_t sig = 1469598103934665603ull;
+            auto mix = [&sig](const void *q, size_t n) { const uint8_t *b = (const uint8_t *)q; for (size_t i = 0; i < n; ++i) { sig ^= b[i]; sig *= 1099511628211ull; } };
+            mix(&P0, sizeof P0);
+            const Carved &K0 = carved[0];
+            mix(&K0.hq, sizeof K0.hq); mix(&K0.counters, sizeof K0.counters); mix(&K0.frame, sizeof K0.frame); mix(&K0.accum, sizeof K0.accum);
+            const uint64_t shape[8] = {levels, S, n0, chunk_tiles, trace_cap, depth, (uint64_t)a.fast | ((uint64_t)ldss << 1), (uint64_t)(uintptr_t)a.lds_image.p};
+            mix(shape, sizeof shape);
+            if (sig == 0) sig = 1;
+            if (c.wf_graph && c.wf_graph_sig == sig) {
+                const hipError_t ge = hipGraphLaunch(c.wf_graph, stream);
+                if (ge == hipSuccess) return;
+                (void)hipGetLastError(); // a replay that is refused: the plain chain below
+                (void)hipGraphExecDestroy(c.wf_graph); c.wf_graph = nullptr; c.wf_graph_sig = 0; c.wf_graph_captures = MAX_GRAPH_CAPTURES;
+            } else if (c.wf_last_sig == sig && c.wf_graph_captures < MAX_GRAPH_CAPTURES) {
+                if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) { capturing = true; c.wf_graph_captures++; }
+                else (void)hipGetLastError();
+            }
+            c.wf_last_sig = sig;
+        }
+    }
+    const uint64_t chain_sig = c.wf_last_sig;
+    auto run_chain = [&] {
     unsigned long long chunk_no = 0;
     for (unsigned long long t0 = 0; t0 < P0.ntiles; t0 += chunk_tiles, ++chunk_no) {
         const Carved &K = carved[chunk_no % carved.size()];
@@ -715,6 +758,25 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
             timed(1, [&] { return launch_wf_resolve(R, (uint32_t)(((unsigned long long)pixel_tiles * 64ull + 255ull) / 256ull), ls); });
         }
     }
+    };
+    if (capturing) { // record the chain, replay it; a capture that was begun is always ended (a stream left in capture mode is lost to its owner)
+        hipGraph_t g = nullptr;
+        try { run_chain(); } catch (...) { (void)hipStreamEndCapture(stream, &g); if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); throw; }
+        bool launched = false;
+        if (hipStreamEndCapture(stream, &g) == hipSuccess && g) {
+            if (c.wf_graph) { (void)hipGraphExecDestroy(c.wf_graph); c.wf_graph = nullptr; c.wf_graph_sig = 0; }
+            hipGraphExec_t x = nullptr;
+            if (hipGraphInstantiate(&x, g, nullptr, nullptr, 0) == hipSuccess && x) {
+                if (hipGraphLaunch(x, stream) == hipSuccess) { c.wf_graph = x; c.wf_graph_sig = chain_sig; launched = true; }
+                else (void)hipGraphExecDestroy(x);
+            }
+        }
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        if (launched) return; // (no bands, no profiling on this path)
+        c.wf_graph_captures = MAX_GRAPH_CAPTURES; // captured but not launched: the frame still has to be rendered, plainly, and this context stops trying
+    }
+    run_chain();
     for (unsigned j = 0; j < nstreams; ++j) { // join: the caller's stream continues when every band is done
         HIP_TRY(hipEventRecord(a.aux_done[j], a.aux_streams[j]));
         HIP_TRY(hipStreamWaitEvent(stream, a.aux_done[j], 0));

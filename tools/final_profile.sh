@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round-end evidence run on the 1-GPU box: bench, rocprofv3 kernel stats, PMC passes, all configs.
-# usage (gpurun, two calls of <= 20 minutes): bash tools/final_profile.sh a ; bash tools/final_profile.sh b  -> gpurun_out/final5/ ;
-# then python3 tools/summarize_profiles.py gpurun_out/final5 profiles r05
+# usage (gpurun, two calls of <= 20 minutes): bash tools/final_profile.sh a ; bash tools/final_profile.sh b  -> gpurun_out/final6/ ;
+# then python3 tools/summarize_profiles.py gpurun_out/final6 profiles r06
 set -u
 export TMPDIR=/tmp
 # the profiler's preloaded library initialises HIP before bench.py can set this: the frames in flight need a hardware queue each
 export GPU_MAX_HW_QUEUES=16
 cd "${GRAFT_REPO_ROOT:?}"
 part=${1:-a}
-O=gpurun_out/final5; mkdir -p "$O"
+O=gpurun_out/final6; mkdir -p "$O"
 if [ "$part" = a ]; then
 timeout -k 10 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"
 # per-kernel durations: frames one after the other (the form bench.py's roofline.kernel_ms_avg is measured in) ...
@@ -22,6 +22,13 @@ run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_THREAD_CYCLES_VA
 run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA
 run sq3 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+# the clock the chip holds under these kernels: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the dispatch's duration (MI355X_MICROARCH.md, DVFS give-back);
+# frames one after the other, so a dispatch's duration is its own; --kernel-trace beside --pmc gives the timestamps (no other trace domain with counters)
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/pmc_grbm" -- python3 bench.py --steps 3 --warmup 1 --no-extras --sequential > "$O/pmc_grbm.log" 2>&1; echo "pmc grbm rc=$?"
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/pmc_grbm_c4" -- python3 tools/bench_configs.py "4 mesh" "5 mixed" > "$O/pmc_grbm_c4.log" 2>&1; echo "pmc grbm c4/c5 rc=$?"
+# configs[4] (8192^2 mixed) and configs[3]: per-kernel durations of their own
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c5" -- python3 tools/bench_configs.py "5 mixed" > "$O/prof_c5.log" 2>&1; echo "stats c5 rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_c4" -- python3 tools/bench_configs.py "4 mesh" > "$O/prof_c4.log" 2>&1; echo "stats c4 rc=$?"
 timeout -k 10 300 python3 tools/bench_configs.py > "$O/configs_parity.jsonl" 2>/dev/null; echo "configs rc=$?"
 timeout -k 10 300 python3 tools/bench_configs.py --fast > "$O/configs_fast.jsonl" 2>/dev/null
 timeout -k 10 300 python3 tools/bench_configs.py --org=megakernel > "$O/configs_megakernel.jsonl" 2>/dev/null

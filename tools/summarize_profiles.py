@@ -7,9 +7,9 @@ import os
 import statistics
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final5"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final6"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-tag = sys.argv[3] if len(sys.argv) > 3 else "r05"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r06"
 
 
 def newest(pattern):
@@ -57,6 +57,43 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for k, cs in acc.items():
         for c, vals in cs.items():
             out["kernels"].setdefault(k, {})[c] = statistics.median(vals)
+# the clock the chip held under each kernel: GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's duration, dispatch by dispatch (counter rows joined with the
+# kernel trace of the same run by dispatch id, or by the timestamps the counter file carries itself), median per kernel
+out["clock_ghz"] = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_grbm*"))):
+    f = newest(os.path.relpath(d, src) + "/**/*counter_collection.csv")
+    t = newest(os.path.relpath(d, src) + "/**/*kernel_trace.csv")
+    if not f:
+        continue
+    dur = {}
+    if t:
+        for r in csv.DictReader(open(t)):
+            try:
+                dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            except (KeyError, ValueError):
+                pass
+    per = {}
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") != "GRBM_GUI_ACTIVE" or "lg::" not in r["Kernel_Name"]:
+            continue
+        ns = dur.get(r.get("Dispatch_Id"))
+        if ns is None and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            ns = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        if not ns or ns < 3e5:  # (the quotient reads high on dispatches shorter than about 0.3 ms)
+            continue
+        k = r["Kernel_Name"].replace("void ", "").replace("(lg::DParams)", "")
+        per.setdefault(k, []).append(float(r["Counter_Value"]) / 8.0 / ns)
+    for k, v in per.items():
+        out["clock_ghz"][k] = {"median": statistics.median(v), "min": min(v), "max": max(v), "dispatches": len(v)}
+for name in ("prof_c4", "prof_c5"):
+    ks2 = newest(name + "/**/*kernel_stats.csv")
+    if ks2:
+        rows = [r for r in csv.DictReader(open(ks2)) if "lg::" in r["Name"]]
+        if rows:
+            with open(os.path.join(dst, tag + "_" + name.replace("prof_c", "config").replace("config5", "config5").replace("config4", "config4") + "_kernel_stats.csv"), "w") as fo:
+                w = csv.DictWriter(fo, fieldnames=rows[0].keys())
+                w.writeheader()
+                w.writerows(rows)
 json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 # the other outputs of tools/final_profile.sh, under the round's tag
 import shutil
