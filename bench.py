@@ -313,7 +313,7 @@ def mixed_roofline(G, la, stream):
         dom = max(raw, key=lambda k: raw[k][0])
         dom_ms, launches = kinds[dom], int(raw[dom][1])
         dst = dict(G.capture_stats_kind(acc, size, size, 2 if "shadow" in dom else 1, 0, size)) if dom.startswith("trace<") else st
-        kernel = "lg::wf_trace_kernel<false, %s, false, %s, true>" % ("true" if "shadow" in dom else "false", "false" if "shadow" in dom else "true") if dom.startswith("trace<") else dom
+        kernel = "lg::wf_trace_kernel<false, %s, false, %s, true, false>" % ("true" if "shadow" in dom else "false", "false" if "shadow" in dom else "true") if dom.startswith("trace<") else dom
     else:
         dom, dom_ms, dst, launches = "trace_kernel", kinds.get("trace_kernel", ms), st, int(raw.get("trace_kernel", (0, 1))[1])
         kernel = {"megakernel": "lg::trace_kernel<false, false, false, true, 1024>", "queue": "lg::queue_kernel<false, true>"}.get(ran_as.split(",")[0], ran_as)
@@ -676,7 +676,9 @@ def main():
             # wavefront pipeline: lg::wf_trace_kernel<FAST, SHADOW, scene tables resident in LDS, level-0 closest pass>, lg::wf_shade_kernel<KIND, L0>
             shadow = "shadow" in dom
             pruned = "true" if G.get_prune(acc) else "false"  # (LASGUN_PRUNE / lg_accel_set_prune: the PRUNE template argument of the kernel that ran)
-            kernel_name = ("lg::wf_trace_kernel<false, %s, %s, %s, %s>" % ("true" if shadow else "false", "true" if lds_scene else "false", "false" if shadow else "true", pruned)
+            # (the sixth argument: the refilling shadow pass -- level 0 of a big launch over an LDS-resident scene, k_wavefront.hip: launch_wf_trace)
+            refill = "true" if (shadow and lds_scene and pruned == "false" and os.environ.get("LASGUN_REFILL", "0") == "1" and w * h >= (1 << 20) * world) else "false"
+            kernel_name = ("lg::wf_trace_kernel<false, %s, %s, %s, %s, %s>" % ("true" if shadow else "false", "true" if lds_scene else "false", "false" if shadow else "true", pruned, refill)
                            if dom.startswith("trace<") else "lg::wf_shade_kernel<0, true>")
         else:  # megakernel (a share too small for the pipeline, e.g. a small --size over many ranks)
             dom_ms, dst, kernel_name = frame_ms, st, "lg::trace_kernel<false, false, %s, %s>" % ("true" if lds_scene else "false", "true" if G.get_prune(acc) else "false")

@@ -661,8 +661,13 @@ static void enqueue_wavefront(const lg_accel &a, DParams &P0, lg_accel::LaunchCt
     // stream (not the null stream), not profiling; captured when the same chain (a hash of every parameter: scene tables, camera, film
     // pointer, carved arrays, grids) comes a second time in a row on the context, so a program that renders one frame never pays
     // for a capture, and re-captured at most MAX_GRAPH_CAPTURES times per context (a caller that changes the film every frame gains nothing
-    // and stops paying).  LASGUN_GRAPH=0: never (A/B); the bytes are the same launches' bytes.
-    static const bool graphs_on = [] { const char *e = std::getenv("LASGUN_GRAPH"); return !(e && e[0] == '0'); }();
+    // and stops paying).  The bytes are the same launches' bytes.
+    // MEASURED, and OFF unless LASGUN_GRAPH=1 (profiles/r06_small_frames.jsonl, tools/ab_small_frames.sh, variants in turn on one box): the
+    // replay is SLOWER where it was meant to pay -- the README sphere at 512^2 0.086 -> 0.093 ms alone and 0.072 -> 0.081 back to back (4 nodes),
+    // Cornell plastic 0.119 -> 0.129 / 0.104 -> 0.116 -- and within +-2 % on every longer chain (simple.rs 9 spp, Cornell glass at 256^2 / 512^2,
+    // spooky.rs, playground.rs, simplecows.rs: 16 - 28 nodes).  On this runtime (ROCm 7.2) a graph launch costs more than the stream launches it
+    // replaces and the gaps between dependent kernels do not shrink.
+    static const bool graphs_on = [] { const char *e = std::getenv("LASGUN_GRAPH"); return e && e[0] == '1'; }();
     constexpr unsigned MAX_GRAPH_CAPTURES = 8;
     bool capturing = false;
     if (graphs_on && stream != nullptr && nstreams == 0 && nchunks == 1 && !a.profiling && (unsigned long long)P0.ntiles * 64ull * S <= (1ull << 20)) {

@@ -1,4 +1,6 @@
 // lasgun_amd/csrc/k_wavefront.hip -- the wavefront pipeline: li() level by level (closest / shadow / shade / combine).
+#include <cstdlib>
+
 #include "shade.h"
 
 namespace lg {
@@ -81,10 +83,89 @@ __device__ __forceinline__ bool hit_of(const DParams &P, const HitSlots &s, uint
     return k < s.n_part;
 }
 
+// (An experiment of round 6, kept as an opt-in for its measurement -- LASGUN_REFILL=1; see launch_wf_trace for what it showed.)
+// The shadow pass as ONE persistent walk per wave (walk.h, REFILL): a lane whose shadow ray is done takes the next hit of the wave's current
+// 64-slot tile (a new tile is claimed when that one is used up) instead of waiting for the slowest of 64 rays -- the any-hit walks of a
+// tile end anywhere between the first box and the whole tree.  Lanes refill when at least LG_REFILL_MIN of them are done: a refill is
+// the frame loads and the ray set-up (three divisions) for however many lanes take part, so it wants company.  Which lane walks which
+// hit never changes a visibility bit.
+#ifndef LG_REFILL_MIN
+#define LG_REFILL_MIN 16
+#endif
+struct ShadowRefill {
+    static constexpr bool enabled = true;
+    static constexpr unsigned long long NONE = ~0ull;
+    const DParams &P;
+    const HitSlots &hs;
+    uint32_t band, left;             // the wave's place among the tile heads (claim_tile_partial)
+    uint32_t tile = NO_TILE, slot = 64u; // the tile being handed out and its next slot (wave-uniform)
+    bool exhausted = false;          // no tile is left (wave-uniform)
+    unsigned long long h = NONE;     // this lane's hit, its light, the bits so far, the point the shadow rays leave from
+    uint32_t light = 0u, vis = 0u;
+    V3 hit_p{0.0, 0.0, 0.0};
+    __device__ __forceinline__ ShadowRefill(const DParams &p, const HitSlots &s, uint32_t b) : P(p), hs(s), band(b), left(TILE_HEADS) {}
+    __device__ __forceinline__ uint32_t threshold() const { return exhausted ? (P.nlights > 1u ? 1u : 65u) : (uint32_t)LG_REFILL_MIN; }
+    __device__ __forceinline__ Ray shadow_ray() const {
+        const DLight L = P.lights[light];
+        return ray_new(hit_p, V3{L.pos[0], L.pos[1], L.pos[2]} - hit_p); // point.rs:43-44
+    }
+    __device__ __forceinline__ void deliver(const Best &b) {
+        if (h == NONE) return;
+        if (!(b.t < 1.0)) vis |= 1u << light; // point.rs:49
+    }
+    __device__ __forceinline__ void finish(const Best &b) { // after the walk: a lane's last result
+        if (h == NONE) return;
+        deliver(b);
+        P.vis[h] = vis;
+        h = NONE;
+    }
+    // called by EVERY lane of the wave, in wave-uniform control flow (tile, slot, band, left, exhausted are the wave's: a lane that sat a call
+    // out would keep stale copies); `done`: this lane's walk is done (or it has no ray yet).  true = `nw` is this lane's next ray
+    __device__ __forceinline__ bool next(const bool done, const Best &b, Ray &nw) {
+        bool more_lights = false;
+        if (done && h != NONE) {
+            deliver(b);
+            if (++light < P.nlights) more_lights = true;
+            else { P.vis[h] = vis; h = NONE; }
+        }
+        bool need = done && h == NONE;
+        const bool wanted = need;
+        while (!exhausted && wave_any(need)) {
+            if (slot >= 64u) { // (wave-uniform)
+                tile = claim_tile_partial(P.tile_counter, hs.tiles, band, left);
+                if (tile == NO_TILE) { exhausted = true; break; }
+                slot = 0u;
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+            const uint32_t want = (uint32_t)__builtin_popcountll(m), room = 64u - slot, take = want < room ? want : room;
+            const uint32_t rank = lanes_below(m);
+            if (need && rank < take) {
+                unsigned long long hh;
+                if (hit_of(P, hs, tile, slot + rank, hh)) { // (a hole of a dense block, a slot past the count: the lane asks again)
+                    h = hh;
+                    const unsigned long long n = P.wf_hit_stride;
+                    // interaction.p + p_err, recomputed from the parked frame exactly as stash_get does
+                    const V3 praw{P.frame[0 * n + h], P.frame[1 * n + h], P.frame[2 * n + h]};
+                    const V3 ng{P.frame[3 * n + h], P.frame[4 * n + h], P.frame[5 * n + h]};
+                    const double err = 2.220446049250313e-16 * 65536.0;
+                    hit_p = praw + ng * err;
+                    light = 0u; vis = 0u;
+                    need = false;
+                }
+            }
+            slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot + take));
+        }
+        const bool got = more_lights || (wanted && !need); // the next light of the same hit, or a hit taken just now
+        if (got) nw = shadow_ray();
+        return got;
+    }
+};
+
 // W1 / W2: persistent traversal kernels of the wavefront pipeline (tile counter, per-lane LDS stack; LDSS as above).
 // L0: the launch is level 0's (rays from the camera, work items = the chunk's pixels in 8x8 tiles).
-template <bool FAST, bool SHADOW, bool LDSS, bool L0, bool PRUNE = false>
+template <bool FAST, bool SHADOW, bool LDSS, bool L0, bool PRUNE = false, bool REFILL = false>
 __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES_PER_SIMD) wf_trace_kernel(const DParams P) {
+    static_assert(!REFILL || (SHADOW && LDSS && !FAST), "the refilling walk: the LDS-resident shadow pass");
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
     static_assert(!(FAST && PRUNE), "the fast mode prunes its own trees by its own rule");
     static_assert(!(SHADOW && L0), "the shadow pass has one form for every level");
@@ -117,6 +198,17 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_TRAV_WAVES
     // Tiles are claimed XCD by XCD (kcommon.h, claim_tile) where the scene sits in LDS and the claim itself is what waves queue on:
     // headline frame 3.39 + 3.52 -> 3.10 + 3.19 ms for the two traversal passes.  With the tables in L2 (mesh scenes) the bands
     // measured no better than one head word (config 5: 68.4 vs 69.4 ms), so those forms keep the single word.
+    if (REFILL) { // one persistent walk per wave: its lanes take hits until none is left (ShadowRefill above)
+        ShadowRefill rf(P, hs, xcc_id());
+        Best b;
+        b.ref = NO_HIT; b.t = INFINITY; b.accel = 0u;
+        Ray first = ray_new(V3{0.0, 0.0, 0.0}, V3{0.0, 0.0, 1.0});
+        const bool live = rf.next(true, b, first); // every lane asks for its first hit
+        bool tie = false;
+        traverse_ref<LDSS, false, PRUNE, false, ShadowRefill>(P, first, true, stack, stride, b, scn, tie, cnt, arec, &rf, live);
+        rf.finish(b);
+        return;
+    }
     uint32_t band = LDSS ? xcc_id() : 0u, bands_left = TILE_HEADS;
     for (bool final = false; !final;) {
         uint32_t tile;
@@ -366,7 +458,18 @@ hipError_t launch_wf_trace(const DParams &P, bool fast, bool shadow, uint32_t bl
         else { if (shadow) LG_LAUNCH_PRUNED(true, false, false); else if (l0) LG_LAUNCH_PRUNED(false, false, true); else LG_LAUNCH_PRUNED(false, false, false); }
     } else
     if (fast) { if (shadow) LG_LAUNCH(true, true, false, false); else if (l0) LG_LAUNCH(true, false, false, true); else LG_LAUNCH(true, false, false, false); }
-    else if (ldss) { if (shadow) LG_LAUNCH(false, true, true, false); else if (l0) LG_LAUNCH(false, false, true, true); else LG_LAUNCH(false, false, true, false); }
+    else if (ldss) {
+        // the refilling shadow pass (ShadowRefill): level 0 of a big launch (every wave of the grid has several tiles to go through: the final-tile
+        // rules of small launches do not apply to it).  MEASURED and OFF unless LASGUN_REFILL=1 (round 6, profiles/r06_ab_refill*): same film, but the
+        // headline's shadow pass issues 2.65e9 VALU wave-instructions instead of 1.61e9 for the same lane-cycles (8.5e10 against 8.6e10) -- lane use
+        // falls from 81 % to ~50 % and the frame goes from 7.13 to > 7.7 ms (the measured choice then takes the megakernel).  The walk's
+        // wave-uniform phases live on the lanes of a wave being at the SAME phase: 64 rays that start together through one tile stay roughly in
+        // step, lanes restarted at the root while their neighbours are deep in the tree do not, and every phase then runs for a few lanes.
+        static const bool refill_on = [] { const char *e = std::getenv("LASGUN_REFILL"); return e && e[0] == '1'; }();
+        const bool refill = refill_on && shadow && P.wf_level == 0u && (unsigned long long)P.ntiles >= 4ull * blocks * (block / 64u);
+        if (shadow) { if (refill) hipLaunchKernelGGL((wf_trace_kernel<false, true, true, false, false, true>), dim3(blocks), dim3(block), lds, stream, P); else LG_LAUNCH(false, true, true, false); }
+        else if (l0) LG_LAUNCH(false, false, true, true); else LG_LAUNCH(false, false, true, false);
+    }
     else { if (shadow) LG_LAUNCH(false, true, false, false); else if (l0) LG_LAUNCH(false, false, false, true); else LG_LAUNCH(false, false, false, false); }
 #undef LG_LAUNCH
 #undef LG_LAUNCH_PRUNED
@@ -408,7 +511,8 @@ hipError_t wf_set_lds_limit(size_t bytes, bool ldss) {
         reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, false>),
         reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, true, true>),
         reinterpret_cast<const void *>(wf_trace_kernel<false, true, true, false, true>),
-        reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, false, true>)};
+        reinterpret_cast<const void *>(wf_trace_kernel<false, false, true, false, true>),
+        reinterpret_cast<const void *>(wf_trace_kernel<false, true, true, false, false, true>)};
     const void *plain_fns[] = {
         reinterpret_cast<const void *>(wf_trace_kernel<false, false, false, true>),
         reinterpret_cast<const void *>(wf_trace_kernel<false, true, false, false>),

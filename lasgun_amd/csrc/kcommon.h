@@ -81,6 +81,29 @@ __device__ __forceinline__ uint32_t claim_tile(uint32_t *counter, uint32_t ntile
     final = __builtin_amdgcn_readfirstlane((int)fin) != 0;
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
 }
+// claim_tile for a wave only SOME of whose lanes are here (the refilling walk, walk.h: the lanes whose ray is done): the leader is the first
+// active lane -- which is also the lane readfirstlane reads -- and there are no "final" tiles (the caller runs big launches only).
+__device__ __forceinline__ uint32_t claim_tile_partial(uint32_t *counter, uint32_t ntiles, uint32_t &band, uint32_t &left) {
+    uint32_t tile = NO_TILE;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+    if ((threadIdx.x & 63u) == leader) {
+        uint32_t gone = 0u;
+        while (left != 0u) {
+            const uint32_t lo = (uint32_t)(((unsigned long long)band * ntiles) / TILE_HEADS), hi = (uint32_t)(((unsigned long long)(band + 1u) * ntiles) / TILE_HEADS);
+            if (!((gone >> band) & 1u)) {
+                const uint32_t t = atomicAdd(counter + TILE_HEAD0 + band * TILE_HEAD_STRIDE, 1u);
+                if (t < hi - lo) { tile = lo + t; break; }
+                if (t == hi - lo) atomicOr(counter + TILE_GONE, 1u << band);
+                gone = __hip_atomic_load(counter + TILE_GONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            band = (band + 1u) & (TILE_HEADS - 1u);
+            --left;
+        }
+    }
+    band = (uint32_t)__builtin_amdgcn_readfirstlane((int)band);
+    left = (uint32_t)__builtin_amdgcn_readfirstlane((int)left);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+}
 // A workgroup copies `n16` 16-byte units into its LDS: four loads in flight per lane before the first store.  (Written as the plain loop
 // `dst[i] = src[i]` hipcc waits for every load before its store: ten dependent L2 round trips for the headline scene's 155 KB image,
 // ~15 microseconds at the head of every traversal launch.)

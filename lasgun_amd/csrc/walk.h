@@ -1049,9 +1049,20 @@ __device__ __forceinline__ bool mesh_leaf2(const DParams &P, const uint4 *scn, c
 // COUNT: the counting instantiation (lg_capture_stats, lg_trace_pixel): the same walk, plus the deterministic work
 // counters and, for lg_trace_pixel, an event log -- 2.x node tested (.1 = taken), 3.x primitive tested (.1 = accepted),
 // 4 accel entered, 5 returned to the parent, 6 triangle accepted.
-template <bool LDSS, bool FAST = false, bool PRUNE = false, bool COUNT = false>
+// REFILL (round 6; the headline's shadow pass, k_wavefront.hip): the walk as a PERSISTENT one.  A lane whose ray is done does not wait for
+// the wave's slowest lane: when at least RF::threshold() lanes are done, each of them hands its result to the caller's `rf` and is given
+// its next ray (rf.next(done, ...), called by EVERY lane in wave-uniform control flow: same lane, same stack, a fresh walk), until the caller has none left.  Which lane walks which ray never
+// changes a result -- a lane's visit sequence is its ray's alone.  `live`: the lane starts with a ray (every lane of the wave enters the
+// walk, so that idle ones can be given work inside it).
+struct NoRefill {
+    static constexpr bool enabled = false;
+    __device__ __forceinline__ uint32_t threshold() const { return 65u; }
+    __device__ __forceinline__ bool next(bool, const Best &, Ray &) { return false; }
+};
+template <bool LDSS, bool FAST = false, bool PRUNE = false, bool COUNT = false, class RF = NoRefill>
 __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, const bool anyhit, uint32_t *stack, const uint32_t stride,
-                                             Best &best, const uint4 *scn, bool &tie, Counters &cnt, const uint4 *arec_in = nullptr) {
+                                             Best &best, const uint4 *scn, bool &tie, Counters &cnt, const uint4 *arec_in = nullptr,
+                                             RF *rf = nullptr, const bool live = true) {
     static_assert(!(FAST && LDSS), "the LDS-resident scene holds the reference tree only");
     const uint4 *const arec = LDSS ? scn + P.lds_accel_off : (FAST ? nullptr : arec_in); // the accel records in LDS, if they are there (lvl_set)
     static_assert(!(FAST && PRUNE), "the fast mode prunes its own trees by its own rule");
@@ -1076,7 +1087,7 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
     double four_a = 4.0 * dd;           // 4.0 * a of its discriminant b*b - 4.0*a*c (core/math.rs:16: (4.0 * a) * c)
     uint32_t negmask = neg_mask_x(ray); // dir_is_neg (bvh.rs:463), + SIGNS_NOT_PLAIN
     uint32_t sp = 0, base = 0, cur = L.node_base, li = 0, le = 0, enter = 0, lcb = 0;
-    uint32_t state = ST_NODE;
+    uint32_t state = (RF::enabled && !live) ? ST_DONE : ST_NODE;
     // ---- PRUNE: per-axis limits of the level the lane is in, and the level's margin
     V3 plim{INFINITY, INFINITY, INFINITY};
     double peps = INFINITY;
@@ -1416,6 +1427,26 @@ __device__ __forceinline__ void traverse_ref(const DParams &P, const Ray &wray, 
 #ifdef LG_STAMPS
         stamp_acc[6] += 1;
 #endif
+        if (RF::enabled) { // (a wave-uniform decision, and EVERY lane calls rf.next -- it keeps wave-wide state, which only uniform control flow can keep in step; the lanes that are done say so)
+            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(state == ST_DONE)) >= rf->threshold()) {
+                {
+                    Ray nw = wray;
+                    if (rf->next(state == ST_DONE, best, nw)) { // a fresh walk for this lane: everything the head of this function set up
+                        best.t = INFINITY; best.ref = NO_HIT; best.accel = 0;
+                        lvl_set<LDSS, FAST>(P, arec, L, 0u);
+                        root = nw;
+                        if (!((L.flags & AF_IDENTITY) && ray_plain(nw))) root = accel_local_ray<LDSS>(P, arec, 0u, nw);
+                        ray = root;
+                        dd = dot(ray.d, ray.d);
+                        four_a = 4.0 * dd;
+                        negmask = neg_mask_x(ray);
+                        sp = 0; base = 0; cur = L.node_base; li = 0; le = 0; enter = 0; lcb = 0;
+                        state = ST_NODE;
+                        if (PRUNE) prune_level();
+                    }
+                }
+            }
+        }
         if (!wave_any(state != ST_DONE)) break;
     }
 #ifdef LG_STAMPS

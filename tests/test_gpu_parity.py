@@ -493,6 +493,54 @@ def test_many_lights(nlights, w, h):
         assert np.array_equal(film.pixels(), ofilm.pixels()), streaming
 
 
+REFILL_CHILD = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import lasgun_amd as la
+from oracle_lib import oracle
+G, S = la.api, la.scenes
+def build(api, scene):
+    if scene == "spheres_3_lights":
+        sc = S.spheres_scene(api, 600)
+        for i in range(2):
+            sc.add_point_light([-1.5 + 3.0 * i, 1.5, 1.0 - 0.05 * i], [0.05, 0.04, 0.06], [1.0, 0.0, 0.05])
+        return sc
+    return S.readme_scene(api) if scene == "readme_sparse" else S.cornell_scene(api, "glass")
+w = h = 1024
+for scene in ("spheres_3_lights", "readme_sparse", "cornell_glass"):
+    acc = G.Accel(build(G, scene))
+    films = {}
+    for streaming in (0, 2):
+        G.set_streaming(acc, streaming)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        films[streaming] = film.pixels().copy()
+    assert np.array_equal(films[0], films[2]), scene
+    o = oracle()
+    n = 97
+    ofilm = o.Film(w, h)
+    o.capture_subset_mt(0, n, o.Accel(build(o, scene)), ofilm, 16)
+    assert np.array_equal(films[2].reshape(-1, 4)[::n], ofilm.pixels().reshape(-1, 4)[::n]), scene
+print("refill ok")
+"""
+
+
+def test_refilling_shadow_pass_is_the_same_film():
+    """The opt-in experiment of round 6 (LASGUN_REFILL=1; measured slower, k_wavefront.hip: launch_wf_trace): level by level, a level-0 shadow
+    pass of >= 4 tiles per wave over an LDS-resident scene as ONE persistent walk per wave whose lanes take the next hit as soon as their own
+    shadow ray is done (ShadowRefill; walk.h: REFILL).  1024^2 is the smallest film that takes that path: several lights per hit (the next
+    light's ray without a new claim), a film whose hits are sparse (appended part of the hit queue, holes), a recursive scene (only level 0
+    refills).  Same bytes as the megakernel -- which has no such pass -- and as the oracle on a strided sample; in a child process, because the
+    switch is read once.  Reference: src/light/point.rs:42-54 (one shadow ray per hit and light; `isect.t < 1.0`)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LASGUN_REFILL="1")
+    p = subprocess.run([sys.executable, "-c", REFILL_CHILD % (root, os.path.join(root, "tests"))], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "refill ok" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
+
+
 @pytest.mark.parametrize("w, h", [(4096, 1), (1, 777), (3, 3), (8192, 2)])
 def test_extreme_film_shapes(w, h):
     o = oracle()
