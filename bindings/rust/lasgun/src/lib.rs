@@ -247,7 +247,7 @@ impl<'s> Drop for Accel<'s> {
     fn drop(&mut self) { unsafe { sys::lg_accel_free(self.ptr) } }
 }
 // The reference shares `&Accel` between its capture threads (lib.rs:67-103).  The C side guards every entry point that takes
-// an accel with that accel's own mutex (capi.cpp), so the handle may be used and dropped from any thread.
+// an accel with that accel's own mutex (internal.h: lg_accel), so the handle may be used and dropped from any thread.
 unsafe impl<'s> Send for Accel<'s> {}
 unsafe impl<'s> Sync for Accel<'s> {}
 

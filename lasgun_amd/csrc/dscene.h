@@ -304,7 +304,7 @@ struct DParams {
     // of every level >= 1: how many of its rays have been written
     uint32_t *q_ctl;
     uint32_t *q_ready;
-    uint32_t *q_err; // sticky error word in pinned HOST memory (capi.cpp, g_err_words): set by a wave that gave up waiting, cleared by the host alone
+    uint32_t *q_err; // sticky error word in pinned HOST memory (devmem.cpp, g_err_words): set by a wave that gave up waiting, cleared by the host alone
     uint32_t q_units, q_unit_tiles; // level 0's work items: units of q_unit_tiles consecutive 8x8 tiles of the tile SEQUENCE
     // the tile sequence: q_order 0 = the tiles in row order (any addressing mode); 1 (rectangles) = blocks of 32 x 32 tiles in row
     // order, Morton order inside a block, the sequence cut into 8 contiguous bands claimed XCD by XCD (k_queue.hip, q_seq_tile)

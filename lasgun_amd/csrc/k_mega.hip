@@ -314,9 +314,9 @@ __global__ void trace_pixel_kernel(const DParams P, uint32_t x, uint32_t y, doub
     out[4 + 2 * P.nlights] = sh.p.x; out[5 + 2 * P.nlights] = sh.p.y; out[6 + 2 * P.nlights] = sh.p.z; // origin of the shadow rays
 }
 
-// ---- host-callable launchers (used by capi.cpp)
+// ---- host-callable launchers (used by launch.cpp, capi.cpp)
 // ------------------------------------------------------------------------------------------
-// host-callable launchers (used by capi.cpp)
+// host-callable launchers (used by launch.cpp, capi.cpp)
 // ------------------------------------------------------------------------------------------
 hipError_t launch_trace(const DParams &P, bool stats, bool fast, uint32_t blocks, uint32_t stack_depth, hipStream_t stream) {
     const bool prune = P.prune && !fast;

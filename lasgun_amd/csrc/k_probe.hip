@@ -105,7 +105,7 @@ hipError_t launch_probe_lds(uint32_t blocks, uint32_t iters, uint32_t *sink, hip
 }
 
 
-// ---- host-callable launchers (used by capi.cpp)
+// ---- host-callable launchers (used by launch.cpp, capi.cpp)
 hipError_t launch_kat(int kind, const double *params, const float *vpos, const uint32_t *tri_v, uint32_t ntri, V3 o, V3 d, double *out,
                       hipStream_t stream) {
     hipLaunchKernelGGL(kat_kernel, dim3(1), dim3(64), 0, stream, kind, params, vpos, tri_v, ntri, o, d, out);

@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(LDSS ? LG_LDSS_BLOCK : LG_BLOCK, LG_WAVES_PER_
     }
 }
 
-// ---- host-callable launchers (used by capi.cpp)
+// ---- host-callable launchers (used by launch.cpp, capi.cpp)
 hipError_t launch_queue(const DParams &P, uint32_t blocks, hipStream_t stream) {
     if (P.lds_image) { // LDS-resident scene: `blocks` = one 1024-lane workgroup per CU
         const size_t lds = (size_t)P.stack_depth * LG_LDSS_BLOCK * sizeof(uint32_t) + (size_t)P.lds_image_n16 * 16u;

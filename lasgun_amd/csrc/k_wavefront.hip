@@ -23,7 +23,7 @@ namespace lg {
 // integrate.rs:79 / 103 / 129; the level-0 pass quantises (Img::set).  Every f64 is produced by the same expression
 // as in the megakernel; what differs is where the intermediate values wait (HBM, SoA by ray index of the level).
 // Queue capacities are worst case (level d: 2^d rays per pixel of the chunk), so nothing can overflow; the host
-// sizes the chunk of the film to its memory budget (capi.cpp).
+// sizes the chunk of the film to its memory budget (launch.cpp).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) { // number of set bits of `mask` below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(LG_BLOCK) wf_resolve_kernel(const DParams P) {
     }
 }
 
-// ---- host-callable launchers (used by capi.cpp)
+// ---- host-callable launchers (used by launch.cpp, capi.cpp)
 hipError_t launch_wf_resolve(const DParams &P, uint32_t blocks, hipStream_t stream) {
     hipLaunchKernelGGL(wf_resolve_kernel, dim3(blocks), dim3(LG_BLOCK), 0, stream, P);
     return hipGetLastError();

@@ -1,7 +1,7 @@
 // lasgun_amd/csrc/tune.h -- the measured choice of a launch's organisation, as a unit of its own: the table of
 // remembered choices, the race that fills it, and its export / import (lg_tune_export / lg_tune_import, include/lasgun_hip.h).
 //
-// The tuner knows nothing about scenes or kernels: a KIND of launch is twelve words the caller makes (capi.cpp: tune_key), a CANDIDATE
+// The tuner knows nothing about scenes or kernels: a KIND of launch is twelve words the caller makes (launch.cpp: tune_key), a CANDIDATE
 // an integer the caller can decode, and a candidate is run by a callback.  Every organisation renders the same bytes (the parity tests
 // hold them to that), so what is chosen here never changes a pixel -- only when it arrives.
 #pragma once

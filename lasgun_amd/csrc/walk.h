@@ -280,7 +280,12 @@ __device__ __forceinline__ void isect_set(Isect &i, double t, V3 dpdu, V3 dpdv) 
 }
 
 // Sphere::intersect (sphere.rs:79-123), for an accepted t
-__device__ __forceinline__ void sphere_full(const DSphere &s, const Ray &ray, double t, bool inside, Isect &is) {
+#ifdef LG_SPHERE_FULL_NOINLINE // (A/B: the four trig evaluations as a function call instead of inline code in every kernel that resolves a hit)
+#define LG_SPHERE_FULL_ATTR static __device__ __noinline__
+#else
+#define LG_SPHERE_FULL_ATTR __device__ __forceinline__
+#endif
+LG_SPHERE_FULL_ATTR void sphere_full(const DSphere &s, const Ray &ray, double t, bool inside, Isect &is) {
     V3 cen{s.cx, s.cy, s.cz};
     V3 p = ray.o + ray.d * t - cen;
     if (p.x == 0.0 && p.y == 0.0) p.x = 1e-5 * s.r;
@@ -289,8 +294,20 @@ __device__ __forceinline__ void sphere_full(const DSphere &s, const Ray &ray, do
     double theta = p_acos(fmin_(fmax_(p.z / s.r, -1.0), 1.0));
     V3 dpdu{-2.0 * PI * p.y, 2.0 * PI * p.x, 0.0};
     double sin_phi, cos_phi;
+#ifdef LG_TRIG_SHARED // (A/B: ONE inlined instance of the double-double sincos for phi and theta -- a two-trip loop -- instead of two)
+    double sin_theta = 0.0;
+    sin_phi = 0.0; cos_phi = 0.0;
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < 2; ++i) {
+        double sn, cs;
+        p_sincos(i == 0 ? phi : theta, sn, cs);
+        if (i == 0) { sin_phi = sn; cos_phi = cs; } else sin_theta = sn;
+    }
+    V3 dpdv = PI * V3{p.z * cos_phi, p.z * sin_phi, -s.r * sin_theta};
+#else
     p_sincos(phi, sin_phi, cos_phi);
     V3 dpdv = PI * V3{p.z * cos_phi, p.z * sin_phi, -s.r * p_sin(theta)};
+#endif
     if (inside) isect_set(is, t, dpdu, dpdv);
     else isect_set(is, t, dpdv, dpdu);
 }
@@ -589,7 +606,7 @@ struct Lvl { // the accel level a lane is walking
 };
 // Node cursor of the second formulation.  Global tables: the node's index in P.nodes (64-byte DNode records).
 // LDS image: the node's BYTE offset in the image -- every record of the image carries "walk words" made by the host
-// (capi.cpp, the image builder): an interior node its second child's cursor and 1 << axis, a leaf its first slot, NODE_LEAF
+// (accel.cpp, the image builder): an interior node its second child's cursor and 1 << axis, a leaf its first slot, NODE_LEAF
 // and its last slot + 1 -- so a step forms the record's address with one add, never multiplies or shifts, and takes a
 // leaf's slot range as it is.
 constexpr uint32_t LDS_NODE_BYTES = LDS_NODE_STRIDE * 16u;

@@ -769,7 +769,7 @@ def test_capture_subsets_in_every_organisation():
 
 def test_the_default_organisation_is_measured_once_per_kind_and_changes_no_byte():
     """lg_accel_set_streaming(1), the default: the first launch of a kind takes the fitted rule's choice (a program that renders one frame
-    pays nothing), the SECOND renders with every organisation that can take it and keeps the fastest for the process (capi.cpp,
+    pays nothing), the SECOND renders with every organisation that can take it and keeps the fastest for the process (launch.cpp + tune.cpp,
     tuned_choice; LASGUN_AUTOTUNE=2: already the first); later launches -- of another accel of the same scene too -- only enqueue.  The film
     is the oracle's whichever organisation runs, and a forced organisation is reported as such."""
     w, h = 200, 136

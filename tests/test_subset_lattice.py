@@ -1,4 +1,4 @@
-"""The lattice addressing of strided subsets (lasgun_amd/csrc/shade.h, pixel_of modes 4 and 5; capi.cpp, set_subset / set_subsets), restated
+"""The lattice addressing of strided subsets (lasgun_amd/csrc/shade.h, pixel_of modes 4 and 5; launch.cpp, set_subset / set_subsets), restated
 in Python and checked as arithmetic: every (tile, lane) pair that the formula marks active is a pixel of the subset, every pixel of the
 subset is reached exactly once, and the compact output index is the pixel's place in the subset.  The device code itself is compared with
 the frame's bytes in tests/test_gpu_parity.py (test_strided_subsets_tile_by_lattice_column); this file is about the formula.
@@ -10,7 +10,7 @@ import pytest
 
 
 def rows(w, h, n):
-    """the host's table (capi.cpp, lattice_rows): floor(y*w / n) and (y*w) mod n per film row"""
+    """the host's table (launch.cpp, lattice_rows): floor(y*w / n) and (y*w) mod n per film row"""
     return [divmod(y * w, n) for y in range(h)]
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Host side (scene description, OBJ reader, HLBVH builder, flattening, C ABI) under AddressSanitizer + UBSan on the CPU:
-# builds lasgun_amd/csrc/{host,capi,tune,multi}.cpp with -fsanitize=address,undefined, links them with the device object, and
+# builds lasgun_amd/csrc/{host,capi,launch,accel,devmem,tune,multi}.cpp with -fsanitize=address,undefined, links them with the device object, and
 # runs tests/test_host.py plus the flattening of 600 random / adversarial scenes (reference trees, and fast trees with their wide records) and the
 # full-size configs through it.
 # (GPU sanitizers are not available on the pool; the kernels are covered by the parity suite and the fuzz campaign.)
@@ -9,10 +9,10 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 b=/tmp/lg_asan; mkdir -p "$b"
 src=$root/lasgun_amd/csrc
 [ -f "$src/k_mega.o" ] || make -C "$src" >/dev/null
-for f in host capi tune multi; do
+for f in host capi launch accel devmem tune multi; do
   g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$src/$f.cpp" -o "$b/$f.o" &
 done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$b/liblasgun_hip_asan.so" "$b/host.o" "$b/capi.o" "$b/tune.o" "$b/multi.o" "$src/k_mega.o" "$src/k_wavefront.o" "$src/k_queue.o" "$src/k_probe.o" -ldl -fsanitize=address,undefined 2>&1 | grep -v hip-link || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$b/liblasgun_hip_asan.so" "$b/host.o" "$b/capi.o" "$b/launch.o" "$b/accel.o" "$b/devmem.o" "$b/tune.o" "$b/multi.o" "$src/k_mega.o" "$src/k_wavefront.o" "$src/k_queue.o" "$src/k_probe.o" -ldl -fsanitize=address,undefined 2>&1 | grep -v hip-link || true
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LASGUN_HIP_LIB="$b/liblasgun_hip_asan.so"
 cd "$root"

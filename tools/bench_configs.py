@@ -104,7 +104,7 @@ UNFITTED = [
 
 
 def org_choice(only):
-    """What the default picks (measured on the launch's first use, capi.cpp: tuned_org) against every organisation forced, one frame at a time."""
+    """What the default picks (measured on the launch's first use, launch.cpp: tuned_choice) against every organisation forced, one frame at a time."""
     def timed(acc, film, size, stream, reps=3):
         G.capture_rows_device(acc, size, size, 0, size, film.data_ptr(), row0=0, stream=stream)
         torch.cuda.synchronize()

@@ -2,7 +2,7 @@ import os
 #!/usr/bin/env python3
 """Frame time against film size, per kernel organisation, on the small scenes (python tools/size_sweep.py readme|plastic|glass|spheres|simple1|simple2
 [sizes]): where a launch's fixed cost -- claims, cold code, one wave's latency -- and where its throughput sets the time.  Round 4's default rules
-(capi.cpp, enqueue) come from these tables."""
+(launch.cpp, enqueue) come from these tables."""
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
