@@ -210,6 +210,14 @@ typedef struct lg_prune_audit {
                                    * shipped margin that property (P) actually needed on this scene (1 would be the edge of a violation) */
 } lg_prune_audit;
 int lg_audit_prune(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, lg_prune_audit *out);
+/* The same for the opt-in FAST mode (lg_accel_set_mode(1)), end to end: every ray of rows [y0, y1) -- primary, shadow and secondary, as the
+ * render generates them -- is traced by the fast walk as shipped (its trees, its pruning, its candidate check and tie fallback) AND by the
+ * reference walk, and the answers are compared on the device: the same primitive in the same accel at the same t, bit for bit, for a
+ * closest-hit ray; the same `t < 1` verdict for a shadow ray (point.rs:49).  `violations` must be 0 for the film to be the reference's;
+ * `fallbacks` counts the rays the fast walk itself sent to the reference walk (exact ties, winners the reference tree would not have tested).
+ * Fast mode's margins are argued, not derived: this is its measurement, frame by frame.  The accel must be in fast mode. */
+typedef struct lg_fast_audit { uint64_t rays, fallbacks, violations; } lg_fast_audit;
+int lg_audit_fast(const lg_accel *, uint32_t width, uint32_t height, uint32_t y0, uint32_t y1, lg_fast_audit *out);
 
 /* Traversal mode of an accel.  0 (default) = the reference's own traversal over the reference's
  * own BVH: the parity path.  1 = opt-in FAST mode: a binned-SAH BVH (one primitive per leaf)

@@ -52,6 +52,7 @@ _EXTRA = {
     "capture_pixels": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_void_p, _C.c_size_t, _C.c_void_p, _C.c_void_p]),
     "capture_rect": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_void_p, _C.c_void_p]),
     "audit_prune": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
+    "audit_fast": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_void_p]),
     "capture_stats": (_C.c_int, [_C.c_void_p, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.c_uint32, _C.POINTER(CStats)]),
     "profile_enable": (None, [_C.c_void_p, _C.c_int]),
     "profile_read_kinds": (_C.c_int, [_C.c_void_p, _C.c_double * 5, _C.c_uint64 * 5]),
@@ -272,6 +273,16 @@ class HipApi(Api):
         if self.call("audit_prune", accel.h, w, h, y0, h if y1 is None else y1, _C.byref(r)):
             raise LasgunError(self.last_error())
         return {k: getattr(r, k) for k, _ in _A._fields_}
+
+    def audit_fast(self, accel, w, h, y0=0, y1=None):
+        """Audit of the opt-in FAST mode on rows [y0, y1) (lg_audit_fast): every ray also walked the reference's way on the device;
+        {"rays", "fallbacks", "violations"} -- `violations` (rays whose answer is not the reference's) must be 0."""
+        class _A(_C.Structure):
+            _fields_ = [("rays", _C.c_uint64), ("fallbacks", _C.c_uint64), ("violations", _C.c_uint64)]
+        r = _A()
+        if self.call("audit_fast", accel.h, w, h, y0, h if y1 is None else y1, _C.byref(r)):
+            raise LasgunError(self.last_error())
+        return {k: int(getattr(r, k)) for k, _ in _A._fields_}
 
     def capture_stats_kind(self, accel, w, h, kind, y0=0, y1=None):
         """Work counters of one kind of traversal: 1 = closest-hit (primary/secondary), 2 = shadow."""

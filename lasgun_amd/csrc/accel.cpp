@@ -78,7 +78,9 @@ static void build_and_upload(lg_accel *a, bool with_fast) {
                 }
                 if (longest > 0.0 && std::isfinite(longest)) min_edge = std::fmin(min_edge, longest);
             }
-            if (std::isfinite(min_edge) && max_abs > min_edge * 0x1p20) {
+            // (LASGUN_FAST_NO_GATE=1: measurement only -- lg_audit_fast on exactly the meshes the gate refuses, tools/fast_adversarial.py)
+            static const bool no_gate = [] { const char *e = std::getenv("LASGUN_FAST_NO_GATE"); return e && e[0] == '1'; }();
+            if (!no_gate && std::isfinite(min_edge) && max_abs > min_edge * 0x1p20) {
                 a->fast_available = false;
                 a->fast_refusal = "fast mode unavailable: a mesh whose coordinates exceed 2^20 times its smallest triangle (a ray in a far triangle's plane is accepted by the reference wherever it passes)";
             }

@@ -632,6 +632,24 @@ int lg_audit_prune(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint3
         *out = lg_prune_audit{s.audit_nodes, s.audit_runs, s.audit_prims, s.audit_violations, slack(s.audit_slack_nodes), slack(s.audit_slack_runs), used};
     });
 }
+int lg_audit_fast(const lg_accel *a, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, lg_fast_audit *out) {
+    return guarded([&] {
+        if (y1 > h || y0 > y1) throw Error("bad row range");
+        if (!out) throw Error("out is NULL");
+        std::lock_guard<std::mutex> g(a->mtx);
+        if (!a->fast) throw Error("the audit is of the FAST walk: select it with lg_accel_set_mode(accel, 1) first");
+        use_device(a->device);
+        DParams P = base_params(*a, w, h);
+        set_rect(P, 0, y0, w, y1);
+        P.out_row0 = y0;
+        P.audit = std::getenv("LASGUN_AUDIT_SABOTAGE") ? 2u : 1u; // (2: the counting fast walk prunes by half its limit on purpose -- the audit's self-test)
+        enqueue(*a, P, true, a->stream); // the counting instantiation of the megakernel, fast mode: every ray also walked the reference's way
+        DStats s;
+        HIP_TRY(hipMemcpyAsync(&s, a->stats.p, sizeof s, hipMemcpyDeviceToHost, a->stream));
+        sync_checked(*a);
+        *out = lg_fast_audit{s.audit_prims, s.audit_runs, s.audit_violations};
+    });
+}
 int lg_accel_set_lds_scene(const lg_accel *a, int enabled) {
     std::lock_guard<std::mutex> lk(a->mtx);
     a->lds_scene = enabled != 0;

@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(LDSS ? LB : LG_BLOCK, (LDSS && LB == LG_MEGA_N
                 {
                     Counters before = cnt;
                     walk<LDSS, FAST, PRUNE, STATS>(P, tray, shadow_job, stack, stride, b, scn, cnt, arec);
+                    if (STATS && FAST && P.audit) audit_fast_ray(P, tray, shadow_job, stack, stride, b, cnt, arec); // lg_audit_fast
                     if (STATS && P.stats_filter != 0u && (P.stats_filter == 2u) != shadow_job) { // not the kind being counted
                         cnt.nodes = before.nodes; cnt.spheres = before.spheres; cnt.cuboids = before.cuboids;
                         cnt.triangles = before.triangles; cnt.entries = before.entries;

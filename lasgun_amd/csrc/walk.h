@@ -280,12 +280,8 @@ __device__ __forceinline__ void isect_set(Isect &i, double t, V3 dpdu, V3 dpdv) 
 }
 
 // Sphere::intersect (sphere.rs:79-123), for an accepted t
-#ifdef LG_SPHERE_FULL_NOINLINE // (A/B: the four trig evaluations as a function call instead of inline code in every kernel that resolves a hit)
-#define LG_SPHERE_FULL_ATTR static __device__ __noinline__
-#else
-#define LG_SPHERE_FULL_ATTR __device__ __forceinline__
-#endif
-LG_SPHERE_FULL_ATTR void sphere_full(const DSphere &s, const Ray &ray, double t, bool inside, Isect &is) {
+// (as a function call instead of inline code -- measured in round 6 -- every kernel loses 10-25 %: the call's register convention spills the walk's state)
+__device__ __forceinline__ void sphere_full(const DSphere &s, const Ray &ray, double t, bool inside, Isect &is) {
     V3 cen{s.cx, s.cy, s.cz};
     V3 p = ray.o + ray.d * t - cen;
     if (p.x == 0.0 && p.y == 0.0) p.x = 1e-5 * s.r;
@@ -294,7 +290,10 @@ LG_SPHERE_FULL_ATTR void sphere_full(const DSphere &s, const Ray &ray, double t,
     double theta = p_acos(fmin_(fmax_(p.z / s.r, -1.0), 1.0));
     V3 dpdu{-2.0 * PI * p.y, 2.0 * PI * p.x, 0.0};
     double sin_phi, cos_phi;
-#ifdef LG_TRIG_SHARED // (A/B: ONE inlined instance of the double-double sincos for phi and theta -- a two-trip loop -- instead of two)
+    // ONE inlined instance of the double-double sincos for phi and theta -- a two-trip loop -- instead of two (p_sin(theta) is the sine that
+    // p_sincos(theta) returns: one function).  Measured, variants in turn (profiles/r06_ab_trig_shared.jsonl): the megakernel of the mesh configs
+    // compiles better around one instance -- config 4 33.58 -> 33.30 ms, 4m 13.22 -> 12.47 (the old 3-ulp algorithm: 33.11 / 12.59) -- at
+    // +1.5 % on simple.rs 9 spp and nothing on the headline.
     double sin_theta = 0.0;
     sin_phi = 0.0; cos_phi = 0.0;
 #pragma clang loop unroll(disable)
@@ -304,10 +303,6 @@ LG_SPHERE_FULL_ATTR void sphere_full(const DSphere &s, const Ray &ray, double t,
         if (i == 0) { sin_phi = sn; cos_phi = cs; } else sin_theta = sn;
     }
     V3 dpdv = PI * V3{p.z * cos_phi, p.z * sin_phi, -s.r * sin_theta};
-#else
-    p_sincos(phi, sin_phi, cos_phi);
-    V3 dpdv = PI * V3{p.z * cos_phi, p.z * sin_phi, -s.r * p_sin(theta)};
-#endif
     if (inside) isect_set(is, t, dpdu, dpdv);
     else isect_set(is, t, dpdv, dpdu);
 }
@@ -1560,7 +1555,9 @@ __device__ __forceinline__ void traverse_fast(const DParams &P, const Ray &wray,
                     hit[k] = slab_intersects_nc_t(mn, mx, ray, tn[k], tf);
                     // (a primitive's computed t can undershoot its box's tnear by the error of its own formula: for a sphere the
                     // quadratic's cancellation, ~sqrt(eps) of the distance to its centre, which lies inside the box)
-                    hit[k] = hit[k] && !(tn[k] - 4e-8 * fabs(tf) > limit) && link[k] != NO_HIT;
+                    // (audit == 2, counting instantiations only: lg_audit_fast's own test -- a deliberately UNSOUND limit, half the real one, so that
+                    // hits the reference finds are skipped and the audit must report them)
+                    hit[k] = hit[k] && !(tn[k] - 4e-8 * fabs(tf) > ((COUNT && P.audit == 2u) ? 0.5 * limit : limit)) && link[k] != NO_HIT;
                 }
                 // the nearest hit child is taken, the others are pushed in record order
                 int near = -1;
@@ -1747,7 +1744,22 @@ __device__ __forceinline__ void walk(const DParams &P, const Ray &ray, const boo
         if (!redo && best.ref != NO_HIT) redo = !ref_candidate(P, ray, best);
 #endif
     }
+    if (COUNT && redo) cnt.a_runs++; // (lg_audit_fast: rays the fast walk itself hands to the reference walk -- an exact tie, a winner the reference tree would not have tested)
     if (redo) traverse_ref<false, false, false, COUNT>(P, ray, anyhit, stack, stride, best, nullptr, tie, cnt, arec);
+}
+// lg_audit_fast (counting instantiations in fast mode, DParams::audit): the ray once more with the reference walk, and whether fast mode's
+// answer is the reference's -- the same primitive in the same accel at the same t (bit for bit) for a closest-hit ray, the same verdict
+// `isect.t < 1.0` for a shadow ray (point.rs:49: which occluder is found first does not matter).
+__device__ __forceinline__ void audit_fast_ray(const DParams &P, const Ray &ray, const bool anyhit, uint32_t *stack, const uint32_t stride, const Best &got,
+                                               Counters &cnt, const uint4 *arec) {
+    Best want;
+    bool tie = false;
+    Counters unused = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    traverse_ref<false, false, false, false>(P, ray, anyhit, stack, stride, want, nullptr, tie, unused, arec);
+    cnt.a_prims++;
+    const bool same = anyhit ? ((got.t < 1.0) == (want.t < 1.0))
+                             : (got.ref == want.ref && (got.ref == NO_HIT || (got.accel == want.accel && __double_as_longlong(got.t) == __double_as_longlong(want.t))));
+    if (!same) cnt.a_viol++;
 }
 
 // ------------------------------------------------------------------------------------------

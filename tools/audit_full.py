@@ -60,6 +60,18 @@ def main():
         print(json.dumps(rec), flush=True)
         if tot["violations"]:
             sys.exit(5)
+        # the same film through lg_audit_fast: every ray of every row traced by the opt-in fast walk as shipped AND by the reference walk
+        G.set_mode(acc, True)
+        ft = {"rays": 0, "fallbacks": 0, "violations": 0}
+        t0 = time.time()
+        for y0 in range(0, size, args.band):
+            r = G.audit_fast(acc, size, size, y0, min(size, y0 + args.band))
+            for k in ft:
+                ft[k] += r[k]
+        rec = dict(ft, audit="fast", scene=name, film=[size, size], full_frame=True, seconds=round(time.time() - t0, 1), device_source_sha16=la.device_source_sha16())
+        with open(args.out, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":

@@ -57,4 +57,6 @@ timeout -k 10 300 python3 tools/tail_probe.py "3 sph" "4 mesh" "4m" "5 mixed" > 
 LASGUN_DEBUG_TIMES=1 timeout -k 10 200 python3 tools/build_times.py > "$O/build_times.log" 2>&1
 (LASGUN_AUTOTUNE=0 timeout -k 10 600 python3 tools/ss_probe.py 256 512 1024; LASGUN_AUTOTUNE=0 timeout -k 10 300 python3 tools/bench_configs.py) > "$O/rule_first_launch.jsonl" 2>/dev/null
 LASGUN_AUDIT_SEEDS=100:300 LASGUN_AUDIT_LOG="$O/prune_audit.jsonl" timeout -k 10 600 python3 -m pytest tests/test_gpu_prune_audit.py -m gpu -x -q > "$O/audit.log" 2>&1; tail -2 "$O/audit.log"
+# every row of configs 4 / 4m / 5: the pruned walk's audit (lg_audit_prune) -- and fast mode's (lg_audit_fast) on the same films
+timeout -k 10 900 python3 tools/audit_full.py --out "$O/prune_audit_full.jsonl" > "$O/prune_audit_full.log" 2>&1; echo "full audit rc=$?"
 ls "$O" | wc -l

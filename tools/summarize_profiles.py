@@ -100,7 +100,7 @@ import shutil
 for name in ("bench.json", "configs_parity.jsonl", "configs_fast.jsonl", "configs_megakernel.jsonl", "configs_wavefront.jsonl", "configs_queue.jsonl",
              "configs_unpruned.jsonl", "configs_pruned.jsonl", "share_time.jsonl", "multi_2x_same_device.json", "multi_2x_same_device_rccl.json",
              "config4_pmc.txt", "config5_pmc.txt", "progressive.jsonl", "org_choice.jsonl", "host_capture.json", "host_capture_one_band.json",
-             "queue_levels.jsonl", "prune_audit.jsonl", "ss_par.jsonl", "tail_probe.jsonl", "host_capture_examples.jsonl", "build_times.log", "rule_first_launch.jsonl"):
+             "queue_levels.jsonl", "prune_audit.jsonl", "prune_audit_full.jsonl", "ss_par.jsonl", "tail_probe.jsonl", "host_capture_examples.jsonl", "build_times.log", "rule_first_launch.jsonl"):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         shutil.copyfile(f, os.path.join(dst, tag + "_" + name))
