@@ -431,7 +431,7 @@ def device_source_sha16():
     src = _os.path.join(_HERE, "csrc")
     h = hashlib.sha256()
     for path in sorted(glob.glob(_os.path.join(src, "*.h")) + glob.glob(_os.path.join(src, "k_*.hip"))):
-        if _os.path.basename(path) in ("host.h",):
+        if _os.path.basename(path) in ("host.h", "internal.h", "tune.h"):  # host-side headers: no kernel is compiled from them
             continue
         h.update(_os.path.basename(path).encode() + b"\0")
         h.update(open(path, "rb").read())

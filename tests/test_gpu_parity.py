@@ -800,6 +800,39 @@ def test_the_default_organisation_is_measured_once_per_kind_and_changes_no_byte(
         G.set_tile_order(acc, 3)
 
 
+def test_the_table_of_measured_choices_can_be_exported_pinned_and_cleared():
+    """lg_tune_export / lg_tune_import / lg_tune_clear (round 6): a measured kind shows up in the export; after a clear nothing is known;
+    an imported entry PINS the kind -- the next launch runs what the entry says, without a measurement, and renders the same bytes; an entry
+    that holds no organisation is refused."""
+    w, h = 192, 144
+    o = oracle()
+    build = lambda api: S.spheres_scene(api, 300, seed=11)
+    want = o.render(build(o), (w, h)).pixels()
+    G.tune_clear()
+    assert G.tune_export() == []
+    acc = G.Accel(build(G))
+    for _ in range(3):  # (measured at the kind's first or second call, LASGUN_AUTOTUNE=2 or 1)
+        film = G.Film(w, h)
+        G.capture_subset(0, 1, acc, film)
+        assert np.array_equal(film.pixels(), want)
+    table = G.tune_export()
+    assert len(table) >= 1 and all(len(k) == 12 and 0 <= c < 256 for k, c in table)
+    measured = G.last_organisation(acc)
+    # pin every known kind to another organisation (the megakernel top-down = 0, or level by level = 1 if the megakernel was what ran)
+    other = 1 if measured.startswith("megakernel") else 0
+    G.tune_clear()
+    assert G.tune_export() == []
+    G.tune_import([(k, other) for k, _ in table])
+    assert sorted(G.tune_export()) == sorted((k, other) for k, _ in table)
+    film = G.Film(w, h)
+    G.capture_subset(0, 1, acc, film)
+    assert np.array_equal(film.pixels(), want)
+    assert G.last_organisation(acc).split(",")[0] == ("wavefront" if other == 1 else "megakernel"), (measured, G.last_organisation(acc))
+    with pytest.raises(la.LasgunError):
+        G.tune_import([(table[0][0], 7)])  # (organisations are 0 .. 2)
+    G.tune_clear()
+
+
 def test_capture_rebuilds_and_render_matches():
     w, h = 64, 48
     scene = S.simple_scene(G, 1)
