@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <vector>
 #include <utility>
 
@@ -178,6 +179,16 @@ inline void capture_subset(size_t k, size_t n, const Accel &root, Film &film) { 
 inline void capture_subsets(const std::vector<size_t> &ks, size_t n, const Accel &root, Film &film) {
     if (lg_capture_subsets(ks.data(), ks.size(), n, root.handle(), film.handle())) throw Error(lg_last_error());
 }
+// the table of measured kernel-organisation choices (lasgun_hip.h, lg_tune_*): export it once, import it at start-up, and no launch of a known kind is measured again
+inline std::vector<lg_tune_entry> tune_export() {
+    std::vector<lg_tune_entry> v(lg_tune_export(nullptr, 0));
+    v.resize(std::min(v.size(), lg_tune_export(v.data(), v.size())));
+    return v;
+}
+inline void tune_import(const std::vector<lg_tune_entry> &entries) {
+    if (lg_tune_import(entries.data(), entries.size())) throw Error(lg_last_error());
+}
+inline void tune_clear() { lg_tune_clear(); }
 inline Film render(const Scene &scene, std::pair<uint32_t, uint32_t> resolution) { // lib.rs:46
     lg_film *f = lg_render(scene.handle(), resolution.first, resolution.second);
     if (!f) throw Error(lg_last_error());

@@ -67,3 +67,21 @@ def test_bench_gpus_n_starts_its_own_ranks():
         return
     assert p.returncode != 0 and "launch with" not in p.stderr
     assert "torch.distributed" in p.stderr or "ChildFailedError" in p.stderr or "rank" in p.stderr.lower(), p.stderr[-2000:]
+
+
+def test_round6_bench_line_carries_the_mixed_config_and_the_clock():
+    """profiles/r06_bench.json (the same command on the GPU box in round 6): `roofline_mixed` -- BASELINE configs[4], 8192^2, whole on one GPU -- beside
+    `roofline` and `roofline_mesh`, and in each block `clock_ghz` / `frac_at_clock` (null until the PMC passes of these sources are committed)."""
+    with open(os.path.join(ROOT, "profiles", "r06_bench.json")) as f:
+        d = json.loads([l for l in f.read().splitlines() if l.startswith("{")][-1])
+    assert d["bit_exact"] is True and d["value"] > 4000.0 and d["n_gpus"] == 1
+    for key in ("roofline", "roofline_mesh", "roofline_mixed"):
+        b = d[key]
+        assert "clock_ghz" in b and "frac_at_clock" in b and 0.0 < b["frac"] < 1.0, key
+    m = d["roofline_mixed"]
+    assert "configs[4]" in m["workload"] and m["rays_per_frame"] == 2 * 8192 * 8192 - 2 and m["work_per_frame"]["triangles_tested"] > 0
+    assert m["kernel_launches_per_frame"] >= 1 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-9 and m["frame_frac"] < m["frac"] + 1e-9
+    with open(os.path.join(ROOT, "profiles", "r06_pmc.json")) as f:
+        pmc = json.load(f)
+    clocks = [v["median"] for v in pmc["clock_ghz"].values()]
+    assert clocks and all(1.5 < c < 2.6 for c in clocks)  # GRBM_GUI_ACTIVE / 8 / duration
