@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where and how a GPU render differs from the oracle: tools/diff_pixels.py <generator> <seed> [w h]
+"""Where and how a GPU render differs from the oracle: tests/diff_pixels.py <generator> <seed> [w h]
 (generator: a function of lasgun_amd.scenes taking (api, seed)).  Prints the differing pixels with both radiances and
 the GPU's trace of each (primary hit, shadow rays); the Python witness (tests/pyref.py) can then be put on the same pixel."""
 import os

@@ -2,13 +2,13 @@
 """How many pixels depend on WHICH trigonometry renders them: the CPU oracle with glibc's atan2 / acos / sin / cos (what the Rust reference calls,
 sphere.rs:99-114) against the same oracle with the portable, correctly rounded algorithm the device shares (tools/gen_trig.py), on the fuzz
 generators of tests/test_gpu_fuzz.py -- the knife-edge generator (spheres touching in a point, rays through the tangent points) above all.
-CPU only.  usage: python tools/libm_sensitivity.py [first_seed last_seed] [generator ...]  -> one JSON line per generator"""
+CPU only.  Test infrastructure (it runs the oracle), like everything else under tests/.  usage: python tests/libm_sensitivity.py [first_seed last_seed] [generator ...]  -> one JSON line per generator"""
 import json
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from lasgun_amd import scenes as S  # noqa: E402  (scene generators only: no device is touched)
 from oracle_lib import oracle  # noqa: E402
 

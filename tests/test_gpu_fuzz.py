@@ -47,7 +47,7 @@ GENERATORS = {
 # budgeted per scene, counted, and the device may differ from the glibc film ONLY on those pixels.
 # Round 6: the portable algorithm is correctly rounded (tools/gen_trig.py); glibc 2.35's own < 1 ulp error is what is left -- 0.06 - 0.15 % of
 # its results are not the nearest double (tests/test_trig_rounding.py) -- and the libm-sensitive pixels went from 31 in 49,600 knife-edge
-# scenes (rounds 1-5, a 1.4 - 3.2 ulp algorithm) to 0 in 50,000 (profiles/r06_libm_sensitivity.jsonl, tools/libm_sensitivity.py).  The budget
+# scenes (rounds 1-5, a 1.4 - 3.2 ulp algorithm) to 0 in 50,000 (profiles/r06_libm_sensitivity.jsonl, tests/libm_sensitivity.py).  The budget
 # is what one such glibc result on a knife edge may still cost.
 KNIFE_EDGE = {"adversarial_prune"}
 LIBM_PIXELS_PER_SCENE = 1        # knife-edge generator (rounds 1-5: 8)
