@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <vector>
 
 namespace lg {
 namespace tune {
@@ -74,8 +75,7 @@ int race(const Key &key, Candidate *cands, int n, int rule, hipStream_t stream, 
         if (e0) (void)hipEventDestroy(e0);
         return cands[rule].choice;
     }
-    float *best_ms = new float[(size_t)n];
-    for (int k = 0; k < n; ++k) best_ms[k] = INFINITY;
+    std::vector<float> best_ms((size_t)n, INFINITY);
     // pass 0 warms every candidate up (buffers, code, clocks); passes 1-3 time them IN TURN, so that a drift of the clocks or a
     // neighbour's launch hits all alike, and the best of the three counts (the persistent kernels' own run-to-run spread is ~5 %:
     // config 4m's megakernel / queue pair, 6 % apart, was called wrongly by one warm-up + best of two in a row); a candidate that
@@ -119,7 +119,6 @@ int race(const Key &key, Candidate *cands, int n, int rule, hipStream_t stream, 
         if (best < 0 || best_ms[k] < best_ms[best] * 0.99f) best = k; // (the rule's choice unless another beats it by 1 %: equal candidates do not flip from run to run)
     }
     if (best_out) for (int k = 0; k < n; ++k) best_out[k] = best_ms[k];
-    delete[] best_ms;
     if (best < 0) return cands[rule].choice; // nothing could be timed: the rule's choice, and the next launch of the kind tries again
     remember(key, cands[best].choice);
     return cands[best].choice;
