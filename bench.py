@@ -668,10 +668,14 @@ def main():
         frame_ms = kernel_ms / max(launches, 1)
         per_kernel = {k: v[0] / v[1] for k, v in kinds.items() if v[1] > 0}
         if per_kernel and (len(per_kernel) > 1 or "trace_kernel" not in per_kernel):  # pipeline: closest trace (+ frame), shadow trace, shade
-            dom = max(per_kernel, key=per_kernel.get)
+            dom = max(kinds, key=lambda k: kinds[k][0])  # the kind the frame spends most time in
             dom_ms = per_kernel[dom]
             dst = dict(share_stats(2 if "shadow" in dom else 1))
             dst["primary_rays"] = 0  # the RGBA write belongs to the shade kernel, not to a traversal kernel
+            # a film cut into chunks (8192^2: two) launches a kind once per chunk: the frame's work of that kind over its launches is one launch's
+            per_frame = max(1, round(kinds[dom][1] / 3.0))  # (three frames were profiled)
+            if per_frame > 1:
+                dst = {k: v / per_frame for k, v in dst.items()}
             # wavefront pipeline: lg::wf_trace_kernel<FAST, SHADOW, scene tables resident in LDS>, lg::wf_shade_kernel
             # wavefront pipeline: lg::wf_trace_kernel<FAST, SHADOW, scene tables resident in LDS, level-0 closest pass>, lg::wf_shade_kernel<KIND, L0>
             shadow = "shadow" in dom
@@ -681,7 +685,7 @@ def main():
             kernel_name = ("lg::wf_trace_kernel<false, %s, %s, %s, %s, %s>" % ("true" if shadow else "false", "true" if lds_scene else "false", "false" if shadow else "true", pruned, refill)
                            if dom.startswith("trace<") else "lg::wf_shade_kernel<0, true>")
         else:  # megakernel (a share too small for the pipeline, e.g. a small --size over many ranks)
-            dom_ms, dst, kernel_name = frame_ms, st, "lg::trace_kernel<false, false, %s, %s>" % ("true" if lds_scene else "false", "true" if G.get_prune(acc) else "false")
+            dom_ms, dst, kernel_name = frame_ms, st, "lg::trace_kernel<false, false, %s, %s, 1024>" % ("true" if lds_scene else "false", "true" if G.get_prune(acc) else "false")
             per_kernel = {"trace_kernel": frame_ms}
         dom_bytes, dom_flops = algorithmic_bytes(dst), algorithmic_flops(dst)
         secs = dom_ms * 1e-3
