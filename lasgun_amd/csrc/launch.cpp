@@ -771,7 +771,10 @@ static int tuned_choice(const lg_accel &a, const DParams &P, lg_accel::LaunchCtx
     const bool was_profiling = a.profiling;
     a.profiling = false; // (the measurement's launches are not the caller's: lg_profile_read must not count them)
     struct Restore { const lg_accel &a; bool was; ~Restore() { a.profiling = was; } } restore{a, was_profiling};
+    // (LASGUN_TUNE_FAIL=<organisation 0..2>: test hook -- every candidate of that organisation throws in the race, as one whose buffers do not fit would)
+    static const int fail_org = [] { const char *e = std::getenv("LASGUN_TUNE_FAIL"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : -1; }();
     const int choice = lg::tune::race(key, cand, NC, rule_k, stream, [&](int k) {
+        if (fail_org >= 0 && (cand[k].choice & (TUNE_REV - 1)) == fail_org) throw Error("LASGUN_TUNE_FAIL: injected failure of a candidate");
         if (k == K_SPLIT) enqueue_org(a, P, c, ORG_MEGA, DIR_DEFAULT, !mega_par_by_rule(a, P, false), true, false, stream);
         else if (k == K_QSPLIT) enqueue_org(a, P, c, ORG_QUEUE, DIR_DEFAULT, false, true, false, stream);
         else enqueue_org(a, P, c, (Org)(k / 6), k % 3, ((k / 3) & 1) != 0, false, false, stream);

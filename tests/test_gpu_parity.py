@@ -668,6 +668,35 @@ def test_capture_subset_partitions_and_preserves_other_pixels():
     assert np.array_equal(buf, want)
 
 
+def test_alternating_periods_and_films_on_one_stream_keep_their_row_tables_apart():
+    """A caller that alternates periods n -- and film sizes -- on ONE stream (progressive refinement with a varying n, two films): the lattice
+    addressing keeps a row table per (w, h, n) in the stream's launch context, the last four of them, each uploaded from pinned staging on the
+    stream itself (launch.cpp: lattice_rows; round 5 kept one and synchronised the whole device on every change).  Seven (film, period) pairs
+    taken in turn three times over, no synchronisation in between: tables are evicted while launches that read older ones are still queued.
+    Every film ends as the frame."""
+    import torch
+    acc = G.Accel(S.cornell_scene(G, "glass"))
+    G.set_streaming(acc, 2)
+    cases = [(160, 96, 9), (160, 96, 17), (160, 96, 23), (131, 67, 8), (131, 67, 50), (160, 96, 64), (200, 80, 11)]
+    stream = torch.cuda.Stream()
+    refs, films = {}, {}
+    for w, h, n in cases:
+        if (w, h) not in refs:
+            full = G.Film(w, h)
+            G.capture_subset(0, 1, acc, full)
+            refs[(w, h)] = full.pixels().copy()
+        films[(w, h, n)] = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for third in range(3):  # each film gets a third of its subsets per round: every (w, h, n) comes back after six other tables were used
+            for w, h, n in cases:
+                for k in range(third, n, 3):
+                    G.capture_subset_device(k, n, acc, w, h, films[(w, h, n)].data_ptr(), stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    for (w, h, n), film in films.items():
+        assert np.array_equal(film.cpu().numpy(), refs[(w, h)]), (w, h, n)
+
+
 @pytest.mark.parametrize("w, h, n, ks", [(96, 80, 10, (0, 3, 9)), (200, 131, 100, (0, 57, 99)), (131, 67, 8, (7, 2)), (64, 200, 64, (0, 63, 31)),
                                          (257, 19, 33, (32, 5)), (120, 72, 16, (120 * 72 - 3, 130, 15 + 16 * 7)), (97, 61, 97, (0, 96)), (97, 61, 50, (49,))])
 def test_strided_subsets_tile_by_lattice_column(w, h, n, ks):
@@ -831,6 +860,42 @@ def test_the_table_of_measured_choices_can_be_exported_pinned_and_cleared():
     with pytest.raises(la.LasgunError):
         G.tune_import([(table[0][0], 7)])  # (organisations are 0 .. 2)
     G.tune_clear()
+
+
+TUNE_FAIL_CHILD = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import lasgun_amd as la
+from oracle_lib import oracle
+G, S = la.api, la.scenes
+w, h = 160, 120
+o = oracle()
+want = o.render(S.cornell_scene(o, "glass"), (w, h)).pixels()
+acc = G.Accel(S.cornell_scene(G, "glass"))
+for _ in range(3):
+    film = G.Film(w, h)
+    G.capture_subset(0, 1, acc, film)   # the race runs inside one of these calls; the injected failures must not reach the caller
+    assert np.array_equal(film.pixels(), want)
+ran = G.last_organisation(acc)
+assert ran is not None and not ran.startswith(%r), ran
+assert len(G.tune_export()) >= 1
+print("tune ok", ran)
+"""
+
+
+@pytest.mark.parametrize("fail_org, name", [(1, "wavefront"), (0, "megakernel")])
+def test_a_candidate_that_cannot_run_drops_out_of_the_measurement(fail_org, name):
+    """an organisation whose buffers do not fit (hipMalloc of the megakernel's accumulator, of the level-by-level state) used to fail the
+    caller's render from inside the measurement, and every later launch of the kind again.  LASGUN_TUNE_FAIL makes every candidate of one
+    organisation throw in the race (a test hook, launch.cpp): the render succeeds with the bytes of the oracle, a choice is remembered, and it is
+    not the organisation that failed.  In a child process (the switch is read once; the table is the process's)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LASGUN_TUNE_FAIL=str(fail_org), LASGUN_AUTOTUNE="2")
+    p = subprocess.run([sys.executable, "-c", TUNE_FAIL_CHILD % (root, os.path.join(root, "tests"), name)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "tune ok" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
 
 
 def test_capture_rebuilds_and_render_matches():
