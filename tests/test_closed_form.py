@@ -31,6 +31,86 @@ def camera_ray(eye, look, up, fov, w, h, x, y):
     return eye, d + half
 
 
+def camera_rays(eye, look, up, w, h, x, y, base=0, fov=None, ortho=None):
+    """Camera::look_at + Camera::sample (camera.rs:85-146) in full: every sample of pixel (x, y) for supersampling base `base` ((base + 1)^2
+    samples, camera.rs:189-193), perspective (fov in degrees; pixel_separation 0: one origin) or orthographic (image plane height `ortho`;
+    pixel_separation 1: the origin moves with the pixel).  [(origin, direction)] in the reference's order (i outer over aux, j inner over up)."""
+    eye, look, up = (np.array(v, float) for v in (eye, look, up))
+    view = look - eye
+    aux = np.cross(view, up)
+    upn = np.cross(aux, view); upn = upn * (1.0 / math.sqrt(upn @ upn))
+    aux = aux * (1.0 / math.sqrt(aux @ aux))
+    H = ortho if ortho is not None else math.sqrt(view @ view) * math.tan(fov * math.pi / 360.0) * 2.0
+    sep = 1.0 if ortho is not None else 0.0
+    W = H * (w / h)
+    pixel = H * (1.0 / h)
+    root = base + 1
+    ssep = (1.0 / root) * pixel
+    sox = (x * (1.0 / w) - 0.5) * W
+    soy = (0.5 - (y + 1) * (1.0 / h)) * H
+    origin = eye + (soy * sep) * upn + (sox * sep) * aux
+    d = view + soy * upn + sox * aux
+    updiff, auxdiff = upn * ssep, aux * ssep
+    half = updiff * 0.5 + auxdiff * 0.5
+    return [(origin, d + j * updiff + i * auxdiff + half) for i in range(root) for j in range(root)]
+
+
+def check_supersampled_background(api, radiance):
+    """3 x 3 samples per pixel (set_supersampling(2)): the pixel is the mean of the nine samples' background values, summed in the reference's
+    order and multiplied by the weight 1 / 9 (lib.rs:147-159, integrate.rs:16-20)."""
+    w, h, fov = 24, 18, 55.0
+    eye, look = [1.0, 2.0, 3.0], [4.0, 1.0, -2.0]
+    inner, outer, scale = [0.26, 0.78, 0.67], [0.1, 0.09, 0.33], 0.5
+    sc = api.Scene.new()
+    cam = sc.set_perspective_camera(fov)
+    cam.look_at(eye, look, [0.0, 1.0, 0.0])
+    cam.set_supersampling(2)
+    sc.set_radial_background(inner, outer, scale)
+    sc.root.add_sphere([0.0, 1.0e6, 0.0], 1.0, api.Material.matte([0.5, 0.5, 0.5], 0.0))
+    rad = radiance(api.Accel(sc), w, h)
+    for x, y in ((0, 0), (w - 1, h - 1), (w // 2, h // 2), (3, 14)):
+        rays = camera_rays(eye, look, [0.0, 1.0, 0.0], w, h, x, y, base=2, fov=fov)
+        assert len(rays) == 9
+        total = np.zeros(3)
+        for _, d in rays:
+            total = total + background(d, inner, outer, scale)
+        assert np.allclose(rad[y, x], total * (1.0 / 9.0), rtol=1e-13, atol=0.0), (x, y)
+
+
+def check_orthographic_lambert(api, radiance):
+    """The orthographic camera (camera.rs:139-146 with pixel_separation 1: the ray's origin moves across the image plane with its pixel, and the
+    direction keeps the pixel's offset as well -- the reference's formula as written) on a Lambertian sphere."""
+    w, h, height = 33, 33, 6.0
+    eye, look = [0.0, 0.0, 0.0], [0.0, 0.0, 2.0]
+    kd, ambient = np.array([0.7, 1.0, 0.7]), np.array([0.1, 0.2, 0.3])
+    lpos, lint, falloff = np.array([3.0, 6.0, -4.0]), np.array([0.8, 0.6, 0.9]), np.array([1.0, 0.001, 0.0])
+    c, r = np.array([0.2, -0.1, 10.0]), 2.5
+    sc = api.Scene.new()
+    sc.set_orthographic_camera(height).look_at(eye, look, [0.0, 1.0, 0.0])
+    sc.set_ambient_light(ambient.tolist())
+    sc.add_point_light(lpos.tolist(), lint.tolist(), falloff.tolist())
+    sc.root.add_sphere(c.tolist(), r, api.Material.matte(kd.tolist(), 0.0))
+    rad = radiance(api.Accel(sc), w, h)
+    checked = 0
+    for x, y in ((16, 16), (15, 16), (17, 17), (16, 15), (17, 15), (15, 18)):  # (near the centre: the direction keeps the pixel's offset too, so the rays fan out)
+        (o, d), = camera_rays(eye, look, [0.0, 1.0, 0.0], w, h, x, y, base=0, ortho=height)
+        t = sphere_hit(o, d, c, r)
+        if t is None:
+            continue
+        p = o + d * t
+        n = (p - c) / r
+        wi = lpos - p
+        dist = math.sqrt(wi @ wi)
+        f_att = falloff[0] + falloff[1] * dist + falloff[2] * dist * dist
+        wi = wi / dist
+        if not (wi @ n) > 0.05:
+            continue
+        want = lint * kd * (wi @ n) / f_att + ambient * kd / math.pi
+        assert np.allclose(rad[y, x], want, rtol=1e-9, atol=0.0), (x, y, rad[y, x], want)
+        checked += 1
+    assert checked >= 4
+
+
 def background(d, inner, outer, scale):
     d = d * (1.0 / math.sqrt(d @ d))
     t = min(math.sqrt(1.0 - abs(d[2]) ** 2) / scale, 1.0)
@@ -466,6 +546,8 @@ def test_closed_forms_on_the_oracle():
     check_metal_sphere(o, lambda acc, w, h: o.capture_radiance(acc, w, h, nthreads=2))
     check_oren_nayar_sphere(o, lambda acc, w, h: o.capture_radiance(acc, w, h, nthreads=2))
     check_glass_pane(o, lambda acc, w, h: o.capture_radiance(acc, w, h, nthreads=2))
+    check_supersampled_background(o, lambda acc, w, h: o.capture_radiance(acc, w, h, nthreads=2))
+    check_orthographic_lambert(o, lambda acc, w, h: o.capture_radiance(acc, w, h, nthreads=2))
 
 
 @pytest.mark.gpu
@@ -486,3 +568,5 @@ def test_closed_forms_on_the_device():
         check_metal_sphere(G, radiance)
         check_oren_nayar_sphere(G, radiance)
         check_glass_pane(G, radiance)
+        check_supersampled_background(G, radiance)
+        check_orthographic_lambert(G, radiance)
