@@ -570,3 +570,26 @@ def test_closed_forms_on_the_device():
         check_glass_pane(G, radiance)
         check_supersampled_background(G, radiance)
         check_orthographic_lambert(G, radiance)
+
+
+def test_to_byte_is_rusts_rounding_and_saturating_cast():
+    """`to_byte` (img.rs:65-67): clamp to [0, 1], times 255, `f64::round` (half away from zero), `as u8` (saturating; NaN -> 0) -- written here
+    from Rust's documented semantics with exact rational arithmetic, against the oracle's (the device is held to the oracle's in
+    tests/test_gpu_parity.py::test_to_byte_quantisation)."""
+    from fractions import Fraction
+    rng = np.random.default_rng(3)
+    k = np.arange(0, 256)
+    a = np.concatenate([rng.uniform(-0.5, 1.5, 20000), (k + 0.5) / 255.0, np.nextafter((k + 0.5) / 255.0, 0), np.nextafter((k + 0.5) / 255.0, 2),
+                        k / 255.0, [np.nan, np.inf, -np.inf, -0.0, 1.0, 0.0, 5e-324, 1.0 - 2.0 ** -53]])
+
+    def rust(c):
+        if c != c:
+            c = 0.0  # f64::max / min return the other operand for a NaN: NaN.max(0.0) = 0.0
+        c = min(max(c, 0.0), 1.0)
+        v = c * 255.0  # one f64 multiplication, rounded
+        f = Fraction(v)
+        n = int(f)  # truncation; v >= 0
+        return min(255, n + 1 if f - n >= Fraction(1, 2) else n)
+    got = oracle().math_eval(8, a)
+    want = np.array([rust(float(c)) for c in a], dtype=np.float64)
+    assert np.array_equal(got, want)
