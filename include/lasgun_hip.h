@@ -271,7 +271,10 @@ int lg_accel_set_streaming(const lg_accel *, int enabled);
  * encoding of lg_accel_last_organisation).  lg_tune_export writes up to `capacity` entries and returns how many the table holds
  * (out = NULL: just the count); lg_tune_import pins entries -- a kind that has one is never measured, and an entry the launch cannot
  * take (another build, less memory) falls back to the fitted rule's choice instead of failing; lg_tune_clear forgets every choice and
- * every first sight.  A caller that knows its workload exports once and imports at start-up; a test runs on a fixed table. */
+ * every first sight.  A caller that knows its workload exports once and imports at start-up; a test runs on a fixed table.
+ * LASGUN_TUNE_FILE=<path> does the same without a line of code: the table is read from the file before the first look-up and rewritten after every
+ * choice that is remembered, so a program that renders one frame and exits -- and therefore never measures -- runs on what an earlier run
+ * (LASGUN_AUTOTUNE=2, or any program that rendered the kind twice) measured. */
 typedef struct lg_tune_entry { uint64_t key[12]; int32_t choice; int32_t reserved; } lg_tune_entry;
 size_t lg_tune_export(lg_tune_entry *out, size_t capacity);
 int lg_tune_import(const lg_tune_entry *entries, size_t count);

@@ -4,9 +4,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace lg {
@@ -15,11 +17,56 @@ namespace tune {
 bool Key::operator<(const Key &o) const { return std::lexicographical_compare(v, v + 12, o.v, o.v + 12); }
 
 namespace {
-std::mutex g_mtx;     // the two tables
+std::mutex g_mtx;     // the two tables (and the file, below)
 std::mutex g_run_mtx; // one race at a time in the process: two accels of one kind measuring side by side would time each other
 // never destroyed: launches at interpreter exit, after static destructors have begun, still find them
 std::map<Key, int> &g_tuned = *new std::map<Key, int>();
 std::map<Key, uint64_t> &g_first_seen = *new std::map<Key, uint64_t>(); // the API call a kind was first launched in
+// LASGUN_TUNE_FILE=<path>: the table persists across processes -- read once before the first look-up, rewritten (temp file + rename) after every
+// choice that is remembered.  A program that renders one frame and exits never measures (mode 1); with a file left by an earlier run it takes the
+// measured choice at no cost.  One line per kind: twelve hexadecimal words and the choice.  A file that cannot be read or parsed is ignored.
+bool g_file_loaded = false;
+const char *tune_file() {
+    static const char *path = [] { const char *e = std::getenv("LASGUN_TUNE_FILE"); return e && e[0] ? e : nullptr; }();
+    return path;
+}
+void load_file_locked() { // caller holds g_mtx
+    if (g_file_loaded) return;
+    g_file_loaded = true;
+    const char *path = tune_file();
+    if (!path) return;
+    std::FILE *f = std::fopen(path, "r");
+    if (!f) return;
+    char line[512];
+    while (std::fgets(line, sizeof line, f)) {
+        Key k{};
+        int choice = -1, used = 0, n = 0;
+        const char *p = line;
+        bool ok = true;
+        for (int i = 0; i < 12 && ok; ++i) {
+            unsigned long long v = 0;
+            ok = std::sscanf(p, "%llx%n", &v, &n) == 1;
+            k.v[i] = v; p += ok ? n : 0;
+        }
+        ok = ok && std::sscanf(p, "%d%n", &choice, &used) == 1 && choice >= 0 && choice < 256 && (choice & 15) <= 2;
+        if (ok) g_tuned.emplace(k, choice); // (a choice made in this process already wins)
+    }
+    std::fclose(f);
+}
+void save_file_locked() { // caller holds g_mtx
+    const char *path = tune_file();
+    if (!path) return;
+    const std::string tmp = std::string(path) + ".tmp";
+    std::FILE *f = std::fopen(tmp.c_str(), "w");
+    if (!f) return;
+    for (const auto &kv : g_tuned) {
+        for (int i = 0; i < 12; ++i) std::fprintf(f, "%llx ", (unsigned long long)kv.first.v[i]);
+        std::fprintf(f, "%d\n", kv.second);
+    }
+    const bool ok = std::fclose(f) == 0;
+    if (ok) (void)std::rename(tmp.c_str(), path);
+    else (void)std::remove(tmp.c_str());
+}
 } // namespace
 
 int mode() {
@@ -29,6 +76,7 @@ int mode() {
 
 bool lookup(const Key &key, int *choice) {
     std::lock_guard<std::mutex> g(g_mtx);
+    load_file_locked();
     auto it = g_tuned.find(key);
     if (it == g_tuned.end()) return false;
     *choice = it->second;
@@ -44,11 +92,14 @@ bool first_call_of_kind(const Key &key, uint64_t serial) {
 
 void remember(const Key &key, int choice) {
     std::lock_guard<std::mutex> g(g_mtx);
+    load_file_locked();
     g_tuned[key] = choice;
+    save_file_locked();
 }
 
 size_t snapshot(Key *keys, int *choices, size_t capacity) {
     std::lock_guard<std::mutex> g(g_mtx);
+    load_file_locked();
     size_t i = 0;
     for (const auto &kv : g_tuned) {
         if (i < capacity) { if (keys) keys[i] = kv.first; if (choices) choices[i] = kv.second; }
@@ -59,8 +110,10 @@ size_t snapshot(Key *keys, int *choices, size_t capacity) {
 
 void clear() {
     std::lock_guard<std::mutex> g(g_mtx);
+    g_file_loaded = true; // (what the file held is forgotten too)
     g_tuned.clear();
     g_first_seen.clear();
+    save_file_locked();
 }
 
 int race(const Key &key, Candidate *cands, int n, int rule, hipStream_t stream, const std::function<void(int)> &launch, float *best_out) {
