@@ -898,6 +898,38 @@ def test_a_candidate_that_cannot_run_drops_out_of_the_measurement(fail_org, name
     assert p.returncode == 0 and "tune ok" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
 
 
+TUNE_FILE_CHILD = r"""
+import sys
+sys.path.insert(0, %r)
+import lasgun_amd as la
+G, S = la.api, la.scenes
+acc = G.Accel(S.cornell_scene(G, "glass"))
+for _ in range(int(sys.argv[1])):
+    G.capture_subset(0, 1, acc, G.Film(200, 150))
+print("RAN", G.last_organisation(acc), len(G.tune_export()))
+"""
+
+
+def test_a_one_frame_program_runs_on_what_an_earlier_run_measured(tmp_path):
+    """LASGUN_TUNE_FILE: a first process measures (LASGUN_AUTOTUNE=2) and leaves its table in the file; a second process in the default mode renders
+    ONE frame -- it would take the fitted rule's choice and never measure -- and finds the kind in the file: same organisation, no race."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "tune.txt")
+
+    def child(frames, autotune):
+        env = dict(os.environ, LASGUN_TUNE_FILE=path, LASGUN_AUTOTUNE=autotune)
+        p = subprocess.run([sys.executable, "-c", TUNE_FILE_CHILD % root, str(frames)], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        _, org, n = p.stdout.strip().splitlines()[-1].split(" ", 2)[0], p.stdout.strip().splitlines()[-1].split(" ", 1)[1].rsplit(" ", 1)[0], int(p.stdout.strip().rsplit(" ", 1)[1])
+        return org, n
+    measured, n1 = child(2, "2")
+    assert n1 >= 1 and os.path.getsize(path) > 0
+    again, n2 = child(1, "1")
+    assert again == measured and n2 == n1, (measured, again)
+
+
 def test_capture_rebuilds_and_render_matches():
     w, h = 64, 48
     scene = S.simple_scene(G, 1)
